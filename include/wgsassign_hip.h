@@ -1,0 +1,152 @@
+/*
+ * wgsassign_hip.h -- C ABI of libwgsassign_hip.so, the MI355X (gfx950) implementation of
+ * WGSassign's hot path: the per-population EM allele-frequency estimator and the per-SNP
+ * assignment log-likelihood summation.
+ *
+ * The reference exposes this path as Python-callable Cython functions (no C plugin ABI), so
+ * the boundary is: Python shim (the modules of wgsassign_amd/, same module/function names as the
+ * reference) -> ctypes -> the functions below.  Each entry point names the reference
+ * interface it stands in for (paths relative to the reference repository).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all matrices are float32, C-contiguous, exactly as the
+ *     reference's typed memoryviews require (emMAF_cy.pyx:10, glassy_cy.pyx:12);
+ *   - every function returns 0 on success, non-zero on failure; wgs_last_error() then holds a
+ *     message for the calling thread (the shim raises RuntimeError/ValueError from it);
+ *   - "host" pointers are ordinary process memory; "dev" pointers are HIP device memory of the
+ *     context's device (so a caller that owns device buffers -- e.g. an RCCL bounce buffer
+ *     allocated elsewhere -- can hand them in directly);
+ *   - arithmetic mode: WGS_MODE_EXACT reproduces the reference's rounding sequence operation
+ *     by operation (double products rounded to float32, float32 (p0+p1)+p2, serial float32
+ *     accumulation over individuals in file order) and is bit-identical to the reference for
+ *     allele frequencies and EM iteration counts; WGS_MODE_FAST evaluates each term in float32
+ *     and is within ~1e-6 relative (documented in DESIGN.md).
+ */
+#ifndef WGSASSIGN_HIP_H
+#define WGSASSIGN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WGS_MODE_EXACT 0
+#define WGS_MODE_FAST 1
+
+typedef struct wgs_ctx wgs_ctx;       /* one HIP device + stream + workspace */
+typedef struct wgs_beagle wgs_beagle; /* device-resident genotype-likelihood matrix (SNP shard) */
+typedef struct wgs_em wgs_em;         /* a batch of EM fits over one wgs_beagle */
+
+/* ------------------------------------------------------------------ context */
+const char *wgs_last_error(void);
+int wgs_version(void);
+int wgs_device_count(int *count);
+int wgs_ctx_create(int device, wgs_ctx **out);
+void wgs_ctx_destroy(wgs_ctx *ctx);
+int wgs_ctx_sync(wgs_ctx *ctx);
+/* The context's hipStream_t (all work of the library is enqueued on it). */
+void *wgs_ctx_stream(wgs_ctx *ctx);
+/* Device name / CU count / total memory of the context's device (for reports). */
+int wgs_ctx_info(wgs_ctx *ctx, char *name, int name_len, int *cus, int64_t *mem_bytes);
+
+/* ------------------------------------------------------------------ (1) thin mirrors
+ * Same arguments, in-place semantics and results as the Cython kernels; host pointers.
+ * They upload, run the HIP kernel and download -- meant for drop-in use and parity tests on
+ * inputs the reference handles in seconds, not for the at-scale path (use (2)). */
+
+/* emMAF_cy.emMAF_update(L, f, t)            -- emMAF_cy.pyx:10-23.  f is updated in place. */
+int wgs_emmaf_update(wgs_ctx *ctx, const float *L, int64_t m, int64_t n, float *f, int mode);
+/* emMAF_cy.rmse1d(v1, v2) -> float          -- emMAF_cy.pyx:26-33.  Bit-exact serial float32
+ * accumulation (see wgs_em_rmse_chain). */
+int wgs_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out);
+/* glassy_cy.loglike(L, A, loglike_vec, t, i, k) -- glassy_cy.pyx:12-21.  vec is accumulated
+ * into, in place.  A is (m, K). */
+int wgs_loglike(wgs_ctx *ctx, const float *L, int64_t m, int64_t n, const float *A, int64_t K,
+                float *vec, int64_t i, int64_t k, int mode);
+
+/* ------------------------------------------------------------------ (2) device-resident path */
+
+/* Genotype-likelihood matrix of m SNPs x n individuals (reader_cy.pyx:71-77 layout on the
+ * host: row s = g0_0 g1_0 g0_1 g1_1 ...).  On the device it is kept as one SNP-major slab of
+ * (g0,g1) float2 pairs per group of individuals ("population slab"): slab g is m x ld_g, its
+ * columns are the individuals with group_of[i] == g in file order -- the on-device equivalent
+ * of the per-population column gather at WGSassign.py:227-233 / glassy.py:69-77, done once.
+ * group_of == NULL puts every individual in one group (the --get_pop_like case).
+ * site0 is the global index of the shard's first SNP (partition labels use global indices). */
+int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_of, int32_t n_groups,
+                      int64_t site0, wgs_beagle **out);
+void wgs_beagle_destroy(wgs_beagle *b);
+/* Copy host rows [row0, row0+nrows) of an (m, 2n) float32 matrix into the slabs. */
+int wgs_beagle_upload_rows(wgs_beagle *b, const float *L_rows, int64_t row0, int64_t nrows);
+/* Copy rows back into (nrows, 2n) host layout (tests, CPU-baseline sample). */
+int wgs_beagle_download_rows(wgs_beagle *b, float *L_rows, int64_t row0, int64_t nrows);
+/* Fill the slabs with synthetic low-depth genotype likelihoods on the device (SURVEY 8d:
+ * Philox-4x32-10 counter RNG keyed by (seed, global SNP, individual), HWE genotypes from
+ * per-group frequencies, Poisson(depth) reads, error 0.01, GLs rounded to 6 decimals). */
+int wgs_beagle_synth(wgs_beagle *b, uint64_t seed, double depth);
+int64_t wgs_beagle_bytes(const wgs_beagle *b);
+
+/* A batch of EM fits (emMAF.py:15-27) over slabs of `b`.  Fit j estimates the frequency of
+ * every SNP from the individuals of group fit_group[j], leaving out individual fit_skip[j]
+ * (global individual index, must belong to that group) or nobody when fit_skip[j] < 0 --
+ * the leave-one-out re-fit of glassy.py:65-78.  All fits start at f = 0.25 (emMAF.py:17-18). */
+int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const int32_t *fit_skip,
+                  int mode, wgs_em **out);
+void wgs_em_destroy(wgs_em *em);
+/* One EM update (emMAF_cy.pyx:10-23) of every still-active fit in ONE sweep over the slabs,
+ * fused with the float64 sum over this shard's SNPs of (f_new - f_old)^2 per fit.  After the
+ * call each swept fit's current frequencies are the updated ones and its previous ones are
+ * kept (for wgs_em_rmse_chain).  ssq_host (n_fits doubles, may be NULL) receives the sums;
+ * fits that were not swept report 0.  Synchronises the context's stream. */
+int wgs_em_step(wgs_em *em, double *ssq_host);
+/* Same, but leaves the sums in device memory at ssq_dev (n_fits doubles, zeroed by the call)
+ * and does NOT synchronise -- for callers that all-reduce them on the device with RCCL. */
+int wgs_em_step_dev(wgs_em *em, double *ssq_dev);
+/* The reference's convergence metric (emMAF_cy.pyx:26-33) is a SERIAL float32 accumulation
+ * over all m SNPs.  This continues that exact chain over this shard's SNPs for one fit:
+ * carry_in is the float32 running sum after the preceding shards (0 for the first shard),
+ * carry_out the running sum after this shard; diff = sqrt((double)(carry / (float)m_total)). */
+int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out);
+/* Freeze (active = 0) or re-activate a fit: frozen fits are skipped by wgs_em_step and keep
+ * the frequencies of their last update -- emMAF.py:23-25 `break`s after the update. */
+int wgs_em_set_active(wgs_em *em, int32_t fit, int active);
+int wgs_em_n_active(wgs_em *em);
+/* The driver loop of emMAF.py:20-26 (step, decide `diff < tole`, freeze) is host code above
+ * this ABI: wgsassign_amd/device.py:EMBatch.run.  It needs, per iteration, the all-reduced
+ * sums of wgs_em_step and -- only when sum/m is within a guard band of tole^2 -- the exact
+ * serial chain of wgs_em_rmse_chain handed from SNP shard to SNP shard in rank order. */
+/* Clamp fit j's frequencies to [lo, hi] the way WGSassign.py:236-240 does (float32 compares,
+ * NaN untouched). */
+int wgs_em_clamp(wgs_em *em, int32_t fit, float lo, float hi);
+/* Copy fit j's current frequencies (m floats) to the host / get their device address. */
+int wgs_em_get_f(wgs_em *em, int32_t fit, float *f_host);
+int wgs_em_set_f(wgs_em *em, int32_t fit, const float *f_host);
+const float *wgs_em_f_dev(wgs_em *em, int32_t fit);
+
+/* Frequency vectors kept on the device for the assignment kernels: K vectors of m floats
+ * (population-major), uploaded from the reference's (m, K) matrix (`.pop_af.npy`,
+ * WGSassign.py:243,303). */
+typedef struct wgs_afset wgs_afset;
+int wgs_afset_create(wgs_ctx *ctx, int64_t m, int32_t K, wgs_afset **out);
+void wgs_afset_destroy(wgs_afset *a);
+int wgs_afset_upload(wgs_afset *a, const float *A_mK);           /* host (m, K) -> K device vectors */
+int wgs_afset_download(wgs_afset *a, float *A_mK);               /* K device vectors -> host (m, K) */
+int wgs_afset_set_column_from_em(wgs_afset *a, int32_t col, wgs_em *em, int32_t fit); /* device copy */
+const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
+
+/* glassy.assignLL(L, af, t) -- glassy.py:18-44 -- for ALL n x K pairs in one sweep over the
+ * slabs: out[i*K + k] = sum over this shard's SNPs of the float32 per-site log-likelihood
+ * (glassy_cy.pyx:18-21), accumulated in float64 (the reference sums with np.sum(dtype=float),
+ * glassy.py:38).  colptr (may be NULL) overrides the frequency vector per (individual, k):
+ * colptr[i*K + k] is a device pointer to m floats -- this is how the leave-one-out scoring of
+ * glassy.py:87-105 (per-individual columns, sticky overwrite) is expressed.  With P > 1 also
+ * fills parts[(i*P + p)*K + k], the sum over SNPs whose GLOBAL index is p modulo P
+ * (utils.py:129-151).  out/parts are host float64 buffers, summed into (caller zeroes). */
+int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
+               double *out, double *parts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGSASSIGN_HIP_H */

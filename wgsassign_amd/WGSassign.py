@@ -1,0 +1,148 @@
+"""`WGSassign` command line: drop-in for the hot-path options of the reference's
+WGSassign.py (--get_reference_af, --loo, --get_pop_like), running on an AMD MI355X.
+
+Same flags, defaults, stdout lines and output files as the reference (WGSassign.py:24-104,
+109-308).  Options of the reference that are outside this build's scope (--ne_obs, z-scores,
+mixture proportions) are recognised and refused with a message.
+"""
+import argparse
+import os
+import sys
+from datetime import datetime
+
+parser = argparse.ArgumentParser(prog="WGSassign")
+parser.add_argument("-b", "--beagle", metavar="FILE",
+                    help="Filepath to genotype likelihoods in gzipped Beagle format from ANGSD")
+parser.add_argument("-t", "--threads", metavar="INT", type=int, default=1,
+                    help="Number of threads (kept for compatibility; the GPU path ignores it)")
+parser.add_argument("-o", "--out", metavar="OUTPUT", default="wgsassign", help="Prefix for output files")
+parser.add_argument("--maf_iter", metavar="INT", type=int, default=200,
+                    help="Maximum iterations for minor allele frequencies estimation - EM (200)")
+parser.add_argument("--maf_tole", metavar="FLOAT", type=float, default=1e-4,
+                    help="Tolerance for minor allele frequencies estimation update - EM (1e-4)")
+parser.add_argument("--pop_af_IDs", metavar="FILE", help="Filepath to individual IDs and populations for beagle")
+parser.add_argument("--get_reference_af", action="store_true",
+                    help="Estimate allele frequencies for reference populations")
+parser.add_argument("--pop_names", metavar="FILE", help="Filepath to population names of allele frequency file")
+parser.add_argument("--loo", action="store_true", help="Perform leave-one-out cross validation")
+parser.add_argument("--loo_downsampled_beagle", metavar="FILE",
+                    help="Optional Beagle file of downsampled genotype likelihoods to use for LOO assignment.")
+parser.add_argument("--pop_af_file", metavar="FILE", help="Filepath to reference population allele frequencies")
+parser.add_argument("--get_pop_like", action="store_true",
+                    help="Estimate log likelihood of individual assignment to each reference population")
+parser.add_argument("--partition_sites", type=int, metavar="INT", default=1,
+                    help="Optional: partition sites into INT subsets (by modulo) and report assignment "
+                         "log-likelihoods for each subset.")
+# recognised but not provided by this build (out of the hot-path scope)
+for _flag in ("--ne_obs", "--get_assignment_z_score", "--get_reference_z_score", "--single_read_threshold",
+              "--get_em_mix", "--get_mcmc_mix"):
+    parser.add_argument(_flag, action="store_true", help=argparse.SUPPRESS)
+for _flag in ("--ind_ad_file", "--allele_count_threshold", "--ind_start", "--ind_end", "--pop_like", "--pop_like_IDs",
+              "--mixture_iter"):
+    parser.add_argument(_flag, help=argparse.SUPPRESS)
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    if len(sys.argv) < 2 and argv is None:
+        parser.print_help()
+        sys.exit()
+    print("WGSassign")
+    print("Matt DeSaix.")
+    print("Using " + str(args.threads) + " thread(s).\n")
+
+    if args.loo_downsampled_beagle and not args.loo:
+        raise ValueError("The --loo_downsampled_beagle option requires that --loo is also specified.")
+    for unsupported in ("ne_obs", "get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
+        if getattr(args, unsupported):
+            raise SystemExit("--%s is outside the scope of the MI355X build (EM allele frequencies, "
+                             "leave-one-out and assignment likelihoods only)" % unsupported)
+
+    # log-file of non-default arguments (WGSassign.py:127-141)
+    full, deaf = vars(args), vars(parser.parse_args([]))
+    with open(args.out + ".args", "w") as fh:
+        fh.write("WGSassign\n")
+        fh.write("Time: " + datetime.now().strftime("%d/%m/%Y %H:%M:%S") + "\n")
+        fh.write("Directory: " + str(os.getcwd()) + "\n")
+        fh.write("Options:\n")
+        for key in full:
+            if full[key] != deaf[key]:
+                if type(full[key]) is bool:
+                    fh.write("\t-" + str(key) + "\n")
+                else:
+                    fh.write("\t-" + str(key) + " " + str(full[key]) + "\n")
+
+    import numpy as np
+
+    from . import emMAF, glassy, reader_cy, utils
+
+    L = None
+    if args.beagle is not None:
+        print("Parsing Beagle file.")
+        assert os.path.isfile(args.beagle), "Beagle file doesn't exist!"
+        L, sample_names, site_names = reader_cy.readBeagle(args.beagle)
+        m, n = L.shape[0], L.shape[1] // 2
+        print("Loaded " + str(m) + " sites and " + str(n) + " individuals.")
+        utils.print_sample_and_site_summary(sample_names, site_names)
+
+    L_ds = None
+    if args.loo_downsampled_beagle is not None:
+        print("Parsing the optional downsampled Beagle file.")
+        assert os.path.isfile(args.loo_downsampled_beagle), "Downsampled beagle file doesn't exist!"
+        L_ds, sample_names_ds, site_names_ds = reader_cy.readBeagle(args.loo_downsampled_beagle)
+        print("Loaded optional downsampled data set with " + str(m) + " sites and " + str(n) + " individuals.")
+        utils.print_sample_and_site_summary(sample_names_ds, site_names_ds)
+        if sample_names != sample_names_ds:
+            raise ValueError("Sample names in downsampled Beagle file do not match original.")
+        print("Retaining only sites from the reference that are in the downsampled beagle file:")
+        L, site_names = utils.filter_sites_to_common(L, site_names, site_names_ds)
+        print("Removing sites from downsampled set that were not in the reference (should not occur...):")
+        L_ds, site_names_ds = utils.filter_sites_to_common(L_ds, site_names_ds, site_names)
+        if site_names != site_names_ds:
+            raise ValueError("Site names in full and downsampled Beagle do not match after filtering.")
+        L, L_ds = np.ascontiguousarray(L), np.ascontiguousarray(L_ds)
+
+    if args.get_reference_af:
+        print("Parsing reference population ID file.")
+        assert os.path.isfile(args.pop_af_IDs), "Reference population ID file does not exist!!"
+        IDs = np.loadtxt(args.pop_af_IDs, delimiter="\t", dtype="str")
+        n = L.shape[1] // 2
+        assert (n == IDs.shape[0]), "Number of individuals in beagle and reference ID file do not match!"
+        pops, af, _ = emMAF.emMAF_populations(L, IDs, args.maf_iter, args.maf_tole)
+        np.save(args.out + ".pop_af", af)
+        print("Saved reference population allele frequencies as " + str(args.out) +
+              ".pop_af.npy (Binary - np.float32)\n")
+        print("Column order of populations is: " + str(pops))
+        np.savetxt(args.out + ".pop_names.txt", pops, fmt="%s")
+        print("Saved reference population names as " + str(args.out) +
+              ".pop_names.txt (String: Order of pops for .pop_af.npy, .ne_obs.npy, and fisher_obs.npy files)\n")
+
+        if args.loo:
+            print("Performing leave-one-out cross validation.")
+            logl_mat_loo, logl_parts_mat_loo = glassy.loo(L, af, IDs, args.threads, args.maf_iter, args.maf_tole,
+                                                          downsampled_L=L_ds, num_partitions=args.partition_sites)
+            suffix = "_downsampled" if L_ds is not None else ""
+            outfile = f"{args.out}.pop_like_LOO{suffix}.tsv"
+            partfile = f"{args.out}.pop_like_LOO{suffix}_partitions_{args.partition_sites}.tsv.gz"
+            utils.write_ass_mats(outfile, logl_mat_loo, sample_names, pops, print_part_column=False,
+                                 sample_locations=IDs[:, 1], doing_LOO=True)
+            print(f"Saved leave-one-out cross validation log likelihoods as {outfile}")
+            if args.partition_sites > 1:
+                utils.write_ass_mats(partfile, logl_parts_mat_loo, sample_names, pops,
+                                     partition_count=args.partition_sites, print_part_column=True,
+                                     sample_locations=IDs[:, 1], doing_LOO=True)
+                print(f"Saved leave-one-out cross validation log likelihoods from partitioned sites as {partfile}")
+            print(f"Column order of populations is: {pops}")
+
+    if args.get_pop_like:
+        print("Parsing population allele frequency file.")
+        assert os.path.isfile(args.pop_af_file), "Population allele frequency file does not exist!!"
+        A = np.load(args.pop_af_file)
+        print("Calculating likelihood of population assignment")
+        logl_mat = glassy.assignLL(L, A, args.threads)
+        np.savetxt(args.out + ".pop_like.txt", logl_mat, fmt="%.7f")
+        print("Saved population assignment log likelihoods as " + str(args.out) + ".pop_like.txt (text)")
+
+
+if __name__ == "__main__":
+    main()

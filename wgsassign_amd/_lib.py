@@ -1,0 +1,105 @@
+"""ctypes binding of libwgsassign_hip.so (include/wgsassign_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or no AMD GPU is visible, every entry
+point raises.  (The CPU restatement under oracle/ is test infrastructure and is never imported
+from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwgsassign_hip.so")
+
+MODE_EXACT = 0
+MODE_FAST = 1
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_vp = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int32
+c_int = ctypes.c_int
+
+# name -> (restype, argtypes); every symbol include/wgsassign_hip.h declares
+SIGNATURES = {
+    "wgs_last_error": (ctypes.c_char_p, []),
+    "wgs_version": (c_int, []),
+    "wgs_device_count": (c_int, [ctypes.POINTER(c_int)]),
+    "wgs_ctx_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
+    "wgs_ctx_destroy": (None, [c_vp]),
+    "wgs_ctx_sync": (c_int, [c_vp]),
+    "wgs_ctx_stream": (c_vp, [c_vp]),
+    "wgs_ctx_info": (c_int, [c_vp, ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
+    "wgs_emmaf_update": (c_int, [c_vp, c_f32p, c_i64, c_i64, c_f32p, c_int]),
+    "wgs_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p]),
+    "wgs_loglike": (c_int, [c_vp, c_f32p, c_i64, c_i64, c_f32p, c_i64, c_f32p, c_i64, c_i64, c_int]),
+    "wgs_beagle_create": (c_int, [c_vp, c_i64, c_i64, c_i32p, c_i32, c_i64, ctypes.POINTER(c_vp)]),
+    "wgs_beagle_destroy": (None, [c_vp]),
+    "wgs_beagle_upload_rows": (c_int, [c_vp, c_f32p, c_i64, c_i64]),
+    "wgs_beagle_download_rows": (c_int, [c_vp, c_f32p, c_i64, c_i64]),
+    "wgs_beagle_synth": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_double]),
+    "wgs_beagle_bytes": (c_i64, [c_vp]),
+    "wgs_em_create": (c_int, [c_vp, c_i32, c_i32p, c_i32p, c_int, ctypes.POINTER(c_vp)]),
+    "wgs_em_destroy": (None, [c_vp]),
+    "wgs_em_step": (c_int, [c_vp, c_f64p]),
+    "wgs_em_step_dev": (c_int, [c_vp, c_vp]),
+    "wgs_em_rmse_chain": (c_int, [c_vp, c_i32, ctypes.c_float, c_f32p]),
+    "wgs_em_set_active": (c_int, [c_vp, c_i32, c_int]),
+    "wgs_em_n_active": (c_int, [c_vp]),
+    "wgs_em_clamp": (c_int, [c_vp, c_i32, ctypes.c_float, ctypes.c_float]),
+    "wgs_em_get_f": (c_int, [c_vp, c_i32, c_f32p]),
+    "wgs_em_set_f": (c_int, [c_vp, c_i32, c_f32p]),
+    "wgs_em_f_dev": (c_vp, [c_vp, c_i32]),
+    "wgs_afset_create": (c_int, [c_vp, c_i64, c_i32, ctypes.POINTER(c_vp)]),
+    "wgs_afset_destroy": (None, [c_vp]),
+    "wgs_afset_upload": (c_int, [c_vp, c_f32p]),
+    "wgs_afset_download": (c_int, [c_vp, c_f32p]),
+    "wgs_afset_set_column_from_em": (c_int, [c_vp, c_i32, c_vp, c_i32]),
+    "wgs_afset_col_dev": (c_vp, [c_vp, c_i32]),
+    "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library and bind every declared symbol (no GPU needed for this)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "wgsassign_amd: %s is missing. Build it with `python -m wgsassign_amd.build` "
+                "(needs hipcc). There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    msg = load().wgs_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(rc):
+    if rc != 0:
+        msg = last_error()
+        if rc == 2:
+            raise ValueError(msg)
+        raise RuntimeError("wgsassign_amd HIP call failed: " + msg)
+
+
+def f32p(a):
+    return a.ctypes.data_as(c_f32p)
+
+
+def f64p(a):
+    return a.ctypes.data_as(c_f64p)
+
+
+def i32p(a):
+    return a.ctypes.data_as(c_i32p)

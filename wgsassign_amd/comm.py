@@ -1,0 +1,54 @@
+"""The one collective the SNP-sharded path needs: a sum all-reduce of a few float64.
+
+SNPs shard trivially (every SNP's update and log-likelihood term is independent:
+emMAF_cy.pyx:16-23, glassy_cy.pyx:17-21); ranks own contiguous SNP ranges in rank order.
+Exchange steps: per EM iteration the per-fit sums of squared differences (n_fits doubles), per
+undecided fit the float32 carry of the serial convergence chain, and once per assignment the
+n x K partial log-likelihood sums.  With the `nccl` backend this is RCCL over xGMI.
+"""
+import numpy as np
+
+
+class LocalComm:
+    rank = 0
+    world = 1
+
+    def allreduce_sum(self, arr):
+        return arr
+
+    def barrier(self):
+        pass
+
+
+class TorchComm:
+    """torch.distributed process group (backend `nccl` == RCCL on ROCm, or `gloo` on CPU)."""
+
+    def __init__(self, device=None):
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self._torch, self._dist = torch, dist
+        self.rank = dist.get_rank()
+        self.world = dist.get_world_size()
+        self._cuda = dist.get_backend() == "nccl"
+        self._device = device
+
+    def allreduce_sum(self, arr):
+        torch, dist = self._torch, self._dist
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        t = torch.from_numpy(a.copy())
+        if self._cuda:
+            t = t.to(self._device if self._device is not None else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.cpu().numpy().reshape(a.shape)
+
+    def barrier(self):
+        self._dist.barrier()
+
+
+def shard_range(m_total, rank, world):
+    """Contiguous SNP range [lo, hi) of `rank`: GPU g owns [g*m/G, (g+1)*m/G)."""
+    lo = (m_total * rank) // world
+    hi = (m_total * (rank + 1)) // world
+    return lo, hi

@@ -1,0 +1,650 @@
+// C ABI of libwgsassign_hip.so (see include/wgsassign_hip.h).  Host-side orchestration only:
+// all arithmetic of the hot path runs in the kernels of em_kernels.hip / assign_kernels.hip.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+
+#include "common.h"
+
+static thread_local std::string g_err;
+
+void wgs_set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+extern "C" {
+
+const char *wgs_last_error(void) { return g_err.c_str(); }
+int wgs_version(void) { return 1; }
+
+int wgs_device_count(int *count)
+{
+    HIP_TRY(hipGetDeviceCount(count));
+    return 0;
+}
+
+int wgs_ctx_create(int device, wgs_ctx **out)
+{
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    WGS_REQUIRE(n > 0, "no HIP device visible: libwgsassign_hip needs an AMD GPU (gfx950); there is no CPU fallback");
+    WGS_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    wgs_ctx *c = new wgs_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->pinned_bytes = 1 << 20;
+    HIP_TRY(hipHostMalloc(&c->pinned, c->pinned_bytes, hipHostMallocDefault));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    c->cus = prop.multiProcessorCount;
+    *out = c;
+    return 0;
+}
+
+void wgs_ctx_destroy(wgs_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    delete ctx;
+}
+
+int wgs_ctx_sync(wgs_ctx *ctx)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+void *wgs_ctx_stream(wgs_ctx *ctx) { return (void *)ctx->stream; }
+
+int wgs_ctx_info(wgs_ctx *ctx, char *name, int name_len, int *cus, int64_t *mem_bytes)
+{
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && name_len > 0) {
+        snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    }
+    if (cus) *cus = prop.multiProcessorCount;
+    if (mem_bytes) *mem_bytes = (int64_t)prop.totalGlobalMem;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ beagle */
+
+void wgs_beagle_destroy(wgs_beagle *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->ctx->device);
+    for (auto &s : b->slabs)
+        if (s.base) (void)hipFree(s.base);
+    if (b->d_group_of) (void)hipFree(b->d_group_of);
+    if (b->d_col_of) (void)hipFree(b->d_col_of);
+    if (b->d_ld) (void)hipFree(b->d_ld);
+    if (b->d_base) (void)hipFree(b->d_base);
+    delete b;
+}
+
+int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_of, int32_t n_groups, int64_t site0,
+                      wgs_beagle **out)
+{
+    WGS_REQUIRE(ctx && out, "null argument");
+    WGS_REQUIRE(m > 0 && n > 0, "beagle matrix must have m > 0 and n > 0 (got m=%lld n=%lld)", (long long)m, (long long)n);
+    WGS_REQUIRE(n < (1 << 30), "too many individuals");
+    if (!group_of) n_groups = 1;
+    WGS_REQUIRE(n_groups >= 1, "n_groups must be >= 1");
+    HIP_TRY(hipSetDevice(ctx->device));
+    wgs_beagle *b = new wgs_beagle();
+    b->ctx = ctx;
+    b->m = m;
+    b->n = n;
+    b->site0 = site0;
+    b->n_groups = n_groups;
+    b->slabs.resize(n_groups);
+    b->group_of.resize(n);
+    b->col_of.resize(n);
+    for (int64_t i = 0; i < n; ++i) {
+        const int g = group_of ? group_of[i] : 0;
+        if (g < 0 || g >= n_groups) {
+            wgs_set_error("group_of[%lld] = %d out of range (0..%d)", (long long)i, g, n_groups - 1);
+            wgs_beagle_destroy(b);
+            return 2;
+        }
+        b->group_of[i] = g;
+        b->col_of[i] = (int32_t)b->slabs[g].members.size();
+        b->slabs[g].members.push_back((int32_t)i);
+    }
+    std::vector<float2 *> bases(n_groups, nullptr);
+    std::vector<int32_t> lds(n_groups, 0);
+    for (int g = 0; g < n_groups; ++g) {
+        Slab &s = b->slabs[g];
+        s.ncols = (int32_t)s.members.size();
+        s.ld = (s.ncols + 1) & ~1;
+        if (s.ncols == 0) continue;
+        const size_t bytes = (size_t)m * s.ld * sizeof(float2) + 512;  // slack: chunk loads may run past the last row
+        if (hipMalloc(&s.base, bytes) != hipSuccess) {
+            wgs_set_error("hipMalloc of %zu bytes for population slab %d failed", bytes, g);
+            wgs_beagle_destroy(b);
+            return 1;
+        }
+        (void)hipMemsetAsync(s.base, 0, bytes, ctx->stream);
+        b->bytes += (int64_t)bytes;
+        bases[g] = s.base;
+        lds[g] = s.ld;
+    }
+    HIP_TRY(hipMalloc(&b->d_group_of, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&b->d_col_of, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&b->d_ld, sizeof(int32_t) * n_groups));
+    HIP_TRY(hipMalloc(&b->d_base, sizeof(float2 *) * n_groups));
+    HIP_TRY(hipMemcpy(b->d_group_of, b->group_of.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_col_of, b->col_of.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_ld, lds.data(), sizeof(int32_t) * n_groups, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_base, bases.data(), sizeof(float2 *) * n_groups, hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = b;
+    return 0;
+}
+
+int64_t wgs_beagle_bytes(const wgs_beagle *b) { return b ? b->bytes : 0; }
+
+static int64_t staging_rows(const wgs_beagle *b, int64_t nrows)
+{
+    const int64_t row_bytes = b->n * 2 * (int64_t)sizeof(float);
+    int64_t r = (256ll << 20) / row_bytes;
+    if (r < 1) r = 1;
+    return std::min(r, nrows);
+}
+
+int wgs_beagle_upload_rows(wgs_beagle *b, const float *L_rows, int64_t row0, int64_t nrows)
+{
+    WGS_REQUIRE(b && L_rows, "null argument");
+    WGS_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->m, "row range [%lld, %lld) outside 0..%lld", (long long)row0,
+                (long long)(row0 + nrows), (long long)b->m);
+    if (nrows == 0) return 0;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    const int64_t chunk = staging_rows(b, nrows);
+    const size_t row_bytes = (size_t)b->n * 2 * sizeof(float);
+    float *d_stage = nullptr;
+    HIP_TRY(hipMalloc(&d_stage, chunk * row_bytes));
+    int rc = 0;
+    for (int64_t r = 0; r < nrows && !rc; r += chunk) {
+        const int64_t cnt = std::min(chunk, nrows - r);
+        if (hipMemcpyAsync(d_stage, L_rows + (size_t)r * b->n * 2, cnt * row_bytes, hipMemcpyHostToDevice, b->ctx->stream) != hipSuccess) {
+            wgs_set_error("upload of rows failed");
+            rc = 1;
+            break;
+        }
+        rc = launch_scatter_rows(b, d_stage, row0 + r, cnt);
+        if (!rc && hipStreamSynchronize(b->ctx->stream) != hipSuccess) {
+            wgs_set_error("scatter kernel failed");
+            rc = 1;
+        }
+    }
+    (void)hipFree(d_stage);
+    return rc;
+}
+
+int wgs_beagle_download_rows(wgs_beagle *b, float *L_rows, int64_t row0, int64_t nrows)
+{
+    WGS_REQUIRE(b && L_rows, "null argument");
+    WGS_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->m, "row range outside matrix");
+    if (nrows == 0) return 0;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    const int64_t chunk = staging_rows(b, nrows);
+    const size_t row_bytes = (size_t)b->n * 2 * sizeof(float);
+    float *d_stage = nullptr;
+    HIP_TRY(hipMalloc(&d_stage, chunk * row_bytes));
+    int rc = 0;
+    for (int64_t r = 0; r < nrows && !rc; r += chunk) {
+        const int64_t cnt = std::min(chunk, nrows - r);
+        rc = launch_gather_rows(b, d_stage, row0 + r, cnt);
+        if (rc) break;
+        if (hipMemcpyAsync(L_rows + (size_t)r * b->n * 2, d_stage, cnt * row_bytes, hipMemcpyDeviceToHost, b->ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(b->ctx->stream) != hipSuccess) {
+            wgs_set_error("download of rows failed");
+            rc = 1;
+        }
+    }
+    (void)hipFree(d_stage);
+    return rc;
+}
+
+int wgs_beagle_synth(wgs_beagle *b, uint64_t seed, double depth)
+{
+    WGS_REQUIRE(b, "null argument");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    return launch_synth(b, seed, depth);
+}
+
+/* ------------------------------------------------------------------ EM */
+
+struct wgs_em {
+    wgs_beagle *b = nullptr;
+    int32_t n_fits = 0;
+    int mode = WGS_MODE_EXACT;
+    std::vector<int32_t> group, skip_local, n_eff;
+    std::vector<uint8_t> cur, active;
+    float *fbuf[2] = {nullptr, nullptr};  // 2 x n_fits x m
+    FitDesc *d_descs = nullptr;
+    FitDesc *h_descs = nullptr;           // pinned
+    double *d_ssq = nullptr;
+    float *d_carry = nullptr;
+    std::vector<int32_t> last;            // fits swept by the last step
+};
+
+void wgs_em_destroy(wgs_em *em)
+{
+    if (!em) return;
+    (void)hipSetDevice(em->b->ctx->device);
+    for (int i = 0; i < 2; ++i)
+        if (em->fbuf[i]) (void)hipFree(em->fbuf[i]);
+    if (em->d_descs) (void)hipFree(em->d_descs);
+    if (em->h_descs) (void)hipHostFree(em->h_descs);
+    if (em->d_ssq) (void)hipFree(em->d_ssq);
+    if (em->d_carry) (void)hipFree(em->d_carry);
+    delete em;
+}
+
+int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const int32_t *fit_skip, int mode, wgs_em **out)
+{
+    WGS_REQUIRE(b && fit_group && out, "null argument");
+    WGS_REQUIRE(n_fits > 0, "n_fits must be positive");
+    WGS_REQUIRE(mode == WGS_MODE_EXACT || mode == WGS_MODE_FAST, "unknown mode %d", mode);
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    wgs_em *em = new wgs_em();
+    em->b = b;
+    em->n_fits = n_fits;
+    em->mode = mode;
+    em->group.resize(n_fits);
+    em->skip_local.resize(n_fits);
+    em->n_eff.resize(n_fits);
+    em->cur.assign(n_fits, 0);
+    em->active.assign(n_fits, 1);
+    for (int j = 0; j < n_fits; ++j) {
+        const int g = fit_group[j];
+        if (g < 0 || g >= b->n_groups || b->slabs[g].ncols == 0) {
+            wgs_set_error("fit %d: group %d is out of range or empty", j, g);
+            delete em;
+            return 2;
+        }
+        int skip = -1;
+        if (fit_skip && fit_skip[j] >= 0) {
+            const int i = fit_skip[j];
+            if (i >= b->n || b->group_of[i] != g) {
+                wgs_set_error("fit %d: left-out individual %d does not belong to group %d", j, i, g);
+                delete em;
+                return 2;
+            }
+            skip = b->col_of[i];
+        }
+        em->group[j] = g;
+        em->skip_local[j] = skip;
+        em->n_eff[j] = b->slabs[g].ncols - (skip >= 0 ? 1 : 0);
+    }
+    const size_t fbytes = (size_t)n_fits * b->m * sizeof(float);
+    for (int i = 0; i < 2; ++i) {
+        if (hipMalloc(&em->fbuf[i], fbytes) != hipSuccess) {
+            wgs_set_error("hipMalloc of %zu bytes for EM frequencies failed", fbytes);
+            wgs_em_destroy(em);
+            return 1;
+        }
+    }
+    HIP_TRY(hipMalloc(&em->d_descs, sizeof(FitDesc) * n_fits));
+    HIP_TRY(hipMalloc(&em->d_ssq, sizeof(double) * n_fits));
+    HIP_TRY(hipMalloc(&em->d_carry, sizeof(float)));
+    HIP_TRY(hipHostMalloc(&em->h_descs, sizeof(FitDesc) * n_fits, hipHostMallocDefault));
+    if (launch_fill(b->ctx, em->fbuf[0], (int64_t)n_fits * b->m, 0.25f)) {   // emMAF.py:17-18
+        wgs_em_destroy(em);
+        return 1;
+    }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    *out = em;
+    return 0;
+}
+
+static float *em_f(wgs_em *em, int fit, int which) { return em->fbuf[which] + (size_t)fit * em->b->m; }
+
+int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
+{
+    WGS_REQUIRE(em && ssq_dev, "null argument");
+    wgs_ctx *ctx = em->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    em->last.clear();
+    for (int j = 0; j < em->n_fits; ++j) {
+        if (!em->active[j]) continue;
+        const Slab &s = em->b->slabs[em->group[j]];
+        FitDesc &d = em->h_descs[em->last.size()];
+        d.slab = s.base;
+        d.f_old = em_f(em, j, em->cur[j]);
+        d.f_new = em_f(em, j, em->cur[j] ^ 1);
+        d.ssq = ssq_dev + j;
+        d.ld = s.ld;
+        d.ncols = s.ncols;
+        d.skip = em->skip_local[j];
+        d.n_eff = em->n_eff[j];
+        em->last.push_back(j);
+    }
+    HIP_TRY(hipMemsetAsync(ssq_dev, 0, sizeof(double) * em->n_fits, ctx->stream));
+    if (em->last.empty()) return 0;
+    // h_descs (pinned) stays untouched until the next step, which the caller only starts after
+    // consuming this step's sums
+    HIP_TRY(hipMemcpyAsync(em->d_descs, em->h_descs, sizeof(FitDesc) * em->last.size(), hipMemcpyHostToDevice, ctx->stream));
+    // launch in slices of <= 65535 fits (grid.y limit)
+    for (size_t off = 0; off < em->last.size(); off += 65535) {
+        const int cnt = (int)std::min<size_t>(65535, em->last.size() - off);
+        if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode)) return 1;
+    }
+    for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
+    return 0;
+}
+
+int wgs_em_step(wgs_em *em, double *ssq_host)
+{
+    WGS_REQUIRE(em, "null argument");
+    if (wgs_em_step_dev(em, em->d_ssq)) return 1;
+    wgs_ctx *ctx = em->b->ctx;
+    if (ssq_host) {
+        HIP_TRY(hipMemcpyAsync(ssq_host, em->d_ssq, sizeof(double) * em->n_fits, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out)
+{
+    WGS_REQUIRE(em && carry_out, "null argument");
+    WGS_REQUIRE(fit >= 0 && fit < em->n_fits, "fit index out of range");
+    wgs_ctx *ctx = em->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (launch_rmse_chain(ctx, em_f(em, fit, em->cur[fit]), em_f(em, fit, em->cur[fit] ^ 1), em->b->m, carry_in, em->d_carry)) return 1;
+    HIP_TRY(hipMemcpyAsync(carry_out, em->d_carry, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wgs_em_set_active(wgs_em *em, int32_t fit, int active)
+{
+    WGS_REQUIRE(em && fit >= 0 && fit < em->n_fits, "fit index out of range");
+    em->active[fit] = active ? 1 : 0;
+    return 0;
+}
+
+int wgs_em_n_active(wgs_em *em)
+{
+    int c = 0;
+    for (int j = 0; j < em->n_fits; ++j) c += em->active[j];
+    return c;
+}
+
+int wgs_em_clamp(wgs_em *em, int32_t fit, float lo, float hi)
+{
+    WGS_REQUIRE(em && fit >= 0 && fit < em->n_fits, "fit index out of range");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    return launch_clamp(em->b->ctx, em_f(em, fit, em->cur[fit]), em->b->m, lo, hi);
+}
+
+int wgs_em_get_f(wgs_em *em, int32_t fit, float *f_host)
+{
+    WGS_REQUIRE(em && f_host && fit >= 0 && fit < em->n_fits, "bad argument");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    HIP_TRY(hipMemcpyAsync(f_host, em_f(em, fit, em->cur[fit]), sizeof(float) * em->b->m, hipMemcpyDeviceToHost, em->b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(em->b->ctx->stream));
+    return 0;
+}
+
+int wgs_em_set_f(wgs_em *em, int32_t fit, const float *f_host)
+{
+    WGS_REQUIRE(em && f_host && fit >= 0 && fit < em->n_fits, "bad argument");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    HIP_TRY(hipMemcpyAsync(em_f(em, fit, em->cur[fit]), f_host, sizeof(float) * em->b->m, hipMemcpyHostToDevice, em->b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(em->b->ctx->stream));
+    return 0;
+}
+
+const float *wgs_em_f_dev(wgs_em *em, int32_t fit)
+{
+    if (!em || fit < 0 || fit >= em->n_fits) return nullptr;
+    return em_f(em, fit, em->cur[fit]);
+}
+
+/* ------------------------------------------------------------------ allele-frequency sets */
+
+int wgs_afset_create(wgs_ctx *ctx, int64_t m, int32_t K, wgs_afset **out)
+{
+    WGS_REQUIRE(ctx && out && m > 0 && K > 0, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    wgs_afset *a = new wgs_afset();
+    a->ctx = ctx;
+    a->m = m;
+    a->K = K;
+    if (hipMalloc(&a->buf, sizeof(float) * (size_t)m * K) != hipSuccess) {
+        wgs_set_error("hipMalloc for allele frequencies failed");
+        delete a;
+        return 1;
+    }
+    *out = a;
+    return 0;
+}
+
+void wgs_afset_destroy(wgs_afset *a)
+{
+    if (!a) return;
+    (void)hipSetDevice(a->ctx->device);
+    if (a->buf) (void)hipFree(a->buf);
+    delete a;
+}
+
+int wgs_afset_upload(wgs_afset *a, const float *A_mK)
+{
+    WGS_REQUIRE(a && A_mK, "null argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    float *tmp = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)a->m * a->K;
+    HIP_TRY(hipMalloc(&tmp, bytes));
+    int rc = 0;
+    if (hipMemcpyAsync(tmp, A_mK, bytes, hipMemcpyHostToDevice, a->ctx->stream) != hipSuccess) rc = 1;
+    if (!rc) rc = launch_transpose_mK_to_Km(a->ctx, tmp, a->buf, a->m, a->K);
+    if (hipStreamSynchronize(a->ctx->stream) != hipSuccess) rc = 1;
+    (void)hipFree(tmp);
+    if (rc) wgs_set_error("allele-frequency upload failed");
+    return rc;
+}
+
+int wgs_afset_download(wgs_afset *a, float *A_mK)
+{
+    WGS_REQUIRE(a && A_mK, "null argument");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    float *tmp = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)a->m * a->K;
+    HIP_TRY(hipMalloc(&tmp, bytes));
+    int rc = launch_transpose_Km_to_mK(a->ctx, a->buf, tmp, a->m, a->K);
+    if (!rc && hipMemcpyAsync(A_mK, tmp, bytes, hipMemcpyDeviceToHost, a->ctx->stream) != hipSuccess) rc = 1;
+    if (hipStreamSynchronize(a->ctx->stream) != hipSuccess) rc = 1;
+    (void)hipFree(tmp);
+    if (rc) wgs_set_error("allele-frequency download failed");
+    return rc;
+}
+
+int wgs_afset_set_column_from_em(wgs_afset *a, int32_t col, wgs_em *em, int32_t fit)
+{
+    WGS_REQUIRE(a && em && col >= 0 && col < a->K && fit >= 0 && fit < em->n_fits, "bad argument");
+    WGS_REQUIRE(a->m == em->b->m, "SNP counts differ");
+    HIP_TRY(hipSetDevice(a->ctx->device));
+    HIP_TRY(hipMemcpyAsync(a->buf + (size_t)col * a->m, wgs_em_f_dev(em, fit), sizeof(float) * a->m, hipMemcpyDeviceToDevice, a->ctx->stream));
+    return 0;
+}
+
+const float *wgs_afset_col_dev(wgs_afset *a, int32_t col)
+{
+    if (!a || col < 0 || col >= a->K) return nullptr;
+    return a->buf + (size_t)col * a->m;
+}
+
+/* ------------------------------------------------------------------ assignment */
+
+int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode, double *out, double *parts)
+{
+    WGS_REQUIRE(b && a && out, "null argument");
+    WGS_REQUIRE(a->m == b->m, "allele frequencies cover %lld SNPs, the Beagle shard %lld", (long long)a->m, (long long)b->m);
+    WGS_REQUIRE(P >= 1, "partition count must be >= 1");
+    WGS_REQUIRE(P == 1 || parts, "parts buffer required when P > 1");
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int K = a->K;
+    const int64_t n = b->n;
+    const size_t cells = (size_t)n * P * K;
+    double *d_out = nullptr;
+    const float **d_acol = nullptr, **d_colptr = nullptr;
+    int32_t *d_members = nullptr;
+    int rc = 0;
+    std::vector<const float *> acol(K);
+    for (int k = 0; k < K; ++k) acol[k] = a->buf + (size_t)k * a->m;
+    std::vector<double> h(cells);
+#define TRY_GOTO(expr)                                                        \
+    if ((expr) != hipSuccess) {                                               \
+        wgs_set_error("%s:%d: %s failed", __FILE__, __LINE__, #expr);        \
+        rc = 1;                                                               \
+        goto done;                                                            \
+    }
+    TRY_GOTO(hipMalloc(&d_out, sizeof(double) * cells));
+    TRY_GOTO(hipMemsetAsync(d_out, 0, sizeof(double) * cells, ctx->stream));
+    TRY_GOTO(hipMalloc(&d_acol, sizeof(float *) * K));
+    TRY_GOTO(hipMemcpy(d_acol, acol.data(), sizeof(float *) * K, hipMemcpyHostToDevice));
+    if (colptr) {
+        TRY_GOTO(hipMalloc(&d_colptr, sizeof(float *) * n * K));
+        TRY_GOTO(hipMemcpy(d_colptr, colptr, sizeof(float *) * n * K, hipMemcpyHostToDevice));
+    }
+    TRY_GOTO(hipMalloc(&d_members, sizeof(int32_t) * n));
+    for (int g = 0; g < b->n_groups && !rc; ++g) {
+        const Slab &s = b->slabs[g];
+        if (s.ncols == 0) continue;
+        TRY_GOTO(hipMemcpyAsync(d_members, s.members.data(), sizeof(int32_t) * s.ncols, hipMemcpyHostToDevice, ctx->stream));
+        AssignArgs args;
+        args.slab = s.base;
+        args.members = d_members;
+        args.colptr = d_colptr;
+        args.acol = d_acol;
+        args.out = d_out;
+        args.m = b->m;
+        args.site0 = b->site0;
+        args.ld = s.ld;
+        args.ncols = s.ncols;
+        args.K = K;
+        args.P = P;
+        args.rows_per_wave = 0;
+        rc = launch_assign(ctx, args, mode);
+        TRY_GOTO(hipStreamSynchronize(ctx->stream));   // d_members is reused by the next slab
+    }
+    if (rc) goto done;
+    TRY_GOTO(hipMemcpy(h.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost));
+    if (P == 1) {
+        for (size_t c = 0; c < cells; ++c) out[c] += h[c];
+    } else {
+        for (size_t c = 0; c < cells; ++c) parts[c] += h[c];
+        for (int64_t i = 0; i < n; ++i)
+            for (int k = 0; k < K; ++k) {
+                double t = 0.0;
+                for (int p = 0; p < P; ++p) t += h[((size_t)i * P + p) * K + k];
+                out[(size_t)i * K + k] += t;
+            }
+    }
+done:
+    if (d_out) (void)hipFree(d_out);
+    if (d_acol) (void)hipFree(d_acol);
+    if (d_colptr) (void)hipFree(d_colptr);
+    if (d_members) (void)hipFree(d_members);
+    return rc;
+#undef TRY_GOTO
+}
+
+/* ------------------------------------------------------------------ thin mirrors */
+
+int wgs_emmaf_update(wgs_ctx *ctx, const float *L, int64_t m, int64_t n, float *f, int mode)
+{
+    WGS_REQUIRE(ctx && L && f, "null argument");
+    wgs_beagle *b = nullptr;
+    wgs_em *em = nullptr;
+    int rc = 0;
+    if (n == 0) {   // emMAF_cy.pyx:17,23 with an empty loop: tmp = 0.0, f[s] = 0.0/0.0
+        for (int64_t s = 0; s < m; ++s) f[s] = nanf("");
+        return 0;
+    }
+    if (m == 0) return 0;
+    const int32_t grp = 0;
+    rc = wgs_beagle_create(ctx, m, n, nullptr, 1, 0, &b);
+    if (!rc) rc = wgs_beagle_upload_rows(b, L, 0, m);
+    if (!rc) rc = wgs_em_create(b, 1, &grp, nullptr, mode, &em);
+    if (!rc) rc = wgs_em_set_f(em, 0, f);
+    if (!rc) rc = wgs_em_step(em, nullptr);
+    if (!rc) rc = wgs_em_get_f(em, 0, f);
+    wgs_em_destroy(em);
+    wgs_beagle_destroy(b);
+    return rc;
+}
+
+int wgs_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out)
+{
+    WGS_REQUIRE(ctx && v1 && v2 && out, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (m == 0) {   // 0.0f / 0.0f
+        *out = nan("");
+        return 0;
+    }
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(float) * (2 * (size_t)m + 1)));
+    int rc = 0;
+    float res = 0.0f;
+    if (hipMemcpyAsync(d, v1, sizeof(float) * m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d + m, v2, sizeof(float) * m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = 1;
+    if (!rc) rc = launch_rmse_chain(ctx, d, d + m, m, 0.0f, d + 2 * m);
+    if (!rc && (hipMemcpyAsync(&res, d + 2 * m, sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = 1;
+    (void)hipFree(d);
+    if (rc) {
+        wgs_set_error("rmse1d: device operation failed");
+        return 1;
+    }
+    res = res / (float)m;           // emMAF_cy.pyx:32
+    *out = sqrt((double)res);       // emMAF_cy.pyx:33
+    return 0;
+}
+
+int wgs_loglike(wgs_ctx *ctx, const float *L, int64_t m, int64_t n, const float *A, int64_t K, float *vec, int64_t i,
+                int64_t k, int mode)
+{
+    WGS_REQUIRE(ctx && L && A && vec, "null argument");
+    WGS_REQUIRE(i >= 0 && i < n && k >= 0 && k < K, "individual %lld / population %lld out of range", (long long)i, (long long)k);
+    if (m == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d = nullptr;   // [2m g | m a | m vec]
+    HIP_TRY(hipMalloc(&d, sizeof(float) * 4 * (size_t)m));
+    int rc = 0;
+    // strided host columns -> compact device vectors
+    if (hipMemcpy2DAsync(d, 2 * sizeof(float), L + 2 * i, sizeof(float) * 2 * n, 2 * sizeof(float), m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpy2DAsync(d + 2 * m, sizeof(float), A + k, sizeof(float) * K, sizeof(float), m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d + 3 * m, vec, sizeof(float) * m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        rc = 1;
+    if (!rc) rc = launch_loglike_site(ctx, reinterpret_cast<const float2 *>(d), d + 2 * m, d + 3 * m, m, mode);
+    if (!rc && (hipMemcpyAsync(vec, d + 3 * m, sizeof(float) * m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = 1;
+    (void)hipFree(d);
+    if (rc) wgs_set_error("loglike: device operation failed");
+    return rc;
+}
+
+}  // extern "C"

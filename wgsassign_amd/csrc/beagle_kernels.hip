@@ -1,0 +1,192 @@
+// Data-movement kernels: host-layout rows <-> population slabs, (m,K) <-> K vectors, and the
+// on-device synthetic Beagle generator used by bench.py.
+#include "common.h"
+
+namespace {
+
+// rows: (nrows, 2n) float32 in the reference's host layout (reader_cy.pyx:71-77);
+// element (r, i) goes to slab[group_of[i]] at (row0 + r, col_of[i]).
+__global__ void scatter_rows_kernel(const float2 *__restrict__ rows, int64_t nrows, int64_t n, int64_t row0,
+                                    const int32_t *__restrict__ group_of, const int32_t *__restrict__ col_of,
+                                    float2 *const *__restrict__ base, const int32_t *__restrict__ ld)
+{
+    const int64_t total = nrows * n;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < total; e += stride) {
+        const int64_t r = e / n;
+        const int i = (int)(e - r * n);
+        const int g = group_of[i];
+        base[g][(row0 + r) * ld[g] + col_of[i]] = rows[e];
+    }
+}
+
+__global__ void gather_rows_kernel(float2 *__restrict__ rows, int64_t nrows, int64_t n, int64_t row0,
+                                   const int32_t *__restrict__ group_of, const int32_t *__restrict__ col_of,
+                                   float2 *const *__restrict__ base, const int32_t *__restrict__ ld)
+{
+    const int64_t total = nrows * n;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; e < total; e += stride) {
+        const int64_t r = e / n;
+        const int i = (int)(e - r * n);
+        const int g = group_of[i];
+        rows[e] = base[g][(row0 + r) * ld[g] + col_of[i]];
+    }
+}
+
+// (m, K) row-major <-> K vectors of m.  K is small (5..20): one thread per SNP.
+__global__ void mK_to_Km_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t m, int K)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; s < m; s += stride)
+        for (int k = 0; k < K; ++k) dst[(int64_t)k * m + s] = src[s * K + k];
+}
+__global__ void Km_to_mK_kernel(const float *__restrict__ src, float *__restrict__ dst, int64_t m, int K)
+{
+    int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; s < m; s += stride)
+        for (int k = 0; k < K; ++k) dst[s * K + k] = src[(int64_t)k * m + s];
+}
+
+// ---- Philox-4x32-10 counter RNG
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// Per-(SNP, group) population frequency: ancestral p ~ arcsine-ish U-shape, drifted by
+// N(0, 0.08^2) per group, clipped to [0.01, 0.99].  Pure function of (seed, global SNP, group).
+__device__ __forceinline__ float pop_freq(uint64_t seed, int64_t gsnp, int g)
+{
+    uint32_t c[4] = {(uint32_t)gsnp, (uint32_t)(gsnp >> 32), 0xA5A5A5A5u, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float u = u01(c[0]);
+    const float anc = 0.5f - 0.5f * cospif(u);                       // Beta(1/2,1/2)
+    uint32_t d[4] = {(uint32_t)gsnp, (uint32_t)(gsnp >> 32), 0x5A5A5A5Au, (uint32_t)g};
+    philox4x32_10(d, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float z = sqrtf(-2.0f * logf(u01(d[0]))) * cospif(2.0f * u01(d[1]));
+    float p = anc + 0.08f * z;
+    return fminf(fmaxf(p, 0.01f), 0.99f);
+}
+
+// One thread per (SNP row, slab column).  Genotype ~ Binomial(2, p); depth ~ Poisson(depth)
+// truncated at 15; alt reads ~ Binomial(depth, {e, 1/2, 1-e}[g]); GL_g ∝ P(reads | g), normalised,
+// rounded to 6 decimals like the ANGSD text the reference parses with atof.
+__global__ void synth_kernel(float2 *__restrict__ slab, int64_t m, int ld, int ncols, const int32_t *__restrict__ members,
+                             int group, int64_t site0, uint64_t seed, float depth)
+{
+    const int64_t total = m * ncols;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float lam = depth;
+    for (; e < total; e += stride) {
+        const int64_t s = e / ncols;
+        const int col = (int)(e - s * ncols);
+        const int64_t gsnp = site0 + s;
+        const int ind = members[col];
+        const float p = pop_freq(seed, gsnp, group);
+        uint32_t c[4] = {(uint32_t)gsnp, (uint32_t)(gsnp >> 32), (uint32_t)ind, 1u};
+        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const int geno = (u01(c[0]) < p) + (u01(c[1]) < p);
+        // Poisson by inversion
+        float cdf = expf(-lam), pm = cdf;
+        const float ud = u01(c[2]);
+        int d = 0;
+        while (ud > cdf && d < 15) { ++d; pm *= lam / (float)d; cdf += pm; }
+        const float qalt = geno == 0 ? 0.01f : (geno == 1 ? 0.5f : 0.99f);
+        int alt = 0;
+        uint32_t bits[4] = {(uint32_t)gsnp, (uint32_t)(gsnp >> 32), (uint32_t)ind, 2u};
+        philox4x32_10(bits, (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int r = 0; r < d; ++r) {
+            const uint32_t w = bits[r >> 2] >> ((r & 3) * 8);
+            alt += ((float)(w & 0xFF) + 0.5f) * (1.0f / 256.0f) < qalt;
+        }
+        const int ref = d - alt;
+        const double e1 = 0.01, e0 = 0.99;
+        double l0 = 1.0, l1 = 1.0, l2 = 1.0;
+        for (int r = 0; r < ref; ++r) { l0 *= e0; l2 *= e1; }
+        for (int r = 0; r < alt; ++r) { l0 *= e1; l2 *= e0; }
+        for (int r = 0; r < d; ++r) l1 *= 0.5;
+        const double tot = l0 + l1 + l2;
+        const double g0 = rint(l0 / tot * 1e6) / 1e6, g1 = rint(l1 / tot * 1e6) / 1e6;
+        slab[s * ld + col] = make_float2((float)g0, (float)g1);
+    }
+}
+
+inline unsigned grid_for(int64_t total)
+{
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+}  // namespace
+
+int launch_scatter_rows(wgs_beagle *b, const float *d_rows, int64_t row0, int64_t nrows)
+{
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(nrows * b->n)), dim3(256), 0, b->ctx->stream,
+                       reinterpret_cast<const float2 *>(d_rows), nrows, b->n, row0, b->d_group_of, b->d_col_of,
+                       b->d_base, b->d_ld);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_gather_rows(wgs_beagle *b, float *d_rows, int64_t row0, int64_t nrows)
+{
+    if (nrows <= 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(nrows * b->n)), dim3(256), 0, b->ctx->stream,
+                       reinterpret_cast<float2 *>(d_rows), nrows, b->n, row0, b->d_group_of, b->d_col_of, b->d_base,
+                       b->d_ld);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_synth(wgs_beagle *b, uint64_t seed, double depth)
+{
+    for (int g = 0; g < b->n_groups; ++g) {
+        Slab &sl = b->slabs[g];
+        if (sl.ncols == 0) continue;
+        int32_t *d_members = nullptr;
+        HIP_TRY(hipMalloc(&d_members, sizeof(int32_t) * sl.ncols));
+        HIP_TRY(hipMemcpyAsync(d_members, sl.members.data(), sizeof(int32_t) * sl.ncols, hipMemcpyHostToDevice, b->ctx->stream));
+        hipLaunchKernelGGL(synth_kernel, dim3(grid_for(b->m * sl.ncols)), dim3(256), 0, b->ctx->stream, sl.base, b->m,
+                           sl.ld, sl.ncols, d_members, g, b->site0, seed, (float)depth);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+        HIP_TRY(hipFree(d_members));
+    }
+    return 0;
+}
+
+int launch_transpose_mK_to_Km(wgs_ctx *ctx, const float *src_mK, float *dst_Km, int64_t m, int32_t K)
+{
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(mK_to_Km_kernel, dim3(grid_for(m)), dim3(256), 0, ctx->stream, src_mK, dst_Km, m, K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_transpose_Km_to_mK(wgs_ctx *ctx, const float *src_Km, float *dst_mK, int64_t m, int32_t K)
+{
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(Km_to_mK_kernel, dim3(grid_for(m)), dim3(256), 0, ctx->stream, src_Km, dst_mK, m, K);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

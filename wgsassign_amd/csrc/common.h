@@ -1,0 +1,98 @@
+// Internal declarations shared by the HIP translation units of libwgsassign_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/wgsassign_hip.h"
+
+void wgs_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            wgs_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return 1;                                                                         \
+        }                                                                                     \
+    } while (0)
+
+#define WGS_REQUIRE(cond, ...)          \
+    do {                                \
+        if (!(cond)) {                  \
+            wgs_set_error(__VA_ARGS__); \
+            return 2;                   \
+        }                               \
+    } while (0)
+
+struct wgs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void *pinned = nullptr;  // small pinned host scratch for async readbacks
+    size_t pinned_bytes = 0;
+    int cus = 0;
+};
+
+// One population slab: SNP-major (g0,g1) pairs of the individuals of one group, file order.
+struct Slab {
+    float2 *base = nullptr;  // m rows x ld float2
+    int32_t ld = 0;          // row stride in float2 (even, so rows are 16-byte aligned)
+    int32_t ncols = 0;       // valid columns
+    std::vector<int32_t> members;  // column -> global individual index
+};
+
+struct wgs_beagle {
+    wgs_ctx *ctx = nullptr;
+    int64_t m = 0, n = 0, site0 = 0;
+    int32_t n_groups = 0;
+    std::vector<Slab> slabs;
+    std::vector<int32_t> group_of, col_of;  // per individual
+    // device-side lookup tables for the scatter/gather/synth kernels
+    int32_t *d_group_of = nullptr, *d_col_of = nullptr, *d_ld = nullptr;
+    float2 **d_base = nullptr;
+    int64_t bytes = 0;
+};
+
+struct wgs_afset {
+    wgs_ctx *ctx = nullptr;
+    int64_t m = 0;
+    int32_t K = 0;
+    float *buf = nullptr;  // K vectors of m floats, population-major
+};
+
+// ---- kernel launchers implemented in the .hip files (all asynchronous on ctx->stream)
+
+struct FitDesc {       // one EM fit as the sweep kernel sees it
+    const float2 *slab;
+    const float *f_old;
+    float *f_new;
+    double *ssq;       // += sum over SNPs of (f_new - f_old)^2
+    int32_t ld, ncols;
+    int32_t skip;      // local column left out (LOO) or -1
+    int32_t n_eff;     // ncols - (skip >= 0)
+};
+
+int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
+int launch_fill(wgs_ctx *ctx, float *p, int64_t count, float v);
+int launch_clamp(wgs_ctx *ctx, float *p, int64_t count, float lo, float hi);
+int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out);
+
+struct AssignArgs {
+    const float2 *slab;
+    const int32_t *members;        // device: slab column -> global individual
+    const float *const *colptr;    // device: [n*K] per-(individual,k) vectors, or nullptr
+    const float *const *acol;      // device: [K] shared vectors
+    double *out;                   // device: [(n*P) * K]
+    int64_t m, site0;
+    int32_t ld, ncols, K, P;
+    int32_t rows_per_wave;
+};
+int launch_assign(wgs_ctx *ctx, const AssignArgs &a, int mode);
+int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode);
+
+int launch_scatter_rows(wgs_beagle *b, const float *d_rows, int64_t row0, int64_t nrows);
+int launch_gather_rows(wgs_beagle *b, float *d_rows, int64_t row0, int64_t nrows);
+int launch_synth(wgs_beagle *b, uint64_t seed, double depth);
+int launch_transpose_mK_to_Km(wgs_ctx *ctx, const float *src_mK, float *dst_Km, int64_t m, int32_t K);
+int launch_transpose_Km_to_mK(wgs_ctx *ctx, const float *src_Km, float *dst_mK, int64_t m, int32_t K);

@@ -1,0 +1,348 @@
+"""Device-resident objects of the HIP path and the host-side EM driver loop.
+
+Host code is Python/NumPy; all arithmetic of the hot path runs in the HIP kernels behind
+include/wgsassign_hip.h.  SNP sharding over ranks needs exactly one collective (a sum
+all-reduce of a few float64), supplied by a `comm` object (wgsassign_amd/comm.py).
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODE_EXACT, MODE_FAST, check, f32p, f64p, i32p
+
+_default_ctx = None
+
+
+def default_mode():
+    m = os.environ.get("WGSASSIGN_MODE", "exact").lower()
+    if m not in ("exact", "fast"):
+        raise ValueError("WGSASSIGN_MODE must be 'exact' or 'fast', got %r" % m)
+    return MODE_EXACT if m == "exact" else MODE_FAST
+
+
+def _as_f32c(a, name):
+    a = np.asarray(a)
+    if a.dtype != np.float32 or not a.flags.c_contiguous:
+        raise ValueError("%s must be a C-contiguous float32 array" % name)
+    return a
+
+
+class Context:
+    """One HIP device + stream (wgs_ctx)."""
+
+    def __init__(self, device=None):
+        lib = _lib.load()
+        if device is None:
+            device = int(os.environ.get("WGSASSIGN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        h = ctypes.c_void_p()
+        check(lib.wgs_ctx_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def sync(self):
+        check(_lib.load().wgs_ctx_sync(self._h))
+
+    def info(self):
+        name = ctypes.create_string_buffer(256)
+        cus = ctypes.c_int()
+        mem = ctypes.c_int64()
+        check(_lib.load().wgs_ctx_info(self._h, name, 256, ctypes.byref(cus), ctypes.byref(mem)))
+        return {"name": name.value.decode(), "cus": cus.value, "mem_bytes": mem.value}
+
+    def close(self):
+        if self._h:
+            _lib.load().wgs_ctx_destroy(self._h)
+            self._h = None
+
+
+def get_context():
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context()
+    return _default_ctx
+
+
+class DeviceBeagle:
+    """Genotype-likelihood matrix (one SNP shard) as population slabs in HBM (wgs_beagle).
+
+    group_of: int array (n,) with the group (population column) of every individual, or None for
+    a single group.  Groups keep individuals in file order, as the reference's sorted column
+    gather does (WGSassign.py:227-233).
+    """
+
+    def __init__(self, m, n, group_of=None, n_groups=1, site0=0, ctx=None):
+        self.ctx = ctx or get_context()
+        self.m, self.n, self.site0 = int(m), int(n), int(site0)
+        if group_of is not None:
+            group_of = np.ascontiguousarray(group_of, dtype=np.int32)
+            if group_of.shape != (self.n,):
+                raise ValueError("group_of must have one entry per individual")
+            n_groups = int(n_groups)
+            gp = i32p(group_of)
+        else:
+            n_groups, gp = 1, None
+        self.group_of = group_of if group_of is not None else np.zeros(self.n, dtype=np.int32)
+        self.n_groups = n_groups
+        h = ctypes.c_void_p()
+        check(_lib.load().wgs_beagle_create(self.ctx.handle, self.m, self.n, gp, n_groups, self.site0, ctypes.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_host(cls, L, group_of=None, n_groups=1, site0=0, ctx=None):
+        L = _as_f32c(L, "L")
+        if L.ndim != 2:
+            raise ValueError("L must be 2-dimensional (m, 2n)")
+        b = cls(L.shape[0], L.shape[1] // 2, group_of, n_groups, site0, ctx)
+        b.upload_rows(L, 0)
+        return b
+
+    @property
+    def handle(self):
+        return self._h
+
+    def upload_rows(self, rows, row0=0):
+        rows = _as_f32c(rows, "rows")
+        if rows.ndim != 2 or rows.shape[1] < 2 * self.n:
+            raise ValueError("rows must be (nrows, 2n)")
+        if rows.shape[1] != 2 * self.n:      # odd trailing column is ignored like n = L.shape[1]//2
+            rows = np.ascontiguousarray(rows[:, :2 * self.n])
+        check(_lib.load().wgs_beagle_upload_rows(self._h, f32p(rows), int(row0), rows.shape[0]))
+
+    def download_rows(self, row0, nrows):
+        out = np.empty((int(nrows), 2 * self.n), dtype=np.float32)
+        check(_lib.load().wgs_beagle_download_rows(self._h, f32p(out), int(row0), int(nrows)))
+        return out
+
+    def synth(self, seed, depth=2.0):
+        check(_lib.load().wgs_beagle_synth(self._h, int(seed), float(depth)))
+
+    def nbytes(self):
+        return int(_lib.load().wgs_beagle_bytes(self._h))
+
+    def close(self):
+        if self._h:
+            _lib.load().wgs_beagle_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AFSet:
+    """K allele-frequency vectors of m SNPs on the device (the (m, K) `.pop_af.npy` matrix)."""
+
+    def __init__(self, m, K, ctx=None):
+        self.ctx = ctx or get_context()
+        self.m, self.K = int(m), int(K)
+        h = ctypes.c_void_p()
+        check(_lib.load().wgs_afset_create(self.ctx.handle, self.m, self.K, ctypes.byref(h)))
+        self._h = h
+
+    @classmethod
+    def from_host(cls, A, ctx=None):
+        A = _as_f32c(A, "af")
+        a = cls(A.shape[0], A.shape[1], ctx)
+        check(_lib.load().wgs_afset_upload(a._h, f32p(A)))
+        return a
+
+    @property
+    def handle(self):
+        return self._h
+
+    def to_host(self):
+        out = np.empty((self.m, self.K), dtype=np.float32)
+        check(_lib.load().wgs_afset_download(self._h, f32p(out)))
+        return out
+
+    def set_column_from_em(self, col, em, fit):
+        check(_lib.load().wgs_afset_set_column_from_em(self._h, int(col), em.handle, int(fit)))
+
+    def col_dev(self, col):
+        return _lib.load().wgs_afset_col_dev(self._h, int(col))
+
+    def close(self):
+        if self._h:
+            _lib.load().wgs_afset_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EMBatch:
+    """A batch of EM fits over the slabs of one DeviceBeagle (wgs_em).
+
+    fit j uses the individuals of group groups[j], leaving out individual skips[j] (global
+    index) when >= 0 -- the leave-one-out re-fit of glassy.py:65-78.
+    """
+
+    GUARD = 0.25   # relative half-width of the band in which the exact serial chain decides
+
+    def __init__(self, beagle, groups, skips=None, mode=None):
+        self.b = beagle
+        self.n_fits = len(groups)
+        self.mode = default_mode() if mode is None else mode
+        g = np.ascontiguousarray(groups, dtype=np.int32)
+        s = np.ascontiguousarray(skips if skips is not None else np.full(self.n_fits, -1), dtype=np.int32)
+        h = ctypes.c_void_p()
+        check(_lib.load().wgs_em_create(beagle.handle, self.n_fits, i32p(g), i32p(s), self.mode, ctypes.byref(h)))
+        self._h = h
+        self.active = np.ones(self.n_fits, dtype=bool)
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- primitives (one C-ABI call each)
+    def step(self):
+        """One EM update of every active fit (emMAF_cy.pyx:10-23); returns the float64 sums of
+        (f_new - f_old)^2 over this shard's SNPs per fit."""
+        ssq = np.zeros(self.n_fits, dtype=np.float64)
+        check(_lib.load().wgs_em_step(self._h, f64p(ssq)))
+        return ssq
+
+    def rmse_chain(self, fit, carry_in):
+        out = ctypes.c_float()
+        check(_lib.load().wgs_em_rmse_chain(self._h, int(fit), ctypes.c_float(carry_in), ctypes.byref(out)))
+        return np.float32(out.value)
+
+    def set_active(self, fit, active):
+        check(_lib.load().wgs_em_set_active(self._h, int(fit), int(bool(active))))
+        self.active[fit] = bool(active)
+
+    def clamp(self, fit, n_pop):
+        """WGSassign.py:236-240 / glassy.py:80-85."""
+        lo = 1 / (2 * (n_pop + 1))
+        hi = 1 - lo
+        check(_lib.load().wgs_em_clamp(self._h, int(fit), np.float32(lo), np.float32(hi)))
+
+    def get_f(self, fit):
+        out = np.empty(self.b.m, dtype=np.float32)
+        check(_lib.load().wgs_em_get_f(self._h, int(fit), f32p(out)))
+        return out
+
+    def set_f(self, fit, f):
+        f = _as_f32c(f, "f")
+        check(_lib.load().wgs_em_set_f(self._h, int(fit), f32p(f)))
+
+    def f_dev(self, fit):
+        return _lib.load().wgs_em_f_dev(self._h, int(fit))
+
+    # ---- the driver loop of emMAF.py:20-26, for all fits at once
+    def run(self, max_iter, tole, comm=None, m_total=None):
+        """Returns iters (n_fits,), the 1-based iteration at which each fit met `diff < tole`
+        (0: max_iter exhausted -- the reference prints nothing then)."""
+        return run_em(self, max_iter, tole, comm, m_total)
+
+    def close(self):
+        if self._h:
+            _lib.load().wgs_em_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def decide_converged(ssq, m_total, tole, guard):
+    """Classify a float64 sum of squared differences against the reference's test
+    `sqrt(float32_serial_sum / float32(m)) < tole` (emMAF_cy.pyx:26-33, emMAF.py:22-23):
+    returns +1 converged, -1 not converged, 0 too close to call (needs the exact chain).
+    NaN never converges (NaN < tole is False)."""
+    if ssq != ssq or not tole > 0:
+        return -1
+    thresh = tole * tole * float(m_total)
+    if ssq <= thresh * (1.0 - guard):
+        return 1
+    if ssq >= thresh * (1.0 + guard):
+        return -1
+    return 0
+
+
+def chain_diff(carry, m_total):
+    """emMAF_cy.pyx:32-33: res / (float)n, then sqrt in double."""
+    res = np.float32(carry) / np.float32(m_total)
+    return math.sqrt(float(res))
+
+
+def run_em(em, max_iter, tole, comm=None, m_total=None):
+    """emMAF.py:20-26 for a batch of fits sharded by SNP over comm.world ranks.
+
+    `em` needs: n_fits, active (bool array), step() -> ssq, rmse_chain(fit, carry_in) -> float32,
+    set_active(fit, bool), GUARD.  (tests drive this loop with a CPU stand-in to cover the
+    multi-rank protocol without a GPU.)
+    """
+    from .comm import LocalComm
+    comm = comm or LocalComm()
+    if m_total is None:
+        m_total = int(comm.allreduce_sum(np.array([float(em.b.m)]))[0]) if comm.world > 1 else em.b.m
+    iters = np.zeros(em.n_fits, dtype=np.int32)
+    for it in range(1, int(max_iter) + 1):
+        if not em.active.any():
+            break
+        ssq = em.step()
+        if comm.world > 1:
+            ssq = comm.allreduce_sum(ssq)
+        undecided = []
+        for j in np.flatnonzero(em.active):
+            d = decide_converged(ssq[j], m_total, tole, em.GUARD)
+            if d > 0:
+                iters[j] = it
+                em.set_active(j, False)
+            elif d == 0:
+                undecided.append(int(j))
+        for j in undecided:
+            # the reference's float32 running sum walks all SNPs in index order: rank r continues
+            # from the carry of rank r-1 (contiguous SNP shards in rank order)
+            carry = np.float32(0.0)
+            for r in range(comm.world):
+                mine = np.zeros(1, dtype=np.float64)
+                if r == comm.rank:
+                    mine[0] = float(em.rmse_chain(j, carry))
+                if comm.world > 1:
+                    mine = comm.allreduce_sum(mine)
+                carry = np.float32(mine[0])
+            if chain_diff(carry, m_total) < tole:
+                iters[j] = it
+                em.set_active(j, False)
+    return iters
+
+
+def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
+    """All n x K assignment log-likelihood sums in one sweep (glassy.py:18-44 / 87-109).
+
+    Returns (out (n, K) float64, parts (n*P, K) float64 or None), already summed over ranks.
+    colptr: optional (n, K) array of device addresses (per-individual frequency vectors).
+    """
+    mode = default_mode() if mode is None else mode
+    n, K = beagle.n, afset.K
+    out = np.zeros((n, K), dtype=np.float64)
+    parts = np.zeros((n * P, K), dtype=np.float64) if P > 1 else None
+    cp = None
+    if colptr is not None:
+        arr = np.ascontiguousarray(colptr, dtype=np.uint64)
+        if arr.shape != (n, K):
+            raise ValueError("colptr must be (n, K)")
+        cp = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
+    check(_lib.load().wgs_assign(beagle.handle, afset.handle, cp, int(P), mode, f64p(out),
+                                 f64p(parts) if parts is not None else None))
+    if comm is not None and comm.world > 1:
+        out = comm.allreduce_sum(out)
+        if parts is not None:
+            parts = comm.allreduce_sum(parts)
+    return out, parts

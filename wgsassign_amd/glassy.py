@@ -1,0 +1,86 @@
+"""Assignment log-likelihoods and leave-one-out: drop-in for the reference's `glassy.py`."""
+import numpy as np
+
+from .device import AFSet, DeviceBeagle, EMBatch, assign
+
+
+def assignLL(L, af, t=1):
+    """glassy.py:18-44: (n, K) float32 matrix of summed per-site log-likelihoods.
+
+    One sweep over the device-resident matrix produces all n*K sums (the reference rescans L
+    once per pair); sums are accumulated in float64 like np.sum(..., dtype=float) (glassy.py:38)
+    and stored as float32 (glassy.py:42).
+    """
+    L = np.asarray(L)
+    af = np.ascontiguousarray(af, dtype=np.float32)
+    n = L.shape[1] // 2
+    k = af.shape[1]
+    print(str(n) + " individuals to assign to " + str(k) + " populations")
+    if n == 0 or L.shape[0] == 0:
+        return np.zeros((n, k), dtype=np.float32)
+    beagle = DeviceBeagle.from_host(L)
+    afset = AFSet.from_host(af[:L.shape[0]])
+    out, _ = assign(beagle, afset)
+    afset.close()
+    beagle.close()
+    with np.errstate(over="ignore"):
+        return out.astype(np.float32)
+
+
+def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1):
+    """glassy.py:47-112: leave-one-out assignment log-likelihoods.
+
+    Semantics kept from the reference:
+      * individual i's own population column is re-estimated without i (glassy.py:65-78) and
+        clamped with n_pop = |pop| - 1 (glassy.py:80-85);
+      * that column OVERWRITES af[:, pop_col] and is never restored (glassy.py:87-89), so when i
+        is scored every other column holds the leave-one-out estimate of the most recent earlier
+        individual of that population (or the full-population estimate if there was none);
+        `af` is mutated in place and ends up holding each population's LAST re-fit;
+      * scoring uses downsampled_L when given (glassy.py:96-98);
+      * per-partition sums use labels = site index % num_partitions (utils.py:147).
+    All n re-fits run as one batch of EM chains on the device; one scoring sweep follows.
+    Returns (logl_mat (n, K) float32, logl_parts_mat (n*P, K) float32).
+    """
+    L = np.asarray(L)
+    IDs = np.asarray(IDs)
+    m = L.shape[0]
+    n = L.shape[1] // 2
+    k = af.shape[1]
+    P = int(num_partitions)
+    print(str(n) + " individuals to assign to " + str(k) + " populations")
+    if downsampled_L is not None:
+        print("Using downsampled GLs for likelihood evaluation in LOO assignment.")
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:n, 1]).astype(np.int32)
+    counts = np.bincount(group_of, minlength=len(pops))
+    beagle = DeviceBeagle.from_host(L, group_of, len(pops))
+    em = EMBatch(beagle, group_of, np.arange(n, dtype=np.int32))
+    iters = em.run(maf_iter, maf_tole)
+    for i in range(n):
+        if iters[i] > 0:
+            print("EM (MAF) converged at iteration: " + str(int(iters[i])))
+        em.clamp(i, int(counts[group_of[i]]) - 1)
+    afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
+    cur = [afset.col_dev(j) for j in range(k)]
+    colptr = np.zeros((n, k), dtype=np.uint64)
+    for i in range(n):
+        cur[group_of[i]] = em.f_dev(i)
+        colptr[i] = cur
+    if downsampled_L is not None:
+        scored = DeviceBeagle.from_host(np.asarray(downsampled_L), group_of, len(pops))
+    else:
+        scored = beagle
+    out, parts = assign(scored, afset, colptr=colptr, P=P)
+    last = {int(g): i for i, g in enumerate(group_of)}
+    for g, i in last.items():
+        af[:, g] = em.get_f(i)
+    if scored is not beagle:
+        scored.close()
+    afset.close()
+    em.close()
+    beagle.close()
+    with np.errstate(over="ignore"):
+        logl = out.astype(np.float32)
+        logl_parts = parts.astype(np.float32) if parts is not None else logl.copy()
+    return logl, logl_parts

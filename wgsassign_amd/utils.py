@@ -1,0 +1,71 @@
+"""Host-side helpers around the hot path: drop-in for the reference's `utils.py`
+(site masks, partition sums, assignment-matrix writer).  Pure NumPy/pandas, no device work."""
+import gzip
+
+import numpy as np
+
+
+def print_sample_and_site_summary(sample_names, site_names):
+    """utils.py:8-18: first two / last two names of each list."""
+    def preview(names):
+        names = list(names)
+        if len(names) <= 4:
+            return ", ".join(names)
+        return ", ".join(names[:2]) + ", ..., " + ", ".join(names[-2:])
+    print(f"sample_names: {len(sample_names)} samples total: {preview(sample_names)}")
+    print(f"site_names: {len(site_names)} sites total: {preview(site_names)}")
+
+
+def site_mask(site_names, site_names_target):
+    """Boolean keep-mask of utils.py:30-33 (bit-exact: membership of each site in the target)."""
+    return np.isin(np.array(site_names), list(set(site_names_target)))
+
+
+def filter_sites_to_common(L, site_names, site_names_target):
+    """utils.py:22-42: keep the rows of L whose site is in site_names_target."""
+    names = np.array(site_names)
+    mask = site_mask(names, site_names_target)
+    dropped = int(np.sum(~mask))
+    if dropped > 0:
+        print(f"\tFiltered out {dropped} sites not present in the target site list.")
+    return L[mask, :], names[mask].tolist()
+
+
+def partition_loglikes(per_site_ll, partition_count):
+    """utils.py:129-151: sums of a per-site vector by label = site index % partition_count
+    (sequential float32 accumulation, like np.add.at)."""
+    if per_site_ll.ndim != 1:
+        raise ValueError("per_site_ll must be a 1D array")
+    labels = np.arange(per_site_ll.shape[0]) % partition_count
+    sums = np.zeros(partition_count, dtype=np.float32)
+    np.add.at(sums, labels, per_site_ll)
+    return sums
+
+
+def write_ass_mats(filename, loglike_mat, sample_names, pop_names, partition_count=1, print_part_column=True,
+                   sample_locations=None, doing_LOO=False):
+    """utils.py:49-123: tab-separated assignment matrix, `%.6f`, gzipped when the name ends in .gz.
+    Columns: sample, [source_pop|location], [data_part], one per population."""
+    import pandas as pd
+    n_ind, K = len(sample_names), len(pop_names)
+    if loglike_mat.shape != (n_ind * partition_count, K):
+        raise ValueError(f"loglike_mat shape mismatch: expected {(n_ind * partition_count, K)}, got {loglike_mat.shape}")
+    if not print_part_column and partition_count != 1:
+        raise ValueError("print_part_column=False is only allowed if partition_count == 1")
+    if sample_locations is not None:
+        if len(sample_locations) != n_ind:
+            raise ValueError("Length of sample_locations does not match sample_names")
+        if doing_LOO and not set(sample_locations).issubset(set(pop_names)):
+            raise ValueError("sample_locations contains values not in pop_names (required for LOO mode)")
+    cols = {"sample": np.repeat(sample_names, partition_count)}
+    if sample_locations is not None:
+        cols["source_pop" if doing_LOO is True else "location"] = np.repeat(sample_locations, partition_count)
+    if print_part_column:
+        cols["data_part"] = np.tile(np.arange(partition_count), n_ind)
+    df = pd.concat([pd.DataFrame(cols), pd.DataFrame(loglike_mat, columns=pop_names)], axis=1)
+    if filename.endswith(".gz"):
+        with gzip.open(filename, "wt") as fh:
+            df.to_csv(fh, sep="\t", index=False, float_format="%.6f")
+    else:
+        df.to_csv(filename, sep="\t", index=False, float_format="%.6f")
+    print(f"Wrote assignment matrix to {filename}")
