@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- WGSassign hot path on MI355X: EM allele-frequency sweep + assignment log-lik sweep.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+A "step" is ONE EM update (emMAF_cy.pyx:10-23) of EVERY population over the whole synthetic
+Beagle matrix, fused with the convergence sums, plus -- for N > 1 -- the one collective the path
+needs (RCCL all-reduce of the K per-population sums).  Workload: BASELINE.json configs[2],
+synthetic 10M SNPs x 1000 individuals, K=10 (the configuration the metric's roofline target is
+quoted on; 80 GB of genotype likelihoods, fits one 288 GB MI355X).  For N > 1 the SAME 10M SNPs
+are sharded by contiguous SNP range over the ranks (scaling = "strong").
+
+metric  = per-population SNP-updates/s (1 SNP-update = one SNP's EM update over the n_call=n/K
+          individuals of one population); whole-job value over all ranks.
+roofline= the EM sweep kernel: algorithmic bytes (8n + 8K per SNP) / HIP-event kernel time.
+cpu_baseline = the oracle's C/OpenMP restatement of the reference path (per-population column
+          gather + emMAF_update per population) on a bounded SNP sample, host cores of this box.
+PyTorch is only used for the process group (rendezvous, barrier, RCCL all-reduce) when N > 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12   # B/s, MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+SEED = 20260313
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--m", type=int, default=10_000_000, help="total SNPs (sharded over ranks)")
+    ap.add_argument("--n", type=int, default=1000, help="individuals")
+    ap.add_argument("--K", type=int, default=10, help="populations")
+    ap.add_argument("--mode", default=os.environ.get("WGSASSIGN_MODE", "exact"), choices=["exact", "fast"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-assign", action="store_true", help="skip the assignment sweep leg")
+    ap.add_argument("--cpu-snps", type=int, default=200_000, help="SNP sample for the CPU baseline")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    from wgsassign_amd import comm as wcomm
+    from wgsassign_amd import device
+    from wgsassign_amd._lib import MODE_EXACT, MODE_FAST
+    mode = MODE_EXACT if args.mode == "exact" else MODE_FAST
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = wcomm.TorchComm(device=torch.device("cuda", local_rank))
+    else:
+        comm = wcomm.LocalComm()
+
+    ctx = device.Context(local_rank)
+    m_total, n, K = args.m, args.n, args.K
+    lo, hi = wcomm.shard_range(m_total, rank, world)
+    m = hi - lo
+    per = n // K
+    group_of = np.minimum(np.arange(n) // per, K - 1).astype(np.int32)
+    n_call = float(n) / K
+
+    t0 = time.time()
+    beagle = device.DeviceBeagle(m, n, group_of, K, site0=lo, ctx=ctx)
+    beagle.synth(SEED, 2.0)
+    ctx.sync()
+    t_gen = time.time() - t0
+    em = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
+
+    def barrier():
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    def step():
+        ssq = em.step()                      # sweep kernel + readback of the K sums
+        if world > 1:
+            ssq = comm.allreduce_sum(ssq)    # RCCL all-reduce (convergence is decided on these)
+        return ssq
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ssq = step()
+        kernel_ms.append(em.last_sweep_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = K * m_total * args.steps / elapsed          # per-population SNP-updates/s, whole job
+
+    # roofline of the dominant kernel (this rank's shard): algorithmic bytes per launch / avg duration
+    alg_bytes = (8.0 * n + 8.0 * K) * m
+    k_avg = float(np.mean(kernel_ms)) * 1e-3
+    achieved = alg_bytes / k_avg
+    roofline = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                "kernel": "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_snp": 8 * n + 8 * K}
+
+    extra = {"gl_pair_terms_per_s": value * n_call, "synth_seconds": round(t_gen, 2),
+             "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
+
+    # assignment log-likelihood sweep (one pass producing all n x K sums), same matrix
+    if not args.no_assign:
+        afs = device.AFSet(m, K, ctx=ctx)
+        for k in range(K):
+            em.clamp(k, per)
+            afs.set_column_from_em(k, em, k)
+        ctx.sync()
+        barrier()
+        t0 = time.perf_counter()
+        out, _ = device.assign(beagle, afs, mode=mode, comm=comm if world > 1 else None)
+        barrier()
+        t_as = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([t_as], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_as = float(t.item())
+        as_ms = device.assign.last_ms
+        extra["assign"] = {"metric": "assignment log-lik SNPs/s (all n x K terms of a SNP = 1)",
+                           "value": m_total / t_as, "unit": "SNPs/s", "seconds": round(t_as, 4),
+                           "terms_per_s": m_total * float(n) * K / t_as,
+                           "kernel_ms": round(as_ms, 3),
+                           "hbm_frac": round((8.0 * n + 4.0 * K) * m / (as_ms * 1e-3) / HBM_PEAK, 4) if as_ms > 0 else None,
+                           "checksum": float(np.sum(out))}
+        afs.close()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(beagle, group_of, K, min(args.cpu_snps, m))
+
+    if rank == 0:
+        line = {"metric": "EM SNP-updates/s (per-population update, n_call=%g)" % n_call, "value": value,
+                "unit": "SNP-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64" if args.mode == "exact" else "f32", "data": "synthetic",
+                "config": {"workload": "synthetic Beagle %d SNPs x %d ind, K=%d, --get_reference_af EM sweep (+ --get_pop_like sweep), SNP-sharded over %d GPU(s)"
+                                       % (m_total, n, K, world), "mode": args.mode, "snps_per_gpu": m,
+                           "gl_bytes_per_gpu": beagle.nbytes()},
+                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+        print(json.dumps(line), flush=True)
+    em.close()
+    beagle.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(beagle, group_of, K, ms):
+    """Reference-shaped CPU path on this box's host cores: for each population gather its
+    columns (WGSassign.py:227-233) and run emMAF_update (emMAF_cy.pyx:10-23) -- the oracle's
+    bit-exact C/OpenMP restatement -- on the first `ms` SNPs of the same synthetic matrix."""
+    from oracle import oracle as orc
+    orc.build()
+    threads = int(os.environ.get("WGS_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # the box's CPU share
+    rows = beagle.download_rows(0, ms)
+    slabs = [orc.gather(rows, np.flatnonzero(group_of == k), threads) for k in range(K)]
+    fs = [np.full(ms, 0.25, dtype=np.float32) for _ in range(K)]
+    for k in range(K):                           # warm-up sweep
+        orc.emMAF_update(slabs[k], fs[k], threads)
+    sweeps, t0 = 0, time.perf_counter()
+    while True:
+        for k in range(K):
+            orc.emMAF_update(slabs[k], fs[k], threads)
+        sweeps += 1
+        el = time.perf_counter() - t0
+        if el > 12.0:
+            break
+    t_g0 = time.perf_counter()
+    for k in range(K):
+        orc.gather(rows, np.flatnonzero(group_of == k), threads)
+    t_gather = time.perf_counter() - t_g0
+    return {"value": K * ms * sweeps / el, "unit": "SNP-updates/s", "cores": threads, "kind": "port",
+            "sample": "first %d SNPs x %d ind of the same synthetic matrix, K=%d populations, %d sweeps in %.1f s "
+                      "(OpenMP threads=%d; per-population gather %.2f s not included)" %
+                      (ms, beagle.n, K, sweeps, el, threads, t_gather)}
+
+
+if __name__ == "__main__":
+    main()

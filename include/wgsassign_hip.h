@@ -108,6 +108,9 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev);
  * carry_in is the float32 running sum after the preceding shards (0 for the first shard),
  * carry_out the running sum after this shard; diff = sqrt((double)(carry / (float)m_total)). */
 int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out);
+/* Duration in milliseconds of the sweep kernel(s) of the last wgs_em_step*, measured with HIP
+ * events recorded on the context's stream around the launch (waits for the kernel). */
+int wgs_em_last_sweep_ms(wgs_em *em, float *ms);
 /* Freeze (active = 0) or re-activate a fit: frozen fits are skipped by wgs_em_step and keep
  * the frequencies of their last update -- emMAF.py:23-25 `break`s after the update. */
 int wgs_em_set_active(wgs_em *em, int32_t fit, int active);
@@ -145,6 +148,9 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
  * (utils.py:129-151).  out/parts are host float64 buffers, summed into (caller zeroes). */
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
                double *out, double *parts);
+
+/* Summed kernel time (HIP events on the context's stream) of the calling thread's last wgs_assign. */
+int wgs_assign_last_ms(float *ms);
 
 #ifdef __cplusplus
 }

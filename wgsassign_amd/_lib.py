@@ -45,6 +45,7 @@ SIGNATURES = {
     "wgs_em_step": (c_int, [c_vp, c_f64p]),
     "wgs_em_step_dev": (c_int, [c_vp, c_vp]),
     "wgs_em_rmse_chain": (c_int, [c_vp, c_i32, ctypes.c_float, c_f32p]),
+    "wgs_em_last_sweep_ms": (c_int, [c_vp, c_f32p]),
     "wgs_em_set_active": (c_int, [c_vp, c_i32, c_int]),
     "wgs_em_n_active": (c_int, [c_vp]),
     "wgs_em_clamp": (c_int, [c_vp, c_i32, ctypes.c_float, ctypes.c_float]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     "wgs_afset_download": (c_int, [c_vp, c_f32p]),
     "wgs_afset_set_column_from_em": (c_int, [c_vp, c_i32, c_vp, c_i32]),
     "wgs_afset_col_dev": (c_vp, [c_vp, c_i32]),
+    "wgs_assign_last_ms": (c_int, [c_f32p]),
     "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),
 }
 

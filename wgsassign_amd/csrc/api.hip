@@ -242,6 +242,7 @@ struct wgs_em {
     double *d_ssq = nullptr;
     float *d_carry = nullptr;
     std::vector<int32_t> last;            // fits swept by the last step
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the sweep kernel(s) of the last step
 };
 
 void wgs_em_destroy(wgs_em *em)
@@ -254,6 +255,8 @@ void wgs_em_destroy(wgs_em *em)
     if (em->h_descs) (void)hipHostFree(em->h_descs);
     if (em->d_ssq) (void)hipFree(em->d_ssq);
     if (em->d_carry) (void)hipFree(em->d_carry);
+    if (em->ev0) (void)hipEventDestroy(em->ev0);
+    if (em->ev1) (void)hipEventDestroy(em->ev1);
     delete em;
 }
 
@@ -304,6 +307,8 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     HIP_TRY(hipMalloc(&em->d_descs, sizeof(FitDesc) * n_fits));
     HIP_TRY(hipMalloc(&em->d_ssq, sizeof(double) * n_fits));
     HIP_TRY(hipMalloc(&em->d_carry, sizeof(float)));
+    HIP_TRY(hipEventCreate(&em->ev0));
+    HIP_TRY(hipEventCreate(&em->ev1));
     HIP_TRY(hipHostMalloc(&em->h_descs, sizeof(FitDesc) * n_fits, hipHostMallocDefault));
     if (launch_fill(b->ctx, em->fbuf[0], (int64_t)n_fits * b->m, 0.25f)) {   // emMAF.py:17-18
         wgs_em_destroy(em);
@@ -342,10 +347,12 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
     // consuming this step's sums
     HIP_TRY(hipMemcpyAsync(em->d_descs, em->h_descs, sizeof(FitDesc) * em->last.size(), hipMemcpyHostToDevice, ctx->stream));
     // launch in slices of <= 65535 fits (grid.y limit)
+    HIP_TRY(hipEventRecord(em->ev0, ctx->stream));
     for (size_t off = 0; off < em->last.size(); off += 65535) {
         const int cnt = (int)std::min<size_t>(65535, em->last.size() - off);
         if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode)) return 1;
     }
+    HIP_TRY(hipEventRecord(em->ev1, ctx->stream));
     for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
     return 0;
 }
@@ -371,6 +378,15 @@ int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out)
     if (launch_rmse_chain(ctx, em_f(em, fit, em->cur[fit]), em_f(em, fit, em->cur[fit] ^ 1), em->b->m, carry_in, em->d_carry)) return 1;
     HIP_TRY(hipMemcpyAsync(carry_out, em->d_carry, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wgs_em_last_sweep_ms(wgs_em *em, float *ms)
+{
+    WGS_REQUIRE(em && ms, "null argument");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    HIP_TRY(hipEventSynchronize(em->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, em->ev0, em->ev1));
     return 0;
 }
 
@@ -494,6 +510,14 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col)
 
 /* ------------------------------------------------------------------ assignment */
 
+static thread_local float g_assign_ms = 0.0f;
+int wgs_assign_last_ms(float *ms)
+{
+    WGS_REQUIRE(ms, "null argument");
+    *ms = g_assign_ms;
+    return 0;
+}
+
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode, double *out, double *parts)
 {
     WGS_REQUIRE(b && a && out, "null argument");
@@ -506,6 +530,8 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     const int64_t n = b->n;
     const size_t cells = (size_t)n * P * K;
     double *d_out = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    g_assign_ms = 0.0f;
     const float **d_acol = nullptr, **d_colptr = nullptr;
     int32_t *d_members = nullptr;
     int rc = 0;
@@ -527,6 +553,8 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
         TRY_GOTO(hipMemcpy(d_colptr, colptr, sizeof(float *) * n * K, hipMemcpyHostToDevice));
     }
     TRY_GOTO(hipMalloc(&d_members, sizeof(int32_t) * n));
+    TRY_GOTO(hipEventCreate(&ev0));
+    TRY_GOTO(hipEventCreate(&ev1));
     for (int g = 0; g < b->n_groups && !rc; ++g) {
         const Slab &s = b->slabs[g];
         if (s.ncols == 0) continue;
@@ -544,8 +572,14 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
         args.K = K;
         args.P = P;
         args.rows_per_wave = 0;
+        TRY_GOTO(hipEventRecord(ev0, ctx->stream));
         rc = launch_assign(ctx, args, mode);
+        TRY_GOTO(hipEventRecord(ev1, ctx->stream));
         TRY_GOTO(hipStreamSynchronize(ctx->stream));   // d_members is reused by the next slab
+        {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) g_assign_ms += ms;
+        }
     }
     if (rc) goto done;
     TRY_GOTO(hipMemcpy(h.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost));
@@ -561,6 +595,8 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
             }
     }
 done:
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
     if (d_out) (void)hipFree(d_out);
     if (d_acol) (void)hipFree(d_acol);
     if (d_colptr) (void)hipFree(d_colptr);

@@ -214,6 +214,11 @@ class EMBatch:
         check(_lib.load().wgs_em_step(self._h, f64p(ssq)))
         return ssq
 
+    def last_sweep_ms(self):
+        ms = ctypes.c_float()
+        check(_lib.load().wgs_em_last_sweep_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
     def rmse_chain(self, fit, carry_in):
         out = ctypes.c_float()
         check(_lib.load().wgs_em_rmse_chain(self._h, int(fit), ctypes.c_float(carry_in), ctypes.byref(out)))
@@ -341,6 +346,9 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
         cp = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
     check(_lib.load().wgs_assign(beagle.handle, afset.handle, cp, int(P), mode, f64p(out),
                                  f64p(parts) if parts is not None else None))
+    ms = ctypes.c_float()
+    check(_lib.load().wgs_assign_last_ms(ctypes.byref(ms)))
+    assign.last_ms = ms.value
     if comm is not None and comm.world > 1:
         out = comm.allreduce_sum(out)
         if parts is not None:
