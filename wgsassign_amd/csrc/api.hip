@@ -88,11 +88,13 @@ void wgs_beagle_destroy(wgs_beagle *b)
 {
     if (!b) return;
     (void)hipSetDevice(b->ctx->device);
-    for (auto &s : b->slabs)
+    for (auto &s : b->slabs) {
         if (s.base) (void)hipFree(s.base);
+        if (s.d_members) (void)hipFree(s.d_members);
+    }
     if (b->d_group_of) (void)hipFree(b->d_group_of);
     if (b->d_col_of) (void)hipFree(b->d_col_of);
-    if (b->d_ld) (void)hipFree(b->d_ld);
+    if (b->d_npairs) (void)hipFree(b->d_npairs);
     if (b->d_base) (void)hipFree(b->d_base);
     delete b;
 }
@@ -126,14 +128,14 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
         b->col_of[i] = (int32_t)b->slabs[g].members.size();
         b->slabs[g].members.push_back((int32_t)i);
     }
-    std::vector<float2 *> bases(n_groups, nullptr);
-    std::vector<int32_t> lds(n_groups, 0);
+    std::vector<float4 *> bases(n_groups, nullptr);
+    std::vector<int32_t> nps(n_groups, 0);
     for (int g = 0; g < n_groups; ++g) {
         Slab &s = b->slabs[g];
         s.ncols = (int32_t)s.members.size();
-        s.ld = (s.ncols + 1) & ~1;
+        s.npairs = (s.ncols + 1) / 2;
         if (s.ncols == 0) continue;
-        const size_t bytes = (size_t)m * s.ld * sizeof(float2) + 512;  // slack: chunk loads may run past the last row
+        const size_t bytes = (size_t)wgs_ntiles(m) * s.npairs * 64 * sizeof(float4);
         if (hipMalloc(&s.base, bytes) != hipSuccess) {
             wgs_set_error("hipMalloc of %zu bytes for population slab %d failed", bytes, g);
             wgs_beagle_destroy(b);
@@ -142,16 +144,22 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
         (void)hipMemsetAsync(s.base, 0, bytes, ctx->stream);
         b->bytes += (int64_t)bytes;
         bases[g] = s.base;
-        lds[g] = s.ld;
+        nps[g] = s.npairs;
+        if (hipMalloc(&s.d_members, sizeof(int32_t) * s.ncols) != hipSuccess ||
+            hipMemcpy(s.d_members, s.members.data(), sizeof(int32_t) * s.ncols, hipMemcpyHostToDevice) != hipSuccess) {
+            wgs_set_error("could not upload the member table of slab %d", g);
+            wgs_beagle_destroy(b);
+            return 1;
+        }
     }
     HIP_TRY(hipMalloc(&b->d_group_of, sizeof(int32_t) * n));
     HIP_TRY(hipMalloc(&b->d_col_of, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&b->d_ld, sizeof(int32_t) * n_groups));
-    HIP_TRY(hipMalloc(&b->d_base, sizeof(float2 *) * n_groups));
+    HIP_TRY(hipMalloc(&b->d_npairs, sizeof(int32_t) * n_groups));
+    HIP_TRY(hipMalloc(&b->d_base, sizeof(float4 *) * n_groups));
     HIP_TRY(hipMemcpy(b->d_group_of, b->group_of.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_col_of, b->col_of.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->d_ld, lds.data(), sizeof(int32_t) * n_groups, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->d_base, bases.data(), sizeof(float2 *) * n_groups, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_npairs, nps.data(), sizeof(int32_t) * n_groups, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->d_base, bases.data(), sizeof(float4 *) * n_groups, hipMemcpyHostToDevice));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *out = b;
     return 0;
@@ -240,6 +248,7 @@ struct wgs_em {
     FitDesc *d_descs = nullptr;
     FitDesc *h_descs = nullptr;           // pinned
     double *d_ssq = nullptr;
+    double *d_part = nullptr;             // n_fits x ntiles per-tile partial sums
     float *d_carry = nullptr;
     std::vector<int32_t> last;            // fits swept by the last step
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the sweep kernel(s) of the last step
@@ -254,6 +263,7 @@ void wgs_em_destroy(wgs_em *em)
     if (em->d_descs) (void)hipFree(em->d_descs);
     if (em->h_descs) (void)hipHostFree(em->h_descs);
     if (em->d_ssq) (void)hipFree(em->d_ssq);
+    if (em->d_part) (void)hipFree(em->d_part);
     if (em->d_carry) (void)hipFree(em->d_carry);
     if (em->ev0) (void)hipEventDestroy(em->ev0);
     if (em->ev1) (void)hipEventDestroy(em->ev1);
@@ -306,6 +316,7 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     }
     HIP_TRY(hipMalloc(&em->d_descs, sizeof(FitDesc) * n_fits));
     HIP_TRY(hipMalloc(&em->d_ssq, sizeof(double) * n_fits));
+    HIP_TRY(hipMalloc(&em->d_part, sizeof(double) * (size_t)n_fits * wgs_ntiles(b->m)));
     HIP_TRY(hipMalloc(&em->d_carry, sizeof(float)));
     HIP_TRY(hipEventCreate(&em->ev0));
     HIP_TRY(hipEventCreate(&em->ev1));
@@ -335,7 +346,8 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
         d.f_old = em_f(em, j, em->cur[j]);
         d.f_new = em_f(em, j, em->cur[j] ^ 1);
         d.ssq = ssq_dev + j;
-        d.ld = s.ld;
+        d.ssq_part = em->d_part + (size_t)j * wgs_ntiles(em->b->m);
+        d.npairs = s.npairs;
         d.ncols = s.ncols;
         d.skip = em->skip_local[j];
         d.n_eff = em->n_eff[j];
@@ -353,6 +365,10 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
         if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode)) return 1;
     }
     HIP_TRY(hipEventRecord(em->ev1, ctx->stream));
+    for (size_t off = 0; off < em->last.size(); off += 65535) {
+        const int cnt = (int)std::min<size_t>(65535, em->last.size() - off);
+        if (launch_ssq_reduce(ctx, em->d_descs + off, cnt, em->b->m)) return 1;
+    }
     for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
     return 0;
 }
@@ -533,7 +549,6 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     g_assign_ms = 0.0f;
     const float **d_acol = nullptr, **d_colptr = nullptr;
-    int32_t *d_members = nullptr;
     int rc = 0;
     std::vector<const float *> acol(K);
     for (int k = 0; k < K; ++k) acol[k] = a->buf + (size_t)k * a->m;
@@ -552,36 +567,31 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
         TRY_GOTO(hipMalloc(&d_colptr, sizeof(float *) * n * K));
         TRY_GOTO(hipMemcpy(d_colptr, colptr, sizeof(float *) * n * K, hipMemcpyHostToDevice));
     }
-    TRY_GOTO(hipMalloc(&d_members, sizeof(int32_t) * n));
     TRY_GOTO(hipEventCreate(&ev0));
     TRY_GOTO(hipEventCreate(&ev1));
+    TRY_GOTO(hipEventRecord(ev0, ctx->stream));
     for (int g = 0; g < b->n_groups && !rc; ++g) {
         const Slab &s = b->slabs[g];
         if (s.ncols == 0) continue;
-        TRY_GOTO(hipMemcpyAsync(d_members, s.members.data(), sizeof(int32_t) * s.ncols, hipMemcpyHostToDevice, ctx->stream));
         AssignArgs args;
         args.slab = s.base;
-        args.members = d_members;
+        args.members = s.d_members;
         args.colptr = d_colptr;
         args.acol = d_acol;
         args.out = d_out;
         args.m = b->m;
         args.site0 = b->site0;
-        args.ld = s.ld;
+        args.npairs = s.npairs;
         args.ncols = s.ncols;
         args.K = K;
         args.P = P;
-        args.rows_per_wave = 0;
-        TRY_GOTO(hipEventRecord(ev0, ctx->stream));
+        args.tiles_per_wave = 0;
         rc = launch_assign(ctx, args, mode);
-        TRY_GOTO(hipEventRecord(ev1, ctx->stream));
-        TRY_GOTO(hipStreamSynchronize(ctx->stream));   // d_members is reused by the next slab
-        {
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) g_assign_ms += ms;
-        }
     }
     if (rc) goto done;
+    TRY_GOTO(hipEventRecord(ev1, ctx->stream));
+    TRY_GOTO(hipStreamSynchronize(ctx->stream));
+    (void)hipEventElapsedTime(&g_assign_ms, ev0, ev1);
     TRY_GOTO(hipMemcpy(h.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost));
     if (P == 1) {
         for (size_t c = 0; c < cells; ++c) out[c] += h[c];
@@ -600,7 +610,6 @@ done:
     if (d_out) (void)hipFree(d_out);
     if (d_acol) (void)hipFree(d_acol);
     if (d_colptr) (void)hipFree(d_colptr);
-    if (d_members) (void)hipFree(d_members);
     return rc;
 #undef TRY_GOTO
 }

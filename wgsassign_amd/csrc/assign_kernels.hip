@@ -3,10 +3,14 @@
 //
 // The reference scans L once per (individual, population) pair: n*K strided passes.  Here ONE
 // sweep over a population slab produces every pair:
-//   lane <-> individual (slab column): row loads are coalesced 512-byte segments, no transpose;
-//   each lane keeps K float64 accumulators (np.sum(..., dtype=float), glassy.py:38) and walks
-//   its wave's SNP range; the per-SNP frequency of population k is a wave-uniform (broadcast)
-//   load, or a per-lane vector when a per-individual column table is given (leave-one-out).
+//   lane <-> PAIR of individuals (slab columns 2p, 2p+1); wave <-> 64 pairs x a range of tiles.
+//   In the tile-interleaved slab a lane's (g0,g1,g0',g1') for consecutive SNPs of a tile are
+//   consecutive 16-byte words (one 128-byte line per 8 SNPs), so each lane streams its own
+//   lines.  The kernel is bound by float64 arithmetic (one double log per (SNP, individual,
+//   population)), not by these loads.
+//   Each lane keeps 2 x KB float64 accumulators (np.sum(..., dtype=float), glassy.py:38); the
+//   per-SNP frequency of population k is a broadcast load, or a per-lane vector when a
+//   per-individual column table is given (leave-one-out).
 #include "common.h"
 
 namespace {
@@ -32,80 +36,69 @@ __device__ __forceinline__ float site_ll_fast(float g0, float g1, float g2, floa
     return logf((like0 + like1) + like2);
 }
 
+typedef const float __attribute__((address_space(1))) *gf32_ptr;
+
 template <int KB, int MODE>
 __global__ __launch_bounds__(256) void assign_kernel(AssignArgs A)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int col = blockIdx.y * 64 + lane;
-    const bool valid = col < A.ncols;
-    const int colc = valid ? col : A.ncols - 1;
-    const int ind = A.members[colc];
+    const int pair = blockIdx.y * 64 + lane;
+    const bool valid_a = 2 * pair < A.ncols, valid_b = 2 * pair + 1 < A.ncols;
+    const int pairc = pair < A.npairs ? pair : A.npairs - 1;
+    const int ind_a = A.members[valid_a ? 2 * pair : 0];
+    const int ind_b = A.members[valid_b ? 2 * pair + 1 : 0];
+    const int64_t ntiles = (A.m + 63) >> 6;
     const int64_t w = (int64_t)blockIdx.x * 4 + wave;
-    int64_t s0 = w * A.rows_per_wave;
-    int64_t s1 = s0 + A.rows_per_wave;
-    if (s1 > A.m) s1 = A.m;
+    const int64_t t0 = w * A.tiles_per_wave;
+    int64_t t1 = t0 + A.tiles_per_wave;
+    if (t1 > ntiles) t1 = ntiles;
+    if (t0 >= t1) return;
+    const int64_t s_begin = t0 << 6;
+    const int64_t s_end = (t1 << 6) < A.m ? (t1 << 6) : A.m;
+    const float4 *base = A.slab + (int64_t)pairc * 64;     // + tile * npairs * 64 + lane-in-tile
 
     for (int kb = 0; kb < A.K; kb += KB) {
-        const float *ptr[KB];
+        gf32_ptr pa[KB], pb[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const int k = kb + j < A.K ? kb + j : A.K - 1;
-            ptr[j] = A.colptr ? A.colptr[(int64_t)ind * A.K + k] : A.acol[k];
+            pa[j] = (gf32_ptr)(A.colptr ? A.colptr[(int64_t)ind_a * A.K + k] : A.acol[k]);
+            pb[j] = (gf32_ptr)(A.colptr ? A.colptr[(int64_t)ind_b * A.K + k] : A.acol[k]);
         }
-        if (A.P <= 1) {
-            double acc[KB];
+        // utils.py:147-149: partition label = global site index % P (P == 1: one pass over all sites).
+        for (int p = 0; p < A.P; ++p) {
+            double acc_a[KB], acc_b[KB];
 #pragma unroll
-            for (int j = 0; j < KB; ++j) acc[j] = 0.0;
-            for (int64_t s = s0; s < s1; ++s) {
-                const float2 g = A.slab[s * A.ld + colc];
-                const double g0d = (double)g.x, g1d = (double)g.y;
-                const double g2d = (1.0 - g0d) - g1d;
-                const float g2f = (1.0f - g.x) - g.y;
+            for (int j = 0; j < KB; ++j) acc_a[j] = 0.0, acc_b[j] = 0.0;
+            const int64_t first = A.P == 1 ? s_begin : s_begin + ((p - (A.site0 + s_begin) % A.P) % A.P + A.P) % A.P;
+            for (int64_t s = first; s < s_end; s += A.P) {
+                const float4 g = base[((s >> 6) * A.npairs << 6) + (s & 63)];
+                const double a0 = (double)g.x, a1 = (double)g.y, a2 = (1.0 - a0) - a1;
+                const double b0 = (double)g.z, b1 = (double)g.w, b2 = (1.0 - b0) - b1;
 #pragma unroll
                 for (int j = 0; j < KB; ++j) {
                     if (kb + j < A.K) {
-                        const float a = ptr[j][s];
-                        const float v = MODE == WGS_MODE_EXACT ? site_ll_exact(g0d, g1d, g2d, a)
-                                                               : site_ll_fast(g.x, g.y, g2f, a);
-                        acc[j] += (double)v;
-                    }
-                }
-            }
-            if (valid && s0 < s1) {
-#pragma unroll
-                for (int j = 0; j < KB; ++j)
-                    if (kb + j < A.K) atomicAdd(&A.out[(int64_t)ind * A.K + kb + j], acc[j]);
-            }
-        } else {
-            // utils.py:147-149: label = global site index % P; one accumulator per partition.
-            // Sites of one partition are visited in index order within the wave's range.
-            for (int p = 0; p < A.P; ++p) {
-                double acc[KB];
-#pragma unroll
-                for (int j = 0; j < KB; ++j) acc[j] = 0.0;
-                int64_t first = s0 + ((p - (A.site0 + s0) % A.P) % A.P + A.P) % A.P;
-                bool any = false;
-                for (int64_t s = first; s < s1; s += A.P) {
-                    any = true;
-                    const float2 g = A.slab[s * A.ld + colc];
-                    const double g0d = (double)g.x, g1d = (double)g.y;
-                    const double g2d = (1.0 - g0d) - g1d;
-                    const float g2f = (1.0f - g.x) - g.y;
-#pragma unroll
-                    for (int j = 0; j < KB; ++j) {
-                        if (kb + j < A.K) {
-                            const float a = ptr[j][s];
-                            const float v = MODE == WGS_MODE_EXACT ? site_ll_exact(g0d, g1d, g2d, a)
-                                                                   : site_ll_fast(g.x, g.y, g2f, a);
-                            acc[j] += (double)v;
+                        const float fa = pa[j][s], fb = pb[j][s];
+                        float va, vb;
+                        if (MODE == WGS_MODE_EXACT) {
+                            va = site_ll_exact(a0, a1, a2, fa);
+                            vb = site_ll_exact(b0, b1, b2, fb);
+                        } else {
+                            va = site_ll_fast(g.x, g.y, (1.0f - g.x) - g.y, fa);
+                            vb = site_ll_fast(g.z, g.w, (1.0f - g.z) - g.w, fb);
                         }
+                        acc_a[j] += (double)va;
+                        acc_b[j] += (double)vb;
                     }
                 }
-                if (valid && any) {
+            }
+            if (first < s_end) {
 #pragma unroll
-                    for (int j = 0; j < KB; ++j)
-                        if (kb + j < A.K)
-                            atomicAdd(&A.out[((int64_t)ind * A.P + p) * A.K + kb + j], acc[j]);
+                for (int j = 0; j < KB; ++j) {
+                    if (kb + j < A.K) {
+                        if (valid_a) atomicAdd(&A.out[((int64_t)ind_a * A.P + p) * A.K + kb + j], acc_a[j]);
+                        if (valid_b) atomicAdd(&A.out[((int64_t)ind_b * A.P + p) * A.K + kb + j], acc_b[j]);
+                    }
                 }
             }
         }
@@ -152,20 +145,31 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
 {
     AssignArgs a = a_in;
     if (a.m <= 0 || a.ncols <= 0 || a.K <= 0) return 0;
-    // Enough waves to fill 256 CUs several times over, but ranges long enough to amortise the
+    // Enough waves to fill 256 CUs several times over, but tile ranges long enough to amortise the
     // per-wave prologue (pointer table) and the atomics.
-    const int colblocks = (a.ncols + 63) / 64;
-    int64_t want_waves = (int64_t)ctx->cus * 32 / colblocks;
+    const int pairblocks = (a.npairs + 63) / 64;
+    const int64_t ntiles = wgs_ntiles(a.m);
+    int64_t want_waves = (int64_t)ctx->cus * 32 / pairblocks;
     if (want_waves < 4) want_waves = 4;
-    int64_t rpw = (a.m + want_waves - 1) / want_waves;
-    if (rpw < 64) rpw = 64;
-    if (a.P > 1) rpw = ((rpw + a.P - 1) / a.P) * a.P;
-    a.rows_per_wave = (int32_t)(rpw > 0x7fffffff ? 0x7fffffff : rpw);
-    const int64_t waves = (a.m + a.rows_per_wave - 1) / a.rows_per_wave;
-    dim3 grid((unsigned)((waves + 3) / 4), (unsigned)colblocks);
-    if (a.K <= 4) return launch_assign_kb<4>(ctx, a, mode, grid);
-    if (a.K <= 8) return launch_assign_kb<8>(ctx, a, mode, grid);
-    return launch_assign_kb<16>(ctx, a, mode, grid);
+    int64_t tpw = (ntiles + want_waves - 1) / want_waves;
+    if (tpw < 1) tpw = 1;
+    a.tiles_per_wave = (int32_t)(tpw > 0x7fffffff ? 0x7fffffff : tpw);
+    const int64_t waves = (ntiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
+    dim3 grid((unsigned)((waves + 3) / 4), (unsigned)pairblocks);
+    // KB = populations per register batch: pick the batch size with the fewest passes, then the least padding
+    int best = 4, best_cost = 1 << 30;
+    for (int kb = 4; kb <= 8; ++kb) {
+        const int passes = (a.K + kb - 1) / kb;
+        const int cost = passes * 1000 + passes * kb - a.K;
+        if (cost < best_cost) best_cost = cost, best = kb;
+    }
+    switch (best) {
+        case 4: return launch_assign_kb<4>(ctx, a, mode, grid);
+        case 5: return launch_assign_kb<5>(ctx, a, mode, grid);
+        case 6: return launch_assign_kb<6>(ctx, a, mode, grid);
+        case 7: return launch_assign_kb<7>(ctx, a, mode, grid);
+        default: return launch_assign_kb<8>(ctx, a, mode, grid);
+    }
 }
 
 int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode)

@@ -4,11 +4,18 @@
 
 namespace {
 
+// Slab element (SNP s, local column c) as a float2 index into the tile-interleaved slab
+// (common.h: Slab): tile s/64, pair c/2, lane s%64, half c&1.
+__device__ __forceinline__ int64_t slab_index(int64_t s, int c, int npairs)
+{
+    return ((((s >> 6) * npairs + (c >> 1)) << 6) + (s & 63)) * 2 + (c & 1);
+}
+
 // rows: (nrows, 2n) float32 in the reference's host layout (reader_cy.pyx:71-77);
-// element (r, i) goes to slab[group_of[i]] at (row0 + r, col_of[i]).
+// element (r, i) goes to slab[group_of[i]] at (SNP row0 + r, column col_of[i]).
 __global__ void scatter_rows_kernel(const float2 *__restrict__ rows, int64_t nrows, int64_t n, int64_t row0,
                                     const int32_t *__restrict__ group_of, const int32_t *__restrict__ col_of,
-                                    float2 *const *__restrict__ base, const int32_t *__restrict__ ld)
+                                    float4 *const *__restrict__ base, const int32_t *__restrict__ npairs)
 {
     const int64_t total = nrows * n;
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -17,13 +24,13 @@ __global__ void scatter_rows_kernel(const float2 *__restrict__ rows, int64_t nro
         const int64_t r = e / n;
         const int i = (int)(e - r * n);
         const int g = group_of[i];
-        base[g][(row0 + r) * ld[g] + col_of[i]] = rows[e];
+        reinterpret_cast<float2 *>(base[g])[slab_index(row0 + r, col_of[i], npairs[g])] = rows[e];
     }
 }
 
 __global__ void gather_rows_kernel(float2 *__restrict__ rows, int64_t nrows, int64_t n, int64_t row0,
                                    const int32_t *__restrict__ group_of, const int32_t *__restrict__ col_of,
-                                   float2 *const *__restrict__ base, const int32_t *__restrict__ ld)
+                                   float4 *const *__restrict__ base, const int32_t *__restrict__ npairs)
 {
     const int64_t total = nrows * n;
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -32,7 +39,7 @@ __global__ void gather_rows_kernel(float2 *__restrict__ rows, int64_t nrows, int
         const int64_t r = e / n;
         const int i = (int)(e - r * n);
         const int g = group_of[i];
-        rows[e] = base[g][(row0 + r) * ld[g] + col_of[i]];
+        rows[e] = reinterpret_cast<const float2 *>(base[g])[slab_index(row0 + r, col_of[i], npairs[g])];
     }
 }
 
@@ -84,47 +91,61 @@ __device__ __forceinline__ float pop_freq(uint64_t seed, int64_t gsnp, int g)
     return fminf(fmaxf(p, 0.01f), 0.99f);
 }
 
-// One thread per (SNP row, slab column).  Genotype ~ Binomial(2, p); depth ~ Poisson(depth)
+// (g0, g1) of one (SNP, individual): genotype ~ Binomial(2, p); depth ~ Poisson(depth)
 // truncated at 15; alt reads ~ Binomial(depth, {e, 1/2, 1-e}[g]); GL_g ∝ P(reads | g), normalised,
 // rounded to 6 decimals like the ANGSD text the reference parses with atof.
-__global__ void synth_kernel(float2 *__restrict__ slab, int64_t m, int ld, int ncols, const int32_t *__restrict__ members,
+__device__ float2 synth_gl(uint64_t seed, int64_t gsnp, int ind, float p, float lam, float cdf0)
+{
+    uint32_t c[4] = {(uint32_t)gsnp, (uint32_t)(gsnp >> 32), (uint32_t)ind, 1u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const int geno = (u01(c[0]) < p) + (u01(c[1]) < p);
+    float cdf = cdf0, pm = cdf0;              // Poisson by inversion
+    const float ud = u01(c[2]);
+    int d = 0;
+    while (ud > cdf && d < 15) { ++d; pm *= lam / (float)d; cdf += pm; }
+    const float qalt = geno == 0 ? 0.01f : (geno == 1 ? 0.5f : 0.99f);
+    // up to 15 read draws from the remaining 32 + 3*32 random bits: 8 bits each
+    uint32_t bits[4] = {c[3], c[0] ^ 0x9E3779B9u, c[1] ^ 0xBB67AE85u, c[2] ^ 0x85EBCA6Bu};
+    int alt = 0;
+    for (int r = 0; r < d; ++r) {
+        const uint32_t w = bits[r >> 2] >> ((r & 3) * 8);
+        alt += ((float)(w & 0xFF) + 0.5f) * (1.0f / 256.0f) < qalt;
+    }
+    const int ref = d - alt;
+    const double e1 = 0.01, e0 = 0.99;
+    double l0 = 1.0, l1 = 1.0, l2 = 1.0;
+    for (int r = 0; r < ref; ++r) { l0 *= e0; l2 *= e1; }
+    for (int r = 0; r < alt; ++r) { l0 *= e1; l2 *= e0; }
+    for (int r = 0; r < d; ++r) l1 *= 0.5;
+    const double tot = l0 + l1 + l2;
+    return make_float2((float)(rint(l0 / tot * 1e6) / 1e6), (float)(rint(l1 / tot * 1e6) / 1e6));
+}
+
+// One thread per slab float4 = (tile, pair, lane): both individuals of the pair for one SNP.
+// Writes are one contiguous 1 KiB per wave.  SNPs beyond m (last tile) get zeros.
+__global__ void synth_kernel(float4 *__restrict__ slab, int64_t m, int npairs, int ncols, const int32_t *__restrict__ members,
                              int group, int64_t site0, uint64_t seed, float depth)
 {
-    const int64_t total = m * ncols;
+    const int64_t total = ((m + 63) / 64) * npairs * 64;
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const float lam = depth;
+    const float cdf0 = expf(-depth);
     for (; e < total; e += stride) {
-        const int64_t s = e / ncols;
-        const int col = (int)(e - s * ncols);
-        const int64_t gsnp = site0 + s;
-        const int ind = members[col];
-        const float p = pop_freq(seed, gsnp, group);
-        uint32_t c[4] = {(uint32_t)gsnp, (uint32_t)(gsnp >> 32), (uint32_t)ind, 1u};
-        philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        const int geno = (u01(c[0]) < p) + (u01(c[1]) < p);
-        // Poisson by inversion
-        float cdf = expf(-lam), pm = cdf;
-        const float ud = u01(c[2]);
-        int d = 0;
-        while (ud > cdf && d < 15) { ++d; pm *= lam / (float)d; cdf += pm; }
-        const float qalt = geno == 0 ? 0.01f : (geno == 1 ? 0.5f : 0.99f);
-        int alt = 0;
-        uint32_t bits[4] = {(uint32_t)gsnp, (uint32_t)(gsnp >> 32), (uint32_t)ind, 2u};
-        philox4x32_10(bits, (uint32_t)seed, (uint32_t)(seed >> 32));
-        for (int r = 0; r < d; ++r) {
-            const uint32_t w = bits[r >> 2] >> ((r & 3) * 8);
-            alt += ((float)(w & 0xFF) + 0.5f) * (1.0f / 256.0f) < qalt;
+        const int lane = (int)(e & 63);
+        const int64_t tp = e >> 6;
+        const int64_t t = tp / npairs;
+        const int pr = (int)(tp - t * npairs);
+        const int64_t s = t * 64 + lane;
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s < m) {
+            const int64_t gsnp = site0 + s;
+            const float p = pop_freq(seed, gsnp, group);
+            const float2 a = synth_gl(seed, gsnp, members[2 * pr], p, depth, cdf0);
+            float2 b = make_float2(0.f, 0.f);
+            if (2 * pr + 1 < ncols) b = synth_gl(seed, gsnp, members[2 * pr + 1], p, depth, cdf0);
+            out = make_float4(a.x, a.y, b.x, b.y);
         }
-        const int ref = d - alt;
-        const double e1 = 0.01, e0 = 0.99;
-        double l0 = 1.0, l1 = 1.0, l2 = 1.0;
-        for (int r = 0; r < ref; ++r) { l0 *= e0; l2 *= e1; }
-        for (int r = 0; r < alt; ++r) { l0 *= e1; l2 *= e0; }
-        for (int r = 0; r < d; ++r) l1 *= 0.5;
-        const double tot = l0 + l1 + l2;
-        const double g0 = rint(l0 / tot * 1e6) / 1e6, g1 = rint(l1 / tot * 1e6) / 1e6;
-        slab[s * ld + col] = make_float2((float)g0, (float)g1);
+        slab[e] = out;
     }
 }
 
@@ -143,7 +164,7 @@ int launch_scatter_rows(wgs_beagle *b, const float *d_rows, int64_t row0, int64_
     if (nrows <= 0) return 0;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(nrows * b->n)), dim3(256), 0, b->ctx->stream,
                        reinterpret_cast<const float2 *>(d_rows), nrows, b->n, row0, b->d_group_of, b->d_col_of,
-                       b->d_base, b->d_ld);
+                       b->d_base, b->d_npairs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -153,7 +174,7 @@ int launch_gather_rows(wgs_beagle *b, float *d_rows, int64_t row0, int64_t nrows
     if (nrows <= 0) return 0;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(nrows * b->n)), dim3(256), 0, b->ctx->stream,
                        reinterpret_cast<float2 *>(d_rows), nrows, b->n, row0, b->d_group_of, b->d_col_of, b->d_base,
-                       b->d_ld);
+                       b->d_npairs);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -163,15 +184,11 @@ int launch_synth(wgs_beagle *b, uint64_t seed, double depth)
     for (int g = 0; g < b->n_groups; ++g) {
         Slab &sl = b->slabs[g];
         if (sl.ncols == 0) continue;
-        int32_t *d_members = nullptr;
-        HIP_TRY(hipMalloc(&d_members, sizeof(int32_t) * sl.ncols));
-        HIP_TRY(hipMemcpyAsync(d_members, sl.members.data(), sizeof(int32_t) * sl.ncols, hipMemcpyHostToDevice, b->ctx->stream));
-        hipLaunchKernelGGL(synth_kernel, dim3(grid_for(b->m * sl.ncols)), dim3(256), 0, b->ctx->stream, sl.base, b->m,
-                           sl.ld, sl.ncols, d_members, g, b->site0, seed, (float)depth);
+        hipLaunchKernelGGL(synth_kernel, dim3(grid_for(wgs_ntiles(b->m) * sl.npairs * 64)), dim3(256), 0, b->ctx->stream,
+                           sl.base, b->m, sl.npairs, sl.ncols, sl.d_members, g, b->site0, seed, (float)depth);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-        HIP_TRY(hipFree(d_members));
     }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     return 0;
 }
 

@@ -34,13 +34,19 @@ struct wgs_ctx {
     int cus = 0;
 };
 
-// One population slab: SNP-major (g0,g1) pairs of the individuals of one group, file order.
+// One population slab: the (g0,g1) pairs of the individuals of one group (file order), stored
+// TILE-INTERLEAVED for lane<->SNP kernels:
+//     base[(tile * npairs + pair) * 64 + lane] = float4{g0,g1 of individual 2*pair, g0,g1 of 2*pair+1}
+// for SNP 64*tile + lane.  One wave-wide 16-byte load is one aligned, contiguous 1 KiB; a tile
+// (64 SNPs x all individuals of the group) is one contiguous npairs KiB block.
 struct Slab {
-    float2 *base = nullptr;  // m rows x ld float2
-    int32_t ld = 0;          // row stride in float2 (even, so rows are 16-byte aligned)
-    int32_t ncols = 0;       // valid columns
+    float4 *base = nullptr;
+    int32_t npairs = 0;      // ceil(ncols / 2)
+    int32_t ncols = 0;       // individuals in the group
     std::vector<int32_t> members;  // column -> global individual index
+    int32_t *d_members = nullptr;
 };
+static inline int64_t wgs_ntiles(int64_t m) { return (m + 63) / 64; }
 
 struct wgs_beagle {
     wgs_ctx *ctx = nullptr;
@@ -49,8 +55,8 @@ struct wgs_beagle {
     std::vector<Slab> slabs;
     std::vector<int32_t> group_of, col_of;  // per individual
     // device-side lookup tables for the scatter/gather/synth kernels
-    int32_t *d_group_of = nullptr, *d_col_of = nullptr, *d_ld = nullptr;
-    float2 **d_base = nullptr;
+    int32_t *d_group_of = nullptr, *d_col_of = nullptr, *d_npairs = nullptr;
+    float4 **d_base = nullptr;
     int64_t bytes = 0;
 };
 
@@ -64,29 +70,31 @@ struct wgs_afset {
 // ---- kernel launchers implemented in the .hip files (all asynchronous on ctx->stream)
 
 struct FitDesc {       // one EM fit as the sweep kernel sees it
-    const float2 *slab;
+    const float4 *slab;
     const float *f_old;
     float *f_new;
-    double *ssq;       // += sum over SNPs of (f_new - f_old)^2
-    int32_t ld, ncols;
+    double *ssq;       // = sum over SNPs of (f_new - f_old)^2 (written by the reduce kernel)
+    double *ssq_part;  // per-tile partial sums of this fit [ntiles]
+    int32_t npairs, ncols;
     int32_t skip;      // local column left out (LOO) or -1
     int32_t n_eff;     // ncols - (skip >= 0)
 };
 
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
+int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m);
 int launch_fill(wgs_ctx *ctx, float *p, int64_t count, float v);
 int launch_clamp(wgs_ctx *ctx, float *p, int64_t count, float lo, float hi);
 int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out);
 
 struct AssignArgs {
-    const float2 *slab;
+    const float4 *slab;
     const int32_t *members;        // device: slab column -> global individual
     const float *const *colptr;    // device: [n*K] per-(individual,k) vectors, or nullptr
     const float *const *acol;      // device: [K] shared vectors
     double *out;                   // device: [(n*P) * K]
     int64_t m, site0;
-    int32_t ld, ncols, K, P;
-    int32_t rows_per_wave;
+    int32_t npairs, ncols, K, P;
+    int32_t tiles_per_wave;
 };
 int launch_assign(wgs_ctx *ctx, const AssignArgs &a, int mode);
 int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode);
