@@ -126,6 +126,8 @@ def main():
                 "kernel": "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_snp": 8 * n + 8 * K}
 
+    roofline["traffic"], roofline["traffic_source"] = pmc_traffic(m, n, K, args.mode)
+
     extra = {"gl_pair_terms_per_s": value * n_call, "synth_seconds": round(t_gen, 2),
              "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
 
@@ -173,6 +175,25 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(m, n, K, mode):
+    """HBM bytes per EM-sweep launch from the committed rocprofv3 PMC passes of this workload
+    (profiles/*/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction applied);
+    None when no committed measurement matches the workload being run."""
+    import glob
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("bench_config") != {"snps_per_gpu": m, "n": n, "K": K, "mode": mode}:
+            continue
+        for k, e in d.get("kernels", {}).items():
+            if "em_sweep_kernel" in k and "traffic_bytes_per_launch" in e:
+                best = (e["traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+    return best
 
 
 def cpu_baseline(beagle, group_of, K, ms):

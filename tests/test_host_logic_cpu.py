@@ -1,0 +1,183 @@
+"""CPU-only tests of the product's host logic: the EM driver loop (single rank and two gloo
+ranks), shard ranges, utils, reader, CLI argument handling.  The arithmetic primitives are
+stood in for by the oracle (tests/cpu_standin.py); everything else is product code."""
+import io
+import contextlib
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import GOLDEN, ROOT
+from cpu_standin import OracleEMBatch
+
+DATA = os.path.join(GOLDEN, "data")
+
+
+def test_cumsum_standin_is_the_serial_chain(oracle):
+    rng = np.random.Generator(np.random.PCG64(1))
+    a = rng.random(50_000, dtype=np.float32)
+    b = (a + rng.normal(0, 1e-4, 50_000).astype(np.float32)).astype(np.float32)
+    em = OracleEMBatch(oracle, np.zeros((50_000, 2), np.float32), [np.array([0])])
+    em.f[0], em.f_prev[0] = a, b
+    from wgsassign_amd.device import chain_diff
+    assert chain_diff(em.rmse_chain(0, 0.0), 50_000) == oracle.rmse1d(a, b)
+    # split in two shards: carry hand-off reproduces the unsplit chain bit for bit
+    em1 = OracleEMBatch(oracle, np.zeros((20_000, 2), np.float32), [np.array([0])])
+    em2 = OracleEMBatch(oracle, np.zeros((30_000, 2), np.float32), [np.array([0])])
+    em1.f[0], em1.f_prev[0] = a[:20_000], b[:20_000]
+    em2.f[0], em2.f_prev[0] = a[20_000:], b[20_000:]
+    assert em2.rmse_chain(0, em1.rmse_chain(0, 0.0)) == em.rmse_chain(0, 0.0)
+
+
+def test_decide_converged():
+    from wgsassign_amd.device import decide_converged
+    m, tole = 1000, 1e-4
+    th = tole * tole * m
+    assert decide_converged(th * 0.5, m, tole, 0.25) == 1
+    assert decide_converged(th * 2.0, m, tole, 0.25) == -1
+    assert decide_converged(th * 1.1, m, tole, 0.25) == 0 and decide_converged(th * 0.9, m, tole, 0.25) == 0
+    assert decide_converged(float("nan"), m, tole, 0.25) == -1          # NaN < tole is False (emMAF.py:23)
+    assert decide_converged(0.0, m, 0.0, 0.25) == -1                     # diff < 0 never holds
+
+
+@pytest.mark.parametrize("guard", [0.25, 1e9])
+def test_run_em_single_rank_matches_reference_iterations(oracle, golden, guard):
+    """The driver loop stops every population at the reference's iteration (17/14/16/14/13) with
+    bit-identical frequencies -- with the default guard band and with the exact chain forced on
+    every iteration (guard = inf)."""
+    from wgsassign_amd.device import run_em
+    g = golden("amre_fit.npz")
+    pops = np.unique(g["IDs"][:, 1])
+    groups = [np.flatnonzero(g["IDs"][:, 1] == p) for p in pops]
+    em = OracleEMBatch(oracle, g["L"], groups, guard=guard)
+    iters = run_em(em, 200, 1e-4, m_total=g["L"].shape[0])
+    assert list(iters) == list(g["iters"])
+    for k in range(len(pops)):
+        assert em.f[k].tobytes() == g["f_raw"][k].tobytes()
+    if guard > 1:
+        assert em.chain_calls == int(np.sum(g["iters"]))
+
+
+def test_run_em_exhausted_and_nan(oracle, golden):
+    from wgsassign_amd.device import run_em
+    g = golden("edge.npz")
+    L = g["mixed_L"]
+    em = OracleEMBatch(oracle, L, [np.arange(L.shape[1] // 2)])
+    assert list(run_em(em, 3, 1e-12, m_total=L.shape[0])) == [0]
+    assert em.f[0].tobytes() == g["exhaust_f"].tobytes()
+    # a population of size 0 (LOO of a singleton): NaN forever, runs all iterations
+    em = OracleEMBatch(oracle, L, [np.array([], dtype=np.int64)])
+    with np.errstate(all="ignore"):
+        assert list(run_em(em, 7, 1e-4, m_total=L.shape[0])) == [0]
+    assert np.isnan(em.f[0]).all()
+
+
+def test_shard_range_covers_everything():
+    from wgsassign_amd.comm import shard_range
+    for m in (1, 7, 449, 10_000_000):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(m, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == m
+            assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+from oracle import oracle as orc
+from cpu_standin import OracleEMBatch
+from wgsassign_amd.comm import TorchComm, shard_range
+from wgsassign_amd.device import run_em
+g = np.load(os.path.join({root!r}, "tests", "golden", "amre_fit.npz"))
+L, IDs = g["L"], g["IDs"]
+comm = TorchComm()
+lo, hi = shard_range(L.shape[0], comm.rank, comm.world)
+pops = np.unique(IDs[:, 1])
+groups = [np.flatnonzero(IDs[:, 1] == p) for p in pops]
+guard = float(sys.argv[2])
+em = OracleEMBatch(orc, np.ascontiguousarray(L[lo:hi]), groups, guard=guard)
+iters = run_em(em, 200, 1e-4, comm=comm, m_total=L.shape[0])
+ok = list(iters) == list(g["iters"])
+for k in range(len(pops)):
+    ok = ok and em.f[k].tobytes() == g["f_raw"][k][lo:hi].tobytes()
+print("RANK", comm.rank, "OK" if ok else "FAIL", list(iters), em.chain_calls, flush=True)
+dist.barrier(); dist.destroy_process_group()
+sys.exit(0 if ok else 1)
+'''
+
+
+@pytest.mark.parametrize("guard", [0.25, 1e9])
+def test_run_em_two_gloo_ranks_snp_sharded(tmp_path, guard):
+    """world_size 2 over gloo: SNPs sharded in two contiguous ranges; the all-reduced sums and the
+    rank-to-rank carry of the serial float32 chain give the single-process iterations and
+    frequencies on both ranks."""
+    port = 29500 + (os.getpid() % 2000) + (1 if guard > 1 else 0)
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, port=port))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(guard)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-2000:])
+        assert "RANK %d OK" % r in o
+
+
+def test_utils_and_reader(golden):
+    from wgsassign_amd import reader_cy, utils
+    g = golden("amre_fit.npz")
+    L, samples, sites = reader_cy.readBeagle(os.path.join(DATA, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"))
+    assert L.tobytes() == g["L"].tobytes() and samples == list(g["samples"]) and sites == list(g["sites"])
+    lo = golden("amre_loo.npz")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        Lf, names = utils.filter_sites_to_common(L, sites, list(lo["sites_ds"]))
+    assert buf.getvalue() == str(lo["filter_text"]) and Lf.shape[0] == 357
+    assert utils.site_mask(sites, list(lo["sites_ds"])).tobytes() == lo["mask"].tobytes()
+    v = np.arange(10, dtype=np.float32)
+    assert list(utils.partition_loglikes(v, 3)) == [18.0, 12.0, 15.0]
+    with pytest.raises(ValueError):
+        utils.partition_loglikes(np.zeros((2, 2), np.float32), 2)
+
+
+def test_write_ass_mats_matches_reference_text(golden, tmp_path):
+    from wgsassign_amd import utils
+    cli, fit, loo = golden("amre_cli.npz"), golden("amre_fit.npz"), golden("amre_loo.npz")
+    out = tmp_path / "x.tsv"
+    with contextlib.redirect_stdout(io.StringIO()):
+        utils.write_ass_mats(str(out), loo["loo_P1"], list(fit["samples"]), fit["pops"], print_part_column=False,
+                             sample_locations=fit["IDs"][:, 1], doing_LOO=True)
+    assert out.read_text() == str(cli["loo_tsv"])
+    outz = tmp_path / "p.tsv.gz"
+    with contextlib.redirect_stdout(io.StringIO()):
+        utils.write_ass_mats(str(outz), loo["parts_P3"], list(fit["samples"]), fit["pops"], partition_count=3,
+                             print_part_column=True, sample_locations=fit["IDs"][:, 1], doing_LOO=True)
+    import gzip
+    assert gzip.open(outz, "rt").read() == str(cli["parts_tsv"])
+    with pytest.raises(ValueError, match="shape mismatch"):
+        utils.write_ass_mats(str(out), loo["loo_P1"][:3], list(fit["samples"]), fit["pops"])
+
+
+def test_cli_flags_and_refusals(tmp_path):
+    from wgsassign_amd import WGSassign
+    a = WGSassign.parser.parse_args([])
+    assert (a.threads, a.out, a.maf_iter, a.maf_tole, a.partition_sites) == (1, "wgsassign", 200, 1e-4, 1)
+    with pytest.raises(ValueError, match="requires that --loo"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            WGSassign.main(["--loo_downsampled_beagle", "x.gz", "--out", str(tmp_path / "o")])
+    with pytest.raises(SystemExit, match="outside the scope"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            WGSassign.main(["--ne_obs", "--out", str(tmp_path / "o")])
+    # the .args log lists non-default options only (WGSassign.py:127-141)
+    with contextlib.redirect_stdout(io.StringIO()):
+        WGSassign.main(["--threads", "3", "--out", str(tmp_path / "log")])
+    txt = (tmp_path / "log.args").read_text()
+    assert txt.startswith("WGSassign\nTime: ") and "\t-threads 3\n" in txt and "maf_iter" not in txt

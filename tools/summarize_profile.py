@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Collect rocprofv3 outputs (gpurun_out/<prefix>_{kt,fetch,write,sq}) into profiles/<name>/.
+
+    python tools/summarize_profile.py p2 r01_v2_interleaved "10000000x1000xK10 exact"
+
+Writes kernel_stats.csv (copy of rocprofv3 --stats), pmc_summary.json (per-kernel means of every
+counter collected, plus traffic = (2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch: FETCH_SIZE
+is in KiB and on gfx950 reports half of a wide coalesced read stream -- MI355X_MICROARCH.md, HBM).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    prefix, name, config = sys.argv[1], sys.argv[2], sys.argv[3]
+    out = os.path.join(ROOT, "profiles", name)
+    os.makedirs(out, exist_ok=True)
+    kt = glob.glob(os.path.join(ROOT, "gpurun_out", prefix + "_kt", "*", "*_kernel_stats.csv"))
+    if kt:
+        shutil.copy(kt[0], os.path.join(out, "kernel_stats.csv"))
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))
+    for sub in ("fetch", "write", "sq"):
+        for f in glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (prefix, sub), "*", "*_counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                k = r["Kernel_Name"]
+                if "em_sweep" in k or "assign_kernel" in k or "ssq_reduce" in k or "rmse" in k:
+                    counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summary = {"config": config, "kernels": {}}
+    if len(sys.argv) > 4:   # m_per_gpu n K mode, so bench.py can match its workload to this measurement
+        summary["bench_config"] = {"snps_per_gpu": int(sys.argv[4]), "n": int(sys.argv[5]), "K": int(sys.argv[6]), "mode": sys.argv[7]}
+    for k, cs in counters.items():
+        e = {c: {"dispatches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()}
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            e["traffic_bytes_per_launch"] = (2 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024
+        summary["kernels"][k] = e
+    json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
+    print(json.dumps(summary, indent=1)[:3000])
+
+
+if __name__ == "__main__":
+    main()
