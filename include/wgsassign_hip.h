@@ -149,6 +149,12 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
                double *out, double *parts);
 
+/* Test hooks for the assignment kernel's double-precision log of float32 arguments
+ * (csrc/assign_kernels.hip: log_f32arg): number of float32 bit patterns in [b0, b1) whose
+ * float32-rounded log differs from the device math library's, and the values themselves. */
+int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first);
+int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, int use_libm);
+
 /* Summed kernel time (HIP events on the context's stream) of the calling thread's last wgs_assign. */
 int wgs_assign_last_ms(float *ms);
 

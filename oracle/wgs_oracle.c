@@ -99,6 +99,14 @@ int orc_emmaf(const float *L, int64_t m, int64_t n, int iter, double tole, float
     return 0;
 }
 
+/* glassy_cy.pyx:21 for a zero-initialised vector: (float)log((double)x), libm's double log. */
+void orc_log_f32(const float *x, float *out, int64_t n, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = (float)log((double)x[i]);
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

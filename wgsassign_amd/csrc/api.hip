@@ -614,6 +614,52 @@ done:
 #undef TRY_GOTO
 }
 
+/* ------------------------------------------------------------------ test hooks */
+
+int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first)
+{
+    WGS_REQUIRE(ctx && count && first, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long *d_count = nullptr;
+    unsigned int *d_first = nullptr;
+    HIP_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&d_first, sizeof(unsigned int)));
+    HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_first, 0xFF, sizeof(unsigned int), ctx->stream));
+    int rc = launch_log_mismatch(ctx, b0, b1, d_count, d_first);
+    unsigned long long c = 0;
+    unsigned int f = 0;
+    if (!rc && (hipMemcpyAsync(&c, d_count, sizeof c, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(&f, d_first, sizeof f, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+        wgs_set_error("log self-test failed on the device");
+        rc = 1;
+    }
+    (void)hipFree(d_count);
+    (void)hipFree(d_first);
+    *count = c;
+    *first = f;
+    return rc;
+}
+
+int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, int use_libm)
+{
+    WGS_REQUIRE(ctx && x && out && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(float) * 2 * (size_t)n));
+    int rc = 0;
+    if (hipMemcpyAsync(d, x, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
+    if (!rc) rc = launch_log_values(ctx, d, d + n, n, use_libm);
+    if (!rc && (hipMemcpyAsync(out, d + n, sizeof(float) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = 1;
+    (void)hipFree(d);
+    if (rc) wgs_set_error("log values: device operation failed");
+    return rc;
+}
+
 /* ------------------------------------------------------------------ thin mirrors */
 
 int wgs_emmaf_update(wgs_ctx *ctx, const float *L, int64_t m, int64_t n, float *f, int mode)

@@ -12,19 +12,70 @@
 //   per-SNP frequency of population k is a broadcast load, or a per-lane vector when a
 //   per-individual column table is given (leave-one-out).
 #include "common.h"
+#include "log_table.h"
 
 namespace {
 
+// ---- double-precision log of a float32 argument -------------------------------------------
+// The reference calls libm's double log on (double)(float) values and stores the result as
+// float32 (glassy_cy.pyx:21).  A general double log (ocml: ~80 VALU instructions, double-double
+// arithmetic) bounds the assignment kernel; this one exploits that the argument has only 24
+// significant bits: table-driven range reduction with an EXACT reduced argument, degree-8
+// Taylor polynomial, compensated reconstruction -- 16 float64 instructions, error < 1 ulp of
+// double, i.e. the float32-rounded result differs from a correctly rounded log's only when the
+// true value lies within ~2^-29 relative of a float32 rounding boundary (tests/test_gpu_log.py
+// counts the cases exhaustively over every positive float32).
+__device__ double2 wgs_log_table_dev[WGS_LOG_N];
+
+__device__ __forceinline__ double log_f32arg(double x, const double2 *tab)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    const unsigned int hi = (unsigned int)(bits >> 32), lo = (unsigned int)bits;
+    const unsigned int tmp = hi - WGS_LOG_OFF;
+    const int k = (int)tmp >> 20;                          // x = z * 2^k, z in [0.6875, 1.375)
+    const unsigned int i = (tmp >> 13) & (WGS_LOG_N - 1);
+    const double z = __hiloint2double((int)(hi - (tmp & 0xFFF00000u)), (int)lo);
+    const double2 t = tab[i];                              // {invc, logc}
+    const double r = __builtin_fma(z, t.x, -1.0);          // exact
+    const double kd = (double)k;
+    const double w = __builtin_fma(kd, WGS_LN2HI, t.y);    // kd*Ln2hi is exact
+    const double hi_ = w + r;
+    const double lo_ = __builtin_fma(kd, WGS_LN2LO, (w - hi_) + r);
+    double q = __builtin_fma(r, -0.125, 1.0 / 7.0);        // log1p(r) = r + r^2 * q(r)
+    q = __builtin_fma(r, q, -1.0 / 6.0);
+    q = __builtin_fma(r, q, 0.2);
+    q = __builtin_fma(r, q, -0.25);
+    q = __builtin_fma(r, q, 1.0 / 3.0);
+    q = __builtin_fma(r, q, -0.5);
+    return __builtin_fma(r * r, q, lo_) + hi_;
+}
+
+// (float)log((double)s) for any float32 s, including the special values libm defines.
+__device__ __forceinline__ float logf_of_f32(float s, const double2 *tab)
+{
+    float v = (float)log_f32arg((double)s, tab);
+    v = s == 0.0f ? -__builtin_inff() : v;                 // log(+-0) = -inf
+    v = s == __builtin_inff() ? s : v;                     // log(+inf) = +inf
+    v = !(s >= 0.0f) ? __builtin_nanf("") : v;             // log(negative), log(NaN) = NaN
+    return v;
+}
+
+__device__ __forceinline__ void load_log_table(double2 *tab)
+{
+    for (int i = threadIdx.x; i < WGS_LOG_N; i += blockDim.x) tab[i] = wgs_log_table_dev[i];
+    __syncthreads();
+}
+
 // glassy_cy.pyx:18-21 for one (SNP, individual, population), exact rounding sequence; returns
 // the float32 the reference stores into loglike_vec[s] (which starts at 0.0f, glassy.py:34).
-__device__ __forceinline__ float site_ll_exact(double g0d, double g1d, double g2d, float a)
+__device__ __forceinline__ float site_ll_exact(double g0d, double g1d, double g2d, float a, const double2 *tab)
 {
     const double ad = (double)a;
     const double oma = 1.0 - ad;
     const float like0 = (float)((g0d * oma) * oma);
     const float like1 = (float)(((g1d * 2.0) * oma) * ad);
     const float like2 = (float)((g2d * ad) * ad);
-    return (float)log((double)((like0 + like1) + like2));
+    return logf_of_f32((like0 + like1) + like2, tab);
 }
 
 __device__ __forceinline__ float site_ll_fast(float g0, float g1, float g2, float a)
@@ -41,6 +92,8 @@ typedef const float __attribute__((address_space(1))) *gf32_ptr;
 template <int KB, int MODE>
 __global__ __launch_bounds__(256) void assign_kernel(AssignArgs A)
 {
+    __shared__ double2 tab[WGS_LOG_N];
+    load_log_table(tab);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pair = blockIdx.y * 64 + lane;
     const bool valid_a = 2 * pair < A.ncols, valid_b = 2 * pair + 1 < A.ncols;
@@ -81,8 +134,8 @@ __global__ __launch_bounds__(256) void assign_kernel(AssignArgs A)
                         const float fa = pa[j][s], fb = pb[j][s];
                         float va, vb;
                         if (MODE == WGS_MODE_EXACT) {
-                            va = site_ll_exact(a0, a1, a2, fa);
-                            vb = site_ll_exact(b0, b1, b2, fb);
+                            va = site_ll_exact(a0, a1, a2, fa, tab);
+                            vb = site_ll_exact(b0, b1, b2, fb, tab);
                         } else {
                             va = site_ll_fast(g.x, g.y, (1.0f - g.x) - g.y, fa);
                             vb = site_ll_fast(g.z, g.w, (1.0f - g.z) - g.w, fb);
@@ -110,6 +163,8 @@ __global__ __launch_bounds__(256) void assign_kernel(AssignArgs A)
 template <int MODE>
 __global__ void loglike_site_kernel(const float2 *__restrict__ g, const float *__restrict__ a, float *vec, int64_t m)
 {
+    __shared__ double2 tab[WGS_LOG_N];
+    load_log_table(tab);
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; s < m; s += stride) {
@@ -121,11 +176,45 @@ __global__ void loglike_site_kernel(const float2 *__restrict__ g, const float *_
             const float like0 = (float)((g0d * oma) * oma);
             const float like1 = (float)(((g1d * 2.0) * oma) * ad);
             const float like2 = (float)((((1.0 - g0d) - g1d) * ad) * ad);
-            vec[s] = (float)((double)vec[s] + log((double)((like0 + like1) + like2)));
+            // vec + log(.) in double, then float32 (glassy_cy.pyx:21); the log itself is needed to
+            // double precision here because vec[s] may be non-zero (accumulate-into semantics)
+            const float sum = (like0 + like1) + like2;
+            double l = log_f32arg((double)sum, tab);
+            l = sum == 0.0f ? -(double)__builtin_inff() : l;
+            l = sum == __builtin_inff() ? (double)sum : l;
+            l = !(sum >= 0.0f) ? (double)__builtin_nanf("") : l;
+            vec[s] = (float)((double)vec[s] + l);
         } else {
             vec[s] = vec[s] + site_ll_fast(gg.x, gg.y, (1.0f - gg.x) - gg.y, av);
         }
     }
+}
+
+// Test hooks: the float32-rounded log of every float32 in a bit-pattern range, custom vs ocml.
+__global__ void log_mismatch_kernel(unsigned int b0, unsigned int b1, unsigned long long *count, unsigned int *first)
+{
+    __shared__ double2 tab[WGS_LOG_N];
+    load_log_table(tab);
+    unsigned long long local = 0;
+    for (unsigned long long b = (unsigned long long)b0 + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; b < b1;
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((unsigned int)b);
+        const float mine = logf_of_f32(x, tab);
+        const float ref = (float)log((double)x);
+        if (__float_as_uint(mine) != __float_as_uint(ref) && !(mine != mine && ref != ref)) {
+            ++local;
+            atomicMin(first, (unsigned int)b);
+        }
+    }
+    if (local) atomicAdd(count, local);
+}
+
+__global__ void log_values_kernel(const float *x, float *out, int64_t n, int use_libm)
+{
+    __shared__ double2 tab[WGS_LOG_N];
+    load_log_table(tab);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = use_libm ? (float)log((double)x[i]) : logf_of_f32(x[i], tab);
 }
 
 template <int KB>
@@ -141,8 +230,35 @@ int launch_assign_kb(wgs_ctx *ctx, const AssignArgs &a, int mode, dim3 grid)
 
 }  // namespace
 
+static int ensure_log_table(wgs_ctx *ctx)
+{
+    // one upload per process and device (the table lives in the code object's __device__ memory)
+    static thread_local int done_for = -1;
+    if (done_for == ctx->device) return 0;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wgs_log_table_dev), wgs_log_table_host, sizeof(double) * 2 * WGS_LOG_N));
+    done_for = ctx->device;
+    return 0;
+}
+
+int launch_log_mismatch(wgs_ctx *ctx, unsigned int b0, unsigned int b1, unsigned long long *d_count, unsigned int *d_first)
+{
+    if (ensure_log_table(ctx)) return 1;
+    hipLaunchKernelGGL(log_mismatch_kernel, dim3(4096), dim3(256), 0, ctx->stream, b0, b1, d_count, d_first);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_log_values(wgs_ctx *ctx, const float *d_x, float *d_out, int64_t n, int use_libm)
+{
+    if (ensure_log_table(ctx)) return 1;
+    hipLaunchKernelGGL(log_values_kernel, dim3(1024), dim3(256), 0, ctx->stream, d_x, d_out, n, use_libm);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
 {
+    if (ensure_log_table(ctx)) return 1;
     AssignArgs a = a_in;
     if (a.m <= 0 || a.ncols <= 0 || a.K <= 0) return 0;
     // Enough waves to fill 256 CUs several times over, but tile ranges long enough to amortise the
@@ -175,6 +291,7 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
 int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode)
 {
     if (m <= 0) return 0;
+    if (ensure_log_table(ctx)) return 1;
     int64_t blocks = (m + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (mode == WGS_MODE_EXACT)

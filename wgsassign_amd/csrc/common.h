@@ -97,6 +97,8 @@ struct AssignArgs {
     int32_t tiles_per_wave;
 };
 int launch_assign(wgs_ctx *ctx, const AssignArgs &a, int mode);
+int launch_log_mismatch(wgs_ctx *ctx, unsigned int b0, unsigned int b1, unsigned long long *d_count, unsigned int *d_first);
+int launch_log_values(wgs_ctx *ctx, const float *d_x, float *d_out, int64_t n, int use_libm);
 int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode);
 
 int launch_scatter_rows(wgs_beagle *b, const float *d_rows, int64_t row0, int64_t nrows);
