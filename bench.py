@@ -37,10 +37,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--m", type=int, default=10_000_000, help="total SNPs (sharded over ranks)")
-    ap.add_argument("--n", type=int, default=1000, help="individuals")
-    ap.add_argument("--K", type=int, default=10, help="populations")
-    ap.add_argument("--mode", default=os.environ.get("WGSASSIGN_MODE", "exact"), choices=["exact", "fast"])
+    ap.add_argument("--snps", dest="m", type=int, default=10_000_000, help="total SNPs (sharded over ranks)")
+    ap.add_argument("--inds", dest="n", type=int, default=1000, help="individuals")
+    ap.add_argument("--pops", dest="K", type=int, default=10, help="populations")
+    ap.add_argument("--arith", dest="mode", default=os.environ.get("WGSASSIGN_MODE", "exact"), choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-assign", action="store_true", help="skip the assignment sweep leg")
     ap.add_argument("--cpu-snps", type=int, default=200_000, help="SNP sample for the CPU baseline")
@@ -63,12 +63,14 @@ def main():
     mode = MODE_EXACT if args.mode == "exact" else MODE_FAST
 
     dist = torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("WGS_FORCE_DIST") == "1"   # WGS_FORCE_DIST: rehearse the RCCL path on 1 GPU
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = wcomm.TorchComm(device=torch.device("cuda", local_rank))
+        comm.force_device = True
     else:
         comm = wcomm.LocalComm()
 
@@ -89,16 +91,15 @@ def main():
 
     def barrier():
         ctx.sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         ctx.sync()
 
     def step():
-        ssq = em.step()                      # sweep kernel + readback of the K sums
-        if world > 1:
-            ssq = comm.allreduce_sum(ssq)    # RCCL all-reduce (convergence is decided on these)
-        return ssq
+        # sweep kernel -> (N > 1: RCCL all-reduce of the K sums, enqueued behind it) -> one readback:
+        # exactly what EMBatch.run does per EM iteration
+        return em.step_reduced(comm if use_dist else None)
 
     for _ in range(args.warmup):
         step()
@@ -110,7 +111,7 @@ def main():
         kernel_ms.append(em.last_sweep_ms())
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -140,10 +141,10 @@ def main():
         ctx.sync()
         barrier()
         t0 = time.perf_counter()
-        out, _ = device.assign(beagle, afs, mode=mode, comm=comm if world > 1 else None)
+        out, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
         barrier()
         t_as = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([t_as], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             t_as = float(t.item())
@@ -172,7 +173,7 @@ def main():
         print(json.dumps(line), flush=True)
     em.close()
     beagle.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

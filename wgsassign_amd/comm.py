@@ -35,6 +35,7 @@ class TorchComm:
         self._device = device
 
     def allreduce_sum(self, arr):
+        """Sum `arr` (float64) over all ranks; every rank gets identical bits."""
         torch, dist = self._torch, self._dist
         a = np.ascontiguousarray(arr, dtype=np.float64)
         t = torch.from_numpy(a.copy())
@@ -42,6 +43,24 @@ class TorchComm:
             t = t.to(self._device if self._device is not None else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.cpu().numpy().reshape(a.shape)
+
+    # ---- device-resident variant: the sums never visit the host before the collective
+    def device_buffer(self, n):
+        """A float64 CUDA tensor of n elements (its data_ptr() is handed to wgs_em_step_dev)."""
+        if not self._cuda:
+            return None
+        return self._torch.zeros(int(n), dtype=self._torch.float64,
+                                 device=self._device if self._device is not None else "cuda")
+
+    def allreduce_device(self, t, stream_ptr):
+        """RCCL all-reduce of tensor t, ordered after the work already enqueued on the library's
+        HIP stream `stream_ptr`; returns the reduced values as a NumPy array."""
+        torch, dist = self._torch, self._dist
+        ext = torch.cuda.ExternalStream(int(stream_ptr), device=t.device)
+        with torch.cuda.stream(ext):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            out = t.cpu()            # enqueued on the same stream, synchronises it
+        return out.numpy()
 
     def barrier(self):
         self._dist.barrier()

@@ -49,6 +49,10 @@ class Context:
     def sync(self):
         check(_lib.load().wgs_ctx_sync(self._h))
 
+    def stream_ptr(self):
+        """The context's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        return int(_lib.load().wgs_ctx_stream(self._h) or 0)
+
     def info(self):
         name = ctypes.create_string_buffer(256)
         cus = ctypes.c_int()
@@ -214,6 +218,20 @@ class EMBatch:
         check(_lib.load().wgs_em_step(self._h, f64p(ssq)))
         return ssq
 
+    def step_reduced(self, comm):
+        """step() followed by the sum over SNP shards.  With an RCCL communicator the per-fit sums
+        stay on the device: the sweep writes them into a device buffer (wgs_em_step_dev), the
+        all-reduce is enqueued behind it on the same stream, one readback ends the iteration."""
+        if comm is None or comm.world == 1 and not getattr(comm, "force_device", False):
+            return self.step()
+        buf = getattr(self, "_ssq_buf", None)
+        if buf is None and hasattr(comm, "device_buffer"):
+            buf = self._ssq_buf = comm.device_buffer(self.n_fits)
+        if buf is None:
+            return comm.allreduce_sum(self.step())
+        check(_lib.load().wgs_em_step_dev(self._h, ctypes.c_void_p(buf.data_ptr())))
+        return comm.allreduce_device(buf, self.b.ctx.stream_ptr())
+
     def last_sweep_ms(self):
         ms = ctypes.c_float()
         check(_lib.load().wgs_em_last_sweep_ms(self._h, ctypes.byref(ms)))
@@ -300,9 +318,12 @@ def run_em(em, max_iter, tole, comm=None, m_total=None):
     for it in range(1, int(max_iter) + 1):
         if not em.active.any():
             break
-        ssq = em.step()
-        if comm.world > 1:
-            ssq = comm.allreduce_sum(ssq)
+        if hasattr(em, "step_reduced"):
+            ssq = em.step_reduced(comm)
+        else:
+            ssq = em.step()
+            if comm.world > 1:
+                ssq = comm.allreduce_sum(ssq)
         undecided = []
         for j in np.flatnonzero(em.active):
             d = decide_converged(ssq[j], m_total, tole, em.GUARD)
