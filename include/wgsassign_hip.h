@@ -149,6 +149,14 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
                double *out, double *parts);
 
+/* Test hooks for the convergence chain: wgs_rmse1d's value through the literal one-lane serial
+ * kernel (serial != 0) or through the block-parallel exact emulation, reporting the number of
+ * 4096-element blocks that fell back to the serial loop; the same count for the last
+ * wgs_em_rmse_chain of an EM batch. */
+int wgs_debug_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out, int serial,
+                     int *serial_blocks);
+int wgs_em_last_chain_serial_blocks(wgs_em *em);
+
 /* Test hooks for the assignment kernel's double-precision log of float32 arguments
  * (csrc/assign_kernels.hip: log_f32arg): number of float32 bit patterns in [b0, b1) whose
  * float32-rounded log differs from the device math library's, and the values themselves. */

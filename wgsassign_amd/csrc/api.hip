@@ -249,8 +249,10 @@ struct wgs_em {
     FitDesc *h_descs = nullptr;           // pinned
     double *d_ssq = nullptr;
     double *d_part = nullptr;             // n_fits x ntiles per-tile partial sums
-    float *d_carry = nullptr;
+    float *d_carry = nullptr;             // [0] carry out, [1] (as int) serial-block count
+    void *d_chain_work = nullptr;
     std::vector<int32_t> last;            // fits swept by the last step
+    int last_chain_serial_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the sweep kernel(s) of the last step
 };
 
@@ -265,6 +267,7 @@ void wgs_em_destroy(wgs_em *em)
     if (em->d_ssq) (void)hipFree(em->d_ssq);
     if (em->d_part) (void)hipFree(em->d_part);
     if (em->d_carry) (void)hipFree(em->d_carry);
+    if (em->d_chain_work) (void)hipFree(em->d_chain_work);
     if (em->ev0) (void)hipEventDestroy(em->ev0);
     if (em->ev1) (void)hipEventDestroy(em->ev1);
     delete em;
@@ -317,7 +320,8 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     HIP_TRY(hipMalloc(&em->d_descs, sizeof(FitDesc) * n_fits));
     HIP_TRY(hipMalloc(&em->d_ssq, sizeof(double) * n_fits));
     HIP_TRY(hipMalloc(&em->d_part, sizeof(double) * (size_t)n_fits * wgs_ntiles(b->m)));
-    HIP_TRY(hipMalloc(&em->d_carry, sizeof(float)));
+    HIP_TRY(hipMalloc(&em->d_carry, 2 * sizeof(float)));
+    HIP_TRY(hipMalloc(&em->d_chain_work, rmse_chain_workspace_bytes(b->m)));
     HIP_TRY(hipEventCreate(&em->ev0));
     HIP_TRY(hipEventCreate(&em->ev1));
     HIP_TRY(hipHostMalloc(&em->h_descs, sizeof(FitDesc) * n_fits, hipHostMallocDefault));
@@ -391,11 +395,18 @@ int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out)
     WGS_REQUIRE(fit >= 0 && fit < em->n_fits, "fit index out of range");
     wgs_ctx *ctx = em->b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (launch_rmse_chain(ctx, em_f(em, fit, em->cur[fit]), em_f(em, fit, em->cur[fit] ^ 1), em->b->m, carry_in, em->d_carry)) return 1;
-    HIP_TRY(hipMemcpyAsync(carry_out, em->d_carry, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (launch_rmse_chain(ctx, em_f(em, fit, em->cur[fit]), em_f(em, fit, em->cur[fit] ^ 1), em->b->m, carry_in, em->d_carry,
+                          em->d_chain_work, reinterpret_cast<int *>(em->d_carry + 1)))
+        return 1;
+    float host[2];
+    HIP_TRY(hipMemcpyAsync(host, em->d_carry, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *carry_out = host[0];
+    memcpy(&em->last_chain_serial_blocks, &host[1], sizeof(int));
     return 0;
 }
+
+int wgs_em_last_chain_serial_blocks(wgs_em *em) { return em ? em->last_chain_serial_blocks : -1; }
 
 int wgs_em_last_sweep_ms(wgs_em *em, float *ms)
 {
@@ -685,7 +696,21 @@ int wgs_emmaf_update(wgs_ctx *ctx, const float *L, int64_t m, int64_t n, float *
     return rc;
 }
 
+static int rmse1d_impl(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out, int serial, int *serial_blocks);
+
 int wgs_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out)
+{
+    return rmse1d_impl(ctx, v1, v2, m, out, 0, nullptr);
+}
+
+/* Test hook: the same value through the literal one-lane serial kernel (serial != 0), or through
+ * the block-parallel exact chain reporting how many blocks fell back to the serial loop. */
+int wgs_debug_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out, int serial, int *serial_blocks)
+{
+    return rmse1d_impl(ctx, v1, v2, m, out, serial, serial_blocks);
+}
+
+static int rmse1d_impl(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out, int serial, int *serial_blocks)
 {
     WGS_REQUIRE(ctx && v1 && v2 && out, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -694,17 +719,25 @@ int wgs_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double
         return 0;
     }
     float *d = nullptr;
-    HIP_TRY(hipMalloc(&d, sizeof(float) * (2 * (size_t)m + 1)));
+    void *work = nullptr;
+    HIP_TRY(hipMalloc(&d, sizeof(float) * (2 * (size_t)m + 2)));
+    HIP_TRY(hipMalloc(&work, rmse_chain_workspace_bytes(m)));
     int rc = 0;
     float res = 0.0f;
+    int nser = 0;
     if (hipMemcpyAsync(d, v1, sizeof(float) * m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(d + m, v2, sizeof(float) * m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         rc = 1;
-    if (!rc) rc = launch_rmse_chain(ctx, d, d + m, m, 0.0f, d + 2 * m);
+    if (!rc && hipMemsetAsync(d + 2 * m, 0, 2 * sizeof(float), ctx->stream) != hipSuccess) rc = 1;
+    if (!rc) rc = serial ? launch_rmse_chain_serial(ctx, d, d + m, m, 0.0f, d + 2 * m)
+                         : launch_rmse_chain(ctx, d, d + m, m, 0.0f, d + 2 * m, work, reinterpret_cast<int *>(d + 2 * m + 1));
     if (!rc && (hipMemcpyAsync(&res, d + 2 * m, sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipMemcpyAsync(&nser, d + 2 * m + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess))
         rc = 1;
     (void)hipFree(d);
+    (void)hipFree(work);
+    if (serial_blocks) *serial_blocks = nser;
     if (rc) {
         wgs_set_error("rmse1d: device operation failed");
         return 1;

@@ -84,7 +84,10 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m);
 int launch_fill(wgs_ctx *ctx, float *p, int64_t count, float v);
 int launch_clamp(wgs_ctx *ctx, float *p, int64_t count, float lo, float hi);
-int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out);
+int launch_rmse_chain_serial(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out);
+size_t rmse_chain_workspace_bytes(int64_t m);
+int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out, void *work,
+                      int *d_serial);
 
 struct AssignArgs {
     const float4 *slab;

@@ -228,6 +228,202 @@ __global__ __launch_bounds__(64) void rmse_chain_kernel(const float *__restrict_
     if (lane == 0) *out = res;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Block-parallel EXACT emulation of the serial float32 chain  res = res + d_i  (emMAF_cy.pyx:31).
+//
+// While the running sum stays in one binade [2^e, 2^(e+1)) it is M * u with u = 2^(e-23) and
+// M an integer in [2^23, 2^24); adding d_i >= 0 and rounding to nearest-even adds the INTEGER
+// r_i = RN(d_i / u) to M, and r_i does not depend on M except at exact ties (d_i/u = q + 1/2),
+// where the parity of M + q decides.  So a block of elements acts on the chain as a function of
+// the incoming parity only: p -> Delta_p, and such functions compose associatively
+// ((A then B)(p) = A_p + B_{(p + A_p) & 1}) -- a parallel reduction.  The incoming binade is
+// predicted from float64 prefix sums (the serial sum deviates from the exact one by a few per
+// cent at most, so candidates e-1, e, e+1 cover it); a single wave then walks the blocks,
+// applying Delta when the prediction holds and M + Delta stays below 2^24, and otherwise redoing
+// that one block with the literal serial loop (binade crossings, the first blocks, NaN/Inf).
+constexpr int RB = 4096;                       // elements per block
+constexpr long long RSAT = 1ll << 40;          // "does not fit": forces the serial fallback
+
+__device__ __forceinline__ float sqdiff(const float *a, const float *b, int64_t i)
+{
+    const float d = a[i] - b[i];               // emMAF_cy.pyx:31, float32 sub and mul
+    return d * d;
+}
+
+__global__ __launch_bounds__(256) void rmse_block_sum_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t m,
+                                                            double *__restrict__ S)
+{
+    __shared__ double red[256];
+    const int64_t base = (int64_t)blockIdx.x * RB;
+    double acc = 0.0;
+    for (int k = 0; k < RB / 256; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < m) acc += (double)sqdiff(a, b, i);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) S[blockIdx.x] = red[0];
+}
+
+// expo[b] = biased float32 exponent predicted for the running sum at the start of block b
+// (0: unknown -> serial; -1: the block adds only zeros -> the sum passes through unchanged).
+__global__ __launch_bounds__(1024) void rmse_predict_kernel(const double *__restrict__ S, int nblocks, float carry, int *__restrict__ expo)
+{
+    __shared__ double part[1024];
+    const int per = (nblocks + 1023) / 1024;
+    const int b0 = threadIdx.x * per;
+    double acc = 0.0;
+    for (int j = 0; j < per; ++j) {
+        const int b = b0 + j;
+        if (b < nblocks) acc += S[b];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {                    // 1024-entry exclusive scan, serial: ~1024 adds
+        double run = (double)carry;
+        for (int t = 0; t < 1024; ++t) {
+            const double v = part[t];
+            part[t] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double run = part[threadIdx.x];
+    for (int j = 0; j < per; ++j) {
+        const int b = b0 + j;
+        if (b >= nblocks) break;
+        const double sb = S[b];
+        int e = 0;
+        if (sb == 0.0) {
+            e = -1;
+        } else if (run == run && sb == sb) {
+            const unsigned int bits = __float_as_uint((float)run);
+            e = (int)((bits >> 23) & 0xFF);
+            if (e == 255) e = 0;
+        }
+        expo[b] = e;
+        run += sb;
+    }
+}
+
+// r(p) for one element d (float32 bits, d >= 0) on the grid of biased exponent be.
+__device__ __forceinline__ void chain_step(unsigned int dbits, int be, long long &D0, long long &D1)
+{
+    const int bd_raw = (int)((dbits >> 23) & 0xFF);
+    if (bd_raw == 255 || (dbits >> 31)) { D0 = RSAT; D1 = RSAT; return; }      // NaN / Inf (never negative)
+    if ((dbits & 0x7FFFFFFF) == 0) return;                                      // + 0.0
+    const int bd = bd_raw ? bd_raw : 1;
+    const unsigned int md = (dbits & 0x7FFFFF) | (bd_raw ? 0x800000u : 0u);     // d = md * 2^(bd-150)
+    const int sh = be - bd;                                                     // d / u = md * 2^-sh
+    if (sh <= 0) {
+        const long long r = sh < -16 ? RSAT : ((long long)md << (-sh));
+        D0 += r; D1 += r;
+    } else if (sh <= 24) {
+        const unsigned int q = md >> sh, rem = md & ((1u << sh) - 1u), half = 1u << (sh - 1);
+        if (rem > half) { D0 += q + 1; D1 += q + 1; }
+        else if (rem < half) { D0 += q; D1 += q; }
+        else {                                                                  // tie: to even of (M + q)
+            D0 += q + (unsigned int)((D0 + q) & 1);                             // chain that entered with even M
+            D1 += q + (unsigned int)((1 + D1 + q) & 1);                         // chain that entered with odd M
+        }
+    }                                                                           // sh >= 25: d < u/2, r = 0
+    if (D0 > RSAT) D0 = RSAT;
+    if (D1 > RSAT) D1 = RSAT;
+}
+
+// cand[b][c][p], c = 0,1,2 for biased exponents expo[b]-1, expo[b], expo[b]+1.
+__global__ __launch_bounds__(256) void rmse_candidates_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t m,
+                                                             const int *__restrict__ expo, long long *__restrict__ cand)
+{
+    __shared__ long long sh[256][6];
+    const int e = expo[blockIdx.x];
+    long long D[6] = {0, 0, 0, 0, 0, 0};
+    if (e > 0) {
+        const int64_t base = (int64_t)blockIdx.x * RB + (int64_t)threadIdx.x * (RB / 256);
+        for (int k = 0; k < RB / 256; ++k) {
+            const int64_t i = base + k;
+            if (i >= m) break;
+            const unsigned int dbits = __float_as_uint(sqdiff(a, b, i));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int be = e - 1 + c;
+                if (be >= 1 && be <= 254) chain_step(dbits, be, D[2 * c], D[2 * c + 1]);
+                else D[2 * c] = D[2 * c + 1] = RSAT;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sh[threadIdx.x][j] = D[j];
+    __syncthreads();
+    // ordered composition: (A then B)(p) = A_p + B_{(p + A_p) & 1}
+    for (int s = 1; s < 256; s <<= 1) {
+        if ((threadIdx.x & (2 * s - 1)) == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const long long A0 = sh[threadIdx.x][2 * c], A1 = sh[threadIdx.x][2 * c + 1];
+                const long long B0 = sh[threadIdx.x + s][2 * c], B1 = sh[threadIdx.x + s][2 * c + 1];
+                long long R0 = A0 + ((A0 & 1) ? B1 : B0);
+                long long R1 = A1 + (((1 + A1) & 1) ? B1 : B0);
+                if (R0 > RSAT) R0 = RSAT;
+                if (R1 > RSAT) R1 = RSAT;
+                sh[threadIdx.x][2 * c] = R0;
+                sh[threadIdx.x][2 * c + 1] = R1;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 6) cand[(int64_t)blockIdx.x * 6 + threadIdx.x] = sh[0][threadIdx.x];
+}
+
+// One wavefront walks the blocks in order.  All 64 lanes hold the same running value (uniform
+// control flow), so the serial fallback of a block can stage its 4096 squares in LDS cooperatively.
+__global__ __launch_bounds__(64) void rmse_walk_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t m,
+                                                       const int *__restrict__ expo, const long long *__restrict__ cand, int nblocks,
+                                                       float carry, float *out, int *n_serial)
+{
+    __shared__ float sq[RB];
+    const int lane = threadIdx.x;
+    float res = carry;
+    int serial = 0;
+    for (int blk = 0; blk < nblocks; ++blk) {
+        const int e = expo[blk];
+        if (e == -1) continue;                                   // res + 0.0f == res
+        const unsigned int bits = __float_as_uint(res);
+        const int be = (int)((bits >> 23) & 0xFF);
+        bool done = false;
+        if (e > 0 && be >= 1 && be <= 254 && !(bits >> 31) && be >= e - 1 && be <= e + 1) {
+            const unsigned int M = (bits & 0x7FFFFF) | 0x800000u;
+            const long long D = cand[(int64_t)blk * 6 + 2 * (be - e + 1) + (M & 1)];
+            if ((long long)M + D < (1ll << 24)) {
+                const unsigned int M2 = (unsigned int)((long long)M + D);
+                res = __uint_as_float(((unsigned int)be << 23) | (M2 & 0x7FFFFF));
+                done = true;
+            }
+        }
+        if (!done) {                                             // literal serial loop for this block
+            ++serial;
+            const int64_t base = (int64_t)blk * RB;
+            for (int k = 0; k < RB / 64; ++k) {
+                const int64_t i = base + k * 64 + lane;
+                sq[k * 64 + lane] = i < m ? sqdiff(a, b, i) : 0.0f;
+            }
+            __syncthreads();
+            const int cnt = (m - base) < RB ? (int)(m - base) : RB;
+            for (int t = 0; t < cnt; ++t) res = res + sq[t];
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        *out = res;
+        if (n_serial) *n_serial = serial;
+    }
+}
+
 }  // namespace
 
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode)
@@ -272,9 +468,37 @@ int launch_clamp(wgs_ctx *ctx, float *p, int64_t count, float lo, float hi)
     return 0;
 }
 
-int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out)
+int launch_rmse_chain_serial(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out)
 {
     hipLaunchKernelGGL(rmse_chain_kernel, dim3(1), dim3(64), 0, ctx->stream, a, b, m, carry_in, d_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t rmse_chain_workspace_bytes(int64_t m)
+{
+    const size_t nb = (size_t)((m + RB - 1) / RB);
+    return nb * (sizeof(double) + sizeof(int) + 6 * sizeof(long long)) + 64;
+}
+
+// work: rmse_chain_workspace_bytes(m) bytes of device memory; d_serial (may be null) receives the
+// number of blocks that took the literal serial loop.
+int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out, void *work,
+                      int *d_serial)
+{
+    if (m <= 0) {
+        hipLaunchKernelGGL(rmse_chain_kernel, dim3(1), dim3(64), 0, ctx->stream, a, b, m, carry_in, d_out);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    const int nb = (int)((m + RB - 1) / RB);
+    long long *cand = reinterpret_cast<long long *>(work);
+    double *S = reinterpret_cast<double *>(cand + (size_t)nb * 6);
+    int *expo = reinterpret_cast<int *>(S + nb);
+    hipLaunchKernelGGL(rmse_block_sum_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, m, S);
+    hipLaunchKernelGGL(rmse_predict_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, nb, carry_in, expo);
+    hipLaunchKernelGGL(rmse_candidates_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, m, expo, cand);
+    hipLaunchKernelGGL(rmse_walk_kernel, dim3(1), dim3(64), 0, ctx->stream, a, b, m, expo, cand, nb, carry_in, d_out, d_serial);
     HIP_TRY(hipGetLastError());
     return 0;
 }
