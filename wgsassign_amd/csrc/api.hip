@@ -364,9 +364,14 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
     HIP_TRY(hipMemcpyAsync(em->d_descs, em->h_descs, sizeof(FitDesc) * em->last.size(), hipMemcpyHostToDevice, ctx->stream));
     // launch in slices of <= 65535 fits (grid.y limit)
     HIP_TRY(hipEventRecord(em->ev0, ctx->stream));
-    for (size_t off = 0; off < em->last.size(); off += 65535) {
-        const int cnt = (int)std::min<size_t>(65535, em->last.size() - off);
-        if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode)) return 1;
+    {
+        // slices keep one launch below 2^31 workgroups
+        const int64_t per_fit = (wgs_ntiles(em->b->m) + 3) / 4;
+        const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
+        for (size_t off = 0; off < em->last.size(); off += max_fits) {
+            const int cnt = (int)std::min<size_t>(max_fits, em->last.size() - off);
+            if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode)) return 1;
+        }
     }
     HIP_TRY(hipEventRecord(em->ev1, ctx->stream));
     for (size_t off = 0; off < em->last.size(); off += 65535) {

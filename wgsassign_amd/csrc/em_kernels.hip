@@ -82,11 +82,15 @@ __device__ __forceinline__ void term_fast(float g0, float g1, const SnpState &st
 }
 
 template <int MODE>
-__global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__restrict__ fits, int64_t m)
+__global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m)
 {
-    const FitDesc fd = fits[blockIdx.y];
+    // Fit index varies fastest across workgroups: leave-one-out fits of one population read the
+    // SAME slab tiles, so consecutive workgroups hit in L2 / Infinity Cache instead of re-streaming
+    // the slab from HBM once per fit.  (Fits of different populations just interleave K streams.)
+    const int fit = (int)(blockIdx.x % (unsigned)n_fits);
+    const FitDesc fd = fits[fit];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t tile = (int64_t)(blockIdx.x / (unsigned)n_fits) * WAVES + wave;
     const int64_t row0 = tile * 64;
     if (row0 >= m) return;                       // wave-uniform; there are no barriers below
 
@@ -430,12 +434,13 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 {
     if (n_fits <= 0 || m <= 0) return 0;
     const int64_t tiles = (m + 63) / 64;
-    dim3 grid((unsigned)((tiles + WAVES - 1) / WAVES), (unsigned)n_fits);
-    WGS_REQUIRE(n_fits <= 65535, "em sweep: more than 65535 fits in one launch (%d)", n_fits);
+    const int64_t blocks = ((tiles + WAVES - 1) / WAVES) * n_fits;
+    WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
+    dim3 grid((unsigned)blocks);
     if (mode == WGS_MODE_EXACT)
-        hipLaunchKernelGGL(em_sweep_kernel<WGS_MODE_EXACT>, grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, m);
+        hipLaunchKernelGGL(em_sweep_kernel<WGS_MODE_EXACT>, grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
     else
-        hipLaunchKernelGGL(em_sweep_kernel<WGS_MODE_FAST>, grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, m);
+        hipLaunchKernelGGL(em_sweep_kernel<WGS_MODE_FAST>, grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }

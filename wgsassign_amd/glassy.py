@@ -53,12 +53,30 @@ def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1)
         print("Using downsampled GLs for likelihood evaluation in LOO assignment.")
     pops = np.unique(IDs[:, 1])
     group_of = np.searchsorted(pops, IDs[:n, 1]).astype(np.int32)
-    counts = np.bincount(group_of, minlength=len(pops))
     beagle = DeviceBeagle.from_host(L, group_of, len(pops))
+    scored = DeviceBeagle.from_host(np.asarray(downsampled_L), group_of, len(pops)) if downsampled_L is not None else beagle
+    logl, logl_parts = loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P)
+    if scored is not beagle:
+        scored.close()
+    beagle.close()
+    return logl, logl_parts
+
+
+def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None, verbose=True, timings=None):
+    """The body of loo() on device-resident matrices: `beagle` holds the GLs the frequencies are
+    re-estimated from, `scored` the GLs that are scored (the same object unless a downsampled
+    matrix is given), both with population slabs `group_of`.  `af` (m, K) float32 is mutated like
+    glassy.py:87-89 does.  With `comm`, SNPs are sharded over ranks (af is this rank's shard)."""
+    import time
+    n, k = beagle.n, af.shape[1]
+    counts = np.bincount(group_of, minlength=k)
+    t0 = time.perf_counter()
     em = EMBatch(beagle, group_of, np.arange(n, dtype=np.int32))
-    iters = em.run(maf_iter, maf_tole)
+    iters = em.run(maf_iter, maf_tole, comm=comm)
+    beagle.ctx.sync()
+    t1 = time.perf_counter()
     for i in range(n):
-        if iters[i] > 0:
+        if verbose and iters[i] > 0:
             print("EM (MAF) converged at iteration: " + str(int(iters[i])))
         em.clamp(i, int(counts[group_of[i]]) - 1)
     afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
@@ -67,19 +85,15 @@ def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1)
     for i in range(n):
         cur[group_of[i]] = em.f_dev(i)
         colptr[i] = cur
-    if downsampled_L is not None:
-        scored = DeviceBeagle.from_host(np.asarray(downsampled_L), group_of, len(pops))
-    else:
-        scored = beagle
-    out, parts = assign(scored, afset, colptr=colptr, P=P)
+    out, parts = assign(scored, afset, colptr=colptr, P=P, comm=comm)
+    t2 = time.perf_counter()
     last = {int(g): i for i, g in enumerate(group_of)}
     for g, i in last.items():
         af[:, g] = em.get_f(i)
-    if scored is not beagle:
-        scored.close()
     afset.close()
     em.close()
-    beagle.close()
+    if timings is not None:
+        timings.update(em_seconds=t1 - t0, score_seconds=t2 - t1, iters=iters)
     with np.errstate(over="ignore"):
         logl = out.astype(np.float32)
         logl_parts = parts.astype(np.float32) if parts is not None else logl.copy()
