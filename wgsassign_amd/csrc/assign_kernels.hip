@@ -50,14 +50,15 @@ __device__ __forceinline__ double log_f32arg(double x, const double2 *tab)
     return __builtin_fma(r * r, q, lo_) + hi_;
 }
 
-// (float)log((double)s) for any float32 s, including the special values libm defines.
+// (float)log((double)s) for any float32 s, including the special values libm defines:
+// log(+-0) = -inf, log(+inf) = +inf, log(negative) = log(NaN) = NaN.  The hardware's float32
+// log2 returns exactly those for exactly those arguments, so one v_log_f32 supplies every
+// special value and one class test selects it -- no branches in the per-term code.
 __device__ __forceinline__ float logf_of_f32(float s, const double2 *tab)
 {
-    float v = (float)log_f32arg((double)s, tab);
-    v = s == 0.0f ? -__builtin_inff() : v;                 // log(+-0) = -inf
-    v = s == __builtin_inff() ? s : v;                     // log(+inf) = +inf
-    v = !(s >= 0.0f) ? __builtin_nanf("") : v;             // log(negative), log(NaN) = NaN
-    return v;
+    const float v = (float)log_f32arg((double)s, tab);
+    const float special = __builtin_amdgcn_logf(s);
+    return __builtin_isfpclass(s, 0x0100 | 0x0080) ? v : special;   // +normal | +subnormal
 }
 
 __device__ __forceinline__ void load_log_table(double2 *tab)
@@ -158,6 +159,144 @@ __global__ __launch_bounds__(256) void assign_kernel(AssignArgs A)
     }
 }
 
+// ---- P == 1 path: lane <-> SNP -----------------------------------------------------------------
+// wave <-> (group of NP individual pairs, range of tiles); lane <-> SNP of the tile.  GL loads are
+// the slab's native 1 KiB wave loads, the K frequencies of a SNP are loaded once per tile and
+// their double forms (a, 1-a) hoisted over the individuals (shared-A mode), and in leave-one-out
+// mode the per-individual frequency vectors are read coalesced (lane = SNP).  Each lane keeps
+// NP x 2 x KB float64 partial sums over the tiles of its range; one cross-lane reduction per
+// (individual, population) ends the range.  Pair-group index varies fastest over workgroups, so
+// waves that need the same tile's frequencies run together (L2 hits).
+__device__ __forceinline__ float site_ll_exact2(double g0d, double g1d2, double g2d, double ad, double oma, const double2 *tab)
+{
+    const float like0 = (float)((g0d * oma) * oma);
+    const float like1 = (float)((g1d2 * oma) * ad);        // ((g1*2.0)*(1-a))*a, g1*2.0 exact
+    const float like2 = (float)((g2d * ad) * ad);
+    return logf_of_f32((like0 + like1) + like2, tab);
+}
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    return x;
+}
+
+template <int KB, int NP, int MODE, bool PER_IND>
+__global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
+{
+    __shared__ double2 tab[WGS_LOG_N];
+    load_log_table(tab);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int npg = (A.npairs + NP - 1) / NP;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int pg = (int)(wid % npg);
+    const int64_t tr = wid / npg;
+    const int64_t ntiles = (A.m + 63) >> 6;
+    const int64_t t0 = tr * A.tiles_per_wave;
+    int64_t t1 = t0 + A.tiles_per_wave;
+    if (t1 > ntiles) t1 = ntiles;
+    if (t0 >= t1) return;
+
+    int ind[NP][2];
+    bool ok[NP][2];
+    int pairc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int pair = pg * NP + q;
+        pairc[q] = pair < A.npairs ? pair : A.npairs - 1;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            ok[q][h] = 2 * pair + h < A.ncols;
+            ind[q][h] = A.members[ok[q][h] ? 2 * pair + h : 0];
+        }
+    }
+
+    for (int kb = 0; kb < A.K; kb += KB) {
+        gf32_ptr ptr[PER_IND ? NP * 2 * KB : KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int k = kb + j < A.K ? kb + j : A.K - 1;
+            if (PER_IND) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) ptr[(q * 2 + h) * KB + j] = (gf32_ptr)A.colptr[(int64_t)ind[q][h] * A.K + k];
+            } else {
+                ptr[j] = (gf32_ptr)A.acol[k];
+            }
+        }
+        double acc[NP][2][KB];
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < KB; ++j) acc[q][h][j] = 0.0;
+
+        for (int64_t t = t0; t < t1; ++t) {
+            const int64_t s = (t << 6) + lane;
+            const bool live = s < A.m;
+            const int64_t sc = live ? s : A.m - 1;
+            // Lanes past the last SNP (only in the final tile) are given g = (1, 0) and a = 0, for
+            // which the site likelihood is exactly 1 and its log exactly 0: no masking per term.
+            double ad[KB], oma[KB];
+            float af[KB];
+            if (!PER_IND) {
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    const float a_ld = ptr[j][sc];          // unconditional (clamped index), then select
+                    af[j] = live ? a_ld : 0.0f;
+                    ad[j] = (double)af[j];
+                    oma[j] = 1.0 - ad[j];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const float4 g = A.slab[((t * A.npairs + pairc[q]) << 6) + lane];
+                const float gl[2][2] = {{live ? g.x : 1.0f, live ? g.y : 0.0f}, {live ? g.z : 1.0f, live ? g.w : 0.0f}};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const double g0d = (double)gl[h][0], g1d = (double)gl[h][1];
+                    const double g1d2 = g1d * 2.0, g2d = (1.0 - g0d) - g1d;
+                    const float g2f = (1.0f - gl[h][0]) - gl[h][1];
+                    // all KB slots are computed (slots past K repeat population K-1 and are dropped
+                    // in the epilogue): the tile body stays one basic block the scheduler can interleave
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        float v;
+                        if (PER_IND) {
+                            const float a_ld = ptr[(q * 2 + h) * KB + j][sc];
+                            const float a = live ? a_ld : 0.0f;
+                            if (MODE == WGS_MODE_EXACT) {
+                                const double a_d = (double)a;
+                                v = site_ll_exact2(g0d, g1d2, g2d, a_d, 1.0 - a_d, tab);
+                            } else {
+                                v = site_ll_fast(gl[h][0], gl[h][1], g2f, a);
+                            }
+                        } else {
+                            v = MODE == WGS_MODE_EXACT ? site_ll_exact2(g0d, g1d2, g2d, ad[j], oma[j], tab)
+                                                       : site_ll_fast(gl[h][0], gl[h][1], g2f, af[j]);
+                        }
+                        acc[q][h][j] += (double)v;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < KB; ++j) {
+                    if (kb + j < A.K) {
+                        const double tot = wave_sum(acc[q][h][j]);
+                        if (lane == 0 && ok[q][h]) atomicAdd(&A.out[(int64_t)ind[q][h] * A.K + kb + j], tot);
+                    }
+                }
+    }
+}
+
 // The thin mirror of glassy_cy.loglike: vec[s] = (float)((double)vec[s] + log(...)), one
 // individual (its (g0,g1) column compacted to g[m]) and one population (a[m]).
 template <int MODE>
@@ -215,6 +354,33 @@ __global__ void log_values_kernel(const float *x, float *out, int64_t n, int use
     load_log_table(tab);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = use_libm ? (float)log((double)x[i]) : logf_of_f32(x[i], tab);
+}
+
+template <int KB, int NP>
+int launch_assign_snp(wgs_ctx *ctx, AssignArgs a, int mode)
+{
+    // waves = pair groups x tile ranges; aim at ~32 waves per CU with ranges of >= 8 tiles
+    const int npg = (a.npairs + NP - 1) / NP;
+    const int64_t ntiles = wgs_ntiles(a.m);
+    int64_t ranges = ((int64_t)ctx->cus * 32 + npg - 1) / npg;
+    if (ranges < 1) ranges = 1;
+    int64_t tpw = (ntiles + ranges - 1) / ranges;
+    if (tpw < 8) tpw = 8;
+    if (tpw > ntiles) tpw = ntiles;
+    a.tiles_per_wave = (int32_t)tpw;
+    ranges = (ntiles + tpw - 1) / tpw;
+    const int64_t waves = ranges * npg;
+    dim3 grid((unsigned)((waves + 3) / 4));
+    const bool per_ind = a.colptr != nullptr;
+#define WGS_LAUNCH(M, PI) hipLaunchKernelGGL((assign_snp_kernel<KB, NP, M, PI>), grid, dim3(256), 0, ctx->stream, a)
+    if (mode == WGS_MODE_EXACT) {
+        if (per_ind) WGS_LAUNCH(WGS_MODE_EXACT, true); else WGS_LAUNCH(WGS_MODE_EXACT, false);
+    } else {
+        if (per_ind) WGS_LAUNCH(WGS_MODE_FAST, true); else WGS_LAUNCH(WGS_MODE_FAST, false);
+    }
+#undef WGS_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 template <int KB>
@@ -278,6 +444,15 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
         const int passes = (a.K + kb - 1) / kb;
         const int cost = passes * 1000 + passes * kb - a.K;
         if (cost < best_cost) best_cost = cost, best = kb;
+    }
+    if (a.P == 1) {
+        switch (best) {
+            case 4: return launch_assign_snp<4, 1>(ctx, a, mode);
+            case 5: return launch_assign_snp<5, 1>(ctx, a, mode);
+            case 6: return launch_assign_snp<6, 1>(ctx, a, mode);
+            case 7: return launch_assign_snp<7, 1>(ctx, a, mode);
+            default: return launch_assign_snp<8, 1>(ctx, a, mode);
+        }
     }
     switch (best) {
         case 4: return launch_assign_kb<4>(ctx, a, mode, grid);
