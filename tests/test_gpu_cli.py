@@ -1,0 +1,74 @@
+"""End-to-end: the `WGSassign` command line of this build against the reference CLI's recorded
+outputs on the bundled AMRE data (tests/golden/amre_cli.npz, made by running the real reference)."""
+import contextlib
+import gzip
+import io
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(GOLDEN, "data")
+BREED = os.path.join(DATA, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz")
+IDS = os.path.join(DATA, "amre.breeding.ind85.reference_k5.IDs.txt")
+NONBREED = os.path.join(DATA, "amre.nonbreeding.ind34.ds_2x.sites-filter.top_50_each.beagle.gz")
+
+
+def run_cli(argv):
+    from wgsassign_amd import WGSassign
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        WGSassign.main(argv)
+    return buf.getvalue()
+
+
+def table(text):
+    rows = [line.split("\t") for line in text.strip().split("\n")]
+    return rows[0], rows[1:]
+
+
+def test_reference_af_loo_partitions(tmp_path, golden):
+    g = golden("amre_cli.npz")
+    out = str(tmp_path / "ref")
+    stdout = run_cli(["--beagle", BREED, "--pop_af_IDs", IDS, "--get_reference_af", "--loo", "--partition_sites", "3",
+                      "--out", out, "--threads", "2"])
+    # binary allele frequencies: identical bytes; population names file identical
+    assert np.load(out + ".pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
+    assert open(out + ".pop_names.txt").read() == str(g["pop_names"])
+    # stdout: same lines as the reference except paths (the reference run used a temp dir)
+    ref_lines = [l for l in str(g["stdout_ref"]).replace("<TMP>/", "").splitlines()]
+    got_lines = [l.replace(str(tmp_path) + "/", "") for l in stdout.splitlines()]
+    assert got_lines == ref_lines
+    # LOO table: same header/labels; values within 1e-6 relative of the reference's printed numbers
+    h_ref, r_ref = table(str(g["loo_tsv"]))
+    h_got, r_got = table(open(out + ".pop_like_LOO.tsv").read())
+    assert h_got == h_ref and [r[:2] for r in r_got] == [r[:2] for r in r_ref]
+    a = np.array([[float(x) for x in r[2:]] for r in r_got])
+    b = np.array([[float(x) for x in r[2:]] for r in r_ref])
+    assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b) + 1.5e-6)        # %.6f text: half a unit of the last digit each side
+    h_ref, r_ref = table(str(g["parts_tsv"]))
+    h_got, r_got = table(gzip.open(out + ".pop_like_LOO_partitions_3.tsv.gz", "rt").read())
+    assert h_got == h_ref and [r[:3] for r in r_got] == [r[:3] for r in r_ref]
+    a = np.array([[float(x) for x in r[3:]] for r in r_got])
+    b = np.array([[float(x) for x in r[3:]] for r in r_ref])
+    assert np.all(np.abs(a - b) <= 2e-5 * np.abs(b))
+    assert os.path.exists(out + ".args")
+
+
+def test_get_pop_like(tmp_path, golden):
+    g = golden("amre_cli.npz")
+    af = tmp_path / "ref.pop_af.npy"
+    np.save(af, g["pop_af_npy"])
+    out = str(tmp_path / "nb")
+    stdout = run_cli(["--beagle", NONBREED, "--pop_af_file", str(af), "--get_pop_like", "--out", out, "--threads", "2"])
+    got = np.loadtxt(out + ".pop_like.txt")
+    ref = np.loadtxt(io.StringIO(str(g["pop_like_txt"])))
+    assert got.shape == ref.shape == (34, 5)
+    assert np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref))
+    same = open(out + ".pop_like.txt").read() == str(g["pop_like_txt"])
+    print("pop_like.txt text identical to the reference's:", same)
+    assert [l.replace(str(tmp_path) + "/", "") for l in stdout.splitlines()] == \
+        str(g["stdout_like"]).replace("<TMP>/", "").splitlines()

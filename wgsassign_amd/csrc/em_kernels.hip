@@ -12,11 +12,12 @@
 //   lanes process the same individual at the same time, so the leave-one-out skip and the
 //   column bound are wave-uniform branches.  Loads for the next U pairs are issued before the
 //   current U pairs are consumed (register double buffer).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int U = 4;                  // individual pairs per register buffer (2 x 4 KiB in flight per wave)
 constexpr int WAVES = 4;
 typedef float f4 __attribute__((ext_vector_type(4)));   // plain vector type: stays in VGPRs
 // Pointers read out of the descriptor table are generic to the compiler (-> flat_load, which
@@ -24,6 +25,13 @@ typedef float f4 __attribute__((ext_vector_type(4)));   // plain vector type: st
 typedef const f4 __attribute__((address_space(1))) *gf4_ptr;
 typedef const float __attribute__((address_space(1))) *gf32_ptr;
 typedef float __attribute__((address_space(1))) *gf32_wptr;
+
+template <bool NT>
+__device__ __forceinline__ f4 ldg(gf4_ptr p)
+{
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
 
 struct SnpState {
     double fd, omf, fd2;              // f, 1-f, 2f in double (per SNP, hoisted)
@@ -81,7 +89,7 @@ __device__ __forceinline__ void term_fast(float g0, float g1, const SnpState &st
     tmp = tmp + num * __builtin_amdgcn_rcpf(2.0f * s);
 }
 
-template <int MODE>
+template <int MODE, int U, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m)
 {
     // Fit index varies fastest across workgroups: leave-one-out fits of one population read the
@@ -110,14 +118,14 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
     const int last = npairs - 1;
     f4 cur[U], nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];   // clamped: tail re-reads hit cache
+    for (int u = 0; u < U; ++u) cur[u] = ldg<NT>(src + (u < last ? u : last) * 64);   // clamped: tail re-reads hit cache
     float tmp = 0.0f;
     for (int p0 = 0; p0 < npairs; p0 += U) {
         if (p0 + U < npairs) {                   // one wave-uniform branch per buffer, loads unconditional
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int pp = p0 + U + u;
-                nxt[u] = src[(pp < last ? pp : last) * 64];
+                nxt[u] = ldg<NT>(src + (pp < last ? pp : last) * 64);
             }
         }
         // buffers whose 2U individuals are all present take the branch-free path; the buffer holding
@@ -437,10 +445,26 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     const int64_t blocks = ((tiles + WAVES - 1) / WAVES) * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
     dim3 grid((unsigned)blocks);
-    if (mode == WGS_MODE_EXACT)
-        hipLaunchKernelGGL(em_sweep_kernel<WGS_MODE_EXACT>, grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
-    else
-        hipLaunchKernelGGL(em_sweep_kernel<WGS_MODE_FAST>, grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
+    static const int variant = getenv("WGS_EM_VARIANT") ? atoi(getenv("WGS_EM_VARIANT")) : 0;   // tuning experiments
+#define WGS_EM_LAUNCH(M, UU, NTT) hipLaunchKernelGGL((em_sweep_kernel<M, UU, NTT>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m)
+    if (mode == WGS_MODE_EXACT) {
+        switch (variant) {
+            case 2: WGS_EM_LAUNCH(WGS_MODE_EXACT, 8, false); break;
+            case 3: WGS_EM_LAUNCH(WGS_MODE_EXACT, 8, true); break;
+            case 4: WGS_EM_LAUNCH(WGS_MODE_EXACT, 2, false); break;
+            case 5: WGS_EM_LAUNCH(WGS_MODE_EXACT, 4, false); break;
+            default: WGS_EM_LAUNCH(WGS_MODE_EXACT, 4, true); break;      // measured best: U = 4, nontemporal loads
+        }
+    } else {
+        switch (variant) {
+            case 2: WGS_EM_LAUNCH(WGS_MODE_FAST, 8, false); break;
+            case 3: WGS_EM_LAUNCH(WGS_MODE_FAST, 8, true); break;
+            case 4: WGS_EM_LAUNCH(WGS_MODE_FAST, 2, false); break;
+            case 5: WGS_EM_LAUNCH(WGS_MODE_FAST, 4, false); break;
+            default: WGS_EM_LAUNCH(WGS_MODE_FAST, 4, true); break;
+        }
+    }
+#undef WGS_EM_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
 }
