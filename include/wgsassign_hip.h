@@ -149,6 +149,22 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
                double *out, double *parts);
 
+/* ------------------------------------------------------------------ streamed Beagle reader (host)
+ * reader_cy.readBeagle(path) -- reader_cy.pyx:16-77 -- as a chunked native reader: gzip inflate,
+ * lines parsed in parallel into float32 (rows, 2n) chunks the caller owns (and typically hands
+ * to wgs_beagle_upload_rows), so files larger than host RAM can be streamed.  Needs no GPU. */
+typedef struct wgs_reader wgs_reader;
+int wgs_reader_open(const char *path, int threads, wgs_reader **out);      /* parses the header line */
+void wgs_reader_close(wgs_reader *r);
+int wgs_reader_n_individuals(wgs_reader *r);
+const char *wgs_reader_sample_name(wgs_reader *r, int i);
+/* Parse up to max_rows further sites into rows[max_rows][2n]; *nrows = sites parsed (0 at EOF). */
+int wgs_reader_next(wgs_reader *r, float *rows, int64_t max_rows, int64_t *nrows);
+/* Site names of the last chunk, '\n'-terminated each, *bytes long. */
+const char *wgs_reader_chunk_sites(wgs_reader *r, int64_t *bytes);
+/* Number of data lines (sites) of a gzipped Beagle file: one inflate pass, no parsing. */
+int wgs_reader_count_sites(const char *path, int64_t *sites);
+
 /* Test hooks for the convergence chain: wgs_rmse1d's value through the literal one-lane serial
  * kernel (serial != 0) or through the block-parallel exact emulation, reporting the number of
  * 4096-element blocks that fell back to the serial loop; the same count for the last

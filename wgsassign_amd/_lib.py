@@ -58,6 +58,13 @@ SIGNATURES = {
     "wgs_afset_download": (c_int, [c_vp, c_f32p]),
     "wgs_afset_set_column_from_em": (c_int, [c_vp, c_i32, c_vp, c_i32]),
     "wgs_afset_col_dev": (c_vp, [c_vp, c_i32]),
+    "wgs_reader_open": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_vp)]),
+    "wgs_reader_close": (None, [c_vp]),
+    "wgs_reader_n_individuals": (c_int, [c_vp]),
+    "wgs_reader_sample_name": (ctypes.c_char_p, [c_vp, c_int]),
+    "wgs_reader_next": (c_int, [c_vp, c_f32p, c_i64, ctypes.POINTER(c_i64)]),
+    "wgs_reader_chunk_sites": (c_vp, [c_vp, ctypes.POINTER(c_i64)]),
+    "wgs_reader_count_sites": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),
     "wgs_em_last_chain_serial_blocks": (c_int, [c_vp]),
     "wgs_debug_log_mismatch": (c_int, [c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),

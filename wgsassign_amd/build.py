@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwgsassign_hip.so")
-SOURCES = ["api.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip"]
+SOURCES = ["api.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "reader.cpp"]
 # -ffp-contract=off: the exact-mode kernels restate the reference's rounding sequence operation by
 # operation; hipcc's default (fast) contraction would fuse a*b+c and change results.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -30,14 +30,18 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     cc = hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "wgsassign_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "log_table.h"),
+               os.path.join(HERE, "..", "include", "wgsassign_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([cc] + FLAGS + ["-c", s, "-o", o])
+            if src.endswith(".cpp"):      # host-only C++ (the streamed reader)
+                jobs.append([cc, "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o])
+            else:
+                jobs.append([cc] + FLAGS + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -52,7 +56,7 @@ def build(force=False, verbose=False):
             if verbose and warn.strip():
                 print(warn)
     if force or jobs or _stale(LIB, objs):
-        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread"])
     return LIB
 
 

@@ -1,16 +1,81 @@
-"""Beagle reader: drop-in for `reader_cy.readBeagle` (reader_cy.pyx:16-77).
+"""Beagle reader: drop-in for `reader_cy.readBeagle` (reader_cy.pyx:16-77), backed by the
+native streamed reader of libwgsassign_hip.so (csrc/reader.cpp; host code, needs no GPU).
 
-Host-side text parsing (next-tier component): gzip -> tokens -> float32 (g0, g1)
-pairs.  Header: every 3rd token after the first three is a sample name; per line token 0 is
-the site name, two allele columns are skipped, GL0 and GL1 are kept and GL2 dropped; values
-go through double (atof) and are then rounded to float32.
+Header: every 3rd token after the first three is a sample name; per line token 0 is the site
+name, two allele columns are skipped, GL0 and GL1 are kept and GL2 dropped; values are
+atof(token) rounded to float32.
 """
+import ctypes
 import gzip
+import os
 
 import numpy as np
 
+from . import _lib
+
+
+class BeagleStream:
+    """Chunked reader: iterate (rows float32 (k, 2n), site_names list) until the file ends."""
+
+    def __init__(self, path, threads=None):
+        lib = _lib.load()
+        if threads is None:
+            threads = min(len(os.sched_getaffinity(0)), 16)
+        h = ctypes.c_void_p()
+        _lib.check(lib.wgs_reader_open(os.fsencode(path), int(threads), ctypes.byref(h)))
+        self._h = h
+        self.n = lib.wgs_reader_n_individuals(h)
+        self.sample_names = [lib.wgs_reader_sample_name(h, i).decode() for i in range(self.n)]
+
+    def chunks(self, max_rows=None, target_bytes=256 << 20):
+        lib = _lib.load()
+        if max_rows is None:
+            max_rows = max(1, target_bytes // max(1, 8 * self.n))
+        while True:
+            rows = np.empty((max_rows, 2 * self.n), dtype=np.float32)
+            got = ctypes.c_int64()
+            _lib.check(lib.wgs_reader_next(self._h, _lib.f32p(rows), max_rows, ctypes.byref(got)))
+            if got.value == 0:
+                return
+            nbytes = ctypes.c_int64()
+            ptr = lib.wgs_reader_chunk_sites(self._h, ctypes.byref(nbytes))
+            names = ctypes.string_at(ptr, nbytes.value).decode().split("\n")[:-1]
+            yield rows[:got.value], names
+
+    def close(self):
+        if self._h:
+            _lib.load().wgs_reader_close(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def count_sites(path):
+    n = ctypes.c_int64()
+    _lib.check(_lib.load().wgs_reader_count_sites(os.fsencode(path), ctypes.byref(n)))
+    return n.value
+
 
 def readBeagle(beagle):
+    """reader_cy.pyx:16-77: returns (L float32 (m, 2n) C-contiguous, sample_names, site_names)."""
+    with BeagleStream(beagle) as st:
+        parts, site_names = [], []
+        for rows, names in st.chunks():
+            parts.append(rows.copy() if rows.base is not None and rows.shape[0] * 4 < rows.base.shape[0] else rows)
+            site_names.extend(names)
+        if parts:
+            L = np.ascontiguousarray(np.concatenate(parts, axis=0)) if len(parts) > 1 else np.ascontiguousarray(parts[0])
+        else:
+            L = np.empty((0, 2 * st.n), dtype=np.float32)
+        return L, list(st.sample_names), site_names
+
+
+def readBeagle_py(beagle):
+    """Pure-Python restatement of the same rules (slow; kept as a cross-check of the native reader)."""
     with gzip.open(beagle, "rb") as fh:
         header = fh.readline().split()
         sample_names = [t.decode() for t in header[3::3]]
@@ -25,3 +90,21 @@ def readBeagle(beagle):
             chunks.append(gl[:, :2].astype(np.float32).reshape(-1))
     L = np.ascontiguousarray(np.array(chunks, dtype=np.float32).reshape(len(chunks), 2 * n))
     return L, sample_names, site_names
+
+
+def stream_to_device(path, group_of=None, n_groups=1, ctx=None, site0=0, threads=None):
+    """Two passes over the file: count the sites, then parse chunk by chunk straight into the
+    device slabs -- host memory stays bounded by one chunk (the reference holds two
+    full copies).  Returns (DeviceBeagle, sample_names, site_names)."""
+    from .device import DeviceBeagle
+    m = count_sites(path)
+    with BeagleStream(path, threads) as st:
+        beagle = DeviceBeagle(m, st.n, group_of, n_groups, site0=site0, ctx=ctx)
+        row0, site_names = 0, []
+        for rows, names in st.chunks():
+            beagle.upload_rows(np.ascontiguousarray(rows), row0)
+            row0 += rows.shape[0]
+            site_names.extend(names)
+        if row0 != m:
+            raise RuntimeError("Beagle file changed while reading: counted %d sites, parsed %d" % (m, row0))
+        return beagle, list(st.sample_names), site_names
