@@ -221,7 +221,19 @@ def cpu_baseline(beagle, group_of, K, ms):
     for k in range(K):
         orc.gather(rows, np.flatnonzero(group_of == k), threads)
     t_gather = time.perf_counter() - t_g0
+    # assignment leg of the reference shape: one scan of L per (individual, population) pair
+    # (glassy.py:31-38); time a few pairs and scale to all n*K pairs of one SNP
+    A = np.ascontiguousarray(np.stack(fs, axis=1))
+    pairs, t_a0 = 0, time.perf_counter()
+    while pairs < 6 or time.perf_counter() - t_a0 < 3.0:
+        vec = np.zeros(ms, dtype=np.float32)
+        orc.loglike(rows, A, vec, threads, pairs % beagle.n, pairs % K)
+        float(np.sum(vec, dtype=float))
+        pairs += 1
+    t_pair = (time.perf_counter() - t_a0) / pairs
+    assign_snps_per_s = ms / (t_pair * beagle.n * K)
     return {"value": K * ms * sweeps / el, "unit": "SNP-updates/s", "cores": threads, "kind": "port",
+            "assign_value": assign_snps_per_s, "assign_unit": "SNPs/s (all n x K terms of a SNP = 1)",
             "sample": "first %d SNPs x %d ind of the same synthetic matrix, K=%d populations, %d sweeps in %.1f s "
                       "(OpenMP threads=%d; per-population gather %.2f s not included)" %
                       (ms, beagle.n, K, sweeps, el, threads, t_gather)}
