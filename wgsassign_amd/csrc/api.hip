@@ -249,6 +249,7 @@ struct wgs_em {
     FitDesc *h_descs = nullptr;           // pinned
     double *d_ssq = nullptr;
     double *d_part = nullptr;             // n_fits x ntiles per-tile partial sums
+    double *d_part2 = nullptr;            // n_fits x ssq_reduce_chunks() slice sums
     float *d_carry = nullptr;             // [0] carry out, [1] (as int) serial-block count
     void *d_chain_work = nullptr;
     std::vector<int32_t> last;            // fits swept by the last step
@@ -266,6 +267,7 @@ void wgs_em_destroy(wgs_em *em)
     if (em->h_descs) (void)hipHostFree(em->h_descs);
     if (em->d_ssq) (void)hipFree(em->d_ssq);
     if (em->d_part) (void)hipFree(em->d_part);
+    if (em->d_part2) (void)hipFree(em->d_part2);
     if (em->d_carry) (void)hipFree(em->d_carry);
     if (em->d_chain_work) (void)hipFree(em->d_chain_work);
     if (em->ev0) (void)hipEventDestroy(em->ev0);
@@ -320,6 +322,7 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     HIP_TRY(hipMalloc(&em->d_descs, sizeof(FitDesc) * n_fits));
     HIP_TRY(hipMalloc(&em->d_ssq, sizeof(double) * n_fits));
     HIP_TRY(hipMalloc(&em->d_part, sizeof(double) * (size_t)n_fits * wgs_ntiles(b->m)));
+    HIP_TRY(hipMalloc(&em->d_part2, sizeof(double) * (size_t)n_fits * ssq_reduce_chunks()));
     HIP_TRY(hipMalloc(&em->d_carry, 2 * sizeof(float)));
     HIP_TRY(hipMalloc(&em->d_chain_work, rmse_chain_workspace_bytes(b->m)));
     HIP_TRY(hipEventCreate(&em->ev0));
@@ -376,7 +379,7 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
     HIP_TRY(hipEventRecord(em->ev1, ctx->stream));
     for (size_t off = 0; off < em->last.size(); off += 65535) {
         const int cnt = (int)std::min<size_t>(65535, em->last.size() - off);
-        if (launch_ssq_reduce(ctx, em->d_descs + off, cnt, em->b->m)) return 1;
+        if (launch_ssq_reduce(ctx, em->d_descs + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
     }
     for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
     return 0;

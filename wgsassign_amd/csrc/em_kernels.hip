@@ -174,20 +174,37 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
     if (lane == 0) fd.ssq_part[tile] = sq;
 }
 
-// ssq[fit] = sum over tiles of the per-tile partials, fixed summation order.
-__global__ __launch_bounds__(256) void ssq_reduce_kernel(const FitDesc *__restrict__ fits, int64_t ntiles)
+// ssq[fit] = sum over tiles of the per-tile partials, in a fixed summation order (reproducible):
+// stage 1, RED_CHUNKS workgroups per fit each reduce a contiguous slice of the partials into
+// part2[fit][chunk]; stage 2, one wavefront per fit adds the RED_CHUNKS slice sums.
+constexpr int RED_CHUNKS = 64;
+
+__global__ __launch_bounds__(256) void ssq_reduce1_kernel(const FitDesc *__restrict__ fits, int64_t ntiles, double *__restrict__ part2)
 {
     __shared__ double red[256];
-    const FitDesc fd = fits[blockIdx.x];
+    const int fit = blockIdx.x / RED_CHUNKS, chunk = blockIdx.x % RED_CHUNKS;
+    const FitDesc fd = fits[fit];
+    const int64_t per = (ntiles + RED_CHUNKS - 1) / RED_CHUNKS;
+    const int64_t t0 = chunk * per;
+    int64_t t1 = t0 + per;
+    if (t1 > ntiles) t1 = ntiles;
     double acc = 0.0;
-    for (int64_t t = threadIdx.x; t < ntiles; t += 256) acc += fd.ssq_part[t];
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) acc += fd.ssq_part[t];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *fd.ssq = red[0];
+    if (threadIdx.x == 0) part2[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(64) void ssq_reduce2_kernel(const FitDesc *__restrict__ fits, const double *__restrict__ part2)
+{
+    double v = part2[blockIdx.x * RED_CHUNKS + threadIdx.x];       // RED_CHUNKS == 64 lanes
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (threadIdx.x == 0) *fits[blockIdx.x].ssq = v;
 }
 
 __global__ void fill_kernel(float *p, int64_t count, float v)
@@ -469,10 +486,14 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     return 0;
 }
 
-int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m)
+int ssq_reduce_chunks(void) { return RED_CHUNKS; }
+
+// part2: n_fits * ssq_reduce_chunks() doubles of device scratch
+int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2)
 {
     if (n_fits <= 0 || m <= 0) return 0;
-    hipLaunchKernelGGL(ssq_reduce_kernel, dim3((unsigned)n_fits), dim3(256), 0, ctx->stream, d_descs, wgs_ntiles(m));
+    hipLaunchKernelGGL(ssq_reduce1_kernel, dim3((unsigned)n_fits * RED_CHUNKS), dim3(256), 0, ctx->stream, d_descs, wgs_ntiles(m), part2);
+    hipLaunchKernelGGL(ssq_reduce2_kernel, dim3((unsigned)n_fits), dim3(64), 0, ctx->stream, d_descs, part2);
     HIP_TRY(hipGetLastError());
     return 0;
 }
