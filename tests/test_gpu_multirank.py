@@ -70,3 +70,53 @@ def test_two_ranks_one_gpu(tmp_path, guard):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
         assert "RANK %d OK" % r in o
+
+
+def test_cli_two_ranks_matches_single_process(tmp_path, golden):
+    """`torchrun --nproc-per-node 2 -m wgsassign_amd.WGSassign ...` (gloo, both ranks on the one GPU):
+    same stdout and output files as the reference CLI run recorded in tests/golden/amre_cli.npz."""
+    import gzip
+    import numpy as np
+    from conftest import GOLDEN
+    g = golden("amre_cli.npz")
+    data = os.path.join(GOLDEN, "data")
+    env = dict(os.environ, WGSASSIGN_BACKEND="gloo", WGSASSIGN_DEVICE="0", PYTHONPATH=ROOT)   # both ranks on GPU 0
+    port = 29700 + (os.getpid() % 1000)
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), "-m", "wgsassign_amd.WGSassign"]
+    r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),
+                               "--pop_af_IDs", os.path.join(data, "amre.breeding.ind85.reference_k5.IDs.txt"),
+                               "--get_reference_af", "--loo", "--partition_sites", "3", "--out", "ref", "--threads", "2"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert np.load(tmp_path / "ref.pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
+    assert (tmp_path / "ref.pop_names.txt").read_text() == str(g["pop_names"])
+    ref_lines = str(g["stdout_ref"]).replace("<TMP>/", "").splitlines()
+    got_lines = [l for l in r.stdout.splitlines() if not l.startswith("[Gloo]")]      # gloo prints its own banner
+    assert got_lines == ref_lines, "\n".join(got_lines[:12])
+
+    def table(text):
+        rows = [line.split("\t") for line in text.strip().split("\n")]
+        return rows[0], rows[1:]
+    h_ref, r_ref = table(str(g["loo_tsv"]))
+    h_got, r_got = table((tmp_path / "ref.pop_like_LOO.tsv").read_text())
+    assert h_got == h_ref and [x[:2] for x in r_got] == [x[:2] for x in r_ref]
+    a = np.array([[float(v) for v in x[2:]] for x in r_got])
+    b = np.array([[float(v) for v in x[2:]] for x in r_ref])
+    assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b) + 1.5e-6)
+    h_ref, r_ref = table(str(g["parts_tsv"]))
+    h_got, r_got = table(gzip.open(tmp_path / "ref.pop_like_LOO_partitions_3.tsv.gz", "rt").read())
+    assert h_got == h_ref
+    a = np.array([[float(v) for v in x[3:]] for x in r_got])
+    b = np.array([[float(v) for v in x[3:]] for x in r_ref])
+    assert np.all(np.abs(a - b) <= 2e-5 * np.abs(b))
+    # --get_pop_like, sharded
+    r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.nonbreeding.ind34.ds_2x.sites-filter.top_50_each.beagle.gz"),
+                               "--pop_af_file", "ref.pop_af.npy", "--get_pop_like", "--out", "nb", "--threads", "2"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    got = np.loadtxt(tmp_path / "nb.pop_like.txt")
+    ref = np.loadtxt(__import__("io").StringIO(str(g["pop_like_txt"])))
+    assert np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref))
+    assert [l for l in r.stdout.splitlines() if not l.startswith("[Gloo]")] == \
+        str(g["stdout_like"]).replace("<TMP>/", "").splitlines()

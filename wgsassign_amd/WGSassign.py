@@ -42,11 +42,122 @@ for _flag in ("--ind_ad_file", "--allele_count_threshold", "--ind_start", "--ind
     parser.add_argument(_flag, help=argparse.SUPPRESS)
 
 
+def _main_sharded(args, comm):
+    """The same options with the SNPs sharded over the ranks of a torchrun launch (one process per
+    GPU): every rank parses and holds only its contiguous SNP range; the EM convergence sums,
+    the serial-chain carry and the n x K log-likelihood sums cross ranks through one sum
+    all-reduce (RCCL); rank 0 writes the reference's output files."""
+    import numpy as np
+
+    from . import emMAF, glassy, reader_cy, utils
+    from .device import AFSet, assign, get_context
+
+    root = comm.rank == 0
+
+    def say(*a):
+        if root:
+            print(*a)
+
+    if args.loo_downsampled_beagle:
+        raise SystemExit("--loo_downsampled_beagle is not available in the SNP-sharded (multi-GPU) mode")
+    ctx = get_context()
+    say("Parsing Beagle file.")
+    assert os.path.isfile(args.beagle), "Beagle file doesn't exist!"
+    IDs = pops = None
+    group_of, n_groups = None, 1
+    if args.get_reference_af:
+        assert os.path.isfile(args.pop_af_IDs), "Reference population ID file does not exist!!"
+        IDs = np.loadtxt(args.pop_af_IDs, delimiter="\t", dtype="str")
+        pops = np.unique(IDs[:, 1])
+        group_of, n_groups = np.searchsorted(pops, IDs[:, 1]).astype(np.int32), len(pops)
+    beagle, sample_names, site_names, m = reader_cy.stream_to_device(
+        args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank, world=comm.world)
+    n = beagle.n
+    say("Loaded " + str(m) + " sites and " + str(n) + " individuals.")
+    ends = comm.allgather_object((site_names[:4], site_names[-4:]))
+    if root:
+        heads = [x for e in ends for x in e[0]]
+        tails = [x for e in ends for x in e[1]]
+        shown = heads[:m] if m <= 4 else heads[:2] + tails[-2:]
+        print(f"sample_names: {len(sample_names)} samples total: {utils.preview(sample_names)}")
+        print(f"site_names: {m} sites total: " + (", ".join(shown) if m <= 4 else
+                                                    ", ".join(shown[:2]) + ", ..., " + ", ".join(shown[2:])))
+
+    if args.get_reference_af:
+        say("Parsing reference population ID file.")
+        assert (n == IDs.shape[0]), "Number of individuals in beagle and reference ID file do not match!"
+        import contextlib
+        import io
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            pops, af, _ = emMAF.emMAF_populations(None, IDs, args.maf_iter, args.maf_tole, beagle=beagle, comm=comm)
+        if root:
+            sys.stdout.write(buf.getvalue())
+        af_full = comm.gather_rows(af)
+        if root:
+            np.save(args.out + ".pop_af", af_full)
+        say("Saved reference population allele frequencies as " + str(args.out) + ".pop_af.npy (Binary - np.float32)\n")
+        say("Column order of populations is: " + str(pops))
+        if root:
+            np.savetxt(args.out + ".pop_names.txt", pops, fmt="%s")
+        say("Saved reference population names as " + str(args.out) +
+            ".pop_names.txt (String: Order of pops for .pop_af.npy, .ne_obs.npy, and fisher_obs.npy files)\n")
+        if args.loo:
+            say("Performing leave-one-out cross validation.")
+            say(str(n) + " individuals to assign to " + str(len(pops)) + " populations")
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                ll, parts = glassy.loo_device(beagle, beagle, af, group_of, args.maf_iter, args.maf_tole,
+                                              args.partition_sites, comm=comm)
+            if root:
+                sys.stdout.write(buf.getvalue())
+                outfile = f"{args.out}.pop_like_LOO.tsv"
+                partfile = f"{args.out}.pop_like_LOO_partitions_{args.partition_sites}.tsv.gz"
+                utils.write_ass_mats(outfile, ll, sample_names, pops, print_part_column=False,
+                                     sample_locations=IDs[:, 1], doing_LOO=True)
+                print(f"Saved leave-one-out cross validation log likelihoods as {outfile}")
+                if args.partition_sites > 1:
+                    utils.write_ass_mats(partfile, parts, sample_names, pops, partition_count=args.partition_sites,
+                                         print_part_column=True, sample_locations=IDs[:, 1], doing_LOO=True)
+                    print(f"Saved leave-one-out cross validation log likelihoods from partitioned sites as {partfile}")
+                print(f"Column order of populations is: {pops}")
+
+    if args.get_pop_like:
+        say("Parsing population allele frequency file.")
+        assert os.path.isfile(args.pop_af_file), "Population allele frequency file does not exist!!"
+        from .comm import shard_range
+        lo, hi = shard_range(m, comm.rank, comm.world)
+        A = np.ascontiguousarray(np.load(args.pop_af_file, mmap_mode="r")[lo:hi], dtype=np.float32)
+        say("Calculating likelihood of population assignment")
+        say(str(n) + " individuals to assign to " + str(A.shape[1]) + " populations")
+        if args.get_reference_af:      # slabs are per population; a single-group view is not needed: sums are per individual
+            pass
+        afs = AFSet.from_host(A, ctx=ctx)
+        out, _ = assign(beagle, afs, comm=comm)
+        afs.close()
+        if root:
+            np.savetxt(args.out + ".pop_like.txt", out.astype(np.float32), fmt="%.7f")
+        say("Saved population assignment log likelihoods as " + str(args.out) + ".pop_like.txt (text)")
+    beagle.close()
+    comm.barrier()
+
+
 def main(argv=None):
     args = parser.parse_args(argv)
     if len(sys.argv) < 2 and argv is None:
         parser.print_help()
         sys.exit()
+    from .comm import init_from_env
+    comm = init_from_env()
+    if comm.world > 1:
+        if comm.rank == 0:
+            print("WGSassign")
+            print("Matt DeSaix.")
+            print("Using " + str(args.threads) + " thread(s).\n")
+        for unsupported in ("ne_obs", "get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
+            if getattr(args, unsupported):
+                raise SystemExit("--%s is outside the scope of the MI355X build" % unsupported)
+        return _main_sharded(args, comm)
     print("WGSassign")
     print("Matt DeSaix.")
     print("Using " + str(args.threads) + " thread(s).\n")

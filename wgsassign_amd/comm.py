@@ -16,6 +16,12 @@ class LocalComm:
     def allreduce_sum(self, arr):
         return arr
 
+    def gather_rows(self, arr):
+        return arr
+
+    def allgather_object(self, obj):
+        return [obj]
+
     def barrier(self):
         pass
 
@@ -62,8 +68,40 @@ class TorchComm:
             out = t.cpu()            # enqueued on the same stream, synchronises it
         return out.numpy()
 
+    def gather_rows(self, arr):
+        """Concatenate every rank's rows (SNP shards, rank order) -- the full array on every rank."""
+        parts = [None] * self.world
+        self._dist.all_gather_object(parts, np.ascontiguousarray(arr))
+        return np.concatenate(parts, axis=0)
+
+    def allgather_object(self, obj):
+        parts = [None] * self.world
+        self._dist.all_gather_object(parts, obj)
+        return parts
+
     def barrier(self):
         self._dist.barrier()
+
+
+def init_from_env():
+    """Process group from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*):
+    RCCL (`nccl`) when a GPU per rank is available, `gloo` when WGSASSIGN_BACKEND=gloo (ranks
+    sharing one GPU, CPU-only rehearsals).  Returns LocalComm() outside torchrun."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return LocalComm()
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("WGSASSIGN_BACKEND", "nccl")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not dist.is_initialized():
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    return TorchComm(device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
 
 def shard_range(m_total, rank, world):

@@ -273,6 +273,43 @@ int wgs_reader_next(wgs_reader *r, float *rows, int64_t max_rows, int64_t *nrows
     return 0;
 }
 
+/* Skip up to max_rows data lines without parsing them (a rank that owns a later SNP range). */
+int wgs_reader_skip(wgs_reader *r, int64_t max_rows, int64_t *nrows)
+{
+    if (!r || !nrows || max_rows < 0) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    int64_t done = 0;
+    while (done < max_rows) {
+        bool progressed = false;
+        while (done < max_rows && r->pos < r->len) {
+            const char *b = r->buf.data() + r->pos;
+            const char *nl = (const char *)memchr(b, '\n', r->len - r->pos);
+            if (!nl) {
+                if (!r->eof) break;
+                nl = r->buf.data() + r->len;
+            }
+            const char *t = b;
+            while (t < nl && is_delim(*t)) ++t;
+            done += t < nl;                                   // blank lines do not count
+            r->pos = (size_t)(nl - r->buf.data()) + (nl < r->buf.data() + r->len ? 1 : 0);
+            progressed = true;
+        }
+        if (done >= max_rows) break;
+        if (r->eof && r->pos >= r->len) break;
+        const size_t before = r->len - r->pos;
+        if (!fill(r)) {
+            wgs_set_error("read error while inflating the Beagle file");
+            return 1;
+        }
+        if (!progressed && r->eof && r->len - r->pos == before && before == 0) break;
+    }
+    r->lines_read += done;
+    *nrows = done;
+    return 0;
+}
+
 int wgs_reader_count_sites(const char *path, int64_t *sites)
 {
     if (!path || !sites) {

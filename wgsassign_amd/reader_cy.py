@@ -27,14 +27,27 @@ class BeagleStream:
         self.n = lib.wgs_reader_n_individuals(h)
         self.sample_names = [lib.wgs_reader_sample_name(h, i).decode() for i in range(self.n)]
 
-    def chunks(self, max_rows=None, target_bytes=256 << 20):
+    def skip(self, nrows):
+        """Skip nrows sites without parsing; returns the number actually skipped."""
+        got = ctypes.c_int64()
+        _lib.check(_lib.load().wgs_reader_skip(self._h, int(nrows), ctypes.byref(got)))
+        return got.value
+
+    def chunks(self, max_rows=None, target_bytes=256 << 20, limit=None):
+        """Yield (rows, site_names) chunks; at most `limit` sites in total when given."""
         lib = _lib.load()
         if max_rows is None:
             max_rows = max(1, target_bytes // max(1, 8 * self.n))
+        left = limit
         while True:
-            rows = np.empty((max_rows, 2 * self.n), dtype=np.float32)
+            want = max_rows if left is None else min(max_rows, left)
+            if want <= 0:
+                return
+            rows = np.empty((want, 2 * self.n), dtype=np.float32)
             got = ctypes.c_int64()
-            _lib.check(lib.wgs_reader_next(self._h, _lib.f32p(rows), max_rows, ctypes.byref(got)))
+            _lib.check(lib.wgs_reader_next(self._h, _lib.f32p(rows), want, ctypes.byref(got)))
+            if left is not None:
+                left -= got.value
             if got.value == 0:
                 return
             nbytes = ctypes.c_int64()
@@ -92,19 +105,28 @@ def readBeagle_py(beagle):
     return L, sample_names, site_names
 
 
-def stream_to_device(path, group_of=None, n_groups=1, ctx=None, site0=0, threads=None):
+def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, rank=0, world=1, m_total=None):
     """Two passes over the file: count the sites, then parse chunk by chunk straight into the
     device slabs -- host memory stays bounded by one chunk (the reference holds two
-    full copies).  Returns (DeviceBeagle, sample_names, site_names)."""
+    full copies).  With world > 1 this rank skips to its contiguous SNP range
+    (comm.shard_range) and parses only that.  group_of may be a callable(sample_names) ->
+    (group_of, n_groups).  Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
+    from .comm import shard_range
     from .device import DeviceBeagle
-    m = count_sites(path)
+    if m_total is None:
+        m_total = count_sites(path)
+    lo, hi = shard_range(m_total, rank, world)
     with BeagleStream(path, threads) as st:
-        beagle = DeviceBeagle(m, st.n, group_of, n_groups, site0=site0, ctx=ctx)
+        if callable(group_of):
+            group_of, n_groups = group_of(list(st.sample_names))
+        beagle = DeviceBeagle(hi - lo, st.n, group_of, n_groups, site0=lo, ctx=ctx)
+        if st.skip(lo) != lo:
+            raise RuntimeError("Beagle file shorter than counted")
         row0, site_names = 0, []
-        for rows, names in st.chunks():
+        for rows, names in st.chunks(limit=hi - lo):
             beagle.upload_rows(np.ascontiguousarray(rows), row0)
             row0 += rows.shape[0]
             site_names.extend(names)
-        if row0 != m:
-            raise RuntimeError("Beagle file changed while reading: counted %d sites, parsed %d" % (m, row0))
-        return beagle, list(st.sample_names), site_names
+        if row0 != hi - lo:
+            raise RuntimeError("Beagle file changed while reading: expected %d sites, parsed %d" % (hi - lo, row0))
+        return beagle, list(st.sample_names), site_names, m_total

@@ -5,13 +5,16 @@ import gzip
 import numpy as np
 
 
+def preview(names):
+    """utils.py:9-14: all names when there are at most four, else the first and last two."""
+    names = list(names)
+    if len(names) <= 4:
+        return ", ".join(names)
+    return ", ".join(names[:2]) + ", ..., " + ", ".join(names[-2:])
+
+
 def print_sample_and_site_summary(sample_names, site_names):
     """utils.py:8-18: first two / last two names of each list."""
-    def preview(names):
-        names = list(names)
-        if len(names) <= 4:
-            return ", ".join(names)
-        return ", ".join(names[:2]) + ", ..., " + ", ".join(names[-2:])
     print(f"sample_names: {len(sample_names)} samples total: {preview(sample_names)}")
     print(f"site_names: {len(site_names)} sites total: {preview(site_names)}")
 
