@@ -9,6 +9,16 @@ import sys
 
 import pytest
 
+
+
+def free_port():
+    """A TCP port the OS reports free right now (fixed ports collide when suites overlap)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
@@ -61,7 +71,7 @@ sys.exit(0 if ok else 1)
 
 @pytest.mark.parametrize("guard", [0.25, 1e9])
 def test_two_ranks_one_gpu(tmp_path, guard):
-    port = 29600 + (os.getpid() % 1000) + (1 if guard > 1 else 0)
+    port = free_port()
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT, port=port))
     procs = [subprocess.Popen([sys.executable, str(script), str(r), str(guard)], stdout=subprocess.PIPE,
@@ -81,7 +91,7 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     g = golden("amre_cli.npz")
     data = os.path.join(GOLDEN, "data")
     env = dict(os.environ, WGSASSIGN_BACKEND="gloo", WGSASSIGN_DEVICE="0", PYTHONPATH=ROOT)   # both ranks on GPU 0
-    port = 29700 + (os.getpid() % 1000)
+    port = free_port()
     base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
             "--master-port", str(port), "-m", "wgsassign_amd.WGSassign"]
     r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),

@@ -12,6 +12,16 @@ import numpy as np
 import pytest
 
 import synth
+
+
+def free_port():
+    """A TCP port the OS reports free right now (fixed ports collide when suites overlap)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 from conftest import GOLDEN, ROOT
 from cpu_standin import OracleEMBatch
 
@@ -119,7 +129,7 @@ def test_run_em_two_gloo_ranks_snp_sharded(tmp_path, guard):
     """world_size 2 over gloo: SNPs sharded in two contiguous ranges; the all-reduced sums and the
     rank-to-rank carry of the serial float32 chain give the single-process iterations and
     frequencies on both ranks."""
-    port = 29500 + (os.getpid() % 2000) + (1 if guard > 1 else 0)
+    port = free_port()
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT, port=port))
     env = dict(os.environ, OMP_NUM_THREADS="2")

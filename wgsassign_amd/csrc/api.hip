@@ -58,8 +58,30 @@ void wgs_ctx_destroy(wgs_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->ws) (void)hipFree(ctx->ws);
     delete ctx;
 }
+
+}   // extern "C"
+
+int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->ws_bytes) {
+        if (ctx->ws) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(ctx->ws));
+            ctx->ws = nullptr;
+            ctx->ws_bytes = 0;
+        }
+        const size_t want = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
+        HIP_TRY(hipMalloc(&ctx->ws, want));
+        ctx->ws_bytes = want;
+    }
+    *out = ctx->ws;
+    return 0;
+}
+
+extern "C" {
 
 int wgs_ctx_sync(wgs_ctx *ctx)
 {
@@ -564,32 +586,30 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     const int K = a->K;
     const int64_t n = b->n;
     const size_t cells = (size_t)n * P * K;
-    double *d_out = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     g_assign_ms = 0.0f;
-    const float **d_acol = nullptr, **d_colptr = nullptr;
-    int rc = 0;
+    // one grow-only workspace: [cells doubles | K shared pointers | n*K per-individual pointers]
+    const size_t off_acol = (sizeof(double) * cells + 255) & ~(size_t)255;
+    const size_t off_colptr = (off_acol + sizeof(float *) * K + 255) & ~(size_t)255;
+    const size_t total = off_colptr + (colptr ? sizeof(float *) * n * K : 0);
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, total, &ws)) return 1;
+    double *d_out = reinterpret_cast<double *>(ws);
+    const float **d_acol = reinterpret_cast<const float **>(reinterpret_cast<char *>(ws) + off_acol);
+    const float **d_colptr = colptr ? reinterpret_cast<const float **>(reinterpret_cast<char *>(ws) + off_colptr) : nullptr;
     std::vector<const float *> acol(K);
     for (int k = 0; k < K; ++k) acol[k] = a->buf + (size_t)k * a->m;
     std::vector<double> h(cells);
-#define TRY_GOTO(expr)                                                        \
-    if ((expr) != hipSuccess) {                                               \
-        wgs_set_error("%s:%d: %s failed", __FILE__, __LINE__, #expr);        \
-        rc = 1;                                                               \
-        goto done;                                                            \
+    static thread_local hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (!ev0) {
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
     }
-    TRY_GOTO(hipMalloc(&d_out, sizeof(double) * cells));
-    TRY_GOTO(hipMemsetAsync(d_out, 0, sizeof(double) * cells, ctx->stream));
-    TRY_GOTO(hipMalloc(&d_acol, sizeof(float *) * K));
-    TRY_GOTO(hipMemcpy(d_acol, acol.data(), sizeof(float *) * K, hipMemcpyHostToDevice));
-    if (colptr) {
-        TRY_GOTO(hipMalloc(&d_colptr, sizeof(float *) * n * K));
-        TRY_GOTO(hipMemcpy(d_colptr, colptr, sizeof(float *) * n * K, hipMemcpyHostToDevice));
-    }
-    TRY_GOTO(hipEventCreate(&ev0));
-    TRY_GOTO(hipEventCreate(&ev1));
-    TRY_GOTO(hipEventRecord(ev0, ctx->stream));
-    for (int g = 0; g < b->n_groups && !rc; ++g) {
+    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(double) * cells, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_acol, acol.data(), sizeof(float *) * K, hipMemcpyHostToDevice, ctx->stream));
+    if (colptr) HIP_TRY(hipMemcpyAsync(d_colptr, colptr, sizeof(float *) * n * K, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));      // acol (a local vector) has been consumed
+    HIP_TRY(hipEventRecord(ev0, ctx->stream));
+    for (int g = 0; g < b->n_groups; ++g) {
         const Slab &s = b->slabs[g];
         if (s.ncols == 0) continue;
         AssignArgs args;
@@ -605,13 +625,12 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
         args.K = K;
         args.P = P;
         args.tiles_per_wave = 0;
-        rc = launch_assign(ctx, args, mode);
+        if (launch_assign(ctx, args, mode)) return 1;
     }
-    if (rc) goto done;
-    TRY_GOTO(hipEventRecord(ev1, ctx->stream));
-    TRY_GOTO(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipEventRecord(ev1, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(h.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     (void)hipEventElapsedTime(&g_assign_ms, ev0, ev1);
-    TRY_GOTO(hipMemcpy(h.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost));
     if (P == 1) {
         for (size_t c = 0; c < cells; ++c) out[c] += h[c];
     } else {
@@ -623,14 +642,7 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
                 out[(size_t)i * K + k] += t;
             }
     }
-done:
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    if (d_out) (void)hipFree(d_out);
-    if (d_acol) (void)hipFree(d_acol);
-    if (d_colptr) (void)hipFree(d_colptr);
-    return rc;
-#undef TRY_GOTO
+    return 0;
 }
 
 /* ------------------------------------------------------------------ test hooks */

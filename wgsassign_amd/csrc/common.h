@@ -32,7 +32,11 @@ struct wgs_ctx {
     void *pinned = nullptr;  // small pinned host scratch for async readbacks
     size_t pinned_bytes = 0;
     int cus = 0;
+    void *ws = nullptr;      // grow-only device workspace (assignment outputs / pointer tables)
+    size_t ws_bytes = 0;
 };
+// Device workspace of at least `bytes` (256-byte aligned); contents are not preserved across calls.
+int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out);
 
 // One population slab: the (g0,g1) pairs of the individuals of one group (file order), stored
 // TILE-INTERLEAVED for lane<->SNP kernels:
