@@ -41,6 +41,7 @@ int wgs_ctx_create(int device, wgs_ctx **out)
     WGS_REQUIRE(device >= 0 && device < n, "device %d out of range (0..%d)", device, n - 1);
     HIP_TRY(hipSetDevice(device));
     wgs_ctx *c = new wgs_ctx();
+    auto guard = on_failure([&] { wgs_ctx_destroy(c); });
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     c->pinned_bytes = 1 << 20;
@@ -48,6 +49,7 @@ int wgs_ctx_create(int device, wgs_ctx **out)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->cus = prop.multiProcessorCount;
+    guard.dismiss();
     *out = c;
     return 0;
 }
@@ -131,6 +133,7 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
     WGS_REQUIRE(n_groups >= 1, "n_groups must be >= 1");
     HIP_TRY(hipSetDevice(ctx->device));
     wgs_beagle *b = new wgs_beagle();
+    auto guard = on_failure([&] { wgs_beagle_destroy(b); });
     b->ctx = ctx;
     b->m = m;
     b->n = n;
@@ -143,7 +146,6 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
         const int g = group_of ? group_of[i] : 0;
         if (g < 0 || g >= n_groups) {
             wgs_set_error("group_of[%lld] = %d out of range (0..%d)", (long long)i, g, n_groups - 1);
-            wgs_beagle_destroy(b);
             return 2;
         }
         b->group_of[i] = g;
@@ -160,7 +162,6 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
         const size_t bytes = (size_t)wgs_ntiles(m) * s.npairs * 64 * sizeof(float4);
         if (hipMalloc(&s.base, bytes) != hipSuccess) {
             wgs_set_error("hipMalloc of %zu bytes for population slab %d failed", bytes, g);
-            wgs_beagle_destroy(b);
             return 1;
         }
         (void)hipMemsetAsync(s.base, 0, bytes, ctx->stream);
@@ -170,7 +171,6 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
         if (hipMalloc(&s.d_members, sizeof(int32_t) * s.ncols) != hipSuccess ||
             hipMemcpy(s.d_members, s.members.data(), sizeof(int32_t) * s.ncols, hipMemcpyHostToDevice) != hipSuccess) {
             wgs_set_error("could not upload the member table of slab %d", g);
-            wgs_beagle_destroy(b);
             return 1;
         }
     }
@@ -183,6 +183,7 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
     HIP_TRY(hipMemcpy(b->d_npairs, nps.data(), sizeof(int32_t) * n_groups, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_base, bases.data(), sizeof(float4 *) * n_groups, hipMemcpyHostToDevice));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    guard.dismiss();
     *out = b;
     return 0;
 }
@@ -206,8 +207,9 @@ int wgs_beagle_upload_rows(wgs_beagle *b, const float *L_rows, int64_t row0, int
     HIP_TRY(hipSetDevice(b->ctx->device));
     const int64_t chunk = staging_rows(b, nrows);
     const size_t row_bytes = (size_t)b->n * 2 * sizeof(float);
-    float *d_stage = nullptr;
-    HIP_TRY(hipMalloc(&d_stage, chunk * row_bytes));
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(b->ctx, chunk * row_bytes, &ws)) return 1;
+    float *d_stage = reinterpret_cast<float *>(ws);
     int rc = 0;
     for (int64_t r = 0; r < nrows && !rc; r += chunk) {
         const int64_t cnt = std::min(chunk, nrows - r);
@@ -222,7 +224,6 @@ int wgs_beagle_upload_rows(wgs_beagle *b, const float *L_rows, int64_t row0, int
             rc = 1;
         }
     }
-    (void)hipFree(d_stage);
     return rc;
 }
 
@@ -234,8 +235,9 @@ int wgs_beagle_download_rows(wgs_beagle *b, float *L_rows, int64_t row0, int64_t
     HIP_TRY(hipSetDevice(b->ctx->device));
     const int64_t chunk = staging_rows(b, nrows);
     const size_t row_bytes = (size_t)b->n * 2 * sizeof(float);
-    float *d_stage = nullptr;
-    HIP_TRY(hipMalloc(&d_stage, chunk * row_bytes));
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(b->ctx, chunk * row_bytes, &ws)) return 1;
+    float *d_stage = reinterpret_cast<float *>(ws);
     int rc = 0;
     for (int64_t r = 0; r < nrows && !rc; r += chunk) {
         const int64_t cnt = std::min(chunk, nrows - r);
@@ -247,7 +249,6 @@ int wgs_beagle_download_rows(wgs_beagle *b, float *L_rows, int64_t row0, int64_t
             rc = 1;
         }
     }
-    (void)hipFree(d_stage);
     return rc;
 }
 
@@ -304,6 +305,7 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     WGS_REQUIRE(mode == WGS_MODE_EXACT || mode == WGS_MODE_FAST, "unknown mode %d", mode);
     HIP_TRY(hipSetDevice(b->ctx->device));
     wgs_em *em = new wgs_em();
+    auto guard = on_failure([&] { wgs_em_destroy(em); });
     em->b = b;
     em->n_fits = n_fits;
     em->mode = mode;
@@ -316,7 +318,6 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
         const int g = fit_group[j];
         if (g < 0 || g >= b->n_groups || b->slabs[g].ncols == 0) {
             wgs_set_error("fit %d: group %d is out of range or empty", j, g);
-            delete em;
             return 2;
         }
         int skip = -1;
@@ -324,7 +325,6 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
             const int i = fit_skip[j];
             if (i >= b->n || b->group_of[i] != g) {
                 wgs_set_error("fit %d: left-out individual %d does not belong to group %d", j, i, g);
-                delete em;
                 return 2;
             }
             skip = b->col_of[i];
@@ -337,7 +337,6 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     for (int i = 0; i < 2; ++i) {
         if (hipMalloc(&em->fbuf[i], fbytes) != hipSuccess) {
             wgs_set_error("hipMalloc of %zu bytes for EM frequencies failed", fbytes);
-            wgs_em_destroy(em);
             return 1;
         }
     }
@@ -350,11 +349,9 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     HIP_TRY(hipEventCreate(&em->ev0));
     HIP_TRY(hipEventCreate(&em->ev1));
     HIP_TRY(hipHostMalloc(&em->h_descs, sizeof(FitDesc) * n_fits, hipHostMallocDefault));
-    if (launch_fill(b->ctx, em->fbuf[0], (int64_t)n_fits * b->m, 0.25f)) {   // emMAF.py:17-18
-        wgs_em_destroy(em);
-        return 1;
-    }
+    if (launch_fill(b->ctx, em->fbuf[0], (int64_t)n_fits * b->m, 0.25f)) return 1;   // emMAF.py:17-18
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    guard.dismiss();
     *out = em;
     return 0;
 }

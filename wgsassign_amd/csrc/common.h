@@ -26,6 +26,19 @@ void wgs_set_error(const char *fmt, ...);
         }                               \
     } while (0)
 
+// Runs `fn` when the scope is left unless dismissed: every early error return (HIP_TRY /
+// WGS_REQUIRE) of a create/upload function then releases what was allocated so far.
+template <typename F>
+struct ScopeFail {
+    F fn;
+    bool armed = true;
+    explicit ScopeFail(F f) : fn(f) {}
+    ~ScopeFail() { if (armed) fn(); }
+    void dismiss() { armed = false; }
+};
+template <typename F>
+ScopeFail<F> on_failure(F f) { return ScopeFail<F>(f); }
+
 struct wgs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
