@@ -149,6 +149,17 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
                double *out, double *parts);
 
+/* ------------------------------------------------------------------ Fisher information (--ne_obs)
+ * fisher.fisher_obs(L, af, IDs, t) -- fisher.py:11-44 over fisher_cy.fisher_obs / ne_obs
+ * (fisher_cy.pyx:12-39): per (SNP, population) the serial float32 sum over the population's
+ * individuals of the observed-information term, and n_tilde = 0.5 * f * a * (1 - a).  The slabs of
+ * `b` must be the populations of `a`'s columns.  Outputs are host (m, K) float32 matrices. */
+int wgs_fisher_obs(wgs_beagle *b, wgs_afset *a, float *f_obs_mK, float *ne_obs_mK);
+/* fisher.fisher_obs_ind -- fisher.py:46-60 over fisher_cy.pyx:41-65: ne_sum[i] += the sum over this
+ * shard's SNPs of individual i's n_tilde (float64); the caller divides by the SNP count
+ * (the reference takes np.mean of the float32 per-site vector). */
+int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum);
+
 /* ------------------------------------------------------------------ streamed Beagle reader (host)
  * reader_cy.readBeagle(path) -- reader_cy.pyx:16-77 -- as a chunked native reader: gzip inflate,
  * lines parsed in parallel into float32 (rows, 2n) chunks the caller owns (and typically hands

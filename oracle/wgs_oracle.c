@@ -107,6 +107,51 @@ void orc_log_f32(const float *x, float *out, int64_t n, int threads)
     for (int64_t i = 0; i < n; ++i) out[i] = (float)log((double)x[i]);
 }
 
+/* fisher_cy.pyx:12-30 / 41-56: the observed-information term of one (SNP, individual) under
+ * frequency th.  All locals of the reference are `cdef float`; bare literals are doubles. */
+static inline float fisher_term(float g0, float g1, float th)
+{
+    const float g2 = (float)((1.0 - (double)g0) - (double)g1);
+    const float u = (float)(((((double)g0 * (1.0 - (double)th)) * (1.0 - (double)th)) +
+                             ((((double)g1 * 2.0) * (double)th) * (1.0 - (double)th))) +
+                            (double)((g2 * th) * th));      /* g2 and th are both float: float products */
+    const float n1 = (float)(2.0 * ((double)(g0 + g2) - (2.0 * (double)g1)));
+    const float n2 = (float)((double)(th * n1) + (2.0 * (double)(g1 - g0)));
+    return (float)(-1.0 * (double)((n1 / u) - ((n2 / u) * (n2 / u))));
+}
+
+/* fisher_cy.pyx:12-30 fisher_obs(L_pop, A, t, i, n, f_pop) then :32-39 ne_obs(...): per SNP the
+ * serial float32 sum of the terms over the n individuals of L_pop, accumulated into f_pop; and
+ * n_tilde = 0.5 * f_pop * a * (1 - a) accumulated into ne_pop. */
+void orc_fisher_obs(const float *L_pop, int64_t m, int64_t n, const float *A, int64_t K, int64_t col,
+                    float *f_pop, float *ne_pop, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t s = 0; s < m; ++s) {
+        const float th = A[s * K + col];
+        float term_sum = 0.0f;
+        for (int64_t r = 0; r < n; ++r) term_sum = term_sum + fisher_term(L_pop[s * 2 * n + 2 * r], L_pop[s * 2 * n + 2 * r + 1], th);
+        f_pop[s] = f_pop[s] + term_sum;
+        const float n_tilde = (float)(((0.5 * (double)f_pop[s]) * (double)th) * (1.0 - (double)th));
+        ne_pop[s] = ne_pop[s] + n_tilde;
+    }
+}
+
+/* fisher_cy.pyx:41-56 fisher_obs_ind then :58-65 ne_obs_ind for individual i under column col. */
+void orc_fisher_obs_ind(const float *L, int64_t m, int64_t n, const float *A, int64_t K, int64_t i, int64_t col,
+                        float *f_ind, float *ne_ind, int threads)
+{
+    if (threads < 1) threads = 1;
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t s = 0; s < m; ++s) {
+        const float th = A[s * K + col];
+        f_ind[s] = f_ind[s] + fisher_term(L[s * 2 * n + 2 * i], L[s * 2 * n + 2 * i + 1], th);
+        const float n_tilde = (float)(((0.5 * (double)f_ind[s]) * (double)th) * (1.0 - (double)th));
+        ne_ind[s] = ne_ind[s] + n_tilde;
+    }
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

@@ -298,6 +298,37 @@ def g8_synth_mid():
          af_after=af_mut)
 
 
+def g9_fisher(L, IDs, af):
+    """--ne_obs: fisher.fisher_obs / fisher_obs_ind (fisher.py:11-60, fisher_cy.pyx:12-65)
+    and the text artefacts of WGSassign.py:252-274."""
+    from WGSassign import fisher
+    f_obs, ne_obs = fisher.fisher_obs(L, af.copy(), IDs, 4)
+    ne_ind = fisher.fisher_obs_ind(L, af.copy(), IDs, 4)
+    res = dict(f_obs=f_obs, ne_obs=ne_obs, ne_ind=ne_ind)
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([sys.executable, "-m", "WGSassign.WGSassign", "--beagle", BREED, "--pop_af_IDs", BREED_IDS,
+                            "--get_reference_af", "--ne_obs", "--out", os.path.join(td, "ne"), "--threads", "2"],
+                           cwd=td, capture_output=True, text=True, check=True)
+        res["stdout"] = np.array(r.stdout.replace(td, "<TMP>"))
+        res["ne_obs_txt"] = np.array(open(os.path.join(td, "ne.ne_obs.txt")).read())
+        res["ne_ind_txt"] = np.array(open(os.path.join(td, "ne.ne_ind.txt")).read())
+        assert np.load(os.path.join(td, "ne.fisher_obs.npy")).tobytes() == f_obs.tobytes()
+        assert np.load(os.path.join(td, "ne.ne_obs.npy")).tobytes() == ne_obs.tobytes()
+    # synthetic, larger n per population, interleaved labels
+    Ls, IDs_s = synth.make_beagle(5000, 61, 3, seed=31, interleave=True)
+    pops, f_raw, af_s, iters = ref_fit(Ls, IDs_s)
+    f2, ne2 = fisher.fisher_obs(Ls, af_s.copy(), IDs_s, 4)
+    ni2 = fisher.fisher_obs_ind(Ls, af_s.copy(), IDs_s, 4)
+    res.update(synth_digest=np.array(synth.digest(Ls)), synth_af=af_s, synth_f_obs=f2, synth_ne_obs=ne2, synth_ne_ind=ni2)
+    save("fisher.npz", **res)
+
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "fisher":
+    _g = np.load(os.path.join(HERE, "amre_fit.npz"))
+    g9_fisher(_g["L"], _g["IDs"], _g["pop_af"])
+    sys.exit(0)
+
 if __name__ == "__main__":
     L, samples, sites, IDs, af = g1_g2_amre_fit()
     g3_amre_assign(af)
@@ -307,3 +338,6 @@ if __name__ == "__main__":
     g6_accum_order()
     g7_rmse()
     g8_synth_mid()
+    g9_fisher(L, IDs, af)
+
+

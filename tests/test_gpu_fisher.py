@@ -1,0 +1,51 @@
+"""--ne_obs: observed Fisher information / effective sample sizes on the device
+against the golden vectors of the real reference (fisher.py / fisher_cy.pyx)."""
+import contextlib
+import io
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and a.tobytes() == b.tobytes()
+
+
+def test_fisher_obs_bit_exact(golden):
+    from wgsassign_amd import fisher
+    g, fit = golden("fisher.npz"), golden("amre_fit.npz")
+    f_obs, ne_obs = fisher.fisher_obs(fit["L"], fit["pop_af"].copy(), fit["IDs"], 1)
+    assert same(f_obs, g["f_obs"]) and same(ne_obs, g["ne_obs"])
+    ne_ind = fisher.fisher_obs_ind(fit["L"], fit["pop_af"].copy(), fit["IDs"], 1)
+    assert ne_ind.dtype == np.float32 and np.all(np.abs(ne_ind - g["ne_ind"]) <= 1e-6 * np.abs(g["ne_ind"]))
+    L, IDs = synth.make_beagle(5000, 61, 3, seed=31, interleave=True)
+    f_obs, ne_obs = fisher.fisher_obs(L, g["synth_af"].copy(), IDs, 1)
+    assert same(f_obs, g["synth_f_obs"]) and same(ne_obs, g["synth_ne_obs"])
+    ne_ind = fisher.fisher_obs_ind(L, g["synth_af"].copy(), IDs, 1)
+    assert np.all(np.abs(ne_ind - g["synth_ne_ind"]) <= 1e-6 * np.abs(g["synth_ne_ind"]))
+
+
+def test_cli_ne_obs(tmp_path, golden):
+    from wgsassign_amd import WGSassign
+    g = golden("fisher.npz")
+    data = os.path.join(GOLDEN, "data")
+    out = str(tmp_path / "ne")
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        WGSassign.main(["--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),
+                        "--pop_af_IDs", os.path.join(data, "amre.breeding.ind85.reference_k5.IDs.txt"),
+                        "--get_reference_af", "--ne_obs", "--out", out, "--threads", "2"])
+    assert same(np.load(out + ".fisher_obs.npy"), g["f_obs"]) and same(np.load(out + ".ne_obs.npy"), g["ne_obs"])
+    assert open(out + ".ne_obs.txt").read() == str(g["ne_obs_txt"])          # means of bit-identical columns
+    got = np.loadtxt(out + ".ne_ind.txt")
+    ref = np.loadtxt(io.StringIO(str(g["ne_ind_txt"])))
+    assert np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref) + 1e-7)
+    ref_lines = str(g["stdout"]).replace("<TMP>/", "").splitlines()
+    got_lines = [l.replace(str(tmp_path) + "/", "") for l in buf.getvalue().splitlines()]
+    assert got_lines == ref_lines

@@ -185,7 +185,7 @@ def test_cli_flags_and_refusals(tmp_path):
             WGSassign.main(["--loo_downsampled_beagle", "x.gz", "--out", str(tmp_path / "o")])
     with pytest.raises(SystemExit, match="outside the scope"):
         with contextlib.redirect_stdout(io.StringIO()):
-            WGSassign.main(["--ne_obs", "--out", str(tmp_path / "o")])
+            WGSassign.main(["--get_em_mix", "--out", str(tmp_path / "o")])
     # the .args log lists non-default options only (WGSassign.py:127-141)
     with contextlib.redirect_stdout(io.StringIO()):
         WGSassign.main(["--threads", "3", "--out", str(tmp_path / "log")])

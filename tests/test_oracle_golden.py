@@ -178,3 +178,16 @@ def test_synth_interleaved(oracle, golden):
     assert same(af, g["pop_af"]) and list(iters) == list(g["iters"])
     ll, _ = oracle.loo(L, af, IDs, 8, 200, 1e-4, None, 1)
     assert same(ll, g["loo"]) and same(af, g["af_after"])
+
+
+def test_fisher(oracle, golden):
+    """--ne_obs: fisher.py / fisher_cy.pyx restated, bit-exact incl. np.mean."""
+    g, fit = golden("fisher.npz"), golden("amre_fit.npz")
+    f_obs, ne_obs = oracle.fisher_obs(fit["L"], fit["pop_af"].copy(), fit["IDs"], 2)
+    assert same(f_obs, g["f_obs"]) and same(ne_obs, g["ne_obs"])
+    assert same(oracle.fisher_obs_ind(fit["L"], fit["pop_af"].copy(), fit["IDs"], 2), g["ne_ind"])
+    L, IDs = synth.make_beagle(5000, 61, 3, seed=31, interleave=True)
+    assert synth.digest(L) == str(g["synth_digest"])
+    f_obs, ne_obs = oracle.fisher_obs(L, g["synth_af"].copy(), IDs, 4)
+    assert same(f_obs, g["synth_f_obs"]) and same(ne_obs, g["synth_ne_obs"])
+    assert same(oracle.fisher_obs_ind(L, g["synth_af"].copy(), IDs, 4), g["synth_ne_ind"])

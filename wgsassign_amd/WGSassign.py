@@ -34,7 +34,9 @@ parser.add_argument("--partition_sites", type=int, metavar="INT", default=1,
                     help="Optional: partition sites into INT subsets (by modulo) and report assignment "
                          "log-likelihoods for each subset.")
 # recognised but not provided by this build (out of the hot-path scope)
-for _flag in ("--ne_obs", "--get_assignment_z_score", "--get_reference_z_score", "--single_read_threshold",
+parser.add_argument("--ne_obs", action="store_true",
+                    help="Estimate population and individuals effective sample sizes")
+for _flag in ("--get_assignment_z_score", "--get_reference_z_score", "--single_read_threshold",
               "--get_em_mix", "--get_mcmc_mix"):
     parser.add_argument(_flag, action="store_true", help=argparse.SUPPRESS)
 for _flag in ("--ind_ad_file", "--allele_count_threshold", "--ind_start", "--ind_end", "--pop_like", "--pop_like_IDs",
@@ -156,7 +158,7 @@ def main(argv=None):
             print("Using " + str(args.threads) + " thread(s).\n")
         for unsupported in ("ne_obs", "get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
             if getattr(args, unsupported):
-                raise SystemExit("--%s is outside the scope of the MI355X build" % unsupported)
+                raise SystemExit("--%s is not available in the SNP-sharded (multi-GPU) mode" % unsupported)
         return _main_sharded(args, comm)
     print("WGSassign")
     print("Matt DeSaix.")
@@ -164,10 +166,10 @@ def main(argv=None):
 
     if args.loo_downsampled_beagle and not args.loo:
         raise ValueError("The --loo_downsampled_beagle option requires that --loo is also specified.")
-    for unsupported in ("ne_obs", "get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
+    for unsupported in ("get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
         if getattr(args, unsupported):
-            raise SystemExit("--%s is outside the scope of the MI355X build (EM allele frequencies, "
-                             "leave-one-out and assignment likelihoods only)" % unsupported)
+            raise SystemExit("--%s is outside the scope of the MI355X build (EM allele frequencies, Fisher "
+                             "information, leave-one-out and assignment likelihoods only)" % unsupported)
 
     # log-file of non-default arguments (WGSassign.py:127-141)
     full, deaf = vars(args), vars(parser.parse_args([]))
@@ -185,7 +187,7 @@ def main(argv=None):
 
     import numpy as np
 
-    from . import emMAF, glassy, reader_cy, utils
+    from . import emMAF, fisher, glassy, reader_cy, utils
 
     L = None
     if args.beagle is not None:
@@ -227,6 +229,26 @@ def main(argv=None):
         np.savetxt(args.out + ".pop_names.txt", pops, fmt="%s")
         print("Saved reference population names as " + str(args.out) +
               ".pop_names.txt (String: Order of pops for .pop_af.npy, .ne_obs.npy, and fisher_obs.npy files)\n")
+
+        if args.ne_obs:                                          # WGSassign.py:252-274
+            print("Estimating Fisher information.")
+            f_obs, ne_obs = fisher.fisher_obs(L, af, IDs, args.threads)
+            np.save(args.out + ".fisher_obs", f_obs)
+            print("Saved reference population observed Fisher information per locus as " + str(args.out) +
+                  ".fisher_obs.npy (Binary - np.float32)\n")
+            np.save(args.out + ".ne_obs", ne_obs)
+            print("Saved reference population effective sample size estimates per locus as " + str(args.out) +
+                  ".ne_obs.npy (Binary - np.float32)\n")
+            ne_obs_mean_out = np.empty((2, len(pops)), dtype=np.dtype('U25'))
+            ne_obs_mean_out[0, :] = pops
+            ne_obs_mean_out[1, :] = np.mean(ne_obs, axis=0)
+            np.savetxt(args.out + ".ne_obs.txt", ne_obs_mean_out, fmt="%s")
+            print("Saved reference population effective sample size estimates as " + str(args.out) +
+                  ".ne_obs.txt (String - np.U25)\n")
+            print("Estimating individual effective sample sizes.")
+            ne_ind_full = fisher.fisher_obs_ind(L, af, IDs, args.threads)
+            np.savetxt(args.out + ".ne_ind.txt", ne_ind_full.reshape(-1, 1), fmt="%.7f")
+            print("Save individual effective sample sizes as " + str(args.out) + ".ne_ind.txt")
 
         if args.loo:
             print("Performing leave-one-out cross validation.")

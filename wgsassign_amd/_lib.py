@@ -58,6 +58,8 @@ SIGNATURES = {
     "wgs_afset_download": (c_int, [c_vp, c_f32p]),
     "wgs_afset_set_column_from_em": (c_int, [c_vp, c_i32, c_vp, c_i32]),
     "wgs_afset_col_dev": (c_vp, [c_vp, c_i32]),
+    "wgs_fisher_obs": (c_int, [c_vp, c_vp, c_f32p, c_f32p]),
+    "wgs_fisher_obs_ind": (c_int, [c_vp, c_vp, c_f64p]),
     "wgs_reader_open": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_vp)]),
     "wgs_reader_close": (None, [c_vp]),
     "wgs_reader_n_individuals": (c_int, [c_vp]),

@@ -642,6 +642,70 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     return 0;
 }
 
+/* ------------------------------------------------------------------ Fisher information (--ne_obs) */
+
+int wgs_fisher_obs(wgs_beagle *b, wgs_afset *a, float *f_obs_mK, float *ne_obs_mK)
+{
+    WGS_REQUIRE(b && a && f_obs_mK && ne_obs_mK, "null argument");
+    WGS_REQUIRE(a->m == b->m && a->K == b->n_groups, "allele frequencies (%lld x %d) do not match the population slabs (%lld x %d)",
+                (long long)a->m, a->K, (long long)b->m, b->n_groups);
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int K = a->K;
+    const size_t mk = (size_t)b->m * K;
+    // workspace: [f (K x m) | ne (K x m) | transposed (m x K) | descs]
+    const size_t off_desc = (3 * mk * sizeof(float) + 255) & ~(size_t)255;
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, off_desc + sizeof(FisherDesc) * K, &ws)) return 1;
+    float *d_f = reinterpret_cast<float *>(ws), *d_ne = d_f + mk, *d_t = d_ne + mk;
+    FisherDesc *d_descs = reinterpret_cast<FisherDesc *>(reinterpret_cast<char *>(ws) + off_desc);
+    std::vector<FisherDesc> descs;
+    for (int g = 0; g < K; ++g) {
+        const Slab &s = b->slabs[g];
+        WGS_REQUIRE(s.ncols > 0, "population %d has no individuals", g);
+        FisherDesc d;
+        d.slab = s.base;
+        d.th = a->buf + (size_t)g * a->m;
+        d.f_out = d_f + (size_t)g * b->m;
+        d.ne_out = d_ne + (size_t)g * b->m;
+        d.npairs = s.npairs;
+        d.ncols = s.ncols;
+        descs.push_back(d);
+    }
+    HIP_TRY(hipMemcpyAsync(d_descs, descs.data(), sizeof(FisherDesc) * K, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (launch_fisher_pop(ctx, d_descs, K, b->m)) return 1;
+    if (launch_transpose_Km_to_mK(ctx, d_f, d_t, b->m, K)) return 1;
+    HIP_TRY(hipMemcpyAsync(f_obs_mK, d_t, mk * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (launch_transpose_Km_to_mK(ctx, d_ne, d_t, b->m, K)) return 1;
+    HIP_TRY(hipMemcpyAsync(ne_obs_mK, d_t, mk * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum)
+{
+    WGS_REQUIRE(b && a && ne_sum, "null argument");
+    WGS_REQUIRE(a->m == b->m && a->K == b->n_groups, "allele frequencies do not match the population slabs");
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, sizeof(double) * b->n, &ws)) return 1;
+    double *d_out = reinterpret_cast<double *>(ws);
+    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(double) * b->n, ctx->stream));
+    for (int g = 0; g < b->n_groups; ++g) {
+        const Slab &s = b->slabs[g];
+        if (s.ncols == 0) continue;
+        if (launch_fisher_ind(ctx, s.base, s.d_members, a->buf + (size_t)g * a->m, d_out, b->m, s.npairs, s.ncols)) return 1;
+    }
+    std::vector<double> h(b->n);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_out, sizeof(double) * b->n, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < b->n; ++i) ne_sum[i] += h[i];
+    return 0;
+}
+
 /* ------------------------------------------------------------------ test hooks */
 
 int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first)

@@ -97,6 +97,15 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     int32_t n_eff;     // ncols - (skip >= 0)
 };
 
+struct FisherDesc {    // one population of the --ne_obs sweep
+    const float4 *slab;
+    const float *th;       // the population's (clamped) allele frequencies, m floats
+    float *f_out, *ne_out; // observed Fisher information / effective sample size per SNP
+    int32_t npairs, ncols;
+};
+int launch_fisher_pop(wgs_ctx *ctx, const FisherDesc *d_descs, int32_t n_desc, int64_t m);
+int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, const float *th, double *out, int64_t m,
+                      int npairs, int ncols);
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
 int ssq_reduce_chunks(void);
 int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2);

@@ -453,6 +453,89 @@ __global__ __launch_bounds__(64) void rmse_walk_kernel(const float *__restrict__
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Observed Fisher information / effective sample size (--ne_obs; fisher_cy.pyx:12-65).  Same
+// shape as the EM update: per SNP a serial float32 sum over the individuals of a population,
+// so the same lane<->SNP sweep over the tile-interleaved slab applies.
+//
+// fisher_cy.pyx:21-27, all locals float32, literals double (one rounding per operation):
+//   g2 = (float)((1.0 - g0) - g1)
+//   u  = (float)((g0*(1.0-th))*(1.0-th) + ((g1*2.0)*th)*(1.0-th) + (double)((g2*th)*th))
+//   n1 = (float)(2.0*((double)(g0+g2) - 2.0*g1));  n2 = (float)((double)(th*n1) + 2.0*(double)(g1-g0))
+//   term = -((n1/u) - (n2/u)*(n2/u))                                   (float32 divides)
+__device__ __forceinline__ float fisher_term(float g0, float g1, float th, double thd, double omt)
+{
+    const double g0d = (double)g0, g1d = (double)g1;
+    const float g2 = (float)((1.0 - g0d) - g1d);
+    const float u = (float)((((g0d * omt) * omt) + (((g1d * 2.0) * thd) * omt)) + (double)((g2 * th) * th));
+    const float n1 = (float)(2.0 * ((double)(g0 + g2) - (2.0 * g1d)));
+    const float n2 = (float)((double)(th * n1) + (2.0 * (double)(g1 - g0)));
+    const float q = n2 / u;
+    return -((n1 / u) - (q * q));
+}
+
+__global__ __launch_bounds__(WAVES * 64) void fisher_pop_kernel(const FisherDesc *__restrict__ descs, int n_desc, int64_t m)
+{
+    const FisherDesc fd = descs[blockIdx.x % (unsigned)n_desc];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)(blockIdx.x / (unsigned)n_desc) * WAVES + wave;
+    const int64_t row0 = tile * 64;
+    if (row0 >= m) return;
+    const int64_t my_row = row0 + lane;
+    const int64_t my_row_c = my_row < m ? my_row : m - 1;
+    const float th = ((gf32_ptr)fd.th)[my_row_c];
+    const double thd = (double)th, omt = 1.0 - thd;
+    gf4_ptr src = (gf4_ptr)fd.slab + tile * fd.npairs * 64 + lane;
+    float term_sum = 0.0f;
+    for (int p = 0; p < fd.npairs; ++p) {
+        const f4 v = __builtin_nontemporal_load(src + p * 64);
+        term_sum = term_sum + fisher_term(v.x, v.y, th, thd, omt);                        // fisher_cy.pyx:28
+        if (2 * p + 1 < fd.ncols) term_sum = term_sum + fisher_term(v.z, v.w, th, thd, omt);
+    }
+    if (my_row < m) {
+        ((gf32_wptr)fd.f_out)[my_row] = term_sum;                                         // 0.0f + term_sum (fisher_cy.pyx:29)
+        ((gf32_wptr)fd.ne_out)[my_row] = (float)(((0.5 * (double)term_sum) * thd) * omt);  // fisher_cy.pyx:37-38
+    }
+}
+
+// Per individual: sum over this shard's SNPs of its effective-sample-size term (fisher_cy.pyx:41-65,
+// fisher.py:52-59 takes the mean).  lane <-> SNP, wave <-> (pair of individuals, range of tiles).
+__global__ __launch_bounds__(256) void fisher_ind_kernel(const float4 *__restrict__ slab, const int32_t *__restrict__ members,
+                                                        const float *__restrict__ th_vec, double *__restrict__ out, int64_t m,
+                                                        int npairs, int ncols, int tiles_per_wave)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int pair = (int)(wid % npairs);
+    const int64_t ntiles = (m + 63) >> 6;
+    const int64_t t0 = (wid / npairs) * tiles_per_wave;
+    int64_t t1 = t0 + tiles_per_wave;
+    if (t1 > ntiles) t1 = ntiles;
+    if (t0 >= t1) return;
+    double acc_a = 0.0, acc_b = 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const int64_t s = (t << 6) + lane;
+        const bool live = s < m;
+        const float th = th_vec[live ? s : m - 1];
+        const double thd = (double)th, omt = 1.0 - thd;
+        const float4 g = slab[((t * npairs + pair) << 6) + lane];
+        const float fa = fisher_term(g.x, g.y, th, thd, omt), fb = fisher_term(g.z, g.w, th, thd, omt);
+        const float na = (float)(((0.5 * (double)fa) * thd) * omt), nb = (float)(((0.5 * (double)fb) * thd) * omt);
+        acc_a += live ? (double)na : 0.0;
+        acc_b += live ? (double)nb : 0.0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        acc_a += __shfl_down(acc_a, off, 64);
+        acc_b += __shfl_down(acc_b, off, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&out[members[2 * pair]], acc_a);
+        if (2 * pair + 1 < ncols) atomicAdd(&out[members[2 * pair + 1]], acc_b);
+    }
+}
+
 }  // namespace
 
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode)
@@ -489,6 +572,34 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 int ssq_reduce_chunks(void) { return RED_CHUNKS; }
 
 // part2: n_fits * ssq_reduce_chunks() doubles of device scratch
+int launch_fisher_pop(wgs_ctx *ctx, const FisherDesc *d_descs, int32_t n_desc, int64_t m)
+{
+    if (n_desc <= 0 || m <= 0) return 0;
+    const int64_t blocks = ((wgs_ntiles(m) + WAVES - 1) / WAVES) * n_desc;
+    WGS_REQUIRE(blocks < (1ll << 31), "fisher sweep: too many workgroups");
+    hipLaunchKernelGGL(fisher_pop_kernel, dim3((unsigned)blocks), dim3(WAVES * 64), 0, ctx->stream, d_descs, n_desc, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, const float *th, double *out, int64_t m,
+                      int npairs, int ncols)
+{
+    if (m <= 0 || npairs <= 0) return 0;
+    const int64_t ntiles = wgs_ntiles(m);
+    int64_t ranges = ((int64_t)ctx->cus * 32 + npairs - 1) / npairs;
+    if (ranges < 1) ranges = 1;
+    int64_t tpw = (ntiles + ranges - 1) / ranges;
+    if (tpw < 8) tpw = 8;
+    if (tpw > ntiles) tpw = ntiles;
+    ranges = (ntiles + tpw - 1) / tpw;
+    const int64_t waves = ranges * npairs;
+    hipLaunchKernelGGL(fisher_ind_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, slab, members, th, out, m,
+                       npairs, ncols, (int)tpw);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2)
 {
     if (n_fits <= 0 || m <= 0) return 0;
