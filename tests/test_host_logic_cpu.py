@@ -191,3 +191,13 @@ def test_cli_flags_and_refusals(tmp_path):
         WGSassign.main(["--threads", "3", "--out", str(tmp_path / "log")])
     txt = (tmp_path / "log.args").read_text()
     assert txt.startswith("WGSassign\nTime: ") and "\t-threads 3\n" in txt and "maf_iter" not in txt
+
+
+def test_reference_import_paths_resolve():
+    """`from WGSassign import ...` (the reference's import paths, WGSassign.py:148-159) reach this build."""
+    from WGSassign import emMAF, emMAF_cy, fisher, glassy, glassy_cy, reader_cy, utils
+    import WGSassign.WGSassign as cli
+    assert emMAF.emMAF.__module__ == "wgsassign_amd.emMAF" and glassy.loo.__module__ == "wgsassign_amd.glassy"
+    assert emMAF_cy.emMAF_update.__module__ == "wgsassign_amd.emMAF_cy" and callable(glassy_cy.loglike)
+    assert callable(reader_cy.readBeagle) and callable(utils.write_ass_mats) and callable(fisher.fisher_obs)
+    assert cli.parser.prog == "WGSassign" and callable(cli.main)
