@@ -349,3 +349,28 @@ def test_loo_fit_equals_explicit_removal(wg, oracle):
         assert iters[j] > 0 and same(f, em.get_f(j)[100_000:101_024]), i
     em.close()
     b.close()
+
+
+def test_fast_mode_synthetic_mid(wg, golden):
+    """WGS_MODE_FAST on the 50k x 100 x K=5 fixture: identical iteration counts, frequencies within
+    2e-6 relative of the reference (measured max 9.2e-7), assignment sums within 1e-6 (measured 1.2e-7)."""
+    from wgsassign_amd._lib import MODE_FAST
+    g = golden("synth_mid.npz")
+    L, IDs = synth.make_beagle(int(g["m"]), int(g["n"]), int(g["K"]))
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    b = wg.device.DeviceBeagle.from_host(L, group_of, len(pops))
+    em = wg.device.EMBatch(b, np.arange(5, dtype=np.int32), mode=MODE_FAST)
+    assert list(em.run(200, 1e-4)) == list(g["iters"])
+    worst = 0.0
+    for k in range(5):
+        em.clamp(k, 20)
+        f, ref = em.get_f(k).astype(np.float64), g["pop_af"][:, k].astype(np.float64)
+        worst = max(worst, float(np.max(np.abs(f - ref) / ref)))
+    assert worst <= 2e-6, worst
+    bs = wg.device.DeviceBeagle.from_host(np.ascontiguousarray(L[:5000]))
+    afs = wg.device.AFSet.from_host(np.ascontiguousarray(g["pop_af"][:5000]))
+    out, _ = wg.device.assign(bs, afs, mode=MODE_FAST)
+    assert close(out.astype(np.float32), g["logl_5000"], 1e-6)
+    for x in (em, afs, bs, b):
+        x.close()
