@@ -64,17 +64,25 @@ def main():
 
     dist = torch = None
     use_dist = world > 1 or os.environ.get("WGS_FORCE_DIST") == "1"   # WGS_FORCE_DIST: rehearse the RCCL path on 1 GPU
-    if use_dist:
+    native = os.environ.get("WGSASSIGN_COMM") == "rccl"              # the library's own RCCL communicator, no torch
+    if use_dist and not native:
+        # torch ships its own HIP runtime: it must initialise BEFORE libwgsassign_hip.so touches the
+        # device (the other order leaves torch with "No HIP GPUs are available")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = device.Context(local_rank)
+    if use_dist and native:
+        comm = wcomm.RcclComm(ctx, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                              int(os.environ.get("MASTER_PORT", "29400")))
+        comm.force_device = True
+    elif use_dist:
         comm = wcomm.TorchComm(device=torch.device("cuda", local_rank))
         comm.force_device = True
     else:
         comm = wcomm.LocalComm()
 
-    ctx = device.Context(local_rank)
     m_total, n, K = args.m, args.n, args.K
     lo, hi = wcomm.shard_range(m_total, rank, world)
     m = hi - lo
@@ -91,10 +99,23 @@ def main():
 
     def barrier():
         ctx.sync()
-        if use_dist:
+        if use_dist and native:
+            comm.barrier()
+        elif use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         ctx.sync()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        if native:      # max via sums: one slot per rank
+            slots = np.zeros(world)
+            slots[rank] = x
+            return float(np.max(comm.allreduce_sum(slots)))
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     def step():
         # sweep kernel -> (N > 1: RCCL all-reduce of the K sums, enqueued behind it) -> one readback:
@@ -110,11 +131,7 @@ def main():
         ssq = step()
         kernel_ms.append(em.last_sweep_ms())
     barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     ms_per_step = elapsed / args.steps * 1e3
     value = K * m_total * args.steps / elapsed          # per-population SNP-updates/s, whole job
 
@@ -143,11 +160,7 @@ def main():
         t0 = time.perf_counter()
         out, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
         barrier()
-        t_as = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([t_as], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            t_as = float(t.item())
+        t_as = max_over_ranks(time.perf_counter() - t0)
         as_ms = device.assign.last_ms
         extra["assign"] = {"metric": "assignment log-lik SNPs/s (all n x K terms of a SNP = 1)",
                            "value": m_total / t_as, "unit": "SNPs/s", "seconds": round(t_as, 4),
@@ -173,7 +186,10 @@ def main():
         print(json.dumps(line), flush=True)
     em.close()
     beagle.close()
-    if use_dist:
+    if use_dist and native:
+        comm.barrier()
+        comm.close()
+    elif use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -149,6 +149,24 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
                double *out, double *parts);
 
+/* ------------------------------------------------------------------ RCCL communicator (SNP shards)
+ * The one collective of the sharded path -- a sum all-reduce of a few float64 over xGMI -- without
+ * a tensor framework: librccl is dlopen'ed on first use.  Rank 0 creates the 128-byte unique id,
+ * the host side distributes it (wgsassign_amd/comm.py: TCP on MASTER_ADDR), every rank inits. */
+typedef struct wgs_comm wgs_comm;
+int wgs_comm_unique_id(uint8_t *id128);
+int wgs_comm_init(wgs_ctx *ctx, const uint8_t *id128, int rank, int world, wgs_comm **out);
+void wgs_comm_destroy(wgs_comm *c);
+/* In-place sum of n float64 in device memory, enqueued on the context's stream (pairs with wgs_em_step_dev). */
+int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n);
+/* Same for a host buffer (staged through the device); returns when the result is back. */
+int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n);
+/* The communicator's device bounce buffer (>= n float64), e.g. as the target of wgs_em_step_dev;
+ * wgs_comm_allreduce_buffer reduces its first n elements in place on the stream, copies them to
+ * host_out and synchronises: sweep -> all-reduce -> one readback, nothing in between on the host. */
+double *wgs_comm_buffer(wgs_comm *c, int64_t n);
+int wgs_comm_allreduce_buffer(wgs_comm *c, int64_t n, double *host_out);
+
 /* ------------------------------------------------------------------ Fisher information (--ne_obs)
  * fisher.fisher_obs(L, af, IDs, t) -- fisher.py:11-44 over fisher_cy.fisher_obs / ne_obs
  * (fisher_cy.pyx:12-39): per (SNP, population) the serial float32 sum over the population's

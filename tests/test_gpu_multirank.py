@@ -82,6 +82,15 @@ def test_two_ranks_one_gpu(tmp_path, guard):
         assert "RANK %d OK" % r in o
 
 
+def clean(stdout):
+    """Program output without the launcher's noise: gloo prints a banner per rank and torchrun may
+    emit a blank line before the first program line."""
+    lines = [l for l in stdout.splitlines() if not l.startswith("[Gloo]")]
+    while lines and lines[0] == "":
+        lines.pop(0)
+    return lines
+
+
 def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     """`torchrun --nproc-per-node 2 -m wgsassign_amd.WGSassign ...` (gloo, both ranks on the one GPU):
     same stdout and output files as the reference CLI run recorded in tests/golden/amre_cli.npz."""
@@ -102,7 +111,7 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     assert np.load(tmp_path / "ref.pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
     assert (tmp_path / "ref.pop_names.txt").read_text() == str(g["pop_names"])
     ref_lines = str(g["stdout_ref"]).replace("<TMP>/", "").splitlines()
-    got_lines = [l for l in r.stdout.splitlines() if not l.startswith("[Gloo]")]      # gloo prints its own banner
+    got_lines = clean(r.stdout)
     assert got_lines == ref_lines, "\n".join(got_lines[:12])
 
     def table(text):
@@ -128,5 +137,20 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     got = np.loadtxt(tmp_path / "nb.pop_like.txt")
     ref = np.loadtxt(__import__("io").StringIO(str(g["pop_like_txt"])))
     assert np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref))
-    assert [l for l in r.stdout.splitlines() if not l.startswith("[Gloo]")] == \
-        str(g["stdout_like"]).replace("<TMP>/", "").splitlines()
+    assert clean(r.stdout) == str(g["stdout_like"]).replace("<TMP>/", "").splitlines()
+
+
+def test_native_rccl_single_rank():
+    """The library's own RCCL communicator (dlopen'ed librccl, no torch): with one rank the all-reduce
+    is the identity -- exercises loading, unique id, init, the stream-ordered collective, destroy."""
+    import numpy as np
+    from wgsassign_amd import comm as wcomm
+    from wgsassign_amd import device
+    c = wcomm.RcclComm(device.get_context(), 0, 1)
+    x = np.array([1.5, -2.25, 1e300, 0.0])
+    assert np.array_equal(c.allreduce_sum(x), x)
+    assert c.allgather_object({"a": 1}) == [{"a": 1}]
+    big = np.arange(200_000, dtype=np.float64)
+    assert np.array_equal(c.allreduce_sum(big), big)
+    c.barrier()
+    c.close()

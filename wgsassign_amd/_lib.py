@@ -58,6 +58,13 @@ SIGNATURES = {
     "wgs_afset_download": (c_int, [c_vp, c_f32p]),
     "wgs_afset_set_column_from_em": (c_int, [c_vp, c_i32, c_vp, c_i32]),
     "wgs_afset_col_dev": (c_vp, [c_vp, c_i32]),
+    "wgs_comm_unique_id": (c_int, [ctypes.POINTER(ctypes.c_uint8)]),
+    "wgs_comm_init": (c_int, [c_vp, ctypes.POINTER(ctypes.c_uint8), c_int, c_int, ctypes.POINTER(c_vp)]),
+    "wgs_comm_destroy": (None, [c_vp]),
+    "wgs_comm_allreduce_f64_dev": (c_int, [c_vp, c_vp, c_i64]),
+    "wgs_comm_allreduce_f64": (c_int, [c_vp, c_f64p, c_i64]),
+    "wgs_comm_buffer": (c_vp, [c_vp, c_i64]),
+    "wgs_comm_allreduce_buffer": (c_int, [c_vp, c_i64, c_f64p]),
     "wgs_fisher_obs": (c_int, [c_vp, c_vp, c_f32p, c_f32p]),
     "wgs_fisher_obs_ind": (c_int, [c_vp, c_vp, c_f64p]),
     "wgs_reader_open": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_vp)]),

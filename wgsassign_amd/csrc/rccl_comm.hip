@@ -1,0 +1,172 @@
+// Native RCCL communicator: the one collective of the SNP-sharded path (sum all-reduce of a few
+// float64 over xGMI) without any tensor framework.  librccl is dlopen'ed on first use, so the
+// library has no link-time dependency on it and single-GPU use never loads it.
+//
+// Bootstrap: rank 0 obtains the 128-byte ncclUniqueId (wgs_comm_unique_id), the host side hands it
+// to the other ranks (wgsassign_amd/comm.py does that over a TCP socket on MASTER_ADDR), every
+// rank calls wgs_comm_init.  The all-reduce is enqueued on the context's HIP stream, i.e. behind
+// the EM sweep that produced the sums.
+#include <dlfcn.h>
+#include <string.h>
+
+#include "common.h"
+
+namespace {
+
+typedef struct { char internal[128]; } rcclUniqueId;
+typedef void *rcclComm_t;
+// values from rccl.h (ncclDataType_t / ncclRedOp_t)
+constexpr int kFloat64 = 8, kSum = 0;
+
+struct Api {
+    void *handle = nullptr;
+    int (*GetUniqueId)(rcclUniqueId *) = nullptr;
+    int (*CommInitRank)(rcclComm_t *, int, rcclUniqueId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(rcclComm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+Api *api()
+{
+    static Api a;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : names) {
+            a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (a.handle) break;
+        }
+        if (a.handle) {
+            a.GetUniqueId = (int (*)(rcclUniqueId *))dlsym(a.handle, "ncclGetUniqueId");
+            a.CommInitRank = (int (*)(rcclComm_t *, int, rcclUniqueId, int))dlsym(a.handle, "ncclCommInitRank");
+            a.AllReduce = (int (*)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t))dlsym(a.handle, "ncclAllReduce");
+            a.CommDestroy = (int (*)(rcclComm_t))dlsym(a.handle, "ncclCommDestroy");
+            a.GetErrorString = (const char *(*)(int))dlsym(a.handle, "ncclGetErrorString");
+        }
+    }
+    if (!a.handle || !a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) return nullptr;
+    return &a;
+}
+
+}  // namespace
+
+struct wgs_comm {
+    wgs_ctx *ctx = nullptr;
+    rcclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    double *buf = nullptr;     // device bounce buffer for host-side reductions
+    size_t buf_elems = 0;
+};
+
+#define RCCL_TRY(expr)                                                                              \
+    do {                                                                                            \
+        int r_ = (expr);                                                                            \
+        if (r_ != 0) {                                                                              \
+            wgs_set_error("%s failed: %s", #expr, A->GetErrorString ? A->GetErrorString(r_) : "RCCL error"); \
+            return 1;                                                                               \
+        }                                                                                           \
+    } while (0)
+
+extern "C" {
+
+int wgs_comm_unique_id(uint8_t *id128)
+{
+    WGS_REQUIRE(id128, "null argument");
+    Api *A = api();
+    WGS_REQUIRE(A, "librccl could not be loaded (dlopen librccl.so.1)");
+    rcclUniqueId id;
+    RCCL_TRY(A->GetUniqueId(&id));
+    memcpy(id128, id.internal, 128);
+    return 0;
+}
+
+int wgs_comm_init(wgs_ctx *ctx, const uint8_t *id128, int rank, int world, wgs_comm **out)
+{
+    WGS_REQUIRE(ctx && id128 && out && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    Api *A = api();
+    WGS_REQUIRE(A, "librccl could not be loaded (dlopen librccl.so.1)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    wgs_comm *c = new wgs_comm();
+    auto guard = on_failure([&] { delete c; });
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    rcclUniqueId id;
+    memcpy(id.internal, id128, 128);
+    RCCL_TRY(A->CommInitRank(&c->comm, world, id, rank));
+    guard.dismiss();
+    *out = c;
+    return 0;
+}
+
+void wgs_comm_destroy(wgs_comm *c)
+{
+    if (!c) return;
+    Api *A = api();
+    (void)hipSetDevice(c->ctx->device);
+    if (A && c->comm) (void)A->CommDestroy(c->comm);
+    if (c->buf) (void)hipFree(c->buf);
+    delete c;
+}
+
+/* In-place sum all-reduce of n float64 in DEVICE memory, enqueued on the context's stream. */
+int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n)
+{
+    WGS_REQUIRE(c && dev_buf && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    Api *A = api();
+    WGS_REQUIRE(A, "librccl not loaded");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    RCCL_TRY(A->AllReduce(dev_buf, dev_buf, (size_t)n, kFloat64, kSum, c->comm, c->ctx->stream));
+    return 0;
+}
+
+/* The communicator's device bounce buffer, grown to hold n float64 (contents not preserved when it grows). */
+double *wgs_comm_buffer(wgs_comm *c, int64_t n)
+{
+    if (!c || n < 0) return nullptr;
+    if (hipSetDevice(c->ctx->device) != hipSuccess) return nullptr;
+    if ((size_t)n > c->buf_elems) {
+        (void)hipStreamSynchronize(c->ctx->stream);
+        if (c->buf) (void)hipFree(c->buf);
+        c->buf = nullptr;
+        c->buf_elems = 0;
+        const size_t want = (size_t)n < 1024 ? 1024 : (size_t)n;
+        if (hipMalloc(&c->buf, sizeof(double) * want) != hipSuccess) {
+            wgs_set_error("hipMalloc of the communicator bounce buffer failed");
+            return nullptr;
+        }
+        c->buf_elems = want;
+    }
+    return c->buf;
+}
+
+/* All-reduce the first n float64 of the bounce buffer in place (behind the work already on the
+ * stream, e.g. wgs_em_step_dev into wgs_comm_buffer) and copy them to host_out; synchronises. */
+int wgs_comm_allreduce_buffer(wgs_comm *c, int64_t n, double *host_out)
+{
+    WGS_REQUIRE(c && host_out && n >= 0 && (size_t)n <= c->buf_elems, "bad argument");
+    if (n == 0) return 0;
+    if (wgs_comm_allreduce_f64_dev(c, c->buf, n)) return 1;
+    HIP_TRY(hipMemcpyAsync(host_out, c->buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    return 0;
+}
+
+/* Same for a HOST buffer: staged through the bounce buffer; returns after the result is back. */
+int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n)
+{
+    WGS_REQUIRE(c && host_buf && n >= 0, "bad argument");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    if (!wgs_comm_buffer(c, n)) return 1;
+    HIP_TRY(hipMemcpyAsync(c->buf, host_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->ctx->stream));
+    if (wgs_comm_allreduce_f64_dev(c, c->buf, n)) return 1;
+    HIP_TRY(hipMemcpyAsync(host_buf, c->buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+    return 0;
+}
+
+}  // extern "C"

@@ -224,6 +224,8 @@ class EMBatch:
         all-reduce is enqueued behind it on the same stream, one readback ends the iteration."""
         if comm is None or comm.world == 1 and not getattr(comm, "force_device", False):
             return self.step()
+        if hasattr(comm, "step_reduced"):      # library-native RCCL: sweep, all-reduce and readback on one stream
+            return comm.step_reduced(self._h, self.n_fits)
         buf = getattr(self, "_ssq_buf", None)
         if buf is None and hasattr(comm, "device_buffer"):
             buf = self._ssq_buf = comm.device_buffer(self.n_fits)
