@@ -149,6 +149,15 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
                double *out, double *parts);
 
+/* utils.partition_loglikes(per_site_ll, P) -- utils.py:129-151 -- for every (individual, population)
+ * pair, BIT-EXACT: the reference accumulates each partition serially in float32 in site order
+ * (np.add.at); one GPU lane per (individual, population, partition) chain does the same.
+ * carry_in (float32 [n*P*K], NULL for the first SNP shard) is the running value after the
+ * preceding shards, parts_out (float32 [n*P*K], index (i*P + p)*K + k) the value after this one.
+ * Always exact-mode arithmetic.  Cost ~ (m / P) x one site's latency (parallel over chains only). */
+int wgs_assign_parts_exact(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P,
+                           const float *carry_in, float *parts_out);
+
 /* ------------------------------------------------------------------ RCCL communicator (SNP shards)
  * The one collective of the sharded path -- a sum all-reduce of a few float64 over xGMI -- without
  * a tensor framework: librccl is dlopen'ed on first use.  Rank 0 creates the 128-byte unique id,

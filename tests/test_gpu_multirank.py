@@ -55,7 +55,7 @@ ok &= list(iters) == list(fit["iters"]) and af.tobytes() == np.ascontiguousarray
 # --loo with 3 partitions (labels use GLOBAL site indices)
 with contextlib.redirect_stdout(io.StringIO()):
     ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, 3, comm=comm, verbose=False)
-ok &= close(ll, loo["loo_P3"], 1e-6) and close(parts, loo["parts_P3"], 2e-5)
+ok &= close(ll, loo["loo_P3"], 1e-6) and parts.tobytes() == loo["parts_P3"].tobytes()   # float32 carries cross the ranks
 ok &= af.tobytes() == np.ascontiguousarray(loo["af_after_P3"][lo:hi]).tobytes()
 # --get_pop_like on the other file
 La = asg["L"]
@@ -85,7 +85,7 @@ def test_two_ranks_one_gpu(tmp_path, guard):
 def clean(stdout):
     """Program output without the launcher's noise: gloo prints a banner per rank and torchrun may
     emit a blank line before the first program line."""
-    lines = [l for l in stdout.splitlines() if not l.startswith("[Gloo]")]
+    lines = [l for l in stdout.splitlines() if "[Gloo]" not in l and "connected peer ranks" not in l]   # ranks interleave
     while lines and lines[0] == "":
         lines.pop(0)
     return lines
@@ -126,9 +126,7 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     h_ref, r_ref = table(str(g["parts_tsv"]))
     h_got, r_got = table(gzip.open(tmp_path / "ref.pop_like_LOO_partitions_3.tsv.gz", "rt").read())
     assert h_got == h_ref
-    a = np.array([[float(v) for v in x[3:]] for x in r_got])
-    b = np.array([[float(v) for v in x[3:]] for x in r_ref])
-    assert np.all(np.abs(a - b) <= 2e-5 * np.abs(b))
+    assert r_got == r_ref                       # partition sums are bit-exact -> identical text
     # --get_pop_like, sharded
     r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.nonbreeding.ind34.ds_2x.sites-filter.top_50_each.beagle.gz"),
                                "--pop_af_file", "ref.pop_af.npy", "--get_pop_like", "--out", "nb", "--threads", "2"],

@@ -60,7 +60,8 @@ def main():
     if a.loo:
         tm = {}
         t0 = time.perf_counter()
-        ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, a.partitions, verbose=False, timings=tm)
+        ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, a.partitions, verbose=False, timings=tm,
+                                      need_parts=a.partitions > 1)      # as the command line does
         res["loo"] = {"seconds": round(time.perf_counter() - t0, 3), "em_seconds": round(tm["em_seconds"], 3),
                       "score_seconds": round(tm["score_seconds"], 3), "fits": n,
                       "iters_min_max": [int(tm["iters"].min()), int(tm["iters"].max())],

@@ -110,7 +110,7 @@ def _main_sharded(args, comm):
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
                 ll, parts = glassy.loo_device(beagle, beagle, af, group_of, args.maf_iter, args.maf_tole,
-                                              args.partition_sites, comm=comm)
+                                              args.partition_sites, comm=comm, need_parts=args.partition_sites > 1)
             if root:
                 sys.stdout.write(buf.getvalue())
                 outfile = f"{args.out}.pop_like_LOO.tsv"
@@ -253,7 +253,8 @@ def main(argv=None):
         if args.loo:
             print("Performing leave-one-out cross validation.")
             logl_mat_loo, logl_parts_mat_loo = glassy.loo(L, af, IDs, args.threads, args.maf_iter, args.maf_tole,
-                                                          downsampled_L=L_ds, num_partitions=args.partition_sites)
+                                                          downsampled_L=L_ds, num_partitions=args.partition_sites,
+                                                          need_parts=args.partition_sites > 1)
             suffix = "_downsampled" if L_ds is not None else ""
             outfile = f"{args.out}.pop_like_LOO{suffix}.tsv"
             partfile = f"{args.out}.pop_like_LOO{suffix}_partitions_{args.partition_sites}.tsv.gz"

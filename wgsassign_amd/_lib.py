@@ -58,6 +58,7 @@ SIGNATURES = {
     "wgs_afset_download": (c_int, [c_vp, c_f32p]),
     "wgs_afset_set_column_from_em": (c_int, [c_vp, c_i32, c_vp, c_i32]),
     "wgs_afset_col_dev": (c_vp, [c_vp, c_i32]),
+    "wgs_assign_parts_exact": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_f32p, c_f32p]),
     "wgs_comm_unique_id": (c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "wgs_comm_init": (c_int, [c_vp, ctypes.POINTER(ctypes.c_uint8), c_int, c_int, ctypes.POINTER(c_vp)]),
     "wgs_comm_destroy": (None, [c_vp]),

@@ -642,6 +642,70 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     return 0;
 }
 
+/* Exact partition sums: utils.partition_loglikes (utils.py:129-151) for every (individual,
+ * population) -- serial float32 accumulation per partition in site order, continued from
+ * carry_in (float32 [n*P*K], NULL = zeros: first shard) into parts_out (float32 [n*P*K]). */
+int wgs_assign_parts_exact(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, const float *carry_in,
+                           float *parts_out)
+{
+    WGS_REQUIRE(b && a && parts_out, "null argument");
+    WGS_REQUIRE(a->m == b->m, "allele frequencies cover %lld SNPs, the Beagle shard %lld", (long long)a->m, (long long)b->m);
+    WGS_REQUIRE(P >= 1, "partition count must be >= 1");
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int K = a->K;
+    const int64_t n = b->n;
+    const size_t cells = (size_t)n * P * K;
+    const size_t off_carry = (sizeof(float) * cells + 255) & ~(size_t)255;
+    const size_t off_acol = (off_carry + sizeof(float) * cells + 255) & ~(size_t)255;
+    const size_t off_slabs = (off_acol + sizeof(float *) * K + 255) & ~(size_t)255;
+    const size_t off_colptr = (off_slabs + sizeof(PartsSlab) * b->n_groups + 255) & ~(size_t)255;
+    const size_t total = off_colptr + (colptr ? sizeof(float *) * n * K : 0);
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, total, &ws)) return 1;
+    char *base = reinterpret_cast<char *>(ws);
+    float *d_parts = reinterpret_cast<float *>(base);
+    float *d_carry = carry_in ? reinterpret_cast<float *>(base + off_carry) : nullptr;
+    PartsSlab *d_slabs = reinterpret_cast<PartsSlab *>(base + off_slabs);
+    const float **d_acol = reinterpret_cast<const float **>(base + off_acol);
+    const float **d_colptr = colptr ? reinterpret_cast<const float **>(base + off_colptr) : nullptr;
+    std::vector<const float *> acol(K);
+    for (int k = 0; k < K; ++k) acol[k] = a->buf + (size_t)k * a->m;
+    HIP_TRY(hipMemsetAsync(d_parts, 0, sizeof(float) * cells, ctx->stream));
+    if (carry_in) HIP_TRY(hipMemcpyAsync(d_carry, carry_in, sizeof(float) * cells, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_acol, acol.data(), sizeof(float *) * K, hipMemcpyHostToDevice, ctx->stream));
+    if (colptr) HIP_TRY(hipMemcpyAsync(d_colptr, colptr, sizeof(float *) * n * K, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<PartsSlab> slabs;
+    int blocks = 0;
+    for (int g = 0; g < b->n_groups; ++g) {
+        const Slab &s = b->slabs[g];
+        if (s.ncols == 0) continue;
+        slabs.push_back({s.base, s.d_members, s.npairs, s.ncols, blocks});
+        blocks += (s.ncols + 63) / 64;
+    }
+    HIP_TRY(hipMemcpyAsync(d_slabs, slabs.data(), sizeof(PartsSlab) * slabs.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        AssignArgs args;
+        args.slab = nullptr;
+        args.members = nullptr;
+        args.colptr = d_colptr;
+        args.acol = d_acol;
+        args.out = nullptr;
+        args.m = b->m;
+        args.site0 = b->site0;
+        args.npairs = 0;
+        args.ncols = 0;
+        args.K = K;
+        args.P = P;
+        args.tiles_per_wave = 0;
+        if (launch_parts_exact(ctx, args, d_slabs, (int)slabs.size(), blocks, d_carry, d_parts)) return 1;
+    }
+    HIP_TRY(hipMemcpyAsync(parts_out, d_parts, sizeof(float) * cells, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 /* ------------------------------------------------------------------ Fisher information (--ne_obs) */
 
 int wgs_fisher_obs(wgs_beagle *b, wgs_afset *a, float *f_obs_mK, float *ne_obs_mK)

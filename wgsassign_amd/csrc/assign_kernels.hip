@@ -299,6 +299,63 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
     }
 }
 
+// ---- exact partition sums ----------------------------------------------------------------------
+// utils.py:147-149: labels = arange(m) % P; np.add.at(zeros(P, float32), labels, per_site_ll) -- a
+// SERIAL float32 accumulation per partition in site order.  Reproduced literally: one lane owns one
+// (individual, population, partition) chain and walks the partition's sites of this shard in
+// order, starting from the float32 carry of the previous shard.  Parallelism is across the
+// n x K x P chains only, so the time is ~ (m / P) x one site's latency -- the price of bit-exact
+// partition sums; the float64 sums of the sweeps above are the fast alternative.
+__global__ __launch_bounds__(64) void parts_exact_kernel(AssignArgs A, const PartsSlab *__restrict__ slabs, int n_slabs,
+                                                         const float *__restrict__ carry, float *__restrict__ parts)
+{
+    __shared__ double2 tab[WGS_LOG_N];
+    load_log_table(tab);
+    const int lane = threadIdx.x;
+    // all population slabs share ONE launch (their chains are independent and each slab alone would
+    // put only a handful of waves on the chip): find this workgroup's slab
+    int g = 0;
+    while (g + 1 < n_slabs && (int)blockIdx.x >= slabs[g + 1].block0) ++g;
+    A.slab = slabs[g].slab;
+    A.members = slabs[g].members;
+    A.npairs = slabs[g].npairs;
+    A.ncols = slabs[g].ncols;
+    const int c = ((int)blockIdx.x - slabs[g].block0) * 64 + lane;
+    const bool valid = c < A.ncols;
+    const int cc = valid ? c : A.ncols - 1;
+    const int j = blockIdx.y, p = blockIdx.z;
+    const int ind = A.members[cc];
+    gf32_ptr ptr = (gf32_ptr)(A.colptr ? A.colptr[(int64_t)ind * A.K + j] : A.acol[j]);
+    const int64_t cell = ((int64_t)ind * A.P + p) * A.K + j;
+    float res = carry ? carry[cell] : 0.0f;
+    const float2 *slab2 = reinterpret_cast<const float2 *>(A.slab);
+    const int64_t first = ((p - A.site0 % A.P) % A.P + A.P) % A.P;
+    const int64_t pair_off = (int64_t)(cc >> 1) * 64, half = cc & 1;
+    // Only ~n*K*P/64 waves exist, so nothing hides memory latency but this wave's own loads: the GLs
+    // and frequencies of the next PU sites are requested before the current PU are consumed.
+    constexpr int PU = 16;
+    for (int64_t s = first; s < A.m; s += (int64_t)A.P * PU) {
+        float2 g[PU];
+        float a[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            int64_t ss = s + (int64_t)u * A.P;
+            if (ss >= A.m) ss = A.m - 1;                          // clamped address, value unused
+            g[u] = slab2[((((ss >> 6) * A.npairs) << 6) + pair_off + (ss & 63)) * 2 + half];
+            a[u] = ptr[ss];
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            if (s + (int64_t)u * A.P < A.m) {                     // wave-uniform
+                const double g0d = (double)g[u].x, g1d = (double)g[u].y;
+                const float v = site_ll_exact(g0d, g1d, (1.0 - g0d) - g1d, a[u], tab);
+                res = res + v;                                    // float32 += float32, site order
+            }
+        }
+    }
+    if (valid) parts[cell] = res;
+}
+
 // The thin mirror of glassy_cy.loglike: vec[s] = (float)((double)vec[s] + log(...)), one
 // individual (its (g0,g1) column compacted to g[m]) and one population (a[m]).
 template <int MODE>
@@ -470,6 +527,20 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
         case 7: return launch_assign_kb<7>(ctx, a, mode, grid);
         default: return launch_assign_kb<8>(ctx, a, mode, grid);
     }
+}
+
+// a: the fields common to all slabs (colptr, acol, m, site0, K, P); d_slabs: n_slabs descriptors with
+// block0 = first workgroup of each slab, total_blocks workgroups in all.
+int launch_parts_exact(wgs_ctx *ctx, const AssignArgs &a, const PartsSlab *d_slabs, int n_slabs, int total_blocks,
+                       const float *d_carry, float *d_parts)
+{
+    if (a.m <= 0 || n_slabs <= 0 || total_blocks <= 0 || a.K <= 0 || a.P <= 0) return 0;
+    if (ensure_log_table(ctx)) return 1;
+    WGS_REQUIRE(a.K <= 65535 && a.P <= 65535, "too many populations / partitions for one launch");
+    dim3 grid((unsigned)total_blocks, (unsigned)a.K, (unsigned)a.P);
+    hipLaunchKernelGGL(parts_exact_kernel, grid, dim3(64), 0, ctx->stream, a, d_slabs, n_slabs, d_carry, d_parts);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode)

@@ -127,6 +127,14 @@ struct AssignArgs {
     int32_t tiles_per_wave;
 };
 int launch_assign(wgs_ctx *ctx, const AssignArgs &a, int mode);
+struct PartsSlab {     // one population slab inside the single exact-partition launch
+    const float4 *slab;
+    const int32_t *members;
+    int32_t npairs, ncols;
+    int32_t block0;    // first workgroup (64 columns each) of this slab
+};
+int launch_parts_exact(wgs_ctx *ctx, const AssignArgs &a, const PartsSlab *d_slabs, int n_slabs, int total_blocks,
+                       const float *d_carry, float *d_parts);
 int launch_log_mismatch(wgs_ctx *ctx, unsigned int b0, unsigned int b1, unsigned long long *d_count, unsigned int *d_first);
 int launch_log_values(wgs_ctx *ctx, const float *d_x, float *d_out, int64_t n, int use_libm);
 int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode);

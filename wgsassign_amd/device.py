@@ -377,3 +377,29 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
         if parts is not None:
             parts = comm.allreduce_sum(parts)
     return out, parts
+
+
+def partition_sums_exact(beagle, afset, colptr=None, P=1, comm=None):
+    """utils.partition_loglikes for all n x K pairs, bit-exact (serial float32 per partition in site
+    order).  With SNP shards the float32 carries travel from rank to rank in SNP order.
+    Returns (n*P, K) float32."""
+    n, K = beagle.n, afset.K
+    cp = None
+    if colptr is not None:
+        arr = np.ascontiguousarray(colptr, dtype=np.uint64)
+        cp = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
+    lib = _lib.load()
+    world = comm.world if comm is not None else 1
+    rank = comm.rank if comm is not None else 0
+    carry = None
+    parts = np.zeros((n * P, K), dtype=np.float32)
+    for r in range(world):
+        mine = np.zeros((n * P, K), dtype=np.float64)
+        if r == rank:
+            check(lib.wgs_assign_parts_exact(beagle.handle, afset.handle, cp, int(P),
+                                             f32p(carry) if carry is not None else None, f32p(parts)))
+            mine = parts.astype(np.float64)
+        if world > 1:
+            mine = comm.allreduce_sum(mine)      # only rank r contributes: a broadcast of its float32 values
+        carry = np.ascontiguousarray(mine.astype(np.float32))
+    return carry if world > 1 else parts

@@ -1,7 +1,9 @@
 """Assignment log-likelihoods and leave-one-out: drop-in for the reference's `glassy.py`."""
 import numpy as np
 
-from .device import AFSet, DeviceBeagle, EMBatch, assign
+import os
+
+from .device import AFSet, DeviceBeagle, EMBatch, assign, partition_sums_exact
 
 
 def assignLL(L, af, t=1):
@@ -27,7 +29,7 @@ def assignLL(L, af, t=1):
         return out.astype(np.float32)
 
 
-def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1):
+def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1, need_parts=True):
     """glassy.py:47-112: leave-one-out assignment log-likelihoods.
 
     Semantics kept from the reference:
@@ -40,7 +42,10 @@ def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1)
       * scoring uses downsampled_L when given (glassy.py:96-98);
       * per-partition sums use labels = site index % num_partitions (utils.py:147).
     All n re-fits run as one batch of EM chains on the device; one scoring sweep follows.
-    Returns (logl_mat (n, K) float32, logl_parts_mat (n*P, K) float32).
+    Returns (logl_mat (n, K) float32, logl_parts_mat (n*P, K) float32).  The partition sums are the
+    reference's serial float32 accumulations, bit for bit (WGSASSIGN_PARTS=fast: float64 sums, ~1e-5).
+    need_parts=False with num_partitions == 1 skips that chain (the reference's CLI never writes the
+    one-partition matrix) and returns the totals in its place.
     """
     L = np.asarray(L)
     IDs = np.asarray(IDs)
@@ -55,14 +60,15 @@ def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1)
     group_of = np.searchsorted(pops, IDs[:n, 1]).astype(np.int32)
     beagle = DeviceBeagle.from_host(L, group_of, len(pops))
     scored = DeviceBeagle.from_host(np.asarray(downsampled_L), group_of, len(pops)) if downsampled_L is not None else beagle
-    logl, logl_parts = loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P)
+    logl, logl_parts = loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P, need_parts=need_parts)
     if scored is not beagle:
         scored.close()
     beagle.close()
     return logl, logl_parts
 
 
-def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None, verbose=True, timings=None):
+def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None, verbose=True, timings=None,
+               need_parts=True):
     """The body of loo() on device-resident matrices: `beagle` holds the GLs the frequencies are
     re-estimated from, `scored` the GLs that are scored (the same object unless a downsampled
     matrix is given), both with population slabs `group_of`.  `af` (m, K) float32 is mutated like
@@ -85,7 +91,16 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
     for i in range(n):
         cur[group_of[i]] = em.f_dev(i)
         colptr[i] = cur
-    out, parts = assign(scored, afset, colptr=colptr, P=P, comm=comm)
+    # need_parts=False (the command line with --partition_sites 1, which never writes the partition
+    # matrix): skip the serial float32 chain and return the totals in its place
+    exact_parts = os.environ.get("WGSASSIGN_PARTS", "exact") != "fast" and (need_parts or P > 1)
+    if exact_parts:
+        # sums over all sites in float64 (np.sum(dtype=float), glassy.py:101); partition sums literally
+        # as utils.py:147-149 accumulates them (serial float32) -- for P == 1 too (glassy.py:108-109)
+        out, _ = assign(scored, afset, colptr=colptr, P=1, comm=comm)
+        parts = partition_sums_exact(scored, afset, colptr=colptr, P=P, comm=comm)
+    else:
+        out, parts = assign(scored, afset, colptr=colptr, P=P, comm=comm)
     t2 = time.perf_counter()
     last = {int(g): i for i, g in enumerate(group_of)}
     for g, i in last.items():
