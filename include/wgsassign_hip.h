@@ -213,6 +213,11 @@ int wgs_debug_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, 
                      int *serial_blocks);
 int wgs_em_last_chain_serial_blocks(wgs_em *em);
 
+/* Test hook for the EM kernel's correctly rounded divide (csrc/em_kernels.hip: div_exact): number of
+ * 2^20 x per_thread pseudo-random EM-shaped operand pairs whose quotient differs bitwise from the
+ * compiler's IEEE double divide. */
+int wgs_debug_div_mismatch(wgs_ctx *ctx, uint64_t seed, uint64_t per_thread, uint64_t *mismatch);
+
 /* Test hooks for the assignment kernel's double-precision log of float32 arguments
  * (csrc/assign_kernels.hip: log_f32arg): number of float32 bit patterns in [b0, b1) whose
  * float32-rounded log differs from the device math library's, and the values themselves. */

@@ -64,3 +64,12 @@ def test_special_values(dev):
     ok = ~np.isnan(want)
     assert np.array_equal(got[ok], want[ok])
     assert got[5] == 0.0 and got[0] == -np.inf and got[1] == -np.inf and got[3] == np.inf
+
+
+def test_em_divide_is_ieee_exact(dev):
+    """The EM kernel's Newton-core divide (no v_div_scale) against the compiler's IEEE double divide
+    on 4.3e9 pseudo-random EM-shaped operand pairs (incl. 0/0 and 100 binades of magnitude)."""
+    lib, ctx, _lib = dev
+    bad = ctypes.c_uint64(123)
+    _lib.check(lib.wgs_debug_div_mismatch(ctx.handle, 20260313, 4096, ctypes.byref(bad)))
+    assert bad.value == 0, bad.value

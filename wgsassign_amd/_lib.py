@@ -78,6 +78,7 @@ SIGNATURES = {
     "wgs_reader_count_sites": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),
     "wgs_em_last_chain_serial_blocks": (c_int, [c_vp]),
+    "wgs_debug_div_mismatch": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "wgs_debug_log_mismatch": (c_int, [c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
     "wgs_debug_log_values": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_int]),
     "wgs_assign_last_ms": (c_int, [c_f32p]),

@@ -772,6 +772,24 @@ int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum)
 
 /* ------------------------------------------------------------------ test hooks */
 
+/* pairs = 2^20 threads x per_thread operand pairs; *mismatch = results of the kernel's Newton-core
+ * divide that differ bitwise from the IEEE divide. */
+int wgs_debug_div_mismatch(wgs_ctx *ctx, uint64_t seed, uint64_t per_thread, uint64_t *mismatch)
+{
+    WGS_REQUIRE(ctx && mismatch, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, 256, &ws)) return 1;
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(ws);
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof(unsigned long long), ctx->stream));
+    if (launch_div_check(ctx, seed, per_thread, d)) return 1;
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *mismatch = h;
+    return 0;
+}
+
 int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first)
 {
     WGS_REQUIRE(ctx && count && first, "null argument");

@@ -109,6 +109,7 @@ int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, 
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
 int ssq_reduce_chunks(void);
 int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2);
+int launch_div_check(wgs_ctx *ctx, unsigned long long seed, unsigned long long per_thread, unsigned long long *d_mismatch);
 int launch_fill(wgs_ctx *ctx, float *p, int64_t count, float v);
 int launch_clamp(wgs_ctx *ctx, float *p, int64_t count, float lo, float hi);
 int launch_rmse_chain_serial(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out);

@@ -536,6 +536,42 @@ __global__ __launch_bounds__(256) void fisher_ind_kernel(const float4 *__restric
     }
 }
 
+
+// Test hook: div_exact against the compiler's IEEE divide on operands shaped like the EM term's
+// (den = a float32 sum widened to double, num = p1 + 2*p2 with float32 p1, p2 >= 0, num <~ 2 den,
+// plus den = 0 and tiny/huge magnitudes).  Counts bitwise mismatches.
+__device__ __forceinline__ unsigned int mix32(unsigned int x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+__global__ void div_check_kernel(unsigned long long seed, unsigned long long per_thread, unsigned long long *mismatch)
+{
+    const unsigned long long tid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0;
+    unsigned int st = mix32((unsigned int)(tid ^ seed) + 0x9e3779b9u * (unsigned int)(seed >> 32));
+    for (unsigned long long it = 0; it < per_thread; ++it) {
+        st = mix32(st + 0x6d2b79f5u);
+        const unsigned int a = st;
+        st = mix32(st + 0x6d2b79f5u);
+        const unsigned int b = st;
+        st = mix32(st + 0x6d2b79f5u);
+        const unsigned int c = st;
+        // float32 values with exponents spread over [2^-100, 2^1]: sign 0, exponent 27..128
+        const float p0 = __uint_as_float((((a >> 23) % 102u + 27u) << 23) | (a & 0x7FFFFFu));
+        const float p1 = (c & 7u) == 0 ? 0.0f : __uint_as_float((((b >> 23) % 102u + 27u) << 23) | (b & 0x7FFFFFu));
+        const float p2 = (c & 56u) == 0 ? 0.0f : __uint_as_float((((c >> 23) % 102u + 27u) << 23) | (c & 0x7FFFFFu));
+        const float s = (c & 0x3FFu) == 1 ? 0.0f : (p0 + p1) + p2;
+        const double num = __builtin_fma(2.0, (double)p2, (double)p1), den = (double)s;
+        const double q1 = div_exact(num, den), q2 = num / den;
+        const bool same_bits = __double_as_longlong(q1) == __double_as_longlong(q2);
+        const bool both_nan = q1 != q1 && q2 != q2;
+        bad += !(same_bits || both_nan);
+    }
+    if (bad) atomicAdd(mismatch, bad);
+}
+
 }  // namespace
 
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode)
@@ -572,6 +608,13 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 int ssq_reduce_chunks(void) { return RED_CHUNKS; }
 
 // part2: n_fits * ssq_reduce_chunks() doubles of device scratch
+int launch_div_check(wgs_ctx *ctx, unsigned long long seed, unsigned long long per_thread, unsigned long long *d_mismatch)
+{
+    hipLaunchKernelGGL(div_check_kernel, dim3(4096), dim3(256), 0, ctx->stream, seed, per_thread, d_mismatch);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_fisher_pop(wgs_ctx *ctx, const FisherDesc *d_descs, int32_t n_desc, int64_t m)
 {
     if (n_desc <= 0 || m <= 0) return 0;
