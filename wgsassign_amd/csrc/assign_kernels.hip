@@ -87,7 +87,7 @@ __device__ __forceinline__ float site_ll_fast(float g0, float g1, float g2, floa
     const float like0 = g0 * oma * oma;
     const float like1 = g1 * 2.0f * oma * a;
     const float like2 = g2 * a * a;
-    return logf((like0 + like1) + like2);
+    return __builtin_amdgcn_logf((like0 + like1) + like2) * 0.69314718055994530942f;   // v_log_f32 (log2) * ln 2
 }
 
 typedef const float __attribute__((address_space(1))) *gf32_ptr;
