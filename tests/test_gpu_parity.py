@@ -393,3 +393,29 @@ def test_fast_mode_synthetic_mid(wg, golden):
     assert close(out.astype(np.float32), g["logl_5000"], 1e-6)
     for x in (em, afs, bs, b):
         x.close()
+
+
+def test_c_abi_error_paths(wg):
+    """Invalid arguments come back as ValueError with a message (rc 2), never as a wild read."""
+    dev = wg.device
+    L, IDs = synth.make_beagle(100, 6, 2, seed=2)
+    with pytest.raises(ValueError, match="out of range"):
+        dev.DeviceBeagle.from_host(L, np.array([0, 0, 1, 1, 2, 0], dtype=np.int32), 2)
+    b = dev.DeviceBeagle.from_host(L, np.array([0, 0, 0, 1, 1, 1], dtype=np.int32), 2)
+    with pytest.raises(ValueError, match="does not belong to group"):
+        dev.EMBatch(b, [0], [4])
+    with pytest.raises(ValueError, match="out of range or empty"):
+        dev.EMBatch(b, [5])
+    afs = dev.AFSet.from_host(np.full((99, 2), 0.3, dtype=np.float32))
+    with pytest.raises(ValueError, match="SNPs"):
+        dev.assign(b, afs)
+    with pytest.raises(ValueError, match="outside"):
+        b.upload_rows(L, 50)
+    with pytest.raises(ValueError):
+        wg.glassy_cy.loglike(L, np.full((100, 2), 0.3, dtype=np.float32), np.zeros(100, dtype=np.float32), 1, 6, 0)
+    # an empty group is legal for the matrix, but not as the target of a fit
+    b2 = dev.DeviceBeagle.from_host(L, np.zeros(6, dtype=np.int32), 3)
+    with pytest.raises(ValueError, match="empty"):
+        dev.EMBatch(b2, [1])
+    for x in (afs, b, b2):
+        x.close()
