@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-assign", action="store_true", help="skip the assignment sweep leg")
     ap.add_argument("--cpu-snps", type=int, default=200_000, help="SNP sample for the CPU baseline")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum CPU-baseline EM timing window")
     return ap.parse_args()
 
 
@@ -172,7 +173,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(beagle, group_of, K, min(args.cpu_snps, m))
+        cpu = cpu_baseline(beagle, group_of, K, min(args.cpu_snps, m), args.cpu_seconds)
 
     if rank == 0:
         line = {"metric": "EM SNP-updates/s (per-population update, n_call=%g)" % n_call, "value": value,
@@ -213,7 +214,7 @@ def pmc_traffic(m, n, K, mode):
     return best
 
 
-def cpu_baseline(beagle, group_of, K, ms):
+def cpu_baseline(beagle, group_of, K, ms, seconds=12.0):
     """Reference-shaped CPU path on this box's host cores: for each population gather its
     columns (WGSassign.py:227-233) and run emMAF_update (emMAF_cy.pyx:10-23) -- the oracle's
     bit-exact C/OpenMP restatement -- on the first `ms` SNPs of the same synthetic matrix."""
@@ -231,7 +232,7 @@ def cpu_baseline(beagle, group_of, K, ms):
             orc.emMAF_update(slabs[k], fs[k], threads)
         sweeps += 1
         el = time.perf_counter() - t0
-        if el > 12.0:
+        if el > seconds:
             break
     t_g0 = time.perf_counter()
     for k in range(K):
@@ -241,7 +242,7 @@ def cpu_baseline(beagle, group_of, K, ms):
     # (glassy.py:31-38); time a few pairs and scale to all n*K pairs of one SNP
     A = np.ascontiguousarray(np.stack(fs, axis=1))
     pairs, t_a0 = 0, time.perf_counter()
-    while pairs < 6 or time.perf_counter() - t_a0 < 3.0:
+    while pairs < 6 or time.perf_counter() - t_a0 < min(3.0, seconds):
         vec = np.zeros(ms, dtype=np.float32)
         orc.loglike(rows, A, vec, threads, pairs % beagle.n, pairs % K)
         float(np.sum(vec, dtype=float))
