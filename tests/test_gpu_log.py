@@ -55,6 +55,27 @@ def test_dense_sample_vs_glibc(dev, oracle):
     assert mism <= max(8, total // 20_000_000) and all(w <= 1 for w in worst)     # at most 1 float32 ulp, a handful of cases
 
 
+def test_exhaustive_vs_glibc(dev, oracle):
+    """EVERY positive finite float32 (2,139,095,039 arguments): the device function against
+    (float)log((double)x) of the host's glibc -- the exact expression the reference evaluates
+    (glassy_cy.pyx:21 with a zero-initialised vector)."""
+    threads = min(len(__import__("os").sched_getaffinity(0)), 16)
+    total = mism = 0
+    first = []
+    step = 1 << 26
+    for b0 in range(0, 0x7F800000, step):
+        bits = np.arange(max(b0, 1), min(b0 + step, 0x7F800000), dtype=np.uint32)
+        x = bits.view(np.float32)
+        mine = values(dev, x)
+        ref = oracle.log_f32(x, threads)
+        bad = np.flatnonzero(mine.view(np.uint32) != ref.view(np.uint32))
+        total += len(x)
+        mism += len(bad)
+        first += [hex(int(bits[i])) for i in bad[:4]]
+    print("exhaustive vs glibc: %d of %d float32-rounded logs differ %s" % (mism, total, first[:8]))
+    assert total == 0x7F800000 - 1 and mism <= 16
+
+
 def test_special_values(dev):
     x = np.array([0.0, -0.0, -1.0, np.inf, np.nan, 1.0, 1e-45, 1.1754944e-38, 3.4028235e38, -np.inf], dtype=np.float32)
     with np.errstate(all="ignore"):
