@@ -34,6 +34,14 @@ def same_nan(a, b):
     return a[ok].tobytes() == b[ok].tobytes()
 
 
+def nearly_all_identical(a, b, frac=0.99):
+    """float64-accumulated sums stored as float32: within 1e-6 everywhere and the very same float32
+    in (at least) 99 % of the entries (in practice all: the per-site values are bit-identical and only
+    the float64 summation order differs from NumPy's)."""
+    a, b = np.asarray(a), np.asarray(b)
+    return close(a, b) and np.mean(a.view(np.uint32) == b.view(np.uint32)) >= frac
+
+
 def close(a, b, rtol=RTOL):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     nan_ok = np.array_equal(np.isnan(a), np.isnan(b))
@@ -139,7 +147,7 @@ def test_amre_assign(wg, golden):
     g = golden("amre_assign.npz")
     af = golden("amre_fit.npz")["pop_af"]
     logl, text = quiet(wg.glassy.assignLL, g["L"], af.copy(), 1)
-    assert logl.dtype == np.float32 and close(logl, g["logl"])
+    assert logl.dtype == np.float32 and nearly_all_identical(logl, g["logl"])
     assert text.strip() == "34 individuals to assign to 5 populations"
 
 
@@ -148,7 +156,7 @@ def test_amre_loo(wg, golden, P):
     g, fit = golden("amre_loo.npz"), golden("amre_fit.npz")
     af = fit["pop_af"].copy()
     (ll, parts), _ = quiet(wg.glassy.loo, fit["L"], af, fit["IDs"], 1, 200, 1e-4, None, P)
-    assert close(ll, g["loo_P%d" % P])
+    assert nearly_all_identical(ll, g["loo_P%d" % P])
     assert same(parts, g["parts_P%d" % P])          # serial float32 partition sums: bit-identical
     assert same(af, g["af_after_P%d" % P])          # the in-place, never-restored column overwrite
 
@@ -225,13 +233,13 @@ def test_synth_mid(wg, golden):
     (pops, af, iters), _ = quiet(wg.emMAF.emMAF_populations, L, IDs, 200, 1e-4)
     assert same(af, g["pop_af"]) and list(iters) == list(g["iters"])
     logl, _ = quiet(wg.glassy.assignLL, np.ascontiguousarray(L[:5000]), np.ascontiguousarray(af[:5000]), 1)
-    assert close(logl, g["logl_5000"])
+    assert nearly_all_identical(logl, g["logl_5000"])
     ms = int(g["loo_ms"])
     Ls = np.ascontiguousarray(L[:ms])
     (pops, af2, it2), _ = quiet(wg.emMAF.emMAF_populations, Ls, IDs, 200, 1e-4)
     assert same(af2, g["loo_pop_af"]) and list(it2) == list(g["loo_iters"])
     (ll, parts), _ = quiet(wg.glassy.loo, Ls, af2, IDs, 1, 200, 1e-4, None, 4)
-    assert close(ll, g["loo"]) and same(parts, g["loo_parts"]) and same(af2, g["loo_af_after"])
+    assert nearly_all_identical(ll, g["loo"]) and same(parts, g["loo_parts"]) and same(af2, g["loo_af_after"])
 
 
 def test_fast_partition_sums_within_tolerance(wg, golden, monkeypatch):
