@@ -186,6 +186,9 @@ int wgs_fisher_obs(wgs_beagle *b, wgs_afset *a, float *f_obs_mK, float *ne_obs_m
  * shard's SNPs of individual i's n_tilde (float64); the caller divides by the SNP count
  * (the reference takes np.mean of the float32 per-site vector). */
 int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum);
+/* The per-site float32 values themselves for individuals [i0, i0+count) of ONE population
+ * (rows_out[(i - i0) * m + s]), so the host can apply np.mean to each row exactly as fisher.py:59. */
+int wgs_fisher_ind_sites(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *rows_out);
 
 /* ------------------------------------------------------------------ streamed Beagle reader (host)
  * reader_cy.readBeagle(path) -- reader_cy.pyx:16-77 -- as a chunked native reader: gzip inflate,

@@ -23,12 +23,12 @@ def test_fisher_obs_bit_exact(golden):
     f_obs, ne_obs = fisher.fisher_obs(fit["L"], fit["pop_af"].copy(), fit["IDs"], 1)
     assert same(f_obs, g["f_obs"]) and same(ne_obs, g["ne_obs"])
     ne_ind = fisher.fisher_obs_ind(fit["L"], fit["pop_af"].copy(), fit["IDs"], 1)
-    assert ne_ind.dtype == np.float32 and np.all(np.abs(ne_ind - g["ne_ind"]) <= 1e-6 * np.abs(g["ne_ind"]))
+    assert same(ne_ind, g["ne_ind"])                      # np.mean on the host over device-computed rows
     L, IDs = synth.make_beagle(5000, 61, 3, seed=31, interleave=True)
     f_obs, ne_obs = fisher.fisher_obs(L, g["synth_af"].copy(), IDs, 1)
     assert same(f_obs, g["synth_f_obs"]) and same(ne_obs, g["synth_ne_obs"])
     ne_ind = fisher.fisher_obs_ind(L, g["synth_af"].copy(), IDs, 1)
-    assert np.all(np.abs(ne_ind - g["synth_ne_ind"]) <= 1e-6 * np.abs(g["synth_ne_ind"]))
+    assert same(ne_ind, g["synth_ne_ind"])
 
 
 def test_cli_ne_obs(tmp_path, golden):
@@ -43,9 +43,7 @@ def test_cli_ne_obs(tmp_path, golden):
                         "--get_reference_af", "--ne_obs", "--out", out, "--threads", "2"])
     assert same(np.load(out + ".fisher_obs.npy"), g["f_obs"]) and same(np.load(out + ".ne_obs.npy"), g["ne_obs"])
     assert open(out + ".ne_obs.txt").read() == str(g["ne_obs_txt"])          # means of bit-identical columns
-    got = np.loadtxt(out + ".ne_ind.txt")
-    ref = np.loadtxt(io.StringIO(str(g["ne_ind_txt"])))
-    assert np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref) + 1e-7)
+    assert open(out + ".ne_ind.txt").read() == str(g["ne_ind_txt"])
     ref_lines = str(g["stdout"]).replace("<TMP>/", "").splitlines()
     got_lines = [l.replace(str(tmp_path) + "/", "") for l in buf.getvalue().splitlines()]
     assert got_lines == ref_lines

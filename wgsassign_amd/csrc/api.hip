@@ -770,6 +770,34 @@ int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum)
     return 0;
 }
 
+/* Per-site effective-sample-size terms (float32, fisher_cy.pyx:41-65) of individuals
+ * [i0, i0 + count): rows_out[(i - i0) * m + s].  All of them must lie in one population slab. */
+int wgs_fisher_ind_sites(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *rows_out)
+{
+    WGS_REQUIRE(b && a && rows_out && count > 0 && i0 >= 0 && (int64_t)i0 + count <= b->n, "bad argument");
+    WGS_REQUIRE(a->m == b->m && a->K == b->n_groups, "allele frequencies do not match the population slabs");
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int g = b->group_of[i0];
+    std::vector<int32_t> cols(count);
+    for (int j = 0; j < count; ++j) {
+        WGS_REQUIRE(b->group_of[i0 + j] == g, "individuals %d..%d span more than one population", i0, i0 + count - 1);
+        cols[j] = b->col_of[i0 + j];
+    }
+    const size_t off_cols = ((size_t)count * b->m * sizeof(float) + 255) & ~(size_t)255;
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, off_cols + sizeof(int32_t) * count, &ws)) return 1;
+    float *d_out = reinterpret_cast<float *>(ws);
+    int32_t *d_cols = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws) + off_cols);
+    HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), sizeof(int32_t) * count, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const Slab &s = b->slabs[g];
+    if (launch_fisher_ind_sites(ctx, s.base, d_cols, a->buf + (size_t)g * a->m, d_out, b->m, s.npairs, count)) return 1;
+    HIP_TRY(hipMemcpyAsync(rows_out, d_out, (size_t)count * b->m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 /* ------------------------------------------------------------------ test hooks */
 
 /* pairs = 2^20 threads x per_thread operand pairs; *mismatch = results of the kernel's Newton-core

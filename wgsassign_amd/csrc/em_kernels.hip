@@ -499,6 +499,25 @@ __global__ __launch_bounds__(WAVES * 64) void fisher_pop_kernel(const FisherDesc
     }
 }
 
+// Per-site effective-sample-size terms of `count` individuals (fisher_cy.pyx:41-65: f_ind[s] = term,
+// ne_ind[s] = 0.5 * f_ind[s] * a * (1 - a)) written as float32 rows out[j][s], so that the host can
+// take np.mean of each row exactly as fisher.py:59 does.  Thread <-> (SNP, individual): slab reads
+// and row writes are coalesced along SNPs.
+__global__ __launch_bounds__(256) void fisher_ind_sites_kernel(const float2 *__restrict__ slab2, const int32_t *__restrict__ cols,
+                                                              const float *__restrict__ th_vec, float *__restrict__ out, int64_t m,
+                                                              int npairs, int count)
+{
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (s >= m || j >= count) return;
+    const int c = cols[j];
+    const float th = th_vec[s];
+    const double thd = (double)th, omt = 1.0 - thd;
+    const float2 g = slab2[((((s >> 6) * npairs + (c >> 1)) << 6) + (s & 63)) * 2 + (c & 1)];
+    const float term = fisher_term(g.x, g.y, th, thd, omt);
+    out[(int64_t)j * m + s] = (float)(((0.5 * (double)term) * thd) * omt);
+}
+
 // Per individual: sum over this shard's SNPs of its effective-sample-size term (fisher_cy.pyx:41-65,
 // fisher.py:52-59 takes the mean).  lane <-> SNP, wave <-> (pair of individuals, range of tiles).
 __global__ __launch_bounds__(256) void fisher_ind_kernel(const float4 *__restrict__ slab, const int32_t *__restrict__ members,
@@ -621,6 +640,17 @@ int launch_fisher_pop(wgs_ctx *ctx, const FisherDesc *d_descs, int32_t n_desc, i
     const int64_t blocks = ((wgs_ntiles(m) + WAVES - 1) / WAVES) * n_desc;
     WGS_REQUIRE(blocks < (1ll << 31), "fisher sweep: too many workgroups");
     hipLaunchKernelGGL(fisher_pop_kernel, dim3((unsigned)blocks), dim3(WAVES * 64), 0, ctx->stream, d_descs, n_desc, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_fisher_ind_sites(wgs_ctx *ctx, const float4 *slab, const int32_t *d_cols, const float *th, float *d_out, int64_t m,
+                            int npairs, int count)
+{
+    if (m <= 0 || count <= 0) return 0;
+    dim3 grid((unsigned)((m + 255) / 256), (unsigned)count);
+    hipLaunchKernelGGL(fisher_ind_sites_kernel, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const float2 *>(slab), d_cols, th,
+                       d_out, m, npairs, count);
     HIP_TRY(hipGetLastError());
     return 0;
 }

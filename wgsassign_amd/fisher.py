@@ -29,21 +29,38 @@ def fisher_obs(L, af, IDs, t=1, beagle=None):
     return f_obs, ne_obs
 
 
-def fisher_obs_ind(L, af, IDs, t=1, beagle=None, comm=None, m_total=None):
+def fisher_obs_ind(L, af, IDs, t=1, beagle=None, comm=None, m_total=None, exact_budget_bytes=1 << 30):
     """fisher.py:46-60: per individual the mean over SNPs of its effective-sample-size term under
-    its own population's frequencies (float64 sum on the device; the reference's np.mean
-    accumulates in float32)."""
+    its own population's frequencies.
+
+    Single shard (default): the per-site float32 terms are computed on the device in batches of
+    individuals and np.mean is applied to each row on the host -- the reference's own reduction, so
+    the result is bit-identical.  SNP-sharded (comm given): float64 sums on the device, all-reduced
+    (the reference's float32 pairwise mean cannot be split across shards; ~1e-7 relative)."""
     own = beagle is None
     if own:
         beagle, _ = _slabs(L, np.asarray(IDs))
     afs = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32), ctx=beagle.ctx)
-    sums = np.zeros(beagle.n, dtype=np.float64)
-    _lib.check(_lib.load().wgs_fisher_obs_ind(beagle.handle, afs.handle, _lib.f64p(sums)))
-    afs.close()
-    m = beagle.m
+    lib = _lib.load()
     if comm is not None and comm.world > 1:
-        sums = comm.allreduce_sum(sums)
-        m = m_total
+        sums = np.zeros(beagle.n, dtype=np.float64)
+        _lib.check(lib.wgs_fisher_obs_ind(beagle.handle, afs.handle, _lib.f64p(sums)))
+        out = (comm.allreduce_sum(sums) / m_total).astype(np.float32)
+    else:
+        out = np.zeros(beagle.n, dtype=np.float32)
+        m, group_of = beagle.m, beagle.group_of
+        batch = int(max(1, min(256, exact_budget_bytes // max(1, 4 * m))))
+        i = 0
+        while i < beagle.n:
+            j = i + 1
+            while j < beagle.n and j - i < batch and group_of[j] == group_of[i]:
+                j += 1
+            rows = np.empty((j - i, m), dtype=np.float32)
+            _lib.check(lib.wgs_fisher_ind_sites(beagle.handle, afs.handle, i, j - i, _lib.f32p(rows)))
+            for r in range(j - i):
+                out[i + r] = out[i + r] + np.mean(rows[r])        # fisher.py:59
+            i = j
+    afs.close()
     if own:
         beagle.close()
-    return (sums / m).astype(np.float32)
+    return out
