@@ -28,6 +28,7 @@ namespace {
 // true value lies within ~2^-29 relative of a float32 rounding boundary (tests/test_gpu_log.py
 // counts the cases exhaustively over every positive float32).
 __device__ double2 wgs_log_table_dev[WGS_LOG_N];
+constexpr int WGS_LOG_REP = 16;   // LDS copies of the table (see load_log_table)
 
 __device__ __forceinline__ double log_f32arg(double x, const double2 *tab)
 {
@@ -37,7 +38,7 @@ __device__ __forceinline__ double log_f32arg(double x, const double2 *tab)
     const int k = (int)tmp >> 20;                          // x = z * 2^k, z in [0.6875, 1.375)
     const unsigned int i = (tmp >> 13) & (WGS_LOG_N - 1);
     const double z = __hiloint2double((int)(hi - (tmp & 0xFFF00000u)), (int)lo);
-    const double2 t = tab[i];                              // {invc, logc}
+    const double2 t = tab[i * WGS_LOG_REP];                // {invc, logc}; tab already points at this lane's copy
     const double r = __builtin_fma(z, t.x, -1.0);          // exact
     const double kd = (double)k;
     const double w = __builtin_fma(kd, WGS_LN2HI, t.y);    // kd*Ln2hi is exact
@@ -63,10 +64,16 @@ __device__ __forceinline__ float logf_of_f32(float s, const double2 *tab)
     return __builtin_isfpclass(s, 0x0100 | 0x0080) ? v : special;   // +normal | +subnormal
 }
 
-__device__ __forceinline__ void load_log_table(double2 *tab)
+// LDS image of the table: WGS_LOG_REP = 16 interleaved copies, entry i of copy c at [i*16 + c].
+// A ds_read_b128 is serviced in groups of 16 lanes whose (lane & 15) are all distinct; with lane l
+// reading copy (l & 15) every lane of a group hits its own 16-byte slot of the 256-byte bank row,
+// whatever its index i: the data-dependent lookup is bank-conflict free (a single copy measured
+// 61 % of LDS cycles lost to conflicts).
+__device__ __forceinline__ const double2 *load_log_table(double2 *tab)
 {
-    for (int i = threadIdx.x; i < WGS_LOG_N; i += blockDim.x) tab[i] = wgs_log_table_dev[i];
+    for (int e = threadIdx.x; e < WGS_LOG_N * WGS_LOG_REP; e += blockDim.x) tab[e] = wgs_log_table_dev[e / WGS_LOG_REP];
     __syncthreads();
+    return tab + (threadIdx.x & (WGS_LOG_REP - 1));
 }
 
 // glassy_cy.pyx:18-21 for one (SNP, individual, population), exact rounding sequence; returns
@@ -95,8 +102,8 @@ typedef const float __attribute__((address_space(1))) *gf32_ptr;
 template <int KB, int MODE>
 __global__ __launch_bounds__(256) void assign_kernel(AssignArgs A)
 {
-    __shared__ double2 tab[WGS_LOG_N];
-    load_log_table(tab);
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    const double2 *tab = load_log_table(tab_lds);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int pair = blockIdx.y * 64 + lane;
     const bool valid_a = 2 * pair < A.ncols, valid_b = 2 * pair + 1 < A.ncols;
@@ -187,8 +194,8 @@ __device__ __forceinline__ double wave_sum(double x)
 template <int KB, int NP, int MODE, bool PER_IND>
 __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
 {
-    __shared__ double2 tab[WGS_LOG_N];
-    load_log_table(tab);
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    const double2 *tab = load_log_table(tab_lds);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int npg = (A.npairs + NP - 1) / NP;
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
@@ -236,10 +243,24 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
 #pragma unroll
                 for (int j = 0; j < KB; ++j) acc[q][h][j] = 0.0;
 
-        for (int64_t t = t0; t < t1; ++t) {
+        // One tile ahead: the GLs and frequencies of tile t+1 are requested before tile t is
+        // consumed (a wave owns a long tile range and only ~4 waves share a SIMD, so nothing else
+        // hides the load latency: un-prefetched, 46 % of the wave cycles were spent in s_waitcnt).
+        constexpr int NA = PER_IND ? NP * 2 * KB : KB;
+        float4 g_cur[NP], g_nxt[NP];
+        float a_cur[NA], a_nxt[NA];
+        auto fetch = [&](int64_t t, float4 *gq, float *aq) {
             const int64_t s = (t << 6) + lane;
-            const bool live = s < A.m;
-            const int64_t sc = live ? s : A.m - 1;
+            const int64_t sc = s < A.m ? s : A.m - 1;          // clamped index; dead lanes are neutralised below
+#pragma unroll
+            for (int q = 0; q < NP; ++q) gq[q] = A.slab[((t * A.npairs + pairc[q]) << 6) + lane];
+#pragma unroll
+            for (int x = 0; x < NA; ++x) aq[x] = ptr[x][sc];
+        };
+        fetch(t0, g_cur, a_cur);
+        for (int64_t t = t0; t < t1; ++t) {
+            if (t + 1 < t1) fetch(t + 1, g_nxt, a_nxt);        // wave-uniform
+            const bool live = ((t << 6) + lane) < A.m;
             // Lanes past the last SNP (only in the final tile) are given g = (1, 0) and a = 0, for
             // which the site likelihood is exactly 1 and its log exactly 0: no masking per term.
             double ad[KB], oma[KB];
@@ -247,15 +268,14 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
             if (!PER_IND) {
 #pragma unroll
                 for (int j = 0; j < KB; ++j) {
-                    const float a_ld = ptr[j][sc];          // unconditional (clamped index), then select
-                    af[j] = live ? a_ld : 0.0f;
+                    af[j] = live ? a_cur[j] : 0.0f;
                     ad[j] = (double)af[j];
                     oma[j] = 1.0 - ad[j];
                 }
             }
 #pragma unroll
             for (int q = 0; q < NP; ++q) {
-                const float4 g = A.slab[((t * A.npairs + pairc[q]) << 6) + lane];
+                const float4 g = g_cur[q];
                 const float gl[2][2] = {{live ? g.x : 1.0f, live ? g.y : 0.0f}, {live ? g.z : 1.0f, live ? g.w : 0.0f}};
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -268,8 +288,7 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
                     for (int j = 0; j < KB; ++j) {
                         float v;
                         if (PER_IND) {
-                            const float a_ld = ptr[(q * 2 + h) * KB + j][sc];
-                            const float a = live ? a_ld : 0.0f;
+                            const float a = live ? a_cur[(q * 2 + h) * KB + j] : 0.0f;
                             if (MODE == WGS_MODE_EXACT) {
                                 const double a_d = (double)a;
                                 v = site_ll_exact2(g0d, g1d2, g2d, a_d, 1.0 - a_d, tab);
@@ -284,6 +303,10 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
                     }
                 }
             }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) g_cur[q] = g_nxt[q];
+#pragma unroll
+            for (int x = 0; x < NA; ++x) a_cur[x] = a_nxt[x];
         }
 #pragma unroll
         for (int q = 0; q < NP; ++q)
@@ -309,8 +332,8 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
 __global__ __launch_bounds__(64) void parts_exact_kernel(AssignArgs A, const PartsSlab *__restrict__ slabs, int n_slabs,
                                                          const float *__restrict__ carry, float *__restrict__ parts)
 {
-    __shared__ double2 tab[WGS_LOG_N];
-    load_log_table(tab);
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    const double2 *tab = load_log_table(tab_lds);
     const int lane = threadIdx.x;
     // all population slabs share ONE launch (their chains are independent and each slab alone would
     // put only a handful of waves on the chip): find this workgroup's slab
@@ -361,8 +384,8 @@ __global__ __launch_bounds__(64) void parts_exact_kernel(AssignArgs A, const Par
 template <int MODE>
 __global__ void loglike_site_kernel(const float2 *__restrict__ g, const float *__restrict__ a, float *vec, int64_t m)
 {
-    __shared__ double2 tab[WGS_LOG_N];
-    load_log_table(tab);
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    const double2 *tab = load_log_table(tab_lds);
     int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (; s < m; s += stride) {
@@ -391,8 +414,8 @@ __global__ void loglike_site_kernel(const float2 *__restrict__ g, const float *_
 // Test hooks: the float32-rounded log of every float32 in a bit-pattern range, custom vs ocml.
 __global__ void log_mismatch_kernel(unsigned int b0, unsigned int b1, unsigned long long *count, unsigned int *first)
 {
-    __shared__ double2 tab[WGS_LOG_N];
-    load_log_table(tab);
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    const double2 *tab = load_log_table(tab_lds);
     unsigned long long local = 0;
     for (unsigned long long b = (unsigned long long)b0 + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; b < b1;
          b += (unsigned long long)gridDim.x * blockDim.x) {
@@ -409,8 +432,8 @@ __global__ void log_mismatch_kernel(unsigned int b0, unsigned int b1, unsigned l
 
 __global__ void log_values_kernel(const float *x, float *out, int64_t n, int use_libm)
 {
-    __shared__ double2 tab[WGS_LOG_N];
-    load_log_table(tab);
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    const double2 *tab = load_log_table(tab_lds);
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = use_libm ? (float)log((double)x[i]) : logf_of_f32(x[i], tab);
 }
