@@ -132,8 +132,6 @@ def _main_sharded(args, comm):
         A = np.ascontiguousarray(np.load(args.pop_af_file, mmap_mode="r")[lo:hi], dtype=np.float32)
         say("Calculating likelihood of population assignment")
         say(str(n) + " individuals to assign to " + str(A.shape[1]) + " populations")
-        if args.get_reference_af:      # slabs are per population; a single-group view is not needed: sums are per individual
-            pass
         afs = AFSet.from_host(A, ctx=ctx)
         out, _ = assign(beagle, afs, comm=comm)
         afs.close()

@@ -11,8 +11,6 @@
 //   Each lane keeps 2 x KB float64 accumulators (np.sum(..., dtype=float), glassy.py:38); the
 //   per-SNP frequency of population k is a broadcast load, or a per-lane vector when a
 //   per-individual column table is given (leave-one-out).
-#include <stdlib.h>
-
 #include "common.h"
 #include "log_table.h"
 
@@ -527,14 +525,11 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
         const int cost = passes * 1000 + passes * kb - a.K;
         if (cost < best_cost) best_cost = cost, best = kb;
     }
-    static const int variant = getenv("WGS_ASSIGN_VARIANT") ? atoi(getenv("WGS_ASSIGN_VARIANT")) : 0;   // tuning experiments
-    if (a.P == 1 && variant == 1 && a.K % 10 == 0) return launch_assign_snp<10, 1>(ctx, a, mode);
-    if (a.P == 1 && variant == 2 && a.K % 8 == 0) return launch_assign_snp<8, 2>(ctx, a, mode);
-    if (a.P == 1 && variant == 3 && a.K % 10 == 0) return launch_assign_snp<10, 2>(ctx, a, mode);
     if (a.P == 1) {
         // NP = 2 pairs per wave halves the per-tile frequency loads/conversions per term; measured
-        // 174 -> 150 ms at K = 10 (KB = 5).  Larger KB would spill the occupancy, so NP = 1 there.
-        const bool np2 = a.npairs >= 2 && variant != 4;
+        // 174 -> 150 ms at K = 10 (KB = 5).  For KB >= 7 it only costs occupancy (measured equal at
+        // K = 8; KB = 10 in one pass measured slower than two passes of 5), so NP = 1 there.
+        const bool np2 = a.npairs >= 2;
         switch (best) {
             case 4: return np2 ? launch_assign_snp<4, 2>(ctx, a, mode) : launch_assign_snp<4, 1>(ctx, a, mode);
             case 5: return np2 ? launch_assign_snp<5, 2>(ctx, a, mode) : launch_assign_snp<5, 1>(ctx, a, mode);
