@@ -388,11 +388,18 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
     HIP_TRY(hipEventRecord(em->ev0, ctx->stream));
     {
         // slices keep one launch below 2^31 workgroups
-        const int64_t per_fit = (wgs_ntiles(em->b->m) + 3) / 4;
+        const int64_t per_fit = (wgs_ntiles(em->b->m) + 3) / 4 + 8;
         const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
+        // several fits on one slab (leave-one-out): cacheable loads + XCD-aware order; else streaming
+        std::vector<char> seen(em->b->n_groups, 0);
+        bool shared = false;
+        for (int j : em->last) {
+            shared = shared || seen[em->group[j]];
+            seen[em->group[j]] = 1;
+        }
         for (size_t off = 0; off < em->last.size(); off += max_fits) {
             const int cnt = (int)std::min<size_t>(max_fits, em->last.size() - off);
-            if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode)) return 1;
+            if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode, shared)) return 1;
         }
     }
     HIP_TRY(hipEventRecord(em->ev1, ctx->stream));

@@ -89,16 +89,31 @@ __device__ __forceinline__ void term_fast(float g0, float g1, const SnpState &st
     tmp = tmp + num * __builtin_amdgcn_rcpf(2.0f * s);
 }
 
+// NT = nontemporal slab loads (each byte is used once: fits of different populations);
+// NT = false + XCD-aware workgroup order when several fits share slabs (leave-one-out).
 template <int MODE, int U, bool NT>
 __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m)
 {
     // Fit index varies fastest across workgroups: leave-one-out fits of one population read the
     // SAME slab tiles, so consecutive workgroups hit in L2 / Infinity Cache instead of re-streaming
     // the slab from HBM once per fit.  (Fits of different populations just interleave K streams.)
-    const int fit = (int)(blockIdx.x % (unsigned)n_fits);
+    // In the shared (NT == false) case the order is also XCD-aware: workgroups are dealt round-robin
+    // over the 8 XCDs (blockIdx % 8 labels the XCD), so tile group = 8 * (j / n_fits) + blockIdx % 8
+    // keeps ALL fits of a tile group on one XCD and its tiles enter one L2 once, not eight.  A wrong
+    // guess about placement costs speed only.
+    int fit;
+    int64_t tgroup;
+    if (NT) {
+        fit = (int)(blockIdx.x % (unsigned)n_fits);
+        tgroup = blockIdx.x / (unsigned)n_fits;
+    } else {
+        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        fit = (int)(j % (unsigned)n_fits);
+        tgroup = (int64_t)(j / (unsigned)n_fits) * 8 + xcd;
+    }
     const FitDesc fd = fits[fit];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t tile = (int64_t)(blockIdx.x / (unsigned)n_fits) * WAVES + wave;
+    const int64_t tile = tgroup * WAVES + wave;
     const int64_t row0 = tile * 64;
     if (row0 >= m) return;                       // wave-uniform; there are no barriers below
 
@@ -593,14 +608,17 @@ __global__ void div_check_kernel(unsigned long long seed, unsigned long long per
 
 }  // namespace
 
-int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode)
+int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode, bool shared_slabs)
 {
     if (n_fits <= 0 || m <= 0) return 0;
     const int64_t tiles = (m + 63) / 64;
-    const int64_t blocks = ((tiles + WAVES - 1) / WAVES) * n_fits;
+    int64_t tgroups = (tiles + WAVES - 1) / WAVES;
+    if (shared_slabs) tgroups = (tgroups + 7) / 8 * 8;          // XCD-aware order covers whole groups of 8
+    const int64_t blocks = tgroups * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
     dim3 grid((unsigned)blocks);
-    static const int variant = getenv("WGS_EM_VARIANT") ? atoi(getenv("WGS_EM_VARIANT")) : 0;   // tuning experiments
+    static const int env_variant = getenv("WGS_EM_VARIANT") ? atoi(getenv("WGS_EM_VARIANT")) : 0;   // tuning experiments
+    const int variant = shared_slabs ? 5 : (env_variant == 5 ? 0 : env_variant);   // 5 = temporal loads + XCD-aware order
 #define WGS_EM_LAUNCH(M, UU, NTT) hipLaunchKernelGGL((em_sweep_kernel<M, UU, NTT>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m)
     if (mode == WGS_MODE_EXACT) {
         switch (variant) {
