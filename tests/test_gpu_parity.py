@@ -427,3 +427,29 @@ def test_c_abi_error_paths(wg):
         dev.EMBatch(b2, [1])
     for x in (afs, b, b2):
         x.close()
+
+
+def test_random_small_shapes_against_oracle(wg, oracle):
+    """Fuzz over awkward shapes (m not a multiple of 64, odd population sizes, populations of 1 or 2,
+    more partitions than sites, K = 1): fit, assignment and leave-one-out against the oracle."""
+    rng = np.random.default_rng(2026)
+    for case in range(24):
+        m = int(rng.choice([1, 2, 63, 64, 65, 127, 130, 257]))
+        K = int(rng.integers(1, 5))
+        n = int(rng.integers(K, 4 * K + 3))
+        P = int(rng.choice([1, 2, 3, 7]))
+        L, _ = synth.make_beagle(m, n, 1, seed=1000 + case)
+        labels = rng.integers(0, K, size=n)
+        labels[:K] = np.arange(K)                      # every population non-empty
+        IDs = np.array([["Ind%d" % i, "p%d" % labels[i]] for i in range(n)], dtype=str)
+        with np.errstate(all="ignore"):
+            pops_o, af_o, _, iters_o = oracle.fit_reference_af(L, IDs, t=2)
+            (pops, af, iters), _ = quiet(wg.emMAF.emMAF_populations, L, IDs, 200, 1e-4)
+            assert list(iters) == list(iters_o) and same_nan(af, af_o), (case, m, n, K)
+            ll_o = oracle.assignLL(L, af_o.copy(), 2)
+            ll, _ = quiet(wg.glassy.assignLL, L, af.copy(), 1)
+            assert close(ll, ll_o), (case, "assign")
+            af1, af2 = af_o.copy(), af_o.copy()
+            loo_o, parts_o = oracle.loo(L, af1, IDs, 2, 50, 1e-4, None, P)
+            (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 50, 1e-4, None, P)
+            assert close(loo, loo_o) and same_nan(parts, parts_o) and same_nan(af2, af1), (case, m, n, K, P)
