@@ -127,6 +127,19 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     h_got, r_got = table(gzip.open(tmp_path / "ref.pop_like_LOO_partitions_3.tsv.gz", "rt").read())
     assert h_got == h_ref
     assert r_got == r_ref                       # partition sums are bit-exact -> identical text
+    # --ne_obs, sharded: per-SNP matrices bit-identical, per-individual means within 1e-6
+    gf = golden("fisher.npz")
+    r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),
+                               "--pop_af_IDs", os.path.join(data, "amre.breeding.ind85.reference_k5.IDs.txt"),
+                               "--get_reference_af", "--ne_obs", "--out", "ne", "--threads", "2"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert np.load(tmp_path / "ne.fisher_obs.npy").tobytes() == gf["f_obs"].tobytes()
+    assert np.load(tmp_path / "ne.ne_obs.npy").tobytes() == gf["ne_obs"].tobytes()
+    assert (tmp_path / "ne.ne_obs.txt").read_text() == str(gf["ne_obs_txt"])
+    got = np.loadtxt(tmp_path / "ne.ne_ind.txt")
+    assert np.all(np.abs(got - gf["ne_ind"]) <= 1e-6 * np.abs(gf["ne_ind"]) + 1e-7)
+    assert clean(r.stdout) == str(gf["stdout"]).replace("<TMP>/", "").splitlines()
     # --get_pop_like, sharded
     r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.nonbreeding.ind34.ds_2x.sites-filter.top_50_each.beagle.gz"),
                                "--pop_af_file", "ref.pop_af.npy", "--get_pop_like", "--out", "nb", "--threads", "2"],

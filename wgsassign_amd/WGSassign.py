@@ -51,7 +51,7 @@ def _main_sharded(args, comm):
     all-reduce (RCCL); rank 0 writes the reference's output files."""
     import numpy as np
 
-    from . import emMAF, glassy, reader_cy, utils
+    from . import emMAF, fisher, glassy, reader_cy, utils
     from .device import AFSet, assign, get_context
 
     root = comm.rank == 0
@@ -104,6 +104,33 @@ def _main_sharded(args, comm):
             np.savetxt(args.out + ".pop_names.txt", pops, fmt="%s")
         say("Saved reference population names as " + str(args.out) +
             ".pop_names.txt (String: Order of pops for .pop_af.npy, .ne_obs.npy, and fisher_obs.npy files)\n")
+        if args.ne_obs:                      # per-SNP quantities shard trivially; rank 0 assembles and writes
+            say("Estimating Fisher information.")
+            f_loc, ne_loc = fisher.fisher_obs(None, af, IDs, args.threads, beagle=beagle)
+            f_obs, ne_obs = comm.gather_rows(f_loc), comm.gather_rows(ne_loc)
+            if root:
+                np.save(args.out + ".fisher_obs", f_obs)
+            say("Saved reference population observed Fisher information per locus as " + str(args.out) +
+                ".fisher_obs.npy (Binary - np.float32)\n")
+            if root:
+                np.save(args.out + ".ne_obs", ne_obs)
+            say("Saved reference population effective sample size estimates per locus as " + str(args.out) +
+                ".ne_obs.npy (Binary - np.float32)\n")
+            if root:
+                ne_obs_mean_out = np.empty((2, len(pops)), dtype=np.dtype('U25'))
+                ne_obs_mean_out[0, :] = pops
+                ne_obs_mean_out[1, :] = np.mean(ne_obs, axis=0)
+                np.savetxt(args.out + ".ne_obs.txt", ne_obs_mean_out, fmt="%s")
+            say("Saved reference population effective sample size estimates as " + str(args.out) +
+                ".ne_obs.txt (String - np.U25)\n")
+            say("Estimating individual effective sample sizes.")
+            # float64 device sums all-reduced over the shards (the reference's float32 pairwise mean
+            # cannot be split across SNP shards; ~1e-7 relative)
+            ne_ind_full = fisher.fisher_obs_ind(None, af, IDs, args.threads, beagle=beagle, comm=comm, m_total=m)
+            if root:
+                np.savetxt(args.out + ".ne_ind.txt", ne_ind_full.reshape(-1, 1), fmt="%.7f")
+            say("Save individual effective sample sizes as " + str(args.out) + ".ne_ind.txt")
+
         if args.loo:
             say("Performing leave-one-out cross validation.")
             say(str(n) + " individuals to assign to " + str(len(pops)) + " populations")
@@ -154,9 +181,9 @@ def main(argv=None):
             print("WGSassign")
             print("Matt DeSaix.")
             print("Using " + str(args.threads) + " thread(s).\n")
-        for unsupported in ("ne_obs", "get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
+        for unsupported in ("get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
             if getattr(args, unsupported):
-                raise SystemExit("--%s is not available in the SNP-sharded (multi-GPU) mode" % unsupported)
+                raise SystemExit("--%s is outside the scope of the MI355X build" % unsupported)
         return _main_sharded(args, comm)
     print("WGSassign")
     print("Matt DeSaix.")
