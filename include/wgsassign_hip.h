@@ -203,6 +203,8 @@ const char *wgs_reader_sample_name(wgs_reader *r, int i);
 int wgs_reader_next(wgs_reader *r, float *rows, int64_t max_rows, int64_t *nrows);
 /* Skip up to max_rows sites without parsing them (SNP-sharded reading: each rank parses only its range). */
 int wgs_reader_skip(wgs_reader *r, int64_t max_rows, int64_t *nrows);
+/* Same, keeping the skipped lines' site names (read them with wgs_reader_chunk_sites): a names-only pass. */
+int wgs_reader_skip_names(wgs_reader *r, int64_t max_rows, int64_t *nrows);
 /* Site names of the last chunk, '\n'-terminated each, *bytes long. */
 const char *wgs_reader_chunk_sites(wgs_reader *r, int64_t *bytes);
 /* Number of data lines (sites) of a gzipped Beagle file: one inflate pass, no parsing. */

@@ -324,6 +324,23 @@ def g9_fisher(L, IDs, af):
 
 
 
+def g10_cli_downsampled():
+    """CLI run with --loo_downsampled_beagle (WGSassign.py:172-198, 276-294): stdout and the TSV."""
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        r = subprocess.run([sys.executable, "-m", "WGSassign.WGSassign", "--beagle", BREED, "--pop_af_IDs", BREED_IDS,
+                            "--get_reference_af", "--loo", "--loo_downsampled_beagle", BREED80, "--out",
+                            os.path.join(td, "ds"), "--threads", "2"], cwd=td, capture_output=True, text=True, check=True)
+        res["stdout"] = np.array(r.stdout.replace(td, "<TMP>").replace(DATA, "<DATA>"))
+        res["loo_tsv"] = np.array(open(os.path.join(td, "ds.pop_like_LOO_downsampled.tsv")).read())
+        res["pop_af_npy"] = np.load(os.path.join(td, "ds.pop_af.npy"))
+    save("amre_cli_downsampled.npz", **res)
+
+
+if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "downsampled":
+    g10_cli_downsampled()
+    sys.exit(0)
+
 if __name__ == "__main__" and os.environ.get("GOLDEN_ONLY") == "fisher":
     _g = np.load(os.path.join(HERE, "amre_fit.npz"))
     g9_fisher(_g["L"], _g["IDs"], _g["pop_af"])
@@ -339,5 +356,6 @@ if __name__ == "__main__":
     g7_rmse()
     g8_synth_mid()
     g9_fisher(L, IDs, af)
+    g10_cli_downsampled()
 
 

@@ -70,3 +70,21 @@ def test_get_pop_like(tmp_path, golden):
     print("pop_like.txt text identical to the reference's:", same)
     assert [l.replace(str(tmp_path) + "/", "") for l in stdout.splitlines()] == \
         str(g["stdout_like"]).replace("<TMP>/", "").splitlines()
+
+
+def test_loo_downsampled_cli(tmp_path, golden):
+    """--loo --loo_downsampled_beagle: stdout, filtered allele frequencies and the TSV of the reference CLI."""
+    g = golden("amre_cli_downsampled.npz")
+    ds = os.path.join(DATA, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each_subset_80percent_sites.beagle.gz")
+    out = str(tmp_path / "ds")
+    stdout = run_cli(["--beagle", BREED, "--pop_af_IDs", IDS, "--get_reference_af", "--loo", "--loo_downsampled_beagle", ds,
+                      "--out", out, "--threads", "2"])
+    assert np.load(out + ".pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
+    ref_lines = str(g["stdout"]).replace("<TMP>/", "").splitlines()
+    assert [l.replace(str(tmp_path) + "/", "") for l in stdout.splitlines()] == ref_lines
+    h_ref, r_ref = table(str(g["loo_tsv"]))
+    h_got, r_got = table(open(out + ".pop_like_LOO_downsampled.tsv").read())
+    assert h_got == h_ref and [r[:2] for r in r_got] == [r[:2] for r in r_ref]
+    a = np.array([[float(x) for x in r[2:]] for r in r_got])
+    b = np.array([[float(x) for x in r[2:]] for r in r_ref])
+    assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b) + 1.5e-6)

@@ -127,6 +127,23 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     h_got, r_got = table(gzip.open(tmp_path / "ref.pop_like_LOO_partitions_3.tsv.gz", "rt").read())
     assert h_got == h_ref
     assert r_got == r_ref                       # partition sums are bit-exact -> identical text
+    # --loo --loo_downsampled_beagle, sharded: names-only passes + keep masks
+    gd = golden("amre_cli_downsampled.npz")
+    r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),
+                               "--pop_af_IDs", os.path.join(data, "amre.breeding.ind85.reference_k5.IDs.txt"),
+                               "--get_reference_af", "--loo", "--loo_downsampled_beagle",
+                               os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each_subset_80percent_sites.beagle.gz"),
+                               "--out", "ds", "--threads", "2"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert np.load(tmp_path / "ds.pop_af.npy").tobytes() == gd["pop_af_npy"].tobytes()
+    assert clean(r.stdout) == str(gd["stdout"]).replace("<TMP>/", "").splitlines()
+    h_ref, r_ref = table(str(gd["loo_tsv"]))
+    h_got, r_got = table((tmp_path / "ds.pop_like_LOO_downsampled.tsv").read_text())
+    assert h_got == h_ref and [x[:2] for x in r_got] == [x[:2] for x in r_ref]
+    a = np.array([[float(v) for v in x[2:]] for x in r_got])
+    b = np.array([[float(v) for v in x[2:]] for x in r_ref])
+    assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b) + 1.5e-6)
     # --ne_obs, sharded: per-SNP matrices bit-identical, per-individual means within 1e-6
     gf = golden("fisher.npz")
     r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),

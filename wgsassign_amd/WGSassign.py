@@ -60,8 +60,6 @@ def _main_sharded(args, comm):
         if root:
             print(*a)
 
-    if args.loo_downsampled_beagle:
-        raise SystemExit("--loo_downsampled_beagle is not available in the SNP-sharded (multi-GPU) mode")
     ctx = get_context()
     say("Parsing Beagle file.")
     assert os.path.isfile(args.beagle), "Beagle file doesn't exist!"
@@ -72,18 +70,55 @@ def _main_sharded(args, comm):
         IDs = np.loadtxt(args.pop_af_IDs, delimiter="\t", dtype="str")
         pops = np.unique(IDs[:, 1])
         group_of, n_groups = np.searchsorted(pops, IDs[:, 1]).astype(np.int32), len(pops)
-    beagle, sample_names, site_names, m = reader_cy.stream_to_device(
-        args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank, world=comm.world)
-    n = beagle.n
-    say("Loaded " + str(m) + " sites and " + str(n) + " individuals.")
-    ends = comm.allgather_object((site_names[:4], site_names[-4:]))
-    if root:
+
+    def summary(samples, m_sites, ends):
         heads = [x for e in ends for x in e[0]]
         tails = [x for e in ends for x in e[1]]
-        shown = heads[:m] if m <= 4 else heads[:2] + tails[-2:]
-        print(f"sample_names: {len(sample_names)} samples total: {utils.preview(sample_names)}")
-        print(f"site_names: {m} sites total: " + (", ".join(shown) if m <= 4 else
-                                                    ", ".join(shown[:2]) + ", ..., " + ", ".join(shown[2:])))
+        shown = heads[:m_sites] if m_sites <= 4 else heads[:2] + tails[-2:]
+        print(f"sample_names: {len(samples)} samples total: {utils.preview(samples)}")
+        print(f"site_names: {m_sites} sites total: " + (", ".join(shown) if m_sites <= 4 else
+                                                          ", ".join(shown[:2]) + ", ..., " + ", ".join(shown[2:])))
+
+    scored = None
+    if args.loo_downsampled_beagle:
+        # WGSassign.py:172-198 with names-only passes: every rank derives the same two site masks, then
+        # parses only its range of the KEPT sites of each file
+        assert os.path.isfile(args.loo_downsampled_beagle), "Downsampled beagle file doesn't exist!"
+        sample_names, names_ref = reader_cy.read_site_names(args.beagle)
+        sample_names_ds, names_ds = reader_cy.read_site_names(args.loo_downsampled_beagle)
+        n = len(sample_names)
+        say("Loaded " + str(len(names_ref)) + " sites and " + str(n) + " individuals.")
+        if root:
+            utils.print_sample_and_site_summary(sample_names, names_ref)
+        say("Parsing the optional downsampled Beagle file.")
+        say("Loaded optional downsampled data set with " + str(len(names_ref)) + " sites and " + str(n) + " individuals.")
+        if root:
+            utils.print_sample_and_site_summary(sample_names_ds, names_ds)
+        if sample_names != sample_names_ds:
+            raise ValueError("Sample names in downsampled Beagle file do not match original.")
+        say("Retaining only sites from the reference that are in the downsampled beagle file:")
+        keep_ref = utils.site_mask(names_ref, names_ds)
+        if root and int(np.sum(~keep_ref)) > 0:
+            print(f"\tFiltered out {int(np.sum(~keep_ref))} sites not present in the target site list.")
+        kept_ref = [x for x, k in zip(names_ref, keep_ref) if k]
+        say("Removing sites from downsampled set that were not in the reference (should not occur...):")
+        keep_ds = utils.site_mask(names_ds, kept_ref)
+        if root and int(np.sum(~keep_ds)) > 0:
+            print(f"\tFiltered out {int(np.sum(~keep_ds))} sites not present in the target site list.")
+        if kept_ref != [x for x, k in zip(names_ds, keep_ds) if k]:
+            raise ValueError("Site names in full and downsampled Beagle do not match after filtering.")
+        beagle, _, site_names, m = reader_cy.stream_to_device(args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank,
+                                                              world=comm.world, keep=keep_ref)
+        scored, _, _, _ = reader_cy.stream_to_device(args.loo_downsampled_beagle, group_of, n_groups, ctx=ctx,
+                                                     rank=comm.rank, world=comm.world, keep=keep_ds)
+    else:
+        beagle, sample_names, site_names, m = reader_cy.stream_to_device(
+            args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank, world=comm.world)
+        n = beagle.n
+        say("Loaded " + str(m) + " sites and " + str(n) + " individuals.")
+        ends = comm.allgather_object((site_names[:4], site_names[-4:]))
+        if root:
+            summary(sample_names, m, ends)
 
     if args.get_reference_af:
         say("Parsing reference population ID file.")
@@ -134,14 +169,18 @@ def _main_sharded(args, comm):
         if args.loo:
             say("Performing leave-one-out cross validation.")
             say(str(n) + " individuals to assign to " + str(len(pops)) + " populations")
+            if scored is not None:
+                say("Using downsampled GLs for likelihood evaluation in LOO assignment.")
             buf = io.StringIO()
             with contextlib.redirect_stdout(buf):
-                ll, parts = glassy.loo_device(beagle, beagle, af, group_of, args.maf_iter, args.maf_tole,
+                ll, parts = glassy.loo_device(beagle, scored if scored is not None else beagle, af, group_of,
+                                              args.maf_iter, args.maf_tole,
                                               args.partition_sites, comm=comm, need_parts=args.partition_sites > 1)
             if root:
                 sys.stdout.write(buf.getvalue())
-                outfile = f"{args.out}.pop_like_LOO.tsv"
-                partfile = f"{args.out}.pop_like_LOO_partitions_{args.partition_sites}.tsv.gz"
+                suffix = "_downsampled" if scored is not None else ""
+                outfile = f"{args.out}.pop_like_LOO{suffix}.tsv"
+                partfile = f"{args.out}.pop_like_LOO{suffix}_partitions_{args.partition_sites}.tsv.gz"
                 utils.write_ass_mats(outfile, ll, sample_names, pops, print_part_column=False,
                                      sample_locations=IDs[:, 1], doing_LOO=True)
                 print(f"Saved leave-one-out cross validation log likelihoods as {outfile}")
@@ -165,6 +204,8 @@ def _main_sharded(args, comm):
         if root:
             np.savetxt(args.out + ".pop_like.txt", out.astype(np.float32), fmt="%.7f")
         say("Saved population assignment log likelihoods as " + str(args.out) + ".pop_like.txt (text)")
+    if scored is not None:
+        scored.close()
     beagle.close()
     comm.barrier()
 

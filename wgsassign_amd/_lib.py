@@ -75,6 +75,7 @@ SIGNATURES = {
     "wgs_reader_sample_name": (ctypes.c_char_p, [c_vp, c_int]),
     "wgs_reader_next": (c_int, [c_vp, c_f32p, c_i64, ctypes.POINTER(c_i64)]),
     "wgs_reader_skip": (c_int, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
+    "wgs_reader_skip_names": (c_int, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "wgs_reader_chunk_sites": (c_vp, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_reader_count_sites": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),

@@ -273,13 +273,21 @@ int wgs_reader_next(wgs_reader *r, float *rows, int64_t max_rows, int64_t *nrows
     return 0;
 }
 
+static int skip_impl(wgs_reader *r, int64_t max_rows, int64_t *nrows, bool names);
+
 /* Skip up to max_rows data lines without parsing them (a rank that owns a later SNP range). */
-int wgs_reader_skip(wgs_reader *r, int64_t max_rows, int64_t *nrows)
+int wgs_reader_skip(wgs_reader *r, int64_t max_rows, int64_t *nrows) { return skip_impl(r, max_rows, nrows, false); }
+
+/* Same, but keep the site names of the skipped lines (wgs_reader_chunk_sites): a names-only pass. */
+int wgs_reader_skip_names(wgs_reader *r, int64_t max_rows, int64_t *nrows) { return skip_impl(r, max_rows, nrows, true); }
+
+static int skip_impl(wgs_reader *r, int64_t max_rows, int64_t *nrows, bool names)
 {
     if (!r || !nrows || max_rows < 0) {
         wgs_set_error("bad argument");
         return 2;
     }
+    if (names) r->chunk_sites.clear();
     int64_t done = 0;
     while (done < max_rows) {
         bool progressed = false;
@@ -293,6 +301,12 @@ int wgs_reader_skip(wgs_reader *r, int64_t max_rows, int64_t *nrows)
             const char *t = b;
             while (t < nl && is_delim(*t)) ++t;
             done += t < nl;                                   // blank lines do not count
+            if (names && t < nl) {
+                const char *e = t;
+                while (e < nl && !is_delim(*e)) ++e;
+                r->chunk_sites.append(t, e);
+                r->chunk_sites += '\n';
+            }
             r->pos = (size_t)(nl - r->buf.data()) + (nl < r->buf.data() + r->len ? 1 : 0);
             progressed = true;
         }

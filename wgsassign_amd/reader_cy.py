@@ -73,6 +73,22 @@ def count_sites(path):
     return n.value
 
 
+def read_site_names(path, chunk=1 << 20):
+    """(sample_names, site_names) of a Beagle file without parsing any likelihood (inflate-bound)."""
+    lib = _lib.load()
+    names = []
+    with BeagleStream(path, threads=1) as st:
+        while True:
+            got = ctypes.c_int64()
+            _lib.check(lib.wgs_reader_skip_names(st._h, chunk, ctypes.byref(got)))
+            if got.value == 0:
+                break
+            nbytes = ctypes.c_int64()
+            ptr = lib.wgs_reader_chunk_sites(st._h, ctypes.byref(nbytes))
+            names.extend(ctypes.string_at(ptr, nbytes.value).decode().split("\n")[:-1])
+        return list(st.sample_names), names
+
+
 def readBeagle(beagle):
     """reader_cy.pyx:16-77: returns (L float32 (m, 2n) C-contiguous, sample_names, site_names)."""
     with BeagleStream(beagle) as st:
@@ -105,26 +121,48 @@ def readBeagle_py(beagle):
     return L, sample_names, site_names
 
 
-def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, rank=0, world=1, m_total=None):
+def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, rank=0, world=1, m_total=None,
+                     keep=None):
     """Two passes over the file: count the sites, then parse chunk by chunk straight into the
     device slabs -- host memory stays bounded by one chunk (the reference holds two
     full copies).  With world > 1 this rank skips to its contiguous SNP range
     (comm.shard_range) and parses only that.  group_of may be a callable(sample_names) ->
-    (group_of, n_groups).  Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
+    (group_of, n_groups).  keep (bool array over the file's sites, e.g. the site mask of
+    utils.filter_sites_to_common) restricts the matrix to the kept sites; shard ranges then count
+    kept sites.  Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
     from .comm import shard_range
     from .device import DeviceBeagle
-    if m_total is None:
+    if keep is not None:
+        keep = np.asarray(keep, dtype=bool)
+        kept_rows = np.flatnonzero(keep)
+        m_total = len(kept_rows)
+    elif m_total is None:
         m_total = count_sites(path)
     lo, hi = shard_range(m_total, rank, world)
+    # file rows [r0, r1) cover this rank's (kept) sites
+    if keep is None:
+        r0, r1 = lo, hi
+    elif hi > lo:
+        r0, r1 = int(kept_rows[lo]), int(kept_rows[hi - 1]) + 1
+    else:
+        r0 = r1 = 0
     with BeagleStream(path, threads) as st:
         if callable(group_of):
             group_of, n_groups = group_of(list(st.sample_names))
+        if hi <= lo:
+            raise ValueError("fewer sites (%d) than ranks (%d): nothing to shard" % (m_total, world))
         beagle = DeviceBeagle(hi - lo, st.n, group_of, n_groups, site0=lo, ctx=ctx)
-        if st.skip(lo) != lo:
+        if st.skip(r0) != r0:
             raise RuntimeError("Beagle file shorter than counted")
-        row0, site_names = 0, []
-        for rows, names in st.chunks(limit=hi - lo):
-            beagle.upload_rows(np.ascontiguousarray(rows), row0)
+        row0, frow, site_names = 0, r0, []
+        for rows, names in st.chunks(limit=r1 - r0):
+            if keep is not None:
+                sel = keep[frow:frow + rows.shape[0]]
+                frow += rows.shape[0]
+                rows = rows[sel]
+                names = [x for x, k in zip(names, sel) if k]
+            if rows.shape[0]:
+                beagle.upload_rows(np.ascontiguousarray(rows), row0)
             row0 += rows.shape[0]
             site_names.extend(names)
         if row0 != hi - lo:
