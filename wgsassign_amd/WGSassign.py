@@ -44,9 +44,9 @@ for _flag in ("--ind_ad_file", "--allele_count_threshold", "--ind_start", "--ind
     parser.add_argument(_flag, help=argparse.SUPPRESS)
 
 
-def _main_sharded(args, comm):
-    """The same options with the SNPs sharded over the ranks of a torchrun launch (one process per
-    GPU): every rank parses and holds only its contiguous SNP range; the EM convergence sums,
+def _run(args, comm):
+    """The hot-path options on device-resident data.  Under torchrun (one process per GPU) the SNPs are
+    sharded over the ranks: every rank parses and holds only its contiguous SNP range; the EM convergence sums,
     the serial-chain carry and the n x K log-likelihood sums cross ranks through one sum
     all-reduce (RCCL); rank 0 writes the reference's output files."""
     import numpy as np
@@ -216,19 +216,12 @@ def main(argv=None):
         parser.print_help()
         sys.exit()
     from .comm import init_from_env
-    comm = init_from_env()
-    if comm.world > 1:
-        if comm.rank == 0:
-            print("WGSassign")
-            print("Matt DeSaix.")
-            print("Using " + str(args.threads) + " thread(s).\n")
-        for unsupported in ("get_assignment_z_score", "get_reference_z_score", "get_em_mix", "get_mcmc_mix"):
-            if getattr(args, unsupported):
-                raise SystemExit("--%s is outside the scope of the MI355X build" % unsupported)
-        return _main_sharded(args, comm)
-    print("WGSassign")
-    print("Matt DeSaix.")
-    print("Using " + str(args.threads) + " thread(s).\n")
+    comm = init_from_env()          # LocalComm outside torchrun; one rank per GPU under it
+    root = comm.rank == 0
+    if root:
+        print("WGSassign")
+        print("Matt DeSaix.")
+        print("Using " + str(args.threads) + " thread(s).\n")
 
     if args.loo_downsampled_beagle and not args.loo:
         raise ValueError("The --loo_downsampled_beagle option requires that --loo is also specified.")
@@ -237,111 +230,25 @@ def main(argv=None):
             raise SystemExit("--%s is outside the scope of the MI355X build (EM allele frequencies, Fisher "
                              "information, leave-one-out and assignment likelihoods only)" % unsupported)
 
-    # log-file of non-default arguments (WGSassign.py:127-141)
-    full, deaf = vars(args), vars(parser.parse_args([]))
-    with open(args.out + ".args", "w") as fh:
-        fh.write("WGSassign\n")
-        fh.write("Time: " + datetime.now().strftime("%d/%m/%Y %H:%M:%S") + "\n")
-        fh.write("Directory: " + str(os.getcwd()) + "\n")
-        fh.write("Options:\n")
-        for key in full:
-            if full[key] != deaf[key]:
-                if type(full[key]) is bool:
-                    fh.write("\t-" + str(key) + "\n")
-                else:
-                    fh.write("\t-" + str(key) + " " + str(full[key]) + "\n")
+    if root:        # log-file of non-default arguments (WGSassign.py:127-141)
+        full, deaf = vars(args), vars(parser.parse_args([]))
+        with open(args.out + ".args", "w") as fh:
+            fh.write("WGSassign\n")
+            fh.write("Time: " + datetime.now().strftime("%d/%m/%Y %H:%M:%S") + "\n")
+            fh.write("Directory: " + str(os.getcwd()) + "\n")
+            fh.write("Options:\n")
+            for key in full:
+                if full[key] != deaf[key]:
+                    if type(full[key]) is bool:
+                        fh.write("\t-" + str(key) + "\n")
+                    else:
+                        fh.write("\t-" + str(key) + " " + str(full[key]) + "\n")
 
-    import numpy as np
-
-    from . import emMAF, fisher, glassy, reader_cy, utils
-
-    L = None
-    if args.beagle is not None:
-        print("Parsing Beagle file.")
-        assert os.path.isfile(args.beagle), "Beagle file doesn't exist!"
-        L, sample_names, site_names = reader_cy.readBeagle(args.beagle)
-        m, n = L.shape[0], L.shape[1] // 2
-        print("Loaded " + str(m) + " sites and " + str(n) + " individuals.")
-        utils.print_sample_and_site_summary(sample_names, site_names)
-
-    L_ds = None
-    if args.loo_downsampled_beagle is not None:
-        print("Parsing the optional downsampled Beagle file.")
-        assert os.path.isfile(args.loo_downsampled_beagle), "Downsampled beagle file doesn't exist!"
-        L_ds, sample_names_ds, site_names_ds = reader_cy.readBeagle(args.loo_downsampled_beagle)
-        print("Loaded optional downsampled data set with " + str(m) + " sites and " + str(n) + " individuals.")
-        utils.print_sample_and_site_summary(sample_names_ds, site_names_ds)
-        if sample_names != sample_names_ds:
-            raise ValueError("Sample names in downsampled Beagle file do not match original.")
-        print("Retaining only sites from the reference that are in the downsampled beagle file:")
-        L, site_names = utils.filter_sites_to_common(L, site_names, site_names_ds)
-        print("Removing sites from downsampled set that were not in the reference (should not occur...):")
-        L_ds, site_names_ds = utils.filter_sites_to_common(L_ds, site_names_ds, site_names)
-        if site_names != site_names_ds:
-            raise ValueError("Site names in full and downsampled Beagle do not match after filtering.")
-        L, L_ds = np.ascontiguousarray(L), np.ascontiguousarray(L_ds)
-
-    if args.get_reference_af:
-        print("Parsing reference population ID file.")
-        assert os.path.isfile(args.pop_af_IDs), "Reference population ID file does not exist!!"
-        IDs = np.loadtxt(args.pop_af_IDs, delimiter="\t", dtype="str")
-        n = L.shape[1] // 2
-        assert (n == IDs.shape[0]), "Number of individuals in beagle and reference ID file do not match!"
-        pops, af, _ = emMAF.emMAF_populations(L, IDs, args.maf_iter, args.maf_tole)
-        np.save(args.out + ".pop_af", af)
-        print("Saved reference population allele frequencies as " + str(args.out) +
-              ".pop_af.npy (Binary - np.float32)\n")
-        print("Column order of populations is: " + str(pops))
-        np.savetxt(args.out + ".pop_names.txt", pops, fmt="%s")
-        print("Saved reference population names as " + str(args.out) +
-              ".pop_names.txt (String: Order of pops for .pop_af.npy, .ne_obs.npy, and fisher_obs.npy files)\n")
-
-        if args.ne_obs:                                          # WGSassign.py:252-274
-            print("Estimating Fisher information.")
-            f_obs, ne_obs = fisher.fisher_obs(L, af, IDs, args.threads)
-            np.save(args.out + ".fisher_obs", f_obs)
-            print("Saved reference population observed Fisher information per locus as " + str(args.out) +
-                  ".fisher_obs.npy (Binary - np.float32)\n")
-            np.save(args.out + ".ne_obs", ne_obs)
-            print("Saved reference population effective sample size estimates per locus as " + str(args.out) +
-                  ".ne_obs.npy (Binary - np.float32)\n")
-            ne_obs_mean_out = np.empty((2, len(pops)), dtype=np.dtype('U25'))
-            ne_obs_mean_out[0, :] = pops
-            ne_obs_mean_out[1, :] = np.mean(ne_obs, axis=0)
-            np.savetxt(args.out + ".ne_obs.txt", ne_obs_mean_out, fmt="%s")
-            print("Saved reference population effective sample size estimates as " + str(args.out) +
-                  ".ne_obs.txt (String - np.U25)\n")
-            print("Estimating individual effective sample sizes.")
-            ne_ind_full = fisher.fisher_obs_ind(L, af, IDs, args.threads)
-            np.savetxt(args.out + ".ne_ind.txt", ne_ind_full.reshape(-1, 1), fmt="%.7f")
-            print("Save individual effective sample sizes as " + str(args.out) + ".ne_ind.txt")
-
-        if args.loo:
-            print("Performing leave-one-out cross validation.")
-            logl_mat_loo, logl_parts_mat_loo = glassy.loo(L, af, IDs, args.threads, args.maf_iter, args.maf_tole,
-                                                          downsampled_L=L_ds, num_partitions=args.partition_sites,
-                                                          need_parts=args.partition_sites > 1)
-            suffix = "_downsampled" if L_ds is not None else ""
-            outfile = f"{args.out}.pop_like_LOO{suffix}.tsv"
-            partfile = f"{args.out}.pop_like_LOO{suffix}_partitions_{args.partition_sites}.tsv.gz"
-            utils.write_ass_mats(outfile, logl_mat_loo, sample_names, pops, print_part_column=False,
-                                 sample_locations=IDs[:, 1], doing_LOO=True)
-            print(f"Saved leave-one-out cross validation log likelihoods as {outfile}")
-            if args.partition_sites > 1:
-                utils.write_ass_mats(partfile, logl_parts_mat_loo, sample_names, pops,
-                                     partition_count=args.partition_sites, print_part_column=True,
-                                     sample_locations=IDs[:, 1], doing_LOO=True)
-                print(f"Saved leave-one-out cross validation log likelihoods from partitioned sites as {partfile}")
-            print(f"Column order of populations is: {pops}")
-
-    if args.get_pop_like:
-        print("Parsing population allele frequency file.")
-        assert os.path.isfile(args.pop_af_file), "Population allele frequency file does not exist!!"
-        A = np.load(args.pop_af_file)
-        print("Calculating likelihood of population assignment")
-        logl_mat = glassy.assignLL(L, A, args.threads)
-        np.savetxt(args.out + ".pop_like.txt", logl_mat, fmt="%.7f")
-        print("Saved population assignment log likelihoods as " + str(args.out) + ".pop_like.txt (text)")
+    if args.beagle is None:
+        return
+    # One code path for one or many GPUs: the Beagle file is streamed chunk by chunk into the device
+    # slabs (host memory stays at one chunk; the reference holds two full copies of the matrix).
+    return _run(args, comm)
 
 
 if __name__ == "__main__":
