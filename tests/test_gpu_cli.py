@@ -88,3 +88,14 @@ def test_loo_downsampled_cli(tmp_path, golden):
     a = np.array([[float(x) for x in r[2:]] for r in r_got])
     b = np.array([[float(x) for x in r[2:]] for r in r_ref])
     assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b) + 1.5e-6)
+
+
+def test_cli_streams_in_many_chunks(tmp_path, golden, monkeypatch):
+    """The CLI streams the file in chunks (here ~40 sites each): same outputs as in one piece."""
+    monkeypatch.setenv("WGSASSIGN_CHUNK_BYTES", str(40 * 170 * 4))
+    g = golden("amre_cli.npz")
+    out = str(tmp_path / "ref")
+    run_cli(["--beagle", BREED, "--pop_af_IDs", IDS, "--get_reference_af", "--loo", "--partition_sites", "3",
+             "--out", out, "--threads", "2"])
+    assert np.load(out + ".pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
+    assert gzip.open(out + ".pop_like_LOO_partitions_3.tsv.gz", "rt").read() == str(g["parts_tsv"])

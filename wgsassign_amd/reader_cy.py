@@ -33,9 +33,12 @@ class BeagleStream:
         _lib.check(_lib.load().wgs_reader_skip(self._h, int(nrows), ctypes.byref(got)))
         return got.value
 
-    def chunks(self, max_rows=None, target_bytes=256 << 20, limit=None):
-        """Yield (rows, site_names) chunks; at most `limit` sites in total when given."""
+    def chunks(self, max_rows=None, target_bytes=None, limit=None):
+        """Yield (rows, site_names) chunks; at most `limit` sites in total when given.  Chunk size:
+        max_rows sites, else target_bytes (default 256 MiB, or WGSASSIGN_CHUNK_BYTES) of float32."""
         lib = _lib.load()
+        if target_bytes is None:
+            target_bytes = int(os.environ.get("WGSASSIGN_CHUNK_BYTES", 256 << 20))
         if max_rows is None:
             max_rows = max(1, target_bytes // max(1, 8 * self.n))
         left = limit
