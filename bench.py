@@ -150,6 +150,19 @@ def main():
     extra = {"gl_pair_terms_per_s": value * n_call, "synth_seconds": round(t_gen, 2),
              "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
 
+    # the same sweep in WGS_MODE_FAST (float32 term evaluation, ~1e-6 of the reference), for comparison
+    if args.mode == "exact":
+        em_fast = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=MODE_FAST)
+        fast_ms = []
+        for i in range(4):
+            em_fast.step()
+            if i:
+                fast_ms.append(em_fast.last_sweep_ms())
+        em_fast.close()
+        fk = float(np.mean(fast_ms)) * 1e-3
+        extra["fast_mode_sweep"] = {"kernel_ms_avg": round(fk * 1e3, 4), "hbm_frac": round(alg_bytes / fk / HBM_PEAK, 4),
+                                    "note": "float32 arithmetic, not bit-exact; the headline value above is exact mode"}
+
     # assignment log-likelihood sweep (one pass producing all n x K sums), same matrix
     if not args.no_assign:
         afs = device.AFSet(m, K, ctx=ctx)
