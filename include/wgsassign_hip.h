@@ -47,6 +47,8 @@ void wgs_ctx_destroy(wgs_ctx *ctx);
 int wgs_ctx_sync(wgs_ctx *ctx);
 /* The context's hipStream_t (all work of the library is enqueued on it). */
 void *wgs_ctx_stream(wgs_ctx *ctx);
+/* Free / total device memory right now (hipMemGetInfo): used to size leave-one-out batches. */
+int wgs_ctx_mem_info(wgs_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes);
 /* Device name / CU count / total memory of the context's device (for reports). */
 int wgs_ctx_info(wgs_ctx *ctx, char *name, int name_len, int *cus, int64_t *mem_bytes);
 

@@ -453,3 +453,20 @@ def test_random_small_shapes_against_oracle(wg, oracle):
             loo_o, parts_o = oracle.loo(L, af1, IDs, 2, 50, 1e-4, None, P)
             (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 50, 1e-4, None, P)
             assert close(loo, loo_o) and same_nan(parts, parts_o) and same_nan(af2, af1), (case, m, n, K, P)
+
+
+@pytest.mark.parametrize("batch", ["7", "30"])
+def test_loo_in_batches(wg, golden, monkeypatch, batch):
+    """Leave-one-out re-fits run in file-order batches when they do not fit device memory (forced
+    here): the sticky column overwrite is carried from batch to batch, results unchanged."""
+    monkeypatch.setenv("WGSASSIGN_LOO_BATCH", batch)
+    g, fit = golden("amre_loo.npz"), golden("amre_fit.npz")
+    af = fit["pop_af"].copy()
+    (ll, parts), text = quiet(wg.glassy.loo, fit["L"], af, fit["IDs"], 1, 200, 1e-4, None, 3)
+    assert nearly_all_identical(ll, g["loo_P3"]) and same(parts, g["parts_P3"]) and same(af, g["af_after_P3"])
+    assert len([l for l in text.splitlines() if l.startswith("EM (MAF) converged")]) == 85
+    gi = golden("synth_interleaved.npz")
+    L, IDs = synth.make_beagle(6000, 37, 4, seed=88, interleave=True)
+    af = gi["pop_af"].copy()
+    (ll, _), _ = quiet(wg.glassy.loo, L, af, IDs, 1, 200, 1e-4, None, 1)
+    assert nearly_all_identical(ll, gi["loo"]) and same(af, gi["af_after"])

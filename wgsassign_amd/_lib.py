@@ -30,6 +30,7 @@ SIGNATURES = {
     "wgs_ctx_destroy": (None, [c_vp]),
     "wgs_ctx_sync": (c_int, [c_vp]),
     "wgs_ctx_stream": (c_vp, [c_vp]),
+    "wgs_ctx_mem_info": (c_int, [c_vp, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "wgs_ctx_info": (c_int, [c_vp, ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_i64)]),
     "wgs_emmaf_update": (c_int, [c_vp, c_f32p, c_i64, c_i64, c_f32p, c_int]),
     "wgs_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p]),

@@ -94,6 +94,17 @@ int wgs_ctx_sync(wgs_ctx *ctx)
 
 void *wgs_ctx_stream(wgs_ctx *ctx) { return (void *)ctx->stream; }
 
+int wgs_ctx_mem_info(wgs_ctx *ctx, int64_t *free_bytes, int64_t *total_bytes)
+{
+    WGS_REQUIRE(ctx, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    size_t f = 0, t = 0;
+    HIP_TRY(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (int64_t)f;
+    if (total_bytes) *total_bytes = (int64_t)t;
+    return 0;
+}
+
 int wgs_ctx_info(wgs_ctx *ctx, char *name, int name_len, int *cus, int64_t *mem_bytes)
 {
     hipDeviceProp_t prop;

@@ -53,6 +53,12 @@ class Context:
         """The context's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
         return int(_lib.load().wgs_ctx_stream(self._h) or 0)
 
+    def mem_info(self):
+        """(free, total) device memory in bytes."""
+        free, total = ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.load().wgs_ctx_mem_info(self._h, ctypes.byref(free), ctypes.byref(total)))
+        return free.value, total.value
+
     def info(self):
         name = ctypes.create_string_buffer(256)
         cus = ctypes.c_int()

@@ -76,39 +76,60 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
     import time
     n, k = beagle.n, af.shape[1]
     counts = np.bincount(group_of, minlength=k)
-    t0 = time.perf_counter()
-    em = EMBatch(beagle, group_of, np.arange(n, dtype=np.int32))
-    iters = em.run(maf_iter, maf_tole, comm=comm)
-    beagle.ctx.sync()
-    t1 = time.perf_counter()
-    for i in range(n):
-        if verbose and iters[i] > 0:
-            print("EM (MAF) converged at iteration: " + str(int(iters[i])))
-        em.clamp(i, int(counts[group_of[i]]) - 1)
-    afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
-    cur = [afset.col_dev(j) for j in range(k)]
-    colptr = np.zeros((n, k), dtype=np.uint64)
-    for i in range(n):
-        cur[group_of[i]] = em.f_dev(i)
-        colptr[i] = cur
-    # need_parts=False (the command line with --partition_sites 1, which never writes the partition
-    # matrix): skip the serial float32 chain and return the totals in its place
+    # The n re-fits need 2 float32 vectors + the per-tile partial sums each (~8.2 bytes per SNP and fit).
+    # They run as ONE batch when that fits the free device memory, else in file-order batches: the
+    # "current" columns (afset) carry the sticky overwrite from batch to batch.
+    free_bytes, _ = beagle.ctx.mem_info()
+    per_fit = int(beagle.m * 8.2) + 4096
+    batch = int(os.environ.get("WGSASSIGN_LOO_BATCH", max(1, min(n, int(0.8 * free_bytes) // per_fit))))
     exact_parts = os.environ.get("WGSASSIGN_PARTS", "exact") != "fast" and (need_parts or P > 1)
-    if exact_parts:
-        # sums over all sites in float64 (np.sum(dtype=float), glassy.py:101); partition sums literally
-        # as utils.py:147-149 accumulates them (serial float32) -- for P == 1 too (glassy.py:108-109)
-        out, _ = assign(scored, afset, colptr=colptr, P=1, comm=comm)
-        parts = partition_sums_exact(scored, afset, colptr=colptr, P=P, comm=comm)
-    else:
-        out, parts = assign(scored, afset, colptr=colptr, P=P, comm=comm)
-    t2 = time.perf_counter()
-    last = {int(g): i for i, g in enumerate(group_of)}
-    for g, i in last.items():
-        af[:, g] = em.get_f(i)
+    afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
+    out = np.zeros((n, k), dtype=np.float64)
+    parts = np.zeros((n * P, k), dtype=np.float64 if not exact_parts else np.float32) if (P > 1 or exact_parts) else None
+    iters = np.zeros(n, dtype=np.int32)
+    t_em = t_score = 0.0
+    for i0 in range(0, n, batch):
+        i1 = min(n, i0 + batch)
+        t0 = time.perf_counter()
+        em = EMBatch(beagle, group_of[i0:i1], np.arange(i0, i1, dtype=np.int32))
+        iters[i0:i1] = em.run(maf_iter, maf_tole, comm=comm)
+        beagle.ctx.sync()
+        t1 = time.perf_counter()
+        for i in range(i0, i1):
+            if verbose and iters[i] > 0:
+                print("EM (MAF) converged at iteration: " + str(int(iters[i])))
+            em.clamp(i - i0, int(counts[group_of[i]]) - 1)
+        # column table: individual i is scored against its own re-fit and, for every other population,
+        # the re-fit of the most recent earlier individual of that population (glassy.py:87-105);
+        # individuals outside this batch get valid placeholders and their rows are ignored
+        cur = [afset.col_dev(j) for j in range(k)]
+        colptr = np.empty((n, k), dtype=np.uint64)
+        colptr[:] = cur
+        for i in range(i0, i1):
+            cur[group_of[i]] = em.f_dev(i - i0)
+            colptr[i] = cur
+        if exact_parts:
+            # sums over all sites in float64 (np.sum(dtype=float), glassy.py:101); partition sums literally
+            # as utils.py:147-149 accumulates them (serial float32) -- for P == 1 too (glassy.py:108-109)
+            o, _ = assign(scored, afset, colptr=colptr, P=1, comm=comm)
+            pr = partition_sums_exact(scored, afset, colptr=colptr, P=P, comm=comm)
+        else:
+            o, pr = assign(scored, afset, colptr=colptr, P=P, comm=comm)
+        out[i0:i1] = o[i0:i1]
+        if parts is not None and pr is not None:
+            parts[i0 * P:i1 * P] = pr[i0 * P:i1 * P]
+        # the last re-fit of each population in this batch becomes the current column
+        last = {int(g): i for i, g in zip(range(i0, i1), group_of[i0:i1])}
+        for g, i in last.items():
+            afset.set_column_from_em(g, em, i - i0)
+        beagle.ctx.sync()
+        em.close()
+        t_em += t1 - t0
+        t_score += time.perf_counter() - t1
+    af[:, :] = afset.to_host()           # glassy.py:89: the caller's af ends up holding each population's last re-fit
     afset.close()
-    em.close()
     if timings is not None:
-        timings.update(em_seconds=t1 - t0, score_seconds=t2 - t1, iters=iters)
+        timings.update(em_seconds=t_em, score_seconds=t_score, iters=iters, batch=batch)
     with np.errstate(over="ignore"):
         logl = out.astype(np.float32)
         logl_parts = parts.astype(np.float32) if parts is not None else logl.copy()
