@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- WGSassign hot path on MI355X: EM allele-frequency sweep + assignment log-lik sweep.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (same result)
+
+For N > 1 without a launcher, bench.py starts the N ranks itself (one child process per GPU, RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches the GPU; rank 0 prints the JSON line.
 
 A "step" is ONE EM update (emMAF_cy.pyx:10-23) of EVERY population over the whole synthetic
 Beagle matrix, fused with the convergence sums, plus -- for N > 1 -- the one collective the path
@@ -15,12 +19,16 @@ metric  = per-population SNP-updates/s (1 SNP-update = one SNP's EM update over 
 roofline= the EM sweep kernel: algorithmic bytes (8n + 8K per SNP) / HIP-event kernel time.
 cpu_baseline = the oracle's C/OpenMP restatement of the reference path (per-population column
           gather + emMAF_update per population) on a bounded SNP sample, host cores of this box.
-PyTorch is only used for the process group (rendezvous, barrier, RCCL all-reduce) when N > 1.
+The collective runs over RCCL through the library's own communicator (no PyTorch; WGSASSIGN_COMM=torch
+uses torch.distributed instead, WGSASSIGN_COMM=socket a TCP all-reduce).  A rank whose RCCL communicator
+cannot initialise exits with status 75 and the launcher starts the ranks again over the socket all-reduce.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -45,44 +53,121 @@ def parse():
     ap.add_argument("--no-assign", action="store_true", help="skip the assignment sweep leg")
     ap.add_argument("--cpu-snps", type=int, default=200_000, help="SNP sample for the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum CPU-baseline EM timing window")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)     # one rank, started by the launcher below
     return ap.parse_args()
+
+
+COMM_INIT_FAILED = 75          # wgsassign_amd.comm.COMM_INIT_FAILED (the launcher must not import the package)
+INIT_WATCHDOG_S = float(os.environ.get("WGS_BENCH_INIT_TIMEOUT", "120"))
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n_ranks, fixed_env):
+    """Start worker processes for ranks (rank, local_rank) in `fixed_env` ... and wait: returns the exit
+    status.  Only rank 0's stdout (the JSON line) is forwarded.  Children are separate processes started
+    with subprocess -- this process never initialises the GPU and never execs."""
+    argv = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--worker"] + ["--worker"]
+    for attempt, kind in enumerate(("", "socket")):
+        procs = []
+        for env_r in fixed_env:
+            env = dict(os.environ, **env_r)
+            if kind:
+                env["WGSASSIGN_COMM"] = kind
+                env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 7 * attempt)      # a fresh side-channel port
+            out = None if env["RANK"] == "0" else subprocess.DEVNULL
+            procs.append(subprocess.Popen(argv, env=env, stdout=out))
+        codes = [p.wait() for p in procs]
+        if all(c == 0 for c in codes):
+            return 0
+        if any(c == COMM_INIT_FAILED for c in codes) and not kind and os.environ.get("WGSASSIGN_COMM", "rccl") == "rccl":
+            print("bench.py: RCCL communicator did not initialise (exit 75); restarting the ranks over the socket all-reduce",
+                  file=sys.stderr, flush=True)
+            continue
+        return next(c for c in codes if c != 0)
+    return 1
+
+
+def launcher(args):
+    """Decide how this process takes part: returns None to run the benchmark in-process (one GPU), else
+    the exit status after having run worker processes."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.worker:
+        return None
+    if world_env is None or (int(world_env) == 1 and args.gpus > 1 and "RANK" not in os.environ):
+        if args.gpus <= 1:
+            return None                          # N = 1: everything in this process, exactly as before
+        port = free_port()
+        envs = [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                 "MASTER_PORT": str(port)} for r in range(args.gpus)]
+        return launch_ranks(args.gpus, envs)
+    if int(world_env) == 1:
+        return None
+    # one rank of a torchrun job: supervise ONE worker so that a failed RCCL bootstrap can be retried
+    keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+    return launch_ranks(1, [{k: os.environ[k] for k in keys if k in os.environ}])
 
 
 def main():
     args = parse()
+    rc = launcher(args)
+    if rc is not None:
+        sys.exit(rc)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+
+    use_dist = world > 1 or os.environ.get("WGS_FORCE_DIST") == "1"   # WGS_FORCE_DIST: rehearse the collective path on 1 GPU
+    kind = os.environ.get("WGSASSIGN_COMM", "torch" if os.environ.get("WGSASSIGN_BACKEND") == "gloo" else "rccl")
+    device_index = int(os.environ.get("WGSASSIGN_DEVICE", local_rank))
+    dist = torch = None
+    # a rank that cannot build its communicator in time leaves with status 75: the launcher retries over TCP
+    watchdog = threading.Timer(INIT_WATCHDOG_S, lambda: os._exit(COMM_INIT_FAILED))
+    watchdog.daemon = True
+    if use_dist:
+        watchdog.start()
+    if use_dist and kind == "torch":
+        # torch ships its own HIP runtime: it must initialise BEFORE libwgsassign_hip.so touches the
+        # device (the other order leaves torch with "No HIP GPUs are available")
+        import torch
+        import torch.distributed as dist
+        backend = os.environ.get("WGSASSIGN_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(device_index)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     from wgsassign_amd import comm as wcomm
     from wgsassign_amd import device
     from wgsassign_amd._lib import MODE_EXACT, MODE_FAST
     mode = MODE_EXACT if args.mode == "exact" else MODE_FAST
-
-    dist = torch = None
-    use_dist = world > 1 or os.environ.get("WGS_FORCE_DIST") == "1"   # WGS_FORCE_DIST: rehearse the RCCL path on 1 GPU
-    native = os.environ.get("WGSASSIGN_COMM") == "rccl"              # the library's own RCCL communicator, no torch
-    if use_dist and not native:
-        # torch ships its own HIP runtime: it must initialise BEFORE libwgsassign_hip.so touches the
-        # device (the other order leaves torch with "No HIP GPUs are available")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = device.Context(local_rank)
-    if use_dist and native:
-        comm = wcomm.RcclComm(ctx, rank, world, os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                              int(os.environ.get("MASTER_PORT", "29400")))
-        comm.force_device = True
+    ctx = device.Context(device_index)
+    comm_note = None
+    if use_dist and kind == "torch":
+        comm = wcomm.TorchComm(device=torch.device("cuda", device_index) if dist.get_backend() == "nccl" else None)
+        comm_note = "torch.distributed/" + dist.get_backend()
     elif use_dist:
-        comm = wcomm.TorchComm(device=torch.device("cuda", local_rank))
-        comm.force_device = True
+        addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400"))
+        try:
+            comm = wcomm.SocketComm(rank, world, addr, port) if kind == "socket" else wcomm.RcclComm(ctx, rank, world, addr, port)
+        except Exception as e:
+            print("bench.py rank %d: communicator failed: %s" % (rank, e), file=sys.stderr, flush=True)
+            os._exit(COMM_INIT_FAILED)
+        if kind == "rccl" and not comm.native:
+            comm_note = "socket all-reduce (RCCL init failed: %s)" % comm.native_error
+        else:
+            comm_note = "rccl (library communicator, no torch)" if kind == "rccl" else "socket all-reduce"
     else:
         comm = wcomm.LocalComm()
+    comm.force_device = True
+    watchdog.cancel()
 
     m_total, n, K = args.m, args.n, args.K
     lo, hi = wcomm.shard_range(m_total, rank, world)
@@ -100,23 +185,16 @@ def main():
 
     def barrier():
         ctx.sync()
-        if use_dist and native:
+        if use_dist:
             comm.barrier()
-        elif use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
         ctx.sync()
 
     def max_over_ranks(x):
         if not use_dist:
             return x
-        if native:      # max via sums: one slot per rank
-            slots = np.zeros(world)
-            slots[rank] = x
-            return float(np.max(comm.allreduce_sum(slots)))
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        slots = np.zeros(world)          # max via sums: one slot per rank
+        slots[rank] = x
+        return float(np.max(comm.allreduce_sum(slots)))
 
     def step():
         # sweep kernel -> (N > 1: RCCL all-reduce of the K sums, enqueued behind it) -> one readback:
@@ -195,17 +273,16 @@ def main():
                 "dtype": "f64" if args.mode == "exact" else "f32", "data": "synthetic",
                 "config": {"workload": "synthetic Beagle %d SNPs x %d ind, K=%d, --get_reference_af EM sweep (+ --get_pop_like sweep), SNP-sharded over %d GPU(s)"
                                        % (m_total, n, K, world), "mode": args.mode, "snps_per_gpu": m,
-                           "gl_bytes_per_gpu": beagle.nbytes()},
+                           "gl_bytes_per_gpu": beagle.nbytes(), "comm": comm_note},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
     em.close()
     beagle.close()
-    if use_dist and native:
+    if use_dist:
         comm.barrier()
         comm.close()
-    elif use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.destroy_process_group()
 
 
 def pmc_traffic(m, n, K, mode):

@@ -127,6 +127,9 @@ int wgs_em_clamp(wgs_em *em, int32_t fit, float lo, float hi);
 /* Copy fit j's current frequencies (m floats) to the host / get their device address. */
 int wgs_em_get_f(wgs_em *em, int32_t fit, float *f_host);
 int wgs_em_set_f(wgs_em *em, int32_t fit, const float *f_host);
+/* Rows [row0, row0+nrows) of fit j's current (previous == 0) or previous-iteration (previous != 0)
+ * frequencies: the two vectors emMAF.py:22 hands to rmse1d. */
+int wgs_em_get_f_range(wgs_em *em, int32_t fit, int previous, int64_t row0, int64_t nrows, float *f_host);
 const float *wgs_em_f_dev(wgs_em *em, int32_t fit);
 
 /* Frequency vectors kept on the device for the assignment kernels: K vectors of m floats
@@ -143,7 +146,7 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
 /* glassy.assignLL(L, af, t) -- glassy.py:18-44 -- for ALL n x K pairs in one sweep over the
  * slabs: out[i*K + k] = sum over this shard's SNPs of the float32 per-site log-likelihood
  * (glassy_cy.pyx:18-21), accumulated in float64 (the reference sums with np.sum(dtype=float),
- * glassy.py:38).  colptr (may be NULL) overrides the frequency vector per (individual, k):
+ * glassy.py:38) in a fixed order (run-to-run reproducible).  colptr (may be NULL) overrides the frequency vector per (individual, k):
  * colptr[i*K + k] is a device pointer to m floats -- this is how the leave-one-out scoring of
  * glassy.py:87-105 (per-individual columns, sticky overwrite) is expressed.  With P > 1 also
  * fills parts[(i*P + p)*K + k], the sum over SNPs whose GLOBAL index is p modulo P
@@ -153,12 +156,37 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
 
 /* utils.partition_loglikes(per_site_ll, P) -- utils.py:129-151 -- for every (individual, population)
  * pair, BIT-EXACT: the reference accumulates each partition serially in float32 in site order
- * (np.add.at); one GPU lane per (individual, population, partition) chain does the same.
- * carry_in (float32 [n*P*K], NULL for the first SNP shard) is the running value after the
+ * (np.add.at).  carry_in (float32 [n*P*K], NULL for the first SNP shard) is the running value after the
  * preceding shards, parts_out (float32 [n*P*K], index (i*P + p)*K + k) the value after this one.
- * Always exact-mode arithmetic.  Cost ~ (m / P) x one site's latency (parallel over chains only). */
+ * Always exact-mode arithmetic.  One call = wgs_score_create + _sums + _chains_prepare + _chains_walk
+ * below (block-parallel); more than ~64 partitions fall back to one literal chain per GPU lane. */
 int wgs_assign_parts_exact(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P,
                            const float *carry_in, float *parts_out);
+
+/* The scoring step of glassy.py:31-42 / 92-109 as an object, for callers that need the pieces separately
+ * (leave-one-out in batches, SNP shards whose chains are joined by float32 carries):
+ *   wgs_score_create          b, a, colptr as for wgs_assign; only individuals [row_lo, row_hi) (file order)
+ *                             are scored -- a leave-one-out batch scores its own individuals only;
+ *   wgs_score_sums            the n x K float64 sums, ONE launch over all population slabs; every
+ *                             (individual, population, block of 4096 SNPs) sum has one writer and the blocks
+ *                             are added in order: reproducible bit for bit (host `out`, n*K, overwritten);
+ *   wgs_score_chains_prepare  block functions of the exact float32 partition chains on the ulp grid predicted
+ *                             from those sums; `start` (host n*K float64 or NULL) = the sums over the
+ *                             preceding SNP shards.  All shards can prepare in parallel;
+ *   wgs_score_chains_walk     walks this shard's chains from carry_in (host float32 [n*P*K] or NULL) -- the
+ *                             only step that follows the previous shard -- into parts_out. */
+typedef struct wgs_score wgs_score;
+int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t row_lo, int32_t row_hi,
+                     wgs_score **out);
+void wgs_score_destroy(wgs_score *sc);
+int wgs_score_sums(wgs_score *sc, int mode, double *out);
+int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start);
+int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out);
+/* Test hooks: (chain, block) pairs of the last walk that took the literal serial loop / walked in all;
+ * the literal one-lane-per-chain kernel behind wgs_assign_parts_exact, whatever P. */
+int wgs_score_last_serial_blocks(wgs_score *sc, int64_t *total_blocks);
+int wgs_debug_parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P,
+                                  const float *carry_in, float *parts_out);
 
 /* ------------------------------------------------------------------ RCCL communicator (SNP shards)
  * The one collective of the sharded path -- a sum all-reduce of a few float64 over xGMI -- without
@@ -231,8 +259,8 @@ int wgs_debug_div_mismatch(wgs_ctx *ctx, uint64_t seed, uint64_t per_thread, uin
 int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first);
 int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, int use_libm);
 
-/* Summed kernel time (HIP events on the context's stream) of the calling thread's last wgs_assign. */
-int wgs_assign_last_ms(float *ms);
+/* Kernel time (HIP events on the context's stream) of the context's last wgs_assign / wgs_score_* call. */
+int wgs_assign_last_ms(wgs_ctx *ctx, float *ms);
 
 #ifdef __cplusplus
 }

@@ -16,7 +16,7 @@ class _Shape:
 
 
 class OracleEMBatch:
-    GUARD = 0.25
+    GUARD = 0.0
 
     def __init__(self, oracle, L, groups_idx, guard=None):
         """L: this shard's rows (m, 2n); groups_idx: list of individual-index arrays, one per fit."""

@@ -1,0 +1,131 @@
+"""CPU-only multi-process tests of the TCP-star communicator (wgsassign_amd/comm.py): the bootstrap
+and gather channel of RcclComm and the all-reduce of its SocketComm fallback.  Three ranks issue
+collectives back to back (the pattern that raced when every call accepted fresh connections), and the
+SNP-sharded EM driver loop runs over it with the oracle standing in for the device."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from test_host_logic_cpu import free_port
+
+_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from wgsassign_amd.comm import SocketComm, shard_range
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+comm = SocketComm(rank, world, "127.0.0.1", {port})
+ok = True
+rng = np.random.default_rng(5)
+base = rng.standard_normal((world, 7, 3))
+for rep in range(200):                                   # back-to-back collectives of different kinds
+    tot = comm.allreduce_sum(base[rank] * (rep + 1))
+    ok &= tot.tobytes() == sum(base[r] * (rep + 1) for r in range(world)).tobytes()     # rank-order sum: same bits everywhere
+    objs = comm.allgather_object([["site%d" % (rank * 10 + rep)], rep, rank])
+    ok &= objs == [[["site%d" % (r * 10 + rep)], rep, r] for r in range(world)]
+    rows = comm.gather_rows(np.full((rank + 1, 4), rank + rep, dtype=np.float32))
+    if rank == 0:
+        ok &= rows.shape == (world * (world + 1) // 2, 4) and rows.dtype == np.float32
+        ok &= [int(x) for x in rows[:, 0]] == [r + rep for r in range(world) for _ in range(r + 1)]
+    else:
+        ok &= rows is None
+comm.barrier()
+# a big array through gather_rows (raw buffers, no pickling)
+big = np.arange((rank + 1) * 300_000, dtype=np.float32).reshape(-1, 5)
+rows = comm.gather_rows(big)
+if rank == 0:
+    ok &= rows.shape[0] == sum((r + 1) * 60_000 for r in range(world))
+
+# the collective leave-one-out batch size: ranks see different free memory -> all use the minimum
+from wgsassign_amd import glassy
+class Ctx:
+    def mem_info(self):
+        return (int(1e9) * (3 - rank), int(4e9))
+class B:
+    ctx, m = Ctx(), 1_000_000
+sizes = comm.allgather_object(glassy.loo_batch_size(B(), 5000, comm))
+ok &= len(set(sizes)) == 1 and sizes[0] == int(0.8 * 1e9 * (3 - (world - 1))) // (int(1_000_000 * 8.2) + 4096)
+os.environ["WGSASSIGN_LOO_BATCH"] = str(40 + rank)       # even a forced size is agreed on
+sizes = comm.allgather_object(glassy.loo_batch_size(B(), 5000, comm))
+ok &= sizes == [40] * world
+del os.environ["WGSASSIGN_LOO_BATCH"]
+
+# the SNP-sharded EM driver loop over this communicator (oracle stand-in for the device)
+from oracle import oracle as orc
+from cpu_standin import OracleEMBatch
+from wgsassign_amd.device import run_em
+g = np.load(os.path.join({root!r}, "tests", "golden", "amre_fit.npz"))
+L, IDs = g["L"], g["IDs"]
+lo, hi = shard_range(L.shape[0], rank, world)
+pops = np.unique(IDs[:, 1])
+groups = [np.flatnonzero(IDs[:, 1] == p) for p in pops]
+em = OracleEMBatch(orc, np.ascontiguousarray(L[lo:hi]), groups, guard=float(sys.argv[3]))
+iters = run_em(em, 200, 1e-4, comm=comm, m_total=L.shape[0])
+ok &= list(iters) == list(g["iters"])
+for k in range(len(pops)):
+    ok &= em.f[k].tobytes() == g["f_raw"][k][lo:hi].tobytes()
+print("RANK", rank, "OK" if ok else "FAIL", flush=True)
+comm.barrier(); comm.close()
+sys.exit(0 if ok else 1)
+'''
+
+
+@pytest.mark.parametrize("guard", [0.0, 1e9])
+def test_three_ranks_over_the_tcp_star(tmp_path, guard):
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT, port=port))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", str(guard)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(3)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+        assert "RANK %d OK" % r in o
+
+
+def test_side_channel_rejects_strangers(tmp_path):
+    """A connection that does not present magic | rank | world | token is dropped; the real peer still joins."""
+    import socket
+    import threading
+    import time
+    from wgsassign_amd.comm import SideChannel
+    port = free_port()
+    res = {}
+
+    def hub():
+        res["hub"] = SideChannel(0, 2, "127.0.0.1", port, token="secret", timeout=30)
+
+    t = threading.Thread(target=hub)
+    t.start()
+    time.sleep(0.3)
+    with socket.create_connection(("127.0.0.1", port)) as s:      # a stranger: wrong magic
+        s.sendall(b"GET / HTTP/1.0\r\n\r\n" + b"x" * 64)
+    with pytest.raises(RuntimeError):                              # right magic, wrong token
+        SideChannel(1, 2, "127.0.0.1", port, token="guess", timeout=2)
+    peer = SideChannel(1, 2, "127.0.0.1", port, token="secret", timeout=30)
+    t.join(30)
+    assert not t.is_alive()
+    got = {}
+    th = threading.Thread(target=lambda: got.setdefault("b", peer.bcast(None)))
+    th.start()
+    res["hub"].bcast(b"hello")
+    th.join(10)
+    assert got["b"] == b"hello"
+    peer.close()
+    res["hub"].close()
+
+
+def test_unpack_array_refuses_object_dtype():
+    from wgsassign_amd import comm
+    blob = comm._pack_array(np.arange(6, dtype=np.float32).reshape(2, 3))
+    assert comm._unpack_array(blob).tolist() == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]]
+    import json
+    import struct
+    head = json.dumps({"dtype": "|O", "shape": [1]}).encode()
+    with pytest.raises(RuntimeError):
+        comm._unpack_array(struct.pack("<i", len(head)) + head + b"\0" * 8)

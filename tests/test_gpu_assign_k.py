@@ -1,0 +1,104 @@
+"""Assignment / leave-one-out scoring kernels at the population counts the BASELINE configs launch.
+
+`launch_assign` (csrc/assign_kernels.hip) batches the K populations into register batches of KB:
+K=6 -> KB=6, K=7 -> 7, K=8 -> 8 (config 4), K=10 -> two passes of 5 (config 3), K=13 -> two passes
+of 7 with a padded slot, K=20 -> three passes of 7 with a padded slot (config 5); NP = 2 individual
+pairs per wave for KB <= 6, 1 above.  Every one of them is held to the oracle here, in both
+modes: shared frequency columns (glassy.py:31-42, --get_pop_like) and per-individual columns
+(glassy.py:92-109, --loo), with odd population sizes and SNP counts that are not multiples of 64.
+"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+import synth
+from test_gpu_parity import close, nearly_all_identical, quiet, same, same_nan, RTOL_PARTS
+
+pytestmark = pytest.mark.gpu
+
+KS = [6, 7, 8, 10, 13, 20]
+
+
+def odd_populations(K, rng):
+    """Population sizes 1..7 with both parities, individuals interleaved in file order."""
+    sizes = [int(x) for x in rng.integers(2, 8, size=K)]
+    sizes[0], sizes[-1] = 3, 5
+    labels = np.repeat(np.arange(K), sizes)
+    rng.shuffle(labels)
+    IDs = np.array([["Ind%d" % i, "pop%02d" % labels[i]] for i in range(len(labels))], dtype=str)
+    return IDs
+
+
+@pytest.fixture(scope="module")
+def wg():
+    from wgsassign_amd import device, emMAF, glassy
+    device.get_context()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.device, ns.emMAF, ns.glassy = device, emMAF, glassy
+    return ns
+
+
+@pytest.mark.parametrize("K", KS)
+def test_assign_shared_columns_against_oracle(wg, oracle, K):
+    rng = np.random.default_rng(500 + K)
+    IDs = odd_populations(K, rng)
+    n, m = len(IDs), 1000 + 37 * K + 1
+    L, _ = synth.make_beagle(m, n, 1, seed=4000 + K)
+    pops_o, af_o, _, iters_o = oracle.fit_reference_af(L, IDs, t=4)
+    (pops, af, iters), _ = quiet(wg.emMAF.emMAF_populations, L, IDs, 200, 1e-4)
+    assert list(iters) == list(iters_o) and same(af, af_o)
+    ll_o = oracle.assignLL(L, af_o.copy(), 4)
+    # (a) --get_pop_like shape: all individuals in one slab
+    ll, text = quiet(wg.glassy.assignLL, L, af.copy(), 1)
+    assert text.strip() == "%d individuals to assign to %d populations" % (n, K)
+    assert ll.dtype == np.float32 and nearly_all_identical(ll, ll_o), (K, "one slab")
+    # (b) the same sums from K population slabs of odd sizes (the layout --get_reference_af leaves on the device)
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    b = wg.device.DeviceBeagle.from_host(L, group_of, K)
+    afs = wg.device.AFSet.from_host(af)
+    out, _ = wg.device.assign(b, afs)
+    assert nearly_all_identical(out.astype(np.float32), ll_o), (K, "population slabs")
+    # run-to-run reproducible, bit for bit, in float64
+    out2, _ = wg.device.assign(b, afs)
+    assert same(out, out2)
+    afs.close()
+    b.close()
+
+
+@pytest.mark.parametrize("P", [1, 3])
+@pytest.mark.parametrize("K", KS)
+def test_loo_per_individual_columns_against_oracle(wg, oracle, K, P):
+    rng = np.random.default_rng(900 + K)
+    IDs = odd_populations(K, rng)
+    n, m = len(IDs), 600 + 29 * K + 3
+    L, _ = synth.make_beagle(m, n, 1, seed=5000 + K)
+    _, af_o, _, _ = oracle.fit_reference_af(L, IDs, t=4)
+    af1, af2 = af_o.copy(), af_o.copy()
+    with np.errstate(all="ignore"):
+        loo_o, parts_o = oracle.loo(L, af1, IDs, 4, 200, 1e-4, None, P)
+        (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 200, 1e-4, None, P)
+    assert nearly_all_identical(loo, loo_o), (K, P)
+    assert same_nan(parts, parts_o), (K, P)          # serial float32 partition sums: bit-identical
+    assert same_nan(af2, af1), (K, P)                # the sticky column overwrite
+
+
+@pytest.mark.parametrize("K", [8, 10, 13])
+def test_fast_partition_kernel_large_K(wg, oracle, monkeypatch, K):
+    """WGSASSIGN_PARTS=fast routes P > 1 through assign_kernel<KB> (lane <-> individual pair): float64
+    partition sums, within the reference's own float32 accumulation noise."""
+    monkeypatch.setenv("WGSASSIGN_PARTS", "fast")
+    rng = np.random.default_rng(1300 + K)
+    IDs = odd_populations(K, rng)
+    n, m = len(IDs), 777
+    L, _ = synth.make_beagle(m, n, 1, seed=6000 + K)
+    _, af_o, _, _ = oracle.fit_reference_af(L, IDs, t=4)
+    af1, af2 = af_o.copy(), af_o.copy()
+    with np.errstate(all="ignore"):
+        loo_o, parts_o = oracle.loo(L, af1, IDs, 4, 200, 1e-4, None, 3)
+        (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 200, 1e-4, None, 3)
+    assert close(loo, loo_o) and close(parts, parts_o, RTOL_PARTS) and same_nan(af2, af1)

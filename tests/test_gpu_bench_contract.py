@@ -4,6 +4,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -31,3 +32,34 @@ def test_bench_json_line():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert d["value"] > cb["value"]
     assert abs(d["value"] - 5 * 200000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.parametrize("comm_env", [{"WGSASSIGN_COMM": "socket"}, {"WGSASSIGN_BACKEND": "gloo"}])
+def test_bench_self_launches_two_ranks(comm_env):
+    """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (both on the one
+    GPU of the test box: WGSASSIGN_DEVICE=0; the all-reduce over the TCP star, or over torch's gloo), rank 0
+    prints the one JSON line; the sharded sums of squares equal the single-process ones."""
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--snps", "200000", "--inds", "100", "--pops", "5",
+            "--steps", "3", "--warmup", "1", "--no-cpu", "--no-assign"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = subprocess.run(base, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.strip()][0])
+    two = subprocess.run(base + ["--gpus", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(env, WGSASSIGN_DEVICE="0", **comm_env))
+    assert two.returncode == 0, two.stderr[-3000:]
+    lines = [l for l in two.stdout.splitlines() if l.strip() and "[Gloo]" not in l]
+    assert len(lines) == 1, two.stdout[-2000:]
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["steps"] == 3 and d2["config"]["snps_per_gpu"] == 100000 and d2["scaling"] == "strong"
+    assert abs(d2["value"] - 5 * 200000 * 3 / (d2["ms_per_step"] * 3e-3)) / d2["value"] < 1e-6
+    a, b = np.array(d1["extra"]["ssq_last"]), np.array(d2["extra"]["ssq_last"])
+    assert np.all(np.abs(a - b) <= 1e-12 * np.abs(a)), (a, b)      # same sums, shard partials added in rank order
+
+
+def test_bench_failure_of_a_rank_propagates(tmp_path):
+    """A rank that dies takes the launcher's exit status with it (here: an impossible shape)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--snps", "1", "--inds", "10", "--pops", "2",
+                        "--steps", "1", "--warmup", "0", "--no-cpu", "--no-assign"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WGSASSIGN_DEVICE="0", WGSASSIGN_COMM="socket"))
+    assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,0 +1,242 @@
+"""BASELINE.json configurations at FULL size on the device, through size-independent properties.
+
+The oracle cannot run 10M x 1000 in a test, but every SNP is independent (emMAF_cy.pyx:16-23,
+glassy_cy.pyx:17-21), so
+  * a row window of the device's frequencies equals the oracle iterated on those rows alone;
+  * the n x K sums are additive over SNP shards, and a row window re-scored on the device from the
+    downloaded rows equals the oracle's sums over that window;
+  * the exact float32 chains (convergence metric, partition sums) over the whole shard equal the chains
+    over two parts joined by the float32 carry;
+  * two independent kernels (the float64 sweep and the serial-float32 partition chains) must agree on
+    the same totals to within float32 accumulation noise.
+"""
+import numpy as np
+import pytest
+
+import synth
+from test_gpu_parity import close, nearly_all_identical, quiet, same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wg():
+    from wgsassign_amd import device, emMAF, glassy
+    device.get_context()
+
+    class NS:
+        pass
+    ns = NS()
+    ns.device, ns.emMAF, ns.glassy = device, emMAF, glassy
+    return ns
+
+
+def blocks_of(n, K):
+    return np.minimum(np.arange(n) // (n // K), K - 1).astype(np.int32)
+
+
+def fitted_columns(dev, em, K, per):
+    """Clamp the K fits like WGSassign.py:236-240 and return them as an AFSet."""
+    afs = dev.AFSet(em.b.m, K, ctx=em.b.ctx)
+    for k in range(K):
+        em.clamp(k, per)
+        afs.set_column_from_em(k, em, k)
+    em.b.ctx.sync()
+    return afs
+
+
+def window_assign_check(dev, oracle, b, afs, r0, nr, group_of, K, threads=8):
+    """Rows [r0, r0+nr) downloaded from the device, re-scored (a) by the oracle, (b) by a second device
+    sweep over a DeviceBeagle built from those rows: (a) == (b)."""
+    rows = b.download_rows(r0, nr)
+    A = np.ascontiguousarray(afs.to_host()[r0:r0 + nr])
+    ll_o = oracle.assignLL(rows, A.copy(), threads)
+    bw = dev.DeviceBeagle.from_host(rows, group_of, K, site0=b.site0 + r0, ctx=b.ctx)
+    aw = dev.AFSet.from_host(A, ctx=b.ctx)
+    out_w, _ = dev.assign(bw, aw)
+    aw.close()
+    bw.close()
+    assert nearly_all_identical(out_w.astype(np.float32), ll_o)
+    return out_w
+
+
+def test_config3_10M_x_1000_K10(wg, oracle):
+    """configs[2]: 10M SNPs x 1000 individuals, K=10 (80 GB in HBM), --get_reference_af + --get_pop_like.
+    (a) three EM updates of a row window equal the oracle on those rows; frequencies in [0, 1], sums of
+    squares decrease; (b) the assignment sweep (KB=5, two passes): a row window re-scored on the device
+    equals the oracle; the full-size sums equal the sums over two SNP shards of the same matrix;
+    (c) the exact serial chain over all 10M SNPs equals the chain over the two shards joined by the carry."""
+    dev = wg.device
+    m, n, K = 10_000_000, 1000, 10
+    group_of = blocks_of(n, K)
+    b = dev.DeviceBeagle(m, n, group_of, K)
+    b.synth(synth.SEED, 2.0)
+    assert b.nbytes() == 80_000_000_000
+    em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+    ssq = [em.step() for _ in range(3)]
+    assert np.all(ssq[1] < ssq[0]) and np.all(ssq[2] < ssq[1])
+    r0, nr = 7_654_321, 1024
+    rows = b.download_rows(r0, nr)
+    for k in (0, 4, 9):
+        f_dev = em.get_f(k)
+        assert f_dev.min() >= 0 and f_dev.max() <= 1
+        Lp = oracle.gather(rows, np.flatnonzero(group_of == k), 8)
+        f = np.full(nr, 0.25, dtype=np.float32)
+        for _ in range(3):
+            oracle.emMAF_update(Lp, f, 8)
+        assert same(f, f_dev[r0:r0 + nr])
+    whole = em.rmse_chain(3, 0.0)
+    assert whole > 0 and em.rmse_chain(3, 0.0) == whole
+    f_full = [em.get_f(k) for k in range(K)]           # unclamped, for the shard comparison below
+    afs = fitted_columns(dev, em, K, n // K)
+    out_full, _ = dev.assign(b, afs)
+    assert np.all(np.isfinite(out_full)) and np.all(out_full < 0)
+    assert np.array_equal(np.argmax(out_full, axis=1), group_of)       # every individual assigns to its own population
+    window_assign_check(dev, oracle, b, afs, r0, 512, group_of, K)
+    A_full = afs.to_host()
+    afs.close()
+    em.close()
+    b.close()
+    # the same matrix as two SNP shards (the generator is a pure function of the global SNP index)
+    half = 4_999_968 + 17                               # not a multiple of 64
+    out_sum = np.zeros_like(out_full)
+    carry = np.float32(0.0)
+    for lo, hi in ((0, half), (half, m)):
+        bs = dev.DeviceBeagle(hi - lo, n, group_of, K, site0=lo)
+        bs.synth(synth.SEED, 2.0)
+        ems = dev.EMBatch(bs, np.arange(K, dtype=np.int32))
+        for _ in range(3):
+            ems.step()
+        for k in (0, 3, 9):
+            assert same(ems.get_f(k), f_full[k][lo:hi])
+        carry = ems.rmse_chain(3, carry)
+        a_s = dev.AFSet.from_host(np.ascontiguousarray(A_full[lo:hi]))
+        o, _ = dev.assign(bs, a_s)
+        out_sum += o
+        a_s.close()
+        ems.close()
+        bs.close()
+    assert carry == whole                                # float32 carry handed from shard to shard
+    assert np.max(np.abs(out_sum - out_full) / np.abs(out_full)) < 1e-12
+    assert nearly_all_identical(out_sum.astype(np.float32), out_full.astype(np.float32), frac=0.999)
+
+
+def test_config4_loo_2M_x_500_K8(wg, oracle):
+    """configs[3]: 2M SNPs x 500 individuals, K=8, --loo --partition_sites 3 at full size through
+    glassy.loo_device: 500 leave-one-out re-fits, scoring with per-individual columns (KB=8), exact
+    partition chains."""
+    dev = wg.device
+    m, n, K, P = 2_000_000, 500, 8, 3
+    group_of = blocks_of(n, K)
+    counts = np.bincount(group_of, minlength=K)
+    IDs = np.array([["Ind%d" % i, "pop%02d" % group_of[i]] for i in range(n)], dtype=str)
+    b = dev.DeviceBeagle(m, n, group_of, K)
+    b.synth(synth.SEED + 4, 2.0)
+    (pops, af, iters_full), _ = quiet(wg.emMAF.emMAF_populations, None, IDs, 200, 1e-4, beagle=b)
+    assert np.all(iters_full > 0)
+    af0 = af.copy()
+    r0, nr = 1_234_567, 512
+    cols = np.empty((n, nr), dtype=np.float32)
+
+    def grab(em, i0, i1):
+        for i in range(i0, i1):
+            cols[i] = em.get_f_range(i - i0, r0, nr)
+
+    timings = {}
+    (ll, parts), _ = quiet(wg.glassy.loo_device, b, b, af, group_of, 200, 1e-4, P, timings=timings, inspect=grab)
+    iters = timings["iters"]
+    assert np.all(iters > 0) and iters.min() >= 8 and iters.max() <= 40
+    assert np.array_equal(np.argmax(ll, axis=1), group_of)               # leave-one-out accuracy 1.0 on this data
+    # two kernels, one quantity: serial-float32 partition chains vs the float64 sweep.  The float32 chain is
+    # biased (the same addend -- e.g. every depth-0 site -- rounds the same way each time it meets the running
+    # sum's ulp grid; measured 2.4e-4 here), so this bounds gross errors only; (b) below holds it to the bit
+    tot = parts.reshape(n, P, K).astype(np.float64).sum(axis=1)
+    assert np.max(np.abs(tot - ll) / np.abs(ll)) < 1e-3
+    # the caller's af holds each population's LAST re-fit (glassy.py:89)
+    last = {int(g): i for i, g in enumerate(group_of)}
+    for g, i in last.items():
+        assert same(np.ascontiguousarray(af[r0:r0 + nr, g]), cols[i])
+    # (a) every re-fit on the window == the oracle iterated iters[i] times on the explicitly reduced matrix
+    rows = b.download_rows(r0, nr)
+    for i in range(n):
+        members = np.flatnonzero(group_of == group_of[i])
+        Lp = oracle.gather(rows, members[members != i], 8)
+        f = np.full(nr, 0.25, dtype=np.float32)
+        for _ in range(int(iters[i])):
+            oracle.emMAF_update(Lp, f, 8)
+        assert same(oracle.clamp(f, int(counts[group_of[i]]) - 1), cols[i]), i
+    # (b) scoring with those columns on the window: oracle vs a second device run built from the rows
+    ll_o, parts_o = oracle.loo_score(rows, np.ascontiguousarray(af0[r0:r0 + nr]), cols, group_of, 8, P, site0=r0)
+    bw = dev.DeviceBeagle.from_host(rows, group_of, K, site0=r0)
+    emw = dev.EMBatch(bw, group_of, np.arange(n, dtype=np.int32))
+    for i in range(n):
+        emw.set_f(i, cols[i])
+    afw = dev.AFSet.from_host(np.ascontiguousarray(af0[r0:r0 + nr]))
+    o, pr = wg.glassy.score_loo_batch(bw, afw, emw, group_of, 0, n, P)
+    assert nearly_all_identical(o.astype(np.float32), ll_o) and same(pr, parts_o)
+    for x in (afw, emw, bw):
+        x.close()
+    # (c) the stopping iteration at full size: rmse1d of the oracle on the device's own vectors says
+    # "not yet" one update earlier and "converged" at the reported iteration
+    picks = np.array([0, 61, 62, 250, 499], dtype=np.int32)
+    for i in picks:
+        em = dev.EMBatch(b, group_of[[i]], np.array([i], dtype=np.int32))
+        for _ in range(int(iters[i]) - 1):
+            em.step()
+        assert not oracle.rmse1d(em.get_f(0), em.get_f_range(0, 0, m, previous=True)) < 1e-4
+        em.step()
+        assert oracle.rmse1d(em.get_f(0), em.get_f_range(0, 0, m, previous=True)) < 1e-4
+        em.clamp(0, int(counts[group_of[i]]) - 1)
+        assert same(em.get_f_range(0, r0, nr), cols[i])
+        em.close()
+    b.close()
+
+
+def test_config5_single_gpu_shard_6M25_x_2000_K20(wg, oracle):
+    """configs[4]: one GPU's shard of 50M x 2000, K=20 on 8 GPUs: 6.25M SNPs x 2000 individuals
+    (100 GB), site0 != 0.  EM sweep window vs the oracle, assignment sweep (KB=7, three passes, padded
+    slot) window vs the oracle, additivity over two sub-shards, partition labels from GLOBAL indices."""
+    dev = wg.device
+    m, n, K = 6_250_000, 2000, 20
+    site0 = 5 * m + 1                                   # rank 5's range, deliberately not a multiple of 64 or of P
+    group_of = blocks_of(n, K)
+    b = dev.DeviceBeagle(m, n, group_of, K, site0=site0)
+    b.synth(synth.SEED, 2.0)
+    assert b.nbytes() == 97657 * 64 * 2000 * 8      # whole tiles of 64 SNPs: 100.0008 GB
+    em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+    ssq = [em.step() for _ in range(2)]
+    assert np.all(ssq[1] < ssq[0])
+    r0, nr = 3_210_987, 256
+    rows = b.download_rows(r0, nr)
+    for k in (0, 11, 19):
+        Lp = oracle.gather(rows, np.flatnonzero(group_of == k), 8)
+        f = np.full(nr, 0.25, dtype=np.float32)
+        for _ in range(2):
+            oracle.emMAF_update(Lp, f, 8)
+        assert same(f, em.get_f_range(k, r0, nr))
+    afs = fitted_columns(dev, em, K, n // K)
+    em.close()
+    out_full, _ = dev.assign(b, afs)
+    assert np.all(np.isfinite(out_full)) and np.array_equal(np.argmax(out_full, axis=1), group_of)
+    window_assign_check(dev, oracle, b, afs, r0, nr, group_of, K)
+    # partition sums with global labels: float64 "fast" partition kernel (lane <-> pair) against the sweep,
+    # and against the oracle on a window whose labels start at (site0 + r0) % P
+    P = 3
+    out_p, parts_p = dev.assign(b, afs, P=P)
+    assert np.max(np.abs(out_p - out_full) / np.abs(out_full)) < 1e-12
+    A = np.ascontiguousarray(afs.to_host()[r0:r0 + nr])
+    bw = dev.DeviceBeagle.from_host(rows, group_of, K, site0=site0 + r0)
+    aw = dev.AFSet.from_host(A)
+    _, parts_w = dev.assign(bw, aw, P=P)
+    labels = (site0 + r0 + np.arange(nr)) % P
+    for i in (0, 777, 1999):
+        for k in (0, 6, 7, 13, 19):
+            vec = np.zeros(nr, dtype=np.float32)
+            oracle.loglike(rows, A, vec, 8, i, k)
+            want = np.array([np.sum(vec[labels == p], dtype=float) for p in range(P)])
+            got = parts_w[i * P:(i + 1) * P, k]
+            assert np.max(np.abs(got - want) / np.abs(want)) < 1e-12, (i, k)
+    aw.close()
+    bw.close()
+    afs.close()
+    b.close()

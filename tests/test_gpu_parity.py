@@ -325,36 +325,6 @@ def test_full_size_properties_1M_x_200(wg, oracle):
     em.close(); em2.close(); b.close(); b2.close()
 
 
-def test_full_size_properties_10M_x_1000(wg, oracle):
-    """configs[2]: 10M SNPs x 1000 individuals, K=10 (80 GB in HBM), generated on the device.
-    (a) three EM updates + the assignment sums of a row sample equal the oracle on those rows;
-    (b) frequencies in [0, 1], sums of squares decrease; (c) the exact serial chain over the whole
-    shard equals the chain over two halves joined by the carry."""
-    m, n, K = 10_000_000, 1000, 10
-    group_of = (np.arange(n) // (n // K)).astype(np.int32)
-    b = wg.device.DeviceBeagle(m, n, group_of, K)
-    b.synth(synth.SEED, 2.0)
-    assert b.nbytes() == 80_000_000_000
-    em = wg.device.EMBatch(b, np.arange(K, dtype=np.int32))
-    ssq = [em.step() for _ in range(3)]
-    assert np.all(ssq[1] < ssq[0]) and np.all(ssq[2] < ssq[1])
-    r0, nr = 7_654_321, 2048
-    rows = b.download_rows(r0, nr)
-    for k in (0, 4, 9):
-        f_dev = em.get_f(k)
-        assert f_dev.min() >= 0 and f_dev.max() <= 1
-        Lp = oracle.gather(rows, np.flatnonzero(group_of == k), 8)
-        f = np.full(nr, 0.25, dtype=np.float32)
-        for _ in range(3):
-            oracle.emMAF_update(Lp, f, 8)
-        assert same(f, f_dev[r0:r0 + nr])
-    # chain: whole == first part then second part with carry (the device walks 2442 blocks)
-    whole = em.rmse_chain(3, 0.0)
-    assert whole > 0 and em.rmse_chain(3, 0.0) == whole
-    em.close()
-    b.close()
-
-
 def test_loo_fit_equals_explicit_removal(wg, oracle):
     """configs[3] shape at reduced SNP count (200k x 500, K=8): the leave-one-out fit of individual
     i (slab with one column skipped) equals the oracle's EM on the explicitly reduced matrix."""

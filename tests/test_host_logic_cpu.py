@@ -45,7 +45,7 @@ def test_cumsum_standin_is_the_serial_chain(oracle):
 
 
 def test_decide_converged():
-    from wgsassign_amd.device import decide_converged
+    from wgsassign_amd.device import decide_converged, guard_band
     m, tole = 1000, 1e-4
     th = tole * tole * m
     assert decide_converged(th * 0.5, m, tole, 0.25) == 1
@@ -53,9 +53,37 @@ def test_decide_converged():
     assert decide_converged(th * 1.1, m, tole, 0.25) == 0 and decide_converged(th * 0.9, m, tole, 0.25) == 0
     assert decide_converged(float("nan"), m, tole, 0.25) == -1          # NaN < tole is False (emMAF.py:23)
     assert decide_converged(0.0, m, 0.0, 0.25) == -1                     # diff < 0 never holds
+    # without a floor the band is m * 2^-24 (+1e-6): tiny for small m, +-0.6 at 10^7, one-sided beyond 2^24
+    assert decide_converged(th * 0.999, m, tole) == 1 and decide_converged(th * 1.001, m, tole) == -1
+    assert decide_converged(th * (1 + 1e-7), m, tole) == 0
+    assert abs(guard_band(10_000_000) - 0.596) < 1e-3
+    big = 100_000_000
+    thb = tole * tole * big
+    assert decide_converged(thb * 1e-3, big, tole) == 0       # float64 can never call "converged" at this m
+    assert decide_converged(thb * 6.9, big, tole) == 0 and decide_converged(thb * 7.0, big, tole) == -1
 
 
-@pytest.mark.parametrize("guard", [0.25, 1e9])
+def test_guard_band_covers_float32_stagnation():
+    """At whole-genome SNP counts the reference's serial float32 sum (emMAF_cy.pyx:30-31) absorbs small
+    terms and lands far below the exact sum: with m = 6*10^7 and squared differences whose float64 sum
+    is 1.15x the threshold, the float32 chain says "converged".  The driver must not decide from the
+    float64 sum there (the float32 sum is 17 % low here and 25 %+ at 10^8: no fixed band is safe)."""
+    from wgsassign_amd.device import chain_diff, decide_converged
+    m, tole = 60_000_000, 1e-4
+    rng = np.random.Generator(np.random.PCG64(11))
+    sq = (rng.standard_normal(m, dtype=np.float32) * np.float32(1.07e-4)) ** 2       # float32 squares, as emMAF_cy.pyx:31
+    s64 = float(np.sum(sq, dtype=np.float64))
+    ratio = s64 / (tole * tole * m)
+    assert 1.1 < ratio < 1.2
+    with np.errstate(all="ignore"):
+        f32 = np.cumsum(sq, dtype=np.float32)[-1]          # the serial float32 accumulation
+    assert chain_diff(f32, m) < tole                       # the reference stops here ...
+    assert decide_converged(s64, m, tole) == 0             # ... so the float64 sum must defer to the exact chain
+    # rigorous bound behind the band: |S - F| <= m * 2^-24 * F
+    assert abs(s64 - float(f32)) <= m * 2.0 ** -24 * float(f32)
+
+
+@pytest.mark.parametrize("guard", [0.0, 0.25, 1e9])
 def test_run_em_single_rank_matches_reference_iterations(oracle, golden, guard):
     """The driver loop stops every population at the reference's iteration (17/14/16/14/13) with
     bit-identical frequencies -- with the default guard band and with the exact chain forced on

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--pops", type=int, default=8)
     ap.add_argument("--loo", action="store_true")
     ap.add_argument("--partitions", type=int, default=1)
+    ap.add_argument("--exact-parts", action="store_true", help="also time the bit-exact partition chains when --partitions 1")
     a = ap.parse_args()
     m, n, K = a.snps, a.inds, a.pops
     ctx = device.get_context()
@@ -61,11 +62,13 @@ def main():
         tm = {}
         t0 = time.perf_counter()
         ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, a.partitions, verbose=False, timings=tm,
-                                      need_parts=a.partitions > 1)      # as the command line does
+                                      need_parts=a.partitions > 1 or a.exact_parts)      # as the command line does
         res["loo"] = {"seconds": round(time.perf_counter() - t0, 3), "em_seconds": round(tm["em_seconds"], 3),
                       "score_seconds": round(tm["score_seconds"], 3), "fits": n,
                       "iters_min_max": [int(tm["iters"].min()), int(tm["iters"].max())],
-                      "accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of))}
+                      "accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of)),
+                      "score_kernels_ms": {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")},
+                      "chain_blocks_serial_of_walked": tm.get("serial_blocks")}
     print(json.dumps(res))
 
 

@@ -16,6 +16,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# substrings of the kernel names whose counters are kept (every kernel of the hot path)
+KERNELS = ("em_sweep", "em_decide", "assign_", "parts_", "chain_", "ssq_reduce", "rmse", "fisher_", "block_reduce")
 
 
 def main():
@@ -26,11 +28,11 @@ def main():
     if kt:
         shutil.copy(kt[0], os.path.join(out, "kernel_stats.csv"))
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
-    for sub in ("fetch", "write", "sq"):
+    for sub in ("fetch", "write", "sq", "sq2"):
         for f in glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (prefix, sub), "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
-                if "em_sweep" in k or "assign_kernel" in k or "ssq_reduce" in k or "rmse" in k:
+                if any(t in k for t in KERNELS):
                     counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     summary = {"config": config, "kernels": {}}
     if len(sys.argv) > 4:   # m_per_gpu n K mode, so bench.py can match its workload to this measurement

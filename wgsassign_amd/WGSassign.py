@@ -2,8 +2,10 @@
 WGSassign.py (--get_reference_af, --loo, --get_pop_like), running on an AMD MI355X.
 
 Same flags, defaults, stdout lines and output files as the reference (WGSassign.py:24-104,
-109-308).  Options of the reference that are outside this build's scope (--ne_obs, z-scores,
-mixture proportions) are recognised and refused with a message.
+109-308), including --ne_obs (Fisher information / effective sample sizes).  Options of the
+reference that are outside this build's scope (z-scores, mixture proportions) are recognised and
+refused with a message.  Installed as the console script `WGSassign` (pyproject.toml; reference
+setup.py:48-50).
 """
 import argparse
 import os
@@ -33,9 +35,9 @@ parser.add_argument("--get_pop_like", action="store_true",
 parser.add_argument("--partition_sites", type=int, metavar="INT", default=1,
                     help="Optional: partition sites into INT subsets (by modulo) and report assignment "
                          "log-likelihoods for each subset.")
-# recognised but not provided by this build (out of the hot-path scope)
 parser.add_argument("--ne_obs", action="store_true",
                     help="Estimate population and individuals effective sample sizes")
+# recognised but not provided by this build (out of the hot-path scope)
 for _flag in ("--get_assignment_z_score", "--get_reference_z_score", "--single_read_threshold",
               "--get_em_mix", "--get_mcmc_mix"):
     parser.add_argument(_flag, action="store_true", help=argparse.SUPPRESS)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "wgs_em_clamp": (c_int, [c_vp, c_i32, ctypes.c_float, ctypes.c_float]),
     "wgs_em_get_f": (c_int, [c_vp, c_i32, c_f32p]),
     "wgs_em_set_f": (c_int, [c_vp, c_i32, c_f32p]),
+    "wgs_em_get_f_range": (c_int, [c_vp, c_i32, c_int, c_i64, c_i64, c_f32p]),
     "wgs_em_f_dev": (c_vp, [c_vp, c_i32]),
     "wgs_afset_create": (c_int, [c_vp, c_i64, c_i32, ctypes.POINTER(c_vp)]),
     "wgs_afset_destroy": (None, [c_vp]),
@@ -84,7 +85,14 @@ SIGNATURES = {
     "wgs_debug_div_mismatch": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "wgs_debug_log_mismatch": (c_int, [c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
     "wgs_debug_log_values": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_int]),
-    "wgs_assign_last_ms": (c_int, [c_f32p]),
+    "wgs_assign_last_ms": (c_int, [c_vp, c_f32p]),
+    "wgs_score_create": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_i32, ctypes.POINTER(c_vp)]),
+    "wgs_score_destroy": (None, [c_vp]),
+    "wgs_score_sums": (c_int, [c_vp, c_int, c_f64p]),
+    "wgs_score_chains_prepare": (c_int, [c_vp, c_i32, c_f64p]),
+    "wgs_score_chains_walk": (c_int, [c_vp, c_f32p, c_f32p]),
+    "wgs_score_last_serial_blocks": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
+    "wgs_debug_parts_exact_literal": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_f32p, c_f32p]),
     "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),
 }
 

@@ -3,10 +3,31 @@
 SNPs shard trivially (every SNP's update and log-likelihood term is independent:
 emMAF_cy.pyx:16-23, glassy_cy.pyx:17-21); ranks own contiguous SNP ranges in rank order.
 Exchange steps: per EM iteration the per-fit sums of squared differences (n_fits doubles), per
-undecided fit the float32 carry of the serial convergence chain, and once per assignment the
-n x K partial log-likelihood sums.  With the `nccl` backend this is RCCL over xGMI.
+undecided fit the float32 carry of the serial convergence chain, once per assignment the
+n x K partial log-likelihood sums, and for exact partition sums the float32 carries of the chains.
+
+Communicators (all expose rank, world, allreduce_sum, gather_rows, allgather_object, barrier):
+  LocalComm   one process.
+  RcclComm    default for N > 1: RCCL over xGMI through the library's own communicator
+              (include/wgsassign_hip.h: wgs_comm_*; librccl dlopen'ed, no tensor framework).  Bootstrap
+              and the few host-side gathers go over a persistent TCP star (SideChannel).
+  SocketComm  the same TCP star also carries the all-reduce (host-staged, summed in rank order): the
+              fallback when RCCL cannot initialise, and a CPU-testable multi-rank path without torch.
+  TorchComm   torch.distributed process group (`nccl` == RCCL, or `gloo`): optional, used by the
+              gloo rehearsals that put two ranks on one GPU.
+N > 1 over RCCL has not been executed yet on real hardware (no multi-GPU box was available to the
+build); the protocol is covered by gloo / socket multi-rank tests.
 """
+import hashlib
+import json
+import os
+import socket
+import struct
+import time
+
 import numpy as np
+
+COMM_INIT_FAILED = 75        # exit status of a worker whose communicator could not initialise (EX_TEMPFAIL)
 
 
 class LocalComm:
@@ -25,12 +46,260 @@ class LocalComm:
     def barrier(self):
         pass
 
+    def close(self):
+        pass
+
+
+# ---------------------------------------------------------------------------------------------
+class SideChannel:
+    """Persistent TCP star: rank 0 listens once, every other rank keeps ONE connection for the
+    communicator's lifetime.  All operations are collective and issued in the same order on every
+    rank, so a connection carries them strictly in sequence (no per-call accept, nothing to race).
+    Frames are length-prefixed raw bytes; objects travel as JSON, arrays as a JSON header + raw
+    buffer -- nothing is unpickled.  A connection must open with magic | rank | world | token."""
+
+    MAGIC = b"WGSCOMM2"
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=29401, token=None, timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        self.peers, self.hub = {}, None
+        if self.world == 1:
+            return
+        if token is None:
+            token = os.environ.get("WGSASSIGN_COMM_TOKEN") or "%s:%d:%d:%d:%s" % (
+                addr, port, world, os.getuid(), os.environ.get("TORCHELASTIC_RUN_ID", ""))
+        tok = hashlib.sha256(token.encode()).digest()
+        deadline = time.monotonic() + timeout
+        if self.rank == 0:
+            srv = socket.socket()
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, int(port)))
+            srv.listen(self.world)
+            try:
+                while len(self.peers) < self.world - 1:
+                    srv.settimeout(max(0.1, deadline - time.monotonic()))
+                    try:
+                        conn, _ = srv.accept()
+                    except socket.timeout:
+                        raise RuntimeError("SideChannel: %d of %d ranks connected within %.0f s" %
+                                           (len(self.peers) + 1, self.world, timeout))
+                    conn.settimeout(10.0)
+                    try:
+                        hello = self._take(conn, 8 + 8 + 32)
+                    except Exception:
+                        conn.close()
+                        continue
+                    r, w = struct.unpack("<ii", hello[8:16])
+                    if hello[:8] != self.MAGIC or w != self.world or not 0 < r < self.world or r in self.peers \
+                            or hello[16:] != tok:
+                        conn.close()             # not one of ours
+                        continue
+                    conn.settimeout(None)
+                    conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.peers[r] = conn
+            finally:
+                srv.close()
+            for r in sorted(self.peers):
+                self._send(self.peers[r], b"ok")
+        else:
+            last = None
+            while time.monotonic() < deadline:
+                try:
+                    c = socket.create_connection((addr, int(port)), timeout=5.0)
+                    break
+                except OSError as e:
+                    last = e
+                    time.sleep(0.05)
+            else:
+                raise RuntimeError("SideChannel: cannot reach rank 0 at %s:%d (%s)" % (addr, port, last))
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            c.sendall(self.MAGIC + struct.pack("<ii", self.rank, self.world) + tok)
+            c.settimeout(max(1.0, deadline - time.monotonic()))
+            if self._recv(c) != b"ok":
+                raise RuntimeError("SideChannel: rank 0 refused the connection")
+            c.settimeout(None)
+            self.hub = c
+
+    @staticmethod
+    def _take(conn, k):
+        buf = bytearray(k)
+        view, got = memoryview(buf), 0
+        while got < k:
+            r = conn.recv_into(view[got:], k - got)
+            if r == 0:
+                raise RuntimeError("SideChannel: peer closed the connection")
+            got += r
+        return bytes(buf)
+
+    @classmethod
+    def _recv(cls, conn):
+        return cls._take(conn, struct.unpack("<q", cls._take(conn, 8))[0])
+
+    @staticmethod
+    def _send(conn, data):
+        conn.sendall(struct.pack("<q", len(data)))
+        conn.sendall(data)
+
+    # ---- collectives on bytes
+    def bcast(self, data):
+        """rank 0's bytes on every rank."""
+        if self.world == 1:
+            return data
+        if self.rank == 0:
+            for r in sorted(self.peers):
+                self._send(self.peers[r], data)
+            return data
+        return self._recv(self.hub)
+
+    def gather(self, data):
+        """list of every rank's bytes (rank order) on rank 0, None elsewhere."""
+        if self.world == 1:
+            return [data]
+        if self.rank == 0:
+            return [data] + [self._recv(self.peers[r]) for r in range(1, self.world)]
+        self._send(self.hub, data)
+        return None
+
+    def close(self):
+        for c in list(self.peers.values()) + ([self.hub] if self.hub else []):
+            try:
+                c.close()
+            except OSError:
+                pass
+        self.peers, self.hub = {}, None
+
+
+def _pack_array(a):
+    a = np.ascontiguousarray(a)
+    head = json.dumps({"dtype": a.dtype.str, "shape": list(a.shape)}).encode()
+    return struct.pack("<i", len(head)) + head + a.tobytes()
+
+
+def _unpack_array(blob):
+    k = struct.unpack("<i", blob[:4])[0]
+    head = json.loads(blob[4:4 + k].decode())
+    dt = np.dtype(head["dtype"])
+    if dt.kind not in "fiub":
+        raise RuntimeError("SideChannel: refusing array of dtype %r" % head["dtype"])
+    return np.frombuffer(blob, dtype=dt, offset=4 + k).reshape(head["shape"])
+
+
+class SocketComm:
+    """All collectives over the TCP star (host-staged; sums formed on rank 0 in rank order, so every
+    rank sees identical bits).  Latency ~0.1 ms per all-reduce: fine for the few float64 this path
+    exchanges, and independent of any GPU library."""
+
+    def __init__(self, rank, world, addr="127.0.0.1", port=29400, timeout=120.0):
+        self.rank, self.world = int(rank), int(world)
+        self.ch = SideChannel(rank, world, addr, int(port) + 1, timeout=timeout)
+
+    def allreduce_sum(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        if self.world == 1:
+            return a
+        parts = self.ch.gather(a.tobytes())
+        if self.rank == 0:
+            tot = np.frombuffer(parts[0], dtype=np.float64).copy()
+            for p in parts[1:]:
+                tot += np.frombuffer(p, dtype=np.float64)
+            blob = self.ch.bcast(tot.tobytes())
+        else:
+            blob = self.ch.bcast(None)
+        return np.frombuffer(blob, dtype=np.float64).reshape(a.shape).copy()
+
+    def gather_rows(self, arr):
+        """Every rank's rows (SNP shards, rank order) concatenated on rank 0 -- raw buffers, rank 0 only;
+        the other ranks get None (only rank 0 writes output files)."""
+        parts = self.ch.gather(_pack_array(arr))
+        if self.rank != 0:
+            return None
+        return np.concatenate([_unpack_array(p) for p in parts], axis=0)
+
+    def allgather_object(self, obj):
+        """JSON-serialisable objects (site-name previews, counts) from every rank, on every rank."""
+        parts = self.ch.gather(json.dumps(obj).encode())
+        blob = self.ch.bcast(json.dumps([json.loads(p.decode()) for p in parts]).encode() if self.rank == 0 else None)
+        return json.loads(blob.decode())
+
+    def barrier(self):
+        self.allreduce_sum(np.zeros(1))
+
+    def close(self):
+        self.ch.close()
+
+
+class RcclComm(SocketComm):
+    """RCCL through the library's own communicator (include/wgsassign_hip.h: wgs_comm_*): no tensor
+    framework involved.  The 128-byte unique id travels from rank 0 to the others over the TCP star on
+    MASTER_ADDR:(MASTER_PORT + 1); the all-reduces run on the context's HIP stream over xGMI.  If any
+    rank cannot initialise RCCL, ALL ranks agree (over the star) to keep the socket all-reduce."""
+
+    def __init__(self, ctx, rank, world, addr="127.0.0.1", port=29400, timeout=120.0):
+        import ctypes
+        from . import _lib
+        super().__init__(rank, world, addr, port, timeout)
+        self._lib, self._ct, self.ctx = _lib, ctypes, ctx
+        self._h, self.native, self.native_error = None, False, ""
+        lib = _lib.load()
+        ident = (ctypes.c_uint8 * 128)()
+        ok = 1
+        if self.rank == 0 and lib.wgs_comm_unique_id(ident) != 0:
+            ok, self.native_error = 0, _lib.last_error()
+        blob = self.ch.bcast(bytes([ok]) + bytes(ident) if self.rank == 0 else None)
+        if blob[0]:
+            ident = (ctypes.c_uint8 * 128).from_buffer_copy(blob[1:129])
+            h = ctypes.c_void_p()
+            if lib.wgs_comm_init(ctx.handle, ident, self.rank, self.world, ctypes.byref(h)) == 0:
+                self._h = h
+            else:
+                ok, self.native_error = 0, _lib.last_error()
+        flags = SocketComm.allreduce_sum(self, np.array([float(ok and blob[0])]))
+        self.native = int(flags[0]) == self.world
+        if not self.native and self._h:
+            lib.wgs_comm_destroy(self._h)
+            self._h = None
+
+    # ---- the collective
+    def allreduce_sum(self, arr):
+        if not self.native:
+            return SocketComm.allreduce_sum(self, arr)
+        a = np.ascontiguousarray(arr, dtype=np.float64).copy()
+        self._lib.check(self._lib.load().wgs_comm_allreduce_f64(self._h, self._lib.f64p(a.reshape(-1)), a.size))
+        return a
+
+    def step_reduced(self, em_handle, n_fits):
+        """EM sweep into the communicator's device buffer, all-reduce behind it on the same stream,
+        one readback (the per-iteration exchange of the sharded EM; see EMBatch.step_reduced)."""
+        lib = self._lib.load()
+        if not self.native:
+            out = np.zeros(int(n_fits), dtype=np.float64)
+            self._lib.check(lib.wgs_em_step(em_handle, self._lib.f64p(out)))
+            return SocketComm.allreduce_sum(self, out)
+        buf = lib.wgs_comm_buffer(self._h, int(n_fits))
+        if not buf:
+            raise RuntimeError("wgsassign_amd HIP call failed: " + self._lib.last_error())
+        self._lib.check(lib.wgs_em_step_dev(em_handle, self._ct.c_void_p(buf)))
+        out = np.zeros(int(n_fits), dtype=np.float64)
+        self._lib.check(lib.wgs_comm_allreduce_buffer(self._h, int(n_fits), self._lib.f64p(out)))
+        return out
+
+    @property
+    def handle(self):
+        """wgs_comm* for the C entry points that run whole loops (wgs_em_fit), or None."""
+        return self._h if self.native else None
+
+    def close(self):
+        if self._h:
+            self._lib.load().wgs_comm_destroy(self._h)
+            self._h = None
+        SocketComm.close(self)
+
 
 class TorchComm:
     """torch.distributed process group (backend `nccl` == RCCL on ROCm, or `gloo` on CPU).
 
     Ordering note: torch bundles its own HIP runtime; import torch and initialise the process group
-    BEFORE the first wgsassign_amd device call (init_from_env and bench.py do), otherwise torch
+    BEFORE the first wgsassign_amd device call (init_from_env does), otherwise torch
     reports "No HIP GPUs are available"."""
 
     def __init__(self, device=None):
@@ -44,13 +313,16 @@ class TorchComm:
         self._cuda = dist.get_backend() == "nccl"
         self._device = device
 
+    def _dev(self):
+        return self._device if self._device is not None else "cuda"
+
     def allreduce_sum(self, arr):
         """Sum `arr` (float64) over all ranks; every rank gets identical bits."""
         torch, dist = self._torch, self._dist
         a = np.ascontiguousarray(arr, dtype=np.float64)
         t = torch.from_numpy(a.copy())
         if self._cuda:
-            t = t.to(self._device if self._device is not None else "cuda")
+            t = t.to(self._dev())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t.cpu().numpy().reshape(a.shape)
 
@@ -59,8 +331,7 @@ class TorchComm:
         """A float64 CUDA tensor of n elements (its data_ptr() is handed to wgs_em_step_dev)."""
         if not self._cuda:
             return None
-        return self._torch.zeros(int(n), dtype=self._torch.float64,
-                                 device=self._device if self._device is not None else "cuda")
+        return self._torch.zeros(int(n), dtype=self._torch.float64, device=self._dev())
 
     def allreduce_device(self, t, stream_ptr):
         """RCCL all-reduce of tensor t, ordered after the work already enqueued on the library's
@@ -73,9 +344,24 @@ class TorchComm:
         return out.numpy()
 
     def gather_rows(self, arr):
-        """Concatenate every rank's rows (SNP shards, rank order) -- the full array on every rank."""
-        parts = [None] * self.world
-        self._dist.all_gather_object(parts, np.ascontiguousarray(arr))
+        """Every rank's rows (rank order) concatenated on rank 0 (None elsewhere): row counts by one
+        all-reduce, then point-to-point tensor sends -- raw buffers, nothing pickled."""
+        torch, dist = self._torch, self._dist
+        a = np.ascontiguousarray(arr)
+        counts = np.zeros(self.world)
+        counts[self.rank] = a.shape[0]
+        counts = self.allreduce_sum(counts).astype(np.int64)
+        if self.world == 1:
+            return a
+        dev = self._dev() if self._cuda else "cpu"
+        if self.rank != 0:
+            dist.send(torch.from_numpy(a).to(dev), dst=0)
+            return None
+        parts = [a]
+        for r in range(1, self.world):
+            t = torch.empty((int(counts[r]),) + a.shape[1:], dtype=torch.from_numpy(a[:0]).dtype, device=dev)
+            dist.recv(t, src=r)
+            parts.append(t.cpu().numpy())
         return np.concatenate(parts, axis=0)
 
     def allgather_object(self, obj):
@@ -86,141 +372,33 @@ class TorchComm:
     def barrier(self):
         self._dist.barrier()
 
-
-class RcclComm:
-    """RCCL through the library's own communicator (include/wgsassign_hip.h: wgs_comm_*): no tensor
-    framework involved.  The 128-byte unique id travels from rank 0 to the others over a plain TCP
-    socket on MASTER_ADDR:(MASTER_PORT + 1); objects (gather_rows) use the same channel pattern."""
-
-    def __init__(self, ctx, rank, world, addr="127.0.0.1", port=29400):
-        import ctypes
-        from . import _lib
-        self._lib, self._ct = _lib, ctypes
-        self.rank, self.world, self.ctx = int(rank), int(world), ctx
-        self._addr, self._port = addr, int(port) + 1
-        lib = _lib.load()
-        ident = (ctypes.c_uint8 * 128)()
-        if self.rank == 0:
-            _lib.check(lib.wgs_comm_unique_id(ident))
-        blob = self._bcast_bytes(bytes(ident) if self.rank == 0 else None)
-        ident = (ctypes.c_uint8 * 128).from_buffer_copy(blob)
-        h = ctypes.c_void_p()
-        _lib.check(lib.wgs_comm_init(ctx.handle, ident, self.rank, self.world, ctypes.byref(h)))
-        self._h = h
-        self._dev = None
-
-    # ---- tiny TCP helpers (bootstrap and object gathers only; the data path is RCCL)
-    def _serve(self, handler):
-        import socket
-        with socket.socket() as srv:
-            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((self._addr, self._port))
-            srv.listen(self.world)
-            for _ in range(self.world - 1):
-                conn, _a = srv.accept()
-                with conn:
-                    handler(conn)
-
-    def _connect(self):
-        import socket
-        import time
-        for _ in range(600):
-            try:
-                return socket.create_connection((self._addr, self._port), timeout=60)
-            except OSError:
-                time.sleep(0.1)
-        raise RuntimeError("RcclComm: cannot reach rank 0 at %s:%d" % (self._addr, self._port))
-
-    @staticmethod
-    def _send(conn, data):
-        conn.sendall(len(data).to_bytes(8, "little") + data)
-
-    @staticmethod
-    def _recv(conn):
-        def take(k):
-            buf = b""
-            while len(buf) < k:
-                chunk = conn.recv(k - len(buf))
-                if not chunk:
-                    raise RuntimeError("RcclComm: peer closed the connection")
-                buf += chunk
-            return buf
-        return take(int.from_bytes(take(8), "little"))
-
-    def _bcast_bytes(self, data):
-        if self.world == 1:
-            return data
-        if self.rank == 0:
-            self._serve(lambda c: self._send(c, data))
-            return data
-        with self._connect() as c:
-            return self._recv(c)
-
-    def allgather_object(self, obj):
-        import pickle
-        if self.world == 1:
-            return [obj]
-        if self.rank == 0:
-            parts = {0: obj}
-
-            def take(c):
-                r, o = pickle.loads(self._recv(c))
-                parts[r] = o
-            self._serve(take)
-            out = [parts[r] for r in range(self.world)]
-            blob = pickle.dumps(out)
-            self._serve(lambda c: self._send(c, blob))
-            return out
-        with self._connect() as c:
-            self._send(c, pickle.dumps((self.rank, obj)))
-        with self._connect() as c:
-            return pickle.loads(self._recv(c))
-
-    def gather_rows(self, arr):
-        return np.concatenate(self.allgather_object(np.ascontiguousarray(arr)), axis=0)
-
-    # ---- the collective
-    def allreduce_sum(self, arr):
-        a = np.ascontiguousarray(arr, dtype=np.float64).copy()
-        self._lib.check(self._lib.load().wgs_comm_allreduce_f64(self._h, self._lib.f64p(a.reshape(-1)), a.size))
-        return a
-
-    def step_reduced(self, em_handle, n_fits):
-        """EM sweep into the communicator's device buffer, all-reduce behind it on the same stream,
-        one readback (the per-iteration exchange of the sharded EM; see EMBatch.step_reduced)."""
-        lib = self._lib.load()
-        buf = lib.wgs_comm_buffer(self._h, int(n_fits))
-        if not buf:
-            raise RuntimeError("wgsassign_amd HIP call failed: " + self._lib.last_error())
-        self._lib.check(lib.wgs_em_step_dev(em_handle, self._ct.c_void_p(buf)))
-        out = np.zeros(int(n_fits), dtype=np.float64)
-        self._lib.check(lib.wgs_comm_allreduce_buffer(self._h, int(n_fits), self._lib.f64p(out)))
-        return out
-
-    def barrier(self):
-        self.allreduce_sum(np.zeros(1))
-
     def close(self):
-        if self._h:
-            self._lib.load().wgs_comm_destroy(self._h)
-            self._h = None
+        pass
 
 
-def init_from_env():
-    """Process group from torchrun's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*):
-    RCCL (`nccl`) when a GPU per rank is available, `gloo` when WGSASSIGN_BACKEND=gloo (ranks
-    sharing one GPU, CPU-only rehearsals).  Returns LocalComm() outside torchrun."""
-    import os
+def init_from_env(ctx=None):
+    """Communicator from the launcher's environment (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*, as set by
+    torchrun or by bench.py's own launcher).  WGSASSIGN_COMM selects it: `rccl` (default: the library's
+    own RCCL communicator, no torch), `socket` (TCP all-reduce), `torch` (torch.distributed; backend
+    WGSASSIGN_BACKEND = nccl | gloo -- gloo lets several ranks share one GPU in rehearsals; setting
+    WGSASSIGN_BACKEND=gloo alone implies torch).  Returns LocalComm() when WORLD_SIZE is 1 or unset."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1:
         return LocalComm()
-    if os.environ.get("WGSASSIGN_COMM", "torch") == "rccl":     # the library's own RCCL communicator
+    rank = int(os.environ.get("RANK", "0"))
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("MASTER_PORT", "29400"))
+    backend = os.environ.get("WGSASSIGN_BACKEND", "nccl")
+    kind = os.environ.get("WGSASSIGN_COMM", "torch" if backend == "gloo" else "rccl")
+    if kind == "socket":
+        return SocketComm(rank, world, addr, port)
+    if kind == "rccl":
         from .device import get_context
-        return RcclComm(get_context(), int(os.environ.get("RANK", "0")), world,
-                        os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")))
+        return RcclComm(ctx or get_context(), rank, world, addr, port)
+    if kind != "torch":
+        raise ValueError("WGSASSIGN_COMM must be rccl, socket or torch, got %r" % kind)
     import torch
     import torch.distributed as dist
-    backend = os.environ.get("WGSASSIGN_BACKEND", "nccl")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not dist.is_initialized():
         if backend == "nccl":

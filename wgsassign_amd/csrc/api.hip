@@ -49,6 +49,8 @@ int wgs_ctx_create(int device, wgs_ctx **out)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     c->cus = prop.multiProcessorCount;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
     guard.dismiss();
     *out = c;
     return 0;
@@ -61,6 +63,8 @@ void wgs_ctx_destroy(wgs_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
 }
 
@@ -492,6 +496,19 @@ int wgs_em_get_f(wgs_em *em, int32_t fit, float *f_host)
     return 0;
 }
 
+int wgs_em_get_f_range(wgs_em *em, int32_t fit, int previous, int64_t row0, int64_t nrows, float *f_host)
+{
+    WGS_REQUIRE(em && f_host && fit >= 0 && fit < em->n_fits, "bad argument");
+    WGS_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= em->b->m, "row range [%lld, %lld) outside 0..%lld", (long long)row0,
+                (long long)(row0 + nrows), (long long)em->b->m);
+    if (nrows == 0) return 0;
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    const float *src = em_f(em, fit, previous ? em->cur[fit] ^ 1 : em->cur[fit]) + row0;
+    HIP_TRY(hipMemcpyAsync(f_host, src, sizeof(float) * nrows, hipMemcpyDeviceToHost, em->b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(em->b->ctx->stream));
+    return 0;
+}
+
 int wgs_em_set_f(wgs_em *em, int32_t fit, const float *f_host)
 {
     WGS_REQUIRE(em && f_host && fit >= 0 && fit < em->n_fits, "bad argument");
@@ -580,14 +597,266 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col)
     return a->buf + (size_t)col * a->m;
 }
 
-/* ------------------------------------------------------------------ assignment */
+/* ------------------------------------------------------------------ assignment / scoring */
 
-static thread_local float g_assign_ms = 0.0f;
-int wgs_assign_last_ms(float *ms)
+int wgs_assign_last_ms(wgs_ctx *ctx, float *ms)
 {
-    WGS_REQUIRE(ms, "null argument");
-    *ms = g_assign_ms;
+    WGS_REQUIRE(ctx && ms, "null argument");
+    *ms = ctx->last_assign_ms;
     return 0;
+}
+
+struct wgs_score {
+    wgs_beagle *b = nullptr;
+    wgs_afset *a = nullptr;
+    int32_t K = 0, row_lo = 0, row_hi = 0, nblocks = 0, P = 0;
+    int64_t n = 0, cells = 0;
+    bool per_ind = false, have_prefix = false;
+    const float **d_acol = nullptr, **d_colptr = nullptr;
+    ScoreSlab *d_slabs[2] = {nullptr, nullptr};      // [0] table of the sweep, [1] table of the chain kernel
+    int n_slabs[2] = {0, 0}, total_pg[2] = {0, 0};
+    double *d_S = nullptr, *d_out = nullptr, *d_start = nullptr;
+    uint32_t *d_cand = nullptr;
+    float *d_carry = nullptr, *d_parts = nullptr;
+    int32_t *d_nserial = nullptr;
+    int32_t last_serial_blocks = 0;
+};
+
+void wgs_score_destroy(wgs_score *sc)
+{
+    if (!sc) return;
+    (void)hipSetDevice(sc->b->ctx->device);
+    (void)hipStreamSynchronize(sc->b->ctx->stream);
+    void *bufs[] = {sc->d_acol, sc->d_colptr, sc->d_slabs[0], sc->d_slabs[1] == sc->d_slabs[0] ? nullptr : sc->d_slabs[1], sc->d_S,
+                    sc->d_out, sc->d_start, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete sc;
+}
+
+/* Slab table for NP pairs per wave, restricted to the individuals [row_lo, row_hi): the members of a slab
+ * are in file order, so the scored ones are a contiguous column range. */
+static int build_slab_table(wgs_score *sc, int np, int which)
+{
+    std::vector<ScoreSlab> tab;
+    int pg = 0;
+    for (int g = 0; g < sc->b->n_groups; ++g) {
+        const Slab &s = sc->b->slabs[g];
+        if (s.ncols == 0) continue;
+        const int lo = (int)(std::lower_bound(s.members.begin(), s.members.end(), sc->row_lo) - s.members.begin());
+        const int hi = (int)(std::lower_bound(s.members.begin(), s.members.end(), sc->row_hi) - s.members.begin());
+        if (hi <= lo) continue;
+        ScoreSlab e;
+        e.slab = s.base;
+        e.members = s.d_members;
+        e.npairs = s.npairs;
+        e.ncols = s.ncols;
+        e.pair0 = lo / 2;
+        e.npg = ((hi - 1) / 2 - e.pair0 + 1 + np - 1) / np;
+        e.pg0 = pg;
+        e.col_lo = lo;
+        e.col_hi = hi;
+        pg += e.npg;
+        tab.push_back(e);
+    }
+    sc->n_slabs[which] = (int)tab.size();
+    sc->total_pg[which] = pg;
+    if (tab.empty()) return 0;
+    HIP_TRY(hipMalloc(&sc->d_slabs[which], sizeof(ScoreSlab) * tab.size()));
+    HIP_TRY(hipMemcpy(sc->d_slabs[which], tab.data(), sizeof(ScoreSlab) * tab.size(), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t row_lo, int32_t row_hi, wgs_score **out)
+{
+    WGS_REQUIRE(b && a && out, "null argument");
+    WGS_REQUIRE(a->m == b->m, "allele frequencies cover %lld SNPs, the Beagle shard %lld", (long long)a->m, (long long)b->m);
+    WGS_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= b->n, "individual range [%d, %d) outside 0..%lld", row_lo, row_hi,
+                (long long)b->n);
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    wgs_score *sc = new wgs_score();
+    auto guard = on_failure([&] { wgs_score_destroy(sc); });
+    sc->b = b;
+    sc->a = a;
+    sc->K = a->K;
+    sc->n = b->n;
+    sc->cells = b->n * (int64_t)a->K;
+    sc->row_lo = row_lo;
+    sc->row_hi = row_hi;
+    sc->per_ind = colptr != nullptr;
+    sc->nblocks = (int32_t)((wgs_ntiles(b->m) + WGS_BLOCK_TILES - 1) / WGS_BLOCK_TILES);
+    std::vector<const float *> acol(a->K);
+    for (int k = 0; k < a->K; ++k) acol[k] = a->buf + (size_t)k * a->m;
+    HIP_TRY(hipMalloc(&sc->d_acol, sizeof(float *) * a->K));
+    HIP_TRY(hipMemcpy(sc->d_acol, acol.data(), sizeof(float *) * a->K, hipMemcpyHostToDevice));
+    if (colptr) {
+        HIP_TRY(hipMalloc(&sc->d_colptr, sizeof(float *) * sc->cells));
+        HIP_TRY(hipMemcpy(sc->d_colptr, colptr, sizeof(float *) * sc->cells, hipMemcpyHostToDevice));
+    }
+    const int np_sweep = score_pairs_per_wave(a->K), np_chain = chain_pairs_per_wave(a->K, sc->per_ind);
+    if (build_slab_table(sc, np_sweep, 0)) return 1;
+    if (np_chain == np_sweep) {
+        sc->d_slabs[1] = sc->d_slabs[0];
+        sc->n_slabs[1] = sc->n_slabs[0];
+        sc->total_pg[1] = sc->total_pg[0];
+    } else if (build_slab_table(sc, np_chain, 1)) {
+        return 1;
+    }
+    if (hipMalloc(&sc->d_S, sizeof(double) * (size_t)sc->nblocks * sc->cells) != hipSuccess) {
+        wgs_set_error("hipMalloc of %zu bytes for the block sums failed", sizeof(double) * (size_t)sc->nblocks * sc->cells);
+        return 1;
+    }
+    HIP_TRY(hipMalloc(&sc->d_out, sizeof(double) * sc->cells));
+    guard.dismiss();
+    *out = sc;
+    return 0;
+}
+
+static ScoreArgs score_args(const wgs_score *sc, int which)
+{
+    ScoreArgs A;
+    A.slabs = sc->d_slabs[which];
+    A.n_slabs = sc->n_slabs[which];
+    A.total_pg = sc->total_pg[which];
+    A.colptr = sc->d_colptr;
+    A.acol = sc->d_acol;
+    A.m = sc->b->m;
+    A.site0 = sc->b->site0;
+    A.cells = sc->cells;
+    A.K = sc->K;
+    A.P = 1;
+    A.period = 1;
+    A.nblocks = sc->nblocks;
+    A.S = sc->d_S;
+    A.start = nullptr;
+    A.cand = nullptr;
+    return A;
+}
+
+/* All n x K sums of glassy.py:31-42 / 92-105 for the scored individuals: out[i*K + k] (host, overwritten;
+ * rows outside the scored range are 0) = the float64 sum over this shard's SNPs of the float32 per-site
+ * values, formed in a fixed order (per lane over the tiles of a block, a fixed shuffle tree over lanes,
+ * blocks in order): the same bits on every run. */
+int wgs_score_sums(wgs_score *sc, int mode, double *out)
+{
+    WGS_REQUIRE(sc && out, "null argument");
+    WGS_REQUIRE(mode == WGS_MODE_EXACT || mode == WGS_MODE_FAST, "unknown mode %d", mode);
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(sc->d_S, 0, sizeof(double) * (size_t)sc->nblocks * sc->cells, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (launch_score_sweep(ctx, score_args(sc, 0), mode)) return 1;
+    if (launch_block_prefix(ctx, sc->d_S, sc->nblocks, sc->cells, sc->d_out, 1)) return 1;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, sc->d_out, sizeof(double) * sc->cells, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    sc->have_prefix = (mode == WGS_MODE_EXACT);
+    return 0;
+}
+
+/* Block functions of the exact partition chains (utils.py:147-149) for P partitions; needs the block
+ * sums of wgs_score_sums(WGS_MODE_EXACT).  start (host, n*K doubles, may be NULL) = the float64 sums over
+ * the SNP shards that precede this one (its partitions are predicted to hold equal shares).  rc 2 when P is
+ * too large for the block-parallel kernel (use wgs_assign_parts_exact's literal chains then). */
+int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start)
+{
+    WGS_REQUIRE(sc, "null argument");
+    WGS_REQUIRE(P >= 1, "partition count must be >= 1");
+    WGS_REQUIRE(sc->have_prefix, "wgs_score_chains_prepare needs wgs_score_sums(WGS_MODE_EXACT) first");
+    WGS_REQUIRE(chain_cand_lds_bytes(sc->K, P, sc->per_ind) <= 64 * 1024 && (int64_t)sc->cells * P < (1ll << 31),
+                "too many partitions (%d) for the block-parallel chains", P);
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t chains = (size_t)sc->cells * P;
+    if (sc->P != P) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (void *p : {(void *)sc->d_cand, (void *)sc->d_carry, (void *)sc->d_parts})
+            if (p) (void)hipFree(p);
+        sc->d_cand = nullptr;
+        sc->d_carry = sc->d_parts = nullptr;
+        sc->P = 0;
+        if (hipMalloc(&sc->d_cand, sizeof(uint32_t) * chains * sc->nblocks) != hipSuccess) {
+            wgs_set_error("hipMalloc of %zu bytes for the partition-chain block functions failed", sizeof(uint32_t) * chains * sc->nblocks);
+            return 1;
+        }
+        HIP_TRY(hipMalloc(&sc->d_carry, sizeof(float) * chains));
+        HIP_TRY(hipMalloc(&sc->d_parts, sizeof(float) * chains));
+        if (!sc->d_nserial) HIP_TRY(hipMalloc(&sc->d_nserial, sizeof(int32_t)));
+        if (!sc->d_start) HIP_TRY(hipMalloc(&sc->d_start, sizeof(double) * sc->cells));
+        sc->P = P;
+    }
+    HIP_TRY(hipMemsetAsync(sc->d_cand, 0, sizeof(uint32_t) * chains * sc->nblocks, ctx->stream));
+    if (start) HIP_TRY(hipMemcpyAsync(sc->d_start, start, sizeof(double) * sc->cells, hipMemcpyHostToDevice, ctx->stream));
+    ScoreArgs A = score_args(sc, 1);
+    A.P = P;
+    int g = 64, r = P;                       // gcd(64, P)
+    while (r) {
+        const int t = g % r;
+        g = r;
+        r = t;
+    }
+    A.period = P / g;
+    A.start = start ? sc->d_start : nullptr;
+    A.cand = sc->d_cand;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (launch_chain_cand(ctx, A)) return 1;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));       // `start` (host) has been consumed
+    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    return 0;
+}
+
+/* Walk the chains of this shard: carry_in (host float32 [n*P*K], NULL = zeros) is the running value after
+ * the preceding shards, parts_out (host float32 [n*P*K], index (i*P + p)*K + k) the value after this one;
+ * rows of individuals outside the scored range are 0. */
+int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out)
+{
+    WGS_REQUIRE(sc && parts_out, "null argument");
+    WGS_REQUIRE(sc->P >= 1 && sc->d_cand, "wgs_score_chains_walk needs wgs_score_chains_prepare first");
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t chains = (size_t)sc->cells * sc->P;
+    if (carry_in) HIP_TRY(hipMemcpyAsync(sc->d_carry, carry_in, sizeof(float) * chains, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(sc->d_parts, 0, sizeof(float) * chains, ctx->stream));
+    HIP_TRY(hipMemsetAsync(sc->d_nserial, 0, sizeof(int32_t), ctx->stream));
+    WalkArgs W;
+    W.cand = sc->d_cand;
+    W.carry = carry_in ? sc->d_carry : nullptr;
+    W.parts = sc->d_parts;
+    W.group_of = sc->b->d_group_of;
+    W.col_of = sc->b->d_col_of;
+    W.npairs = sc->b->d_npairs;
+    W.base = sc->b->d_base;
+    W.colptr = sc->d_colptr;
+    W.acol = sc->d_acol;
+    W.m = sc->b->m;
+    W.site0 = sc->b->site0;
+    W.n = (int32_t)sc->n;
+    W.K = sc->K;
+    W.P = sc->P;
+    W.nblocks = sc->nblocks;
+    W.row_lo = sc->row_lo;
+    W.row_hi = sc->row_hi;
+    W.n_serial = sc->d_nserial;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (launch_chain_walk(ctx, W)) return 1;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(parts_out, sc->d_parts, sizeof(float) * chains, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(&sc->last_serial_blocks, sc->d_nserial, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    return 0;
+}
+
+/* Test hook: blocks that took the literal serial loop in the last wgs_score_chains_walk, and the number of
+ * (chain, block) pairs walked. */
+int wgs_score_last_serial_blocks(wgs_score *sc, int64_t *total_blocks)
+{
+    if (!sc) return -1;
+    if (total_blocks) *total_blocks = (int64_t)(sc->row_hi - sc->row_lo) * sc->K * sc->P * sc->nblocks;
+    return sc->last_serial_blocks;
 }
 
 int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode, double *out, double *parts)
@@ -601,7 +870,19 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     const int K = a->K;
     const int64_t n = b->n;
     const size_t cells = (size_t)n * P * K;
-    g_assign_ms = 0.0f;
+    ctx->last_assign_ms = 0.0f;
+    std::vector<double> h(cells);
+    if (P == 1) {
+        // one launch over all population slabs, reproducible sums (wgs_score_sums)
+        wgs_score *sc = nullptr;
+        int rc = wgs_score_create(b, a, colptr, 0, (int32_t)n, &sc);
+        if (!rc) rc = wgs_score_sums(sc, mode, h.data());
+        wgs_score_destroy(sc);
+        if (rc) return rc;
+        for (size_t c = 0; c < cells; ++c) out[c] += h[c];
+        return 0;
+    }
+    // P > 1: float64 partition sums (the WGSASSIGN_PARTS=fast path), lane <-> individual pair, one slab per launch
     // one grow-only workspace: [cells doubles | K shared pointers | n*K per-individual pointers]
     const size_t off_acol = (sizeof(double) * cells + 255) & ~(size_t)255;
     const size_t off_colptr = (off_acol + sizeof(float *) * K + 255) & ~(size_t)255;
@@ -613,17 +894,11 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     const float **d_colptr = colptr ? reinterpret_cast<const float **>(reinterpret_cast<char *>(ws) + off_colptr) : nullptr;
     std::vector<const float *> acol(K);
     for (int k = 0; k < K; ++k) acol[k] = a->buf + (size_t)k * a->m;
-    std::vector<double> h(cells);
-    static thread_local hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (!ev0) {
-        HIP_TRY(hipEventCreate(&ev0));
-        HIP_TRY(hipEventCreate(&ev1));
-    }
     HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(double) * cells, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_acol, acol.data(), sizeof(float *) * K, hipMemcpyHostToDevice, ctx->stream));
     if (colptr) HIP_TRY(hipMemcpyAsync(d_colptr, colptr, sizeof(float *) * n * K, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));      // acol (a local vector) has been consumed
-    HIP_TRY(hipEventRecord(ev0, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     for (int g = 0; g < b->n_groups; ++g) {
         const Slab &s = b->slabs[g];
         if (s.ncols == 0) continue;
@@ -642,33 +917,64 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
         args.tiles_per_wave = 0;
         if (launch_assign(ctx, args, mode)) return 1;
     }
-    HIP_TRY(hipEventRecord(ev1, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipMemcpyAsync(h.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    (void)hipEventElapsedTime(&g_assign_ms, ev0, ev1);
-    if (P == 1) {
-        for (size_t c = 0; c < cells; ++c) out[c] += h[c];
-    } else {
-        for (size_t c = 0; c < cells; ++c) parts[c] += h[c];
-        for (int64_t i = 0; i < n; ++i)
-            for (int k = 0; k < K; ++k) {
-                double t = 0.0;
-                for (int p = 0; p < P; ++p) t += h[((size_t)i * P + p) * K + k];
-                out[(size_t)i * K + k] += t;
-            }
-    }
+    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    for (size_t c = 0; c < cells; ++c) parts[c] += h[c];
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < K; ++k) {
+            double t = 0.0;
+            for (int p = 0; p < P; ++p) t += h[((size_t)i * P + p) * K + k];
+            out[(size_t)i * K + k] += t;
+        }
     return 0;
 }
 
+static int parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, const float *carry_in,
+                               float *parts_out);
+
 /* Exact partition sums: utils.partition_loglikes (utils.py:129-151) for every (individual,
  * population) -- serial float32 accumulation per partition in site order, continued from
- * carry_in (float32 [n*P*K], NULL = zeros: first shard) into parts_out (float32 [n*P*K]). */
+ * carry_in (float32 [n*P*K], NULL = zeros: first shard) into parts_out (float32 [n*P*K]).
+ * literal != 0 forces the one-lane-per-chain kernel (the cross-check of the block-parallel chains). */
 int wgs_assign_parts_exact(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, const float *carry_in,
                            float *parts_out)
 {
     WGS_REQUIRE(b && a && parts_out, "null argument");
     WGS_REQUIRE(a->m == b->m, "allele frequencies cover %lld SNPs, the Beagle shard %lld", (long long)a->m, (long long)b->m);
     WGS_REQUIRE(P >= 1, "partition count must be >= 1");
+    if (chain_cand_lds_bytes(a->K, P, colptr != nullptr) > 64 * 1024 || b->n * (int64_t)a->K * P >= (1ll << 31))
+        return parts_exact_literal(b, a, colptr, P, carry_in, parts_out);
+    const size_t cells = (size_t)b->n * a->K;
+    std::vector<double> sums(cells), start;
+    if (carry_in) {           // the preceding shards' float64 sums are not known here: their float32 chains stand in
+        start.assign(cells, 0.0);
+        for (int64_t i = 0; i < b->n; ++i)
+            for (int p = 0; p < P; ++p)
+                for (int k = 0; k < a->K; ++k) start[(size_t)i * a->K + k] += (double)carry_in[((size_t)i * P + p) * a->K + k];
+    }
+    wgs_score *sc = nullptr;
+    int rc = wgs_score_create(b, a, colptr, 0, (int32_t)b->n, &sc);
+    if (!rc) rc = wgs_score_sums(sc, WGS_MODE_EXACT, sums.data());
+    if (!rc) rc = wgs_score_chains_prepare(sc, P, carry_in ? start.data() : nullptr);
+    if (!rc) rc = wgs_score_chains_walk(sc, carry_in, parts_out);
+    wgs_score_destroy(sc);
+    return rc;
+}
+
+int wgs_debug_parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, const float *carry_in,
+                                  float *parts_out)
+{
+    WGS_REQUIRE(b && a && parts_out, "null argument");
+    WGS_REQUIRE(a->m == b->m, "allele frequencies cover %lld SNPs, the Beagle shard %lld", (long long)a->m, (long long)b->m);
+    WGS_REQUIRE(P >= 1, "partition count must be >= 1");
+    return parts_exact_literal(b, a, colptr, P, carry_in, parts_out);
+}
+
+static int parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, const float *carry_in,
+                               float *parts_out)
+{
     wgs_ctx *ctx = b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const int K = a->K;

@@ -11,6 +11,8 @@
 //   Each lane keeps 2 x KB float64 accumulators (np.sum(..., dtype=float), glassy.py:38); the
 //   per-SNP frequency of population k is a broadcast load, or a per-lane vector when a
 //   per-individual column table is given (leave-one-out).
+#include <type_traits>
+
 #include "common.h"
 #include "log_table.h"
 
@@ -166,20 +168,22 @@ __global__ __launch_bounds__(256) void assign_kernel(AssignArgs A)
     }
 }
 
-// ---- P == 1 path: lane <-> SNP -----------------------------------------------------------------
-// wave <-> (group of NP individual pairs, range of tiles); lane <-> SNP of the tile.  GL loads are
-// the slab's native 1 KiB wave loads, the K frequencies of a SNP are loaded once per tile and
-// their double forms (a, 1-a) hoisted over the individuals (shared-A mode), and in leave-one-out
-// mode the per-individual frequency vectors are read coalesced (lane = SNP).  Each lane keeps
-// NP x 2 x KB float64 partial sums over the tiles of its range; one cross-lane reduction per
-// (individual, population) ends the range.  Pair-group index varies fastest over workgroups, so
-// waves that need the same tile's frequencies run together (L2 hits).
-__device__ __forceinline__ float site_ll_exact2(double g0d, double g1d2, double g2d, double ad, double oma, const double2 *tab)
+// ---- scoring sweep: lane <-> SNP, wave <-> (NP pairs of slab columns, one block of tiles) ---------
+// GL loads are the slab's native 1 KiB wave loads, the K frequencies of a SNP are loaded once per
+// tile and their double forms (a, 1-a) hoisted over the individuals (shared-A mode), and in
+// leave-one-out mode the per-individual frequency vectors are read coalesced (lane = SNP).  Each lane
+// keeps NP x 2 x KB float64 partial sums over the tiles of its block; one cross-lane reduction per
+// (individual, population) ends the block and its result is STORED (one writer per element).  Pair
+// groups of ALL population slabs share one launch, pair-group index fastest over waves, so the waves
+// that need the same tile's frequencies run together (L2 hits) and the launch has one tail, not K.
+
+// (like0 + like1) + like2 of glassy_cy.pyx:18-20 in the reference's rounding sequence.
+__device__ __forceinline__ float like_sum_exact(double g0d, double g1d2, double g2d, double ad, double oma)
 {
     const float like0 = (float)((g0d * oma) * oma);
     const float like1 = (float)((g1d2 * oma) * ad);        // ((g1*2.0)*(1-a))*a, g1*2.0 exact
     const float like2 = (float)((g2d * ad) * ad);
-    return logf_of_f32((like0 + like1) + like2, tab);
+    return (like0 + like1) + like2;
 }
 
 __device__ __forceinline__ double wave_sum(double x)
@@ -189,38 +193,68 @@ __device__ __forceinline__ double wave_sum(double x)
     return x;
 }
 
-template <int KB, int NP, int MODE, bool PER_IND>
-__global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
-{
-    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
-    const double2 *tab = load_log_table(tab_lds);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int npg = (A.npairs + NP - 1) / NP;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-    const int pg = (int)(wid % npg);
-    const int64_t tr = wid / npg;
-    const int64_t ntiles = (A.m + 63) >> 6;
-    const int64_t t0 = tr * A.tiles_per_wave;
-    int64_t t1 = t0 + A.tiles_per_wave;
-    if (t1 > ntiles) t1 = ntiles;
-    if (t0 >= t1) return;
+constexpr unsigned FP_POS_FINITE = 0x0100 | 0x0080;        // +normal | +subnormal: the arguments log_f32arg handles
 
+// What one wavefront works on: decoded once, wave-uniform.
+template <int NP>
+struct WaveWork {
+    ScoreSlab sl;
+    int64_t blk, t0, t1;
+    int pg;                        // pair group within the slab
     int ind[NP][2];
     bool ok[NP][2];
     int pairc[NP];
+};
+
+template <int NP>
+__device__ __forceinline__ bool decode_wave(const ScoreArgs &A, WaveWork<NP> &w)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+    const int pgg = (int)(wid % A.total_pg);
+    w.blk = wid / A.total_pg;
+    if (w.blk >= A.nblocks) return false;
+    int g = 0;
+    while (g + 1 < A.n_slabs && pgg >= A.slabs[g + 1].pg0) ++g;
+    w.sl = A.slabs[g];
+    const int pg = w.pg = pgg - w.sl.pg0;
+    const int64_t ntiles = (A.m + 63) >> 6;
+    w.t0 = w.blk * WGS_BLOCK_TILES;
+    w.t1 = w.t0 + WGS_BLOCK_TILES < ntiles ? w.t0 + WGS_BLOCK_TILES : ntiles;
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-        const int pair = pg * NP + q;
-        pairc[q] = pair < A.npairs ? pair : A.npairs - 1;
+        const int pair = w.sl.pair0 + pg * NP + q;
+        w.pairc[q] = pair < w.sl.npairs ? pair : w.sl.npairs - 1;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            ok[q][h] = 2 * pair + h < A.ncols;
-            ind[q][h] = A.members[ok[q][h] ? 2 * pair + h : 0];
+            const int col = 2 * pair + h;
+            w.ok[q][h] = col >= w.sl.col_lo && col < w.sl.col_hi;
+            w.ind[q][h] = w.sl.members[w.ok[q][h] ? col : w.sl.col_lo];
         }
     }
+    return true;
+}
+
+// Register budget: 3 waves per SIMD (<= 168 VGPRs) with shared columns, 2 (<= 256) with the per-individual
+// pointer and frequency tables of leave-one-out; beyond 256 the compiler would shuttle values through AGPRs.
+#ifndef WGS_SWEEP_MIN_BLOCKS
+#define WGS_SWEEP_MIN_BLOCKS 3
+#endif
+template <int KB, int NP, int MODE, bool PER_IND>
+__global__ __launch_bounds__(256, (PER_IND || KB * NP > 10) ? 2 : WGS_SWEEP_MIN_BLOCKS) void score_sweep_kernel(ScoreArgs A)
+{
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    const double2 *tab = load_log_table(tab_lds);
+    const int lane = threadIdx.x & 63;
+    WaveWork<NP> w;
+    if (!decode_wave<NP>(A, w)) return;
+    const float4 *slab = w.sl.slab;
+    const int npairs = w.sl.npairs;
+    const int64_t t0 = w.t0, t1 = w.t1;
 
     for (int kb = 0; kb < A.K; kb += KB) {
-        gf32_ptr ptr[PER_IND ? NP * 2 * KB : KB];
+        constexpr int NA = PER_IND ? NP * 2 * KB : KB;
+        gf32_ptr ptr[NA];
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
             const int k = kb + j < A.K ? kb + j : A.K - 1;
@@ -228,7 +262,7 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) ptr[(q * 2 + h) * KB + j] = (gf32_ptr)A.colptr[(int64_t)ind[q][h] * A.K + k];
+                    for (int h = 0; h < 2; ++h) ptr[(q * 2 + h) * KB + j] = (gf32_ptr)A.colptr[(int64_t)w.ind[q][h] * A.K + k];
             } else {
                 ptr[j] = (gf32_ptr)A.acol[k];
             }
@@ -241,26 +275,30 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
 #pragma unroll
                 for (int j = 0; j < KB; ++j) acc[q][h][j] = 0.0;
 
-        // One tile ahead: the GLs and frequencies of tile t+1 are requested before tile t is
-        // consumed (a wave owns a long tile range and only ~4 waves share a SIMD, so nothing else
-        // hides the load latency: un-prefetched, 46 % of the wave cycles were spent in s_waitcnt).
-        constexpr int NA = PER_IND ? NP * 2 * KB : KB;
+        // One tile ahead: the GLs and frequencies of tile t+1 are requested before tile t is consumed
+        // (only ~3 waves share a SIMD, so nothing else hides the load latency).
         float4 g_cur[NP], g_nxt[NP];
         float a_cur[NA], a_nxt[NA];
         auto fetch = [&](int64_t t, float4 *gq, float *aq) {
             const int64_t s = (t << 6) + lane;
             const int64_t sc = s < A.m ? s : A.m - 1;          // clamped index; dead lanes are neutralised below
 #pragma unroll
-            for (int q = 0; q < NP; ++q) gq[q] = A.slab[((t * A.npairs + pairc[q]) << 6) + lane];
+            for (int q = 0; q < NP; ++q) gq[q] = slab[((t * npairs + w.pairc[q]) << 6) + lane];
 #pragma unroll
             for (int x = 0; x < NA; ++x) aq[x] = ptr[x][sc];
         };
-        fetch(t0, g_cur, a_cur);
-        for (int64_t t = t0; t < t1; ++t) {
-            if (t + 1 < t1) fetch(t + 1, g_nxt, a_nxt);        // wave-uniform
-            const bool live = ((t << 6) + lane) < A.m;
-            // Lanes past the last SNP (only in the final tile) are given g = (1, 0) and a = 0, for
-            // which the site likelihood is exactly 1 and its log exactly 0: no masking per term.
+        // One tile.  MASKED (only the last, partial tile of the matrix): lanes past the last SNP are given
+        // g = (1, 0) and a = 0, for which the site likelihood is exactly 1 and its log exactly 0.
+        // FIX = false is the hot path: log_f32arg on every sum, whatever it is; the sums that are not
+        // positive finite numbers (0 -> -inf, negative or NaN -> NaN; +inf cannot arise) are noted in
+        // `plain` and the tile is visited again with FIX = true, which adds libm's special value for
+        // exactly those terms.  That is exact: log_f32arg returns a FINITE value for +-0 and +inf, and
+        // finite + (+-inf or NaN) is the same whatever the finite part was; for negative or NaN sums
+        // the result must be NaN and the special value added is NaN.
+        auto tile = [&](int64_t t, auto masked_tag, auto fix_tag) -> bool {
+            constexpr bool MASKED = decltype(masked_tag)::value, FIX = decltype(fix_tag)::value;
+            const bool live = !MASKED || ((t << 6) + lane) < A.m;
+            bool plain = true;
             double ad[KB], oma[KB];
             float af[KB];
             if (!PER_IND) {
@@ -280,26 +318,38 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
                     const double g0d = (double)gl[h][0], g1d = (double)gl[h][1];
                     const double g1d2 = g1d * 2.0, g2d = (1.0 - g0d) - g1d;
                     const float g2f = (1.0f - gl[h][0]) - gl[h][1];
-                    // all KB slots are computed (slots past K repeat population K-1 and are dropped
-                    // in the epilogue): the tile body stays one basic block the scheduler can interleave
+                    // all KB slots are computed (slots past K repeat population K-1 and are dropped in the
+                    // epilogue): the tile body stays one basic block the scheduler can interleave
 #pragma unroll
                     for (int j = 0; j < KB; ++j) {
-                        float v;
-                        if (PER_IND) {
-                            const float a = live ? a_cur[(q * 2 + h) * KB + j] : 0.0f;
-                            if (MODE == WGS_MODE_EXACT) {
-                                const double a_d = (double)a;
-                                v = site_ll_exact2(g0d, g1d2, g2d, a_d, 1.0 - a_d, tab);
+                        const float a = PER_IND ? (live ? a_cur[(q * 2 + h) * KB + j] : 0.0f) : af[j];
+                        if (MODE == WGS_MODE_EXACT) {
+                            const double a_d = PER_IND ? (double)a : ad[j];
+                            const float s = like_sum_exact(g0d, g1d2, g2d, a_d, PER_IND ? 1.0 - a_d : oma[j]);
+                            const bool fin = __builtin_isfpclass(s, FP_POS_FINITE);
+                            if (FIX) {
+                                if (!fin) acc[q][h][j] += (double)__builtin_amdgcn_logf(s);
                             } else {
-                                v = site_ll_fast(gl[h][0], gl[h][1], g2f, a);
+                                plain = plain && fin;
+                                acc[q][h][j] += (double)(float)log_f32arg((double)s, tab);
                             }
                         } else {
-                            v = MODE == WGS_MODE_EXACT ? site_ll_exact2(g0d, g1d2, g2d, ad[j], oma[j], tab)
-                                                       : site_ll_fast(gl[h][0], gl[h][1], g2f, af[j]);
+                            acc[q][h][j] += (double)site_ll_fast(gl[h][0], gl[h][1], g2f, a);
                         }
-                        acc[q][h][j] += (double)v;
                     }
                 }
+            }
+            return plain;
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        fetch(t0, g_cur, a_cur);
+        for (int64_t t = t0; t < t1; ++t) {
+            if (t + 1 < t1) fetch(t + 1, g_nxt, a_nxt);
+            const bool partial = ((t + 1) << 6) > A.m;
+            const bool plain = partial ? tile(t, T{}, F{}) : tile(t, F{}, F{});
+            if (MODE == WGS_MODE_EXACT && !__all(plain)) {       // rare: a likelihood sum of exactly 0, or NaN data
+                if (partial) tile(t, T{}, T{}); else tile(t, F{}, T{});
             }
 #pragma unroll
             for (int q = 0; q < NP; ++q) g_cur[q] = g_nxt[q];
@@ -314,19 +364,287 @@ __global__ __launch_bounds__(256) void assign_snp_kernel(AssignArgs A)
                 for (int j = 0; j < KB; ++j) {
                     if (kb + j < A.K) {
                         const double tot = wave_sum(acc[q][h][j]);
-                        if (lane == 0 && ok[q][h]) atomicAdd(&A.out[(int64_t)ind[q][h] * A.K + kb + j], tot);
+                        if (lane == 0 && w.ok[q][h]) A.S[w.blk * A.cells + (int64_t)w.ind[q][h] * A.K + kb + j] = tot;
                     }
                 }
     }
 }
 
-// ---- exact partition sums ----------------------------------------------------------------------
-// utils.py:147-149: labels = arange(m) % P; np.add.at(zeros(P, float32), labels, per_site_ll) -- a
-// SERIAL float32 accumulation per partition in site order.  Reproduced literally: one lane owns one
-// (individual, population, partition) chain and walks the partition's sites of this shard in
-// order, starting from the float32 carry of the previous shard.  Parallelism is across the
-// n x K x P chains only, so the time is ~ (m / P) x one site's latency -- the price of bit-exact
-// partition sums; the float64 sums of the sweeps above are the fast alternative.
+// out[cell] = sum over blocks of S[block][cell], added in block order (reproducible); with keep_prefix
+// S[block][cell] is replaced by the sum of the blocks before it (what the chain prediction needs).
+__global__ __launch_bounds__(256) void block_prefix_kernel(double *__restrict__ S, int nblocks, int64_t cells, double *__restrict__ out,
+                                                           int keep_prefix)
+{
+    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= cells) return;
+    double run = 0.0;
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = S[(int64_t)(b + u) * cells + cell];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (keep_prefix) S[(int64_t)(b + u) * cells + cell] = run;
+            run += v[u];
+        }
+    }
+    for (; b < nblocks; ++b) {
+        const double v = S[(int64_t)b * cells + cell];
+        if (keep_prefix) S[(int64_t)b * cells + cell] = run;
+        run += v;
+    }
+    out[cell] = run;
+}
+
+// ---- exact partition sums, block-parallel ----------------------------------------------------------
+// utils.py:147-149: labels = arange(m) % P; np.add.at(zeros(P, float32), labels, per_site_ll) is a
+// SERIAL float32 accumulation per partition in site order.  The per-site values v are <= 0 (logs of
+// likelihoods <= 1), so the running sum only grows in magnitude and round-to-nearest-even is symmetric
+// in sign: on magnitudes this is the chain of the convergence metric (em_kernels.hip, rmse_*), and the
+// same decomposition applies.  While |R| stays in one binade it is M * u (u its ulp, M a 24-bit
+// integer) and adding |v| adds the INTEGER RN(|v| / u), which depends on M only at exact ties.  A block
+// of sites without a tie therefore adds a fixed integer D -- a plain, order-free sum -- to M.
+//
+//   chain_cand_kernel  (same sweep as above, one block per wave) forms D for every (individual,
+//                      population, partition, block) on the ulp grid PREDICTED for that block from the
+//                      float64 prefix sums of the sweep: RN(|v| / u) * u = fl(X0 + |v|) - X0 with
+//                      X0 = 2^e, two float32 operations; the rounding error |v| - that is exact, and a
+//                      tie is an error of exactly u / 2.  A block with a tie, a positive or non-finite
+//                      value, or a sum that leaves the binade is marked.
+//   chain_walk_kernel  one wavefront per chain walks the blocks: M += D when the running value really
+//                      is in the predicted binade and stays in it, else that ONE block is redone with
+//                      the literal serial loop (binade crossings, ties, the first blocks).
+// Bit-identical to the serial loop by construction; a wrong prediction costs speed only.
+constexpr unsigned CAND_BAD = 0x80000000u;      // packed word: bad << 31 | biased exponent << 23 | D (< 2^23); 0 = no sites
+
+template <int KB, int NP, bool PER_IND>
+__global__ __launch_bounds__(256, 2) void chain_cand_kernel(ScoreArgs A)
+{
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    extern __shared__ unsigned cand_lds[];                   // [4 waves][2][CW * P]: D sums | exponent + flags
+    const double2 *tab = load_log_table(tab_lds);
+    const int lane = threadIdx.x & 63;
+    WaveWork<NP> w;
+    if (!decode_wave<NP>(A, w)) return;
+    const float4 *slab = w.sl.slab;
+    const int npairs = w.sl.npairs;
+    const int64_t t0 = w.t0, t1 = w.t1;
+    const int P = A.P, period = A.period;
+    const double invP = 1.0 / (double)P;
+    constexpr int CW = NP * 2 * KB;
+    unsigned *wD = cand_lds + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 2 * CW * P;
+    unsigned *wF = wD + CW * P;
+
+    for (int kb = 0; kb < A.K; kb += KB) {
+        constexpr int NA = PER_IND ? NP * 2 * KB : KB;
+        gf32_ptr ptr[NA];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+            const int k = kb + j < A.K ? kb + j : A.K - 1;
+            if (PER_IND) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) ptr[(q * 2 + h) * KB + j] = (gf32_ptr)A.colptr[(int64_t)w.ind[q][h] * A.K + k];
+            } else {
+                ptr[j] = (gf32_ptr)A.acol[k];
+            }
+        }
+        for (int e = lane; e < 2 * CW * P; e += 64) wD[e] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // tiles t0 + c, t0 + c + period, ...: in each such class a lane's partition label is constant
+        for (int c = 0; c < period && t0 + c < t1; ++c) {
+            const int label = (int)((A.site0 + ((t0 + c) << 6) + lane) % P);
+            float X0[NP][2][KB], acc[NP][2][KB], emax[NP][2][KB];
+            float vmax = 0.0f;
+            bool plain = true;          // every likelihood sum of this lane was a positive finite number
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        const int k = kb + j < A.K ? kb + j : A.K - 1;
+                        const int64_t cell = (int64_t)w.ind[q][h] * A.K + k;
+                        // running value predicted at the start of this block: an equal share of the
+                        // float64 sums of everything before it (preceding shards + preceding blocks)
+                        const double before = (A.start ? A.start[cell] : 0.0) + A.S[w.blk * A.cells + cell];
+                        const float est = (float)(before * invP);
+                        const unsigned eb = (__float_as_uint(est) >> 23) & 0xFF;
+                        const bool known = est < 0.0f && eb >= 30 && eb <= 253;        // u/2 = 2^(eb-151) stays a normal float32
+                        X0[q][h][j] = known ? __uint_as_float(eb << 23) : 0.0f;   // 2^e; 0 marks "no prediction"
+                        acc[q][h][j] = 0.0f;
+                        emax[q][h][j] = 0.0f;
+                    }
+            float4 g_cur[NP], g_nxt[NP];
+            float a_cur[NA], a_nxt[NA];
+            auto fetch = [&](int64_t t, float4 *gq, float *aq) {
+                const int64_t s = (t << 6) + lane;
+                const int64_t sc = s < A.m ? s : A.m - 1;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) gq[q] = slab[((t * npairs + w.pairc[q]) << 6) + lane];
+#pragma unroll
+                for (int x = 0; x < NA; ++x) aq[x] = ptr[x][sc];
+            };
+            fetch(t0 + c, g_cur, a_cur);
+            for (int64_t t = t0 + c; t < t1; t += period) {
+                if (t + period < t1) fetch(t + period, g_nxt, a_nxt);
+                const bool live = ((t << 6) + lane) < A.m;
+                double ad[KB], oma[KB];
+                if (!PER_IND) {
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        ad[j] = (double)(live ? a_cur[j] : 0.0f);
+                        oma[j] = 1.0 - ad[j];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const float4 g = g_cur[q];
+                    const float gl[2][2] = {{live ? g.x : 1.0f, live ? g.y : 0.0f}, {live ? g.z : 1.0f, live ? g.w : 0.0f}};
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const double g0d = (double)gl[h][0], g1d = (double)gl[h][1];
+                        const double g1d2 = g1d * 2.0, g2d = (1.0 - g0d) - g1d;
+#pragma unroll
+                        for (int j = 0; j < KB; ++j) {
+                            const double a_d = PER_IND ? (double)(live ? a_cur[(q * 2 + h) * KB + j] : 0.0f) : ad[j];
+                            const float s = like_sum_exact(g0d, g1d2, g2d, a_d, PER_IND ? 1.0 - a_d : oma[j]);
+                            // v = the float32 the reference stores for this site -- unless s is 0, negative or
+                            // NaN (log_f32arg is not defined there): such a lane marks its blocks instead
+                            plain = plain && __builtin_isfpclass(s, FP_POS_FINITE);
+                            const float v = (float)log_f32arg((double)s, tab);
+                            const float mag = -v;                               // >= 0 for every likelihood <= 1
+                            const float r = (X0[q][h][j] + mag) - X0[q][h][j];  // RN(mag / u) * u on the predicted grid
+                            acc[q][h][j] += r;                                  // exact while the block stays in the binade
+                            emax[q][h][j] = __builtin_fmaxf(emax[q][h][j], __builtin_fabsf(mag - r));
+                            vmax = __builtin_fmaxf(vmax, v);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NP; ++q) g_cur[q] = g_nxt[q];
+#pragma unroll
+                for (int x = 0; x < NA; ++x) a_cur[x] = a_nxt[x];
+            }
+            // this lane's share of its (cell, label) block functions -> LDS (integer adds: order-free)
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < KB; ++j) {
+                        const float x0 = X0[q][h][j], a = acc[q][h][j];
+                        const unsigned eb = __float_as_uint(x0) >> 23;
+                        // bad: no prediction; left the binade / non-finite (a < x0 fails for NaN and inf too);
+                        // a tie (rounding error exactly u/2 = x0 * 2^-24); a positive value
+                        const bool bad = !(x0 > 0.0f) || !(a < x0) || emax[q][h][j] == x0 * 0x1p-24f || vmax > 0.0f || !plain;
+                        const unsigned D = bad ? 0u : (unsigned)__builtin_ldexpf(a, 150 - (int)eb);
+                        const int slot = ((q * 2 + h) * KB + j) * P + label;
+                        atomicAdd(&wD[slot], D);
+                        atomicOr(&wF[slot], (bad ? CAND_BAD : 0u) | (eb << 23) | 1u);     // bit 0: the label has sites here
+                    }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e = lane; e < CW * P; e += 64) {
+            const int cellslot = e / P, p = e - cellslot * P;
+            const int j = cellslot % KB, qh = cellslot / KB;
+            const int col = 2 * (w.sl.pair0 + w.pg * NP + qh / 2) + (qh & 1);
+            if (kb + j >= A.K || col < w.sl.col_lo || col >= w.sl.col_hi) continue;
+            const int ind = w.sl.members[col];
+            const unsigned F = wF[e], D = wD[e];
+            unsigned word = 0;
+            if (F & 1u) word = ((F & CAND_BAD) || D >= (1u << 23)) ? CAND_BAD : ((F & 0x7F800000u) | D);
+            A.cand[(((int64_t)ind * P + p) * A.K + kb + j) * A.nblocks + w.blk] = word;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One wavefront per chain (individual, partition, population).  All 64 lanes hold the same running
+// value; the serial fallback of a block computes its per-site values 64 at a time into LDS.
+constexpr int WALK_CHUNK = 1024;
+__global__ __launch_bounds__(256) void chain_walk_kernel(WalkArgs W)
+{
+    __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
+    __shared__ float sq_all[4][WALK_CHUNK];
+    const double2 *tab = load_log_table(tab_lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nchains = (int64_t)W.n * W.P * W.K;
+    const int64_t chain = (int64_t)blockIdx.x * 4 + wave;
+    if (chain >= nchains) return;
+    const int k = (int)(chain % W.K);
+    const int64_t ip = chain / W.K;
+    const int p = (int)(ip % W.P), ind = (int)(ip / W.P);
+    if (ind < W.row_lo || ind >= W.row_hi) return;
+    float *sq = sq_all[wave];
+    const int g = W.group_of[ind], col = W.col_of[ind], npairs = W.npairs[g];
+    const float2 *slab2 = reinterpret_cast<const float2 *>(W.base[g]);
+    gf32_ptr ptr = (gf32_ptr)(W.colptr ? W.colptr[(int64_t)ind * W.K + k] : W.acol[k]);
+    const int64_t pair_off = (int64_t)(col >> 1) * 64, half = col & 1;
+    float res = W.carry ? W.carry[chain] : 0.0f;
+    const unsigned *cw = W.cand + chain * W.nblocks;
+    int serial = 0;
+    for (int b0 = 0; b0 < W.nblocks && res == res; b0 += 64) {      // NaN + anything = NaN: nothing left to do
+        const unsigned mine = b0 + lane < W.nblocks ? cw[b0 + lane] : 0u;
+        const int nb = W.nblocks - b0 < 64 ? W.nblocks - b0 : 64;
+        for (int jb = 0; jb < nb && res == res; ++jb) {
+            const unsigned word = __builtin_amdgcn_readlane(mine, jb);
+            if (word == 0u) continue;                               // no site of this partition in the block
+            const unsigned bits = __float_as_uint(res);
+            if (!(word & CAND_BAD) && (bits >> 31) && ((bits >> 23) & 0xFF) == ((word >> 23) & 0xFF)) {
+                const unsigned M = (bits & 0x7FFFFFu) | 0x800000u, D = word & 0x7FFFFFu;
+                if (M + D < (1u << 24)) {
+                    res = __uint_as_float((bits & 0xFF800000u) | ((M + D) & 0x7FFFFFu));
+                    continue;
+                }
+            }
+            // the literal serial loop for this block: sites s of [64 * 64 * b, ...) with (site0 + s) % P == p
+            ++serial;
+            const int64_t lo = (int64_t)(b0 + jb) * WGS_BLOCK_TILES * 64;
+            int64_t hi = lo + WGS_BLOCK_TILES * 64;
+            if (hi > W.m) hi = W.m;
+            const int64_t first = lo + (((p - (W.site0 + lo)) % W.P) + W.P) % W.P;
+            for (int64_t c0 = first; c0 < hi; c0 += (int64_t)WALK_CHUNK * W.P) {
+                int cnt = 0;
+#pragma unroll 4
+                for (int r = 0; r < WALK_CHUNK / 64; ++r) {
+                    const int64_t s = c0 + (int64_t)(r * 64 + lane) * W.P;
+                    float v = 0.0f;
+                    if (s < hi) {
+                        const float2 gg = slab2[((((s >> 6) * npairs) << 6) + pair_off + (s & 63)) * 2 + half];
+                        const double g0d = (double)gg.x, g1d = (double)gg.y;
+                        v = site_ll_exact(g0d, g1d, (1.0 - g0d) - g1d, ptr[s], tab);
+                    }
+                    sq[r * 64 + lane] = v;
+                }
+                {
+                    const int64_t left = (hi - c0 + W.P - 1) / W.P;
+                    cnt = left < WALK_CHUNK ? (int)left : WALK_CHUNK;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int t = 0; t < cnt; ++t) res = res + sq[t];          // float32 += float32, site order
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    if (lane == 0) {
+        W.parts[chain] = res;
+        if (W.n_serial && serial) atomicAdd(W.n_serial, serial);
+    }
+}
+
+// ---- exact partition sums, literal version -----------------------------------------------------------
+// One lane owns one (individual, population, partition) chain and walks the partition's sites of this
+// shard in order, starting from the float32 carry of the previous shard.  Parallelism is across the
+// n x K x P chains only, so the time is ~ (m / P) x one site's latency.  Kept as the in-device
+// cross-check of the block-parallel chains above and for P > 64 (many short chains).
 __global__ __launch_bounds__(64) void parts_exact_kernel(AssignArgs A, const PartsSlab *__restrict__ slabs, int n_slabs,
                                                          const float *__restrict__ carry, float *__restrict__ parts)
 {
@@ -436,33 +754,6 @@ __global__ void log_values_kernel(const float *x, float *out, int64_t n, int use
     for (; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = use_libm ? (float)log((double)x[i]) : logf_of_f32(x[i], tab);
 }
 
-template <int KB, int NP>
-int launch_assign_snp(wgs_ctx *ctx, AssignArgs a, int mode)
-{
-    // waves = pair groups x tile ranges; aim at ~32 waves per CU with ranges of >= 8 tiles
-    const int npg = (a.npairs + NP - 1) / NP;
-    const int64_t ntiles = wgs_ntiles(a.m);
-    int64_t ranges = ((int64_t)ctx->cus * 32 + npg - 1) / npg;
-    if (ranges < 1) ranges = 1;
-    int64_t tpw = (ntiles + ranges - 1) / ranges;
-    if (tpw < 8) tpw = 8;
-    if (tpw > ntiles) tpw = ntiles;
-    a.tiles_per_wave = (int32_t)tpw;
-    ranges = (ntiles + tpw - 1) / tpw;
-    const int64_t waves = ranges * npg;
-    dim3 grid((unsigned)((waves + 3) / 4));
-    const bool per_ind = a.colptr != nullptr;
-#define WGS_LAUNCH(M, PI) hipLaunchKernelGGL((assign_snp_kernel<KB, NP, M, PI>), grid, dim3(256), 0, ctx->stream, a)
-    if (mode == WGS_MODE_EXACT) {
-        if (per_ind) WGS_LAUNCH(WGS_MODE_EXACT, true); else WGS_LAUNCH(WGS_MODE_EXACT, false);
-    } else {
-        if (per_ind) WGS_LAUNCH(WGS_MODE_FAST, true); else WGS_LAUNCH(WGS_MODE_FAST, false);
-    }
-#undef WGS_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 template <int KB>
 int launch_assign_kb(wgs_ctx *ctx, const AssignArgs &a, int mode, dim3 grid)
 {
@@ -478,11 +769,10 @@ int launch_assign_kb(wgs_ctx *ctx, const AssignArgs &a, int mode, dim3 grid)
 
 static int ensure_log_table(wgs_ctx *ctx)
 {
-    // one upload per process and device (the table lives in the code object's __device__ memory)
-    static thread_local int done_for = -1;
-    if (done_for == ctx->device) return 0;
+    // one upload per context (the table lives in the code object's __device__ memory of the context's device)
+    if (ctx->log_table_ready) return 0;
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wgs_log_table_dev), wgs_log_table_host, sizeof(double) * 2 * WGS_LOG_N));
-    done_for = ctx->device;
+    ctx->log_table_ready = true;
     return 0;
 }
 
@@ -502,6 +792,26 @@ int launch_log_values(wgs_ctx *ctx, const float *d_x, float *d_out, int64_t n, i
     return 0;
 }
 
+// KB = populations per register batch: the batch size with the fewest passes over K, then the least padding
+static int pick_kb(int K)
+{
+    int best = 4, best_cost = 1 << 30;
+    for (int kb = 4; kb <= 8; ++kb) {
+        const int passes = (K + kb - 1) / kb;
+        const int cost = passes * 1000 + passes * kb - K;
+        if (cost < best_cost) best_cost = cost, best = kb;
+    }
+    return best;
+}
+
+// NP = 2 pairs per wave halves the per-tile frequency loads/conversions per term (measured 174 -> 150 ms at
+// K = 10, KB = 5); for KB >= 7 it only costs occupancy (KB = 10 in one pass measured slower than two of 5).
+int score_pairs_per_wave(int K) { return pick_kb(K) <= 6 ? 2 : 1; }
+// The chain kernel keeps three float32 per (cell, lane) instead of one float64; with per-individual columns
+// its pointer and frequency tables leave room for one pair only.
+int chain_pairs_per_wave(int K, bool per_ind) { return per_ind ? 1 : score_pairs_per_wave(K); }
+
+// The float64 partition sums of WGSASSIGN_PARTS=fast (P > 1): lane <-> individual pair, one slab per launch.
 int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
 {
     if (ensure_log_table(ctx)) return 1;
@@ -518,33 +828,93 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
     a.tiles_per_wave = (int32_t)(tpw > 0x7fffffff ? 0x7fffffff : tpw);
     const int64_t waves = (ntiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
     dim3 grid((unsigned)((waves + 3) / 4), (unsigned)pairblocks);
-    // KB = populations per register batch: pick the batch size with the fewest passes, then the least padding
-    int best = 4, best_cost = 1 << 30;
-    for (int kb = 4; kb <= 8; ++kb) {
-        const int passes = (a.K + kb - 1) / kb;
-        const int cost = passes * 1000 + passes * kb - a.K;
-        if (cost < best_cost) best_cost = cost, best = kb;
-    }
-    if (a.P == 1) {
-        // NP = 2 pairs per wave halves the per-tile frequency loads/conversions per term; measured
-        // 174 -> 150 ms at K = 10 (KB = 5).  For KB >= 7 it only costs occupancy (measured equal at
-        // K = 8; KB = 10 in one pass measured slower than two passes of 5), so NP = 1 there.
-        const bool np2 = a.npairs >= 2;
-        switch (best) {
-            case 4: return np2 ? launch_assign_snp<4, 2>(ctx, a, mode) : launch_assign_snp<4, 1>(ctx, a, mode);
-            case 5: return np2 ? launch_assign_snp<5, 2>(ctx, a, mode) : launch_assign_snp<5, 1>(ctx, a, mode);
-            case 6: return np2 ? launch_assign_snp<6, 2>(ctx, a, mode) : launch_assign_snp<6, 1>(ctx, a, mode);
-            case 7: return launch_assign_snp<7, 1>(ctx, a, mode);
-            default: return launch_assign_snp<8, 1>(ctx, a, mode);
-        }
-    }
-    switch (best) {
+    switch (pick_kb(a.K)) {
         case 4: return launch_assign_kb<4>(ctx, a, mode, grid);
         case 5: return launch_assign_kb<5>(ctx, a, mode, grid);
         case 6: return launch_assign_kb<6>(ctx, a, mode, grid);
         case 7: return launch_assign_kb<7>(ctx, a, mode, grid);
         default: return launch_assign_kb<8>(ctx, a, mode, grid);
     }
+}
+
+#define WGS_FOR_KB_NP(X, K)                \
+    switch (pick_kb(K)) {                  \
+        case 4: X(4, 2); break;            \
+        case 5: X(5, 2); break;            \
+        case 6: X(6, 2); break;            \
+        case 7: X(7, 1); break;            \
+        default: X(8, 1); break;           \
+    }
+
+int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode)
+{
+    if (a.m <= 0 || a.total_pg <= 0 || a.K <= 0 || a.nblocks <= 0) return 0;
+    if (ensure_log_table(ctx)) return 1;
+    const int64_t waves = (int64_t)a.total_pg * a.nblocks;
+    WGS_REQUIRE(waves < (1ll << 32), "scoring sweep: too many work units for one launch");
+    dim3 grid((unsigned)((waves + 3) / 4));
+    const bool per_ind = a.colptr != nullptr;
+#define WGS_SWEEP(KB, NP)                                                                                                      \
+    do {                                                                                                                       \
+        if (mode == WGS_MODE_EXACT) {                                                                                          \
+            if (per_ind) hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_EXACT, true>), grid, dim3(256), 0, ctx->stream, a);  \
+            else hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_EXACT, false>), grid, dim3(256), 0, ctx->stream, a);         \
+        } else {                                                                                                               \
+            if (per_ind) hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_FAST, true>), grid, dim3(256), 0, ctx->stream, a);   \
+            else hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_FAST, false>), grid, dim3(256), 0, ctx->stream, a);          \
+        }                                                                                                                      \
+    } while (0)
+    WGS_FOR_KB_NP(WGS_SWEEP, a.K)
+#undef WGS_SWEEP
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix)
+{
+    if (cells <= 0) return 0;
+    hipLaunchKernelGGL(block_prefix_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, S, nblocks, cells, out,
+                       keep_prefix);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t chain_cand_lds_bytes(int K, int P, bool per_ind)
+{
+    const int kb = pick_kb(K), np = chain_pairs_per_wave(K, per_ind);
+    return (size_t)4 * 2 * (np * 2 * kb) * P * sizeof(unsigned);
+}
+
+int launch_chain_cand(wgs_ctx *ctx, const ScoreArgs &a)
+{
+    if (a.m <= 0 || a.total_pg <= 0 || a.K <= 0 || a.nblocks <= 0) return 0;
+    if (ensure_log_table(ctx)) return 1;
+    const int64_t waves = (int64_t)a.total_pg * a.nblocks;
+    WGS_REQUIRE(waves < (1ll << 32), "partition chains: too many work units for one launch");
+    dim3 grid((unsigned)((waves + 3) / 4));
+    const bool per_ind = a.colptr != nullptr;
+    const size_t lds = chain_cand_lds_bytes(a.K, a.P, per_ind);
+    WGS_REQUIRE(lds <= 96 * 1024, "partition chains: too many partitions for the block-parallel kernel");
+#define WGS_CAND(KB, NP)                                                                                              \
+    do {                                                                                                              \
+        if (per_ind) hipLaunchKernelGGL((chain_cand_kernel<KB, 1, true>), grid, dim3(256), lds, ctx->stream, a);      \
+        else hipLaunchKernelGGL((chain_cand_kernel<KB, NP, false>), grid, dim3(256), lds, ctx->stream, a);            \
+    } while (0)
+    WGS_FOR_KB_NP(WGS_CAND, a.K)
+#undef WGS_CAND
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_chain_walk(wgs_ctx *ctx, const WalkArgs &w)
+{
+    const int64_t nchains = (int64_t)w.n * w.P * w.K;
+    if (nchains <= 0 || w.m <= 0) return 0;
+    if (ensure_log_table(ctx)) return 1;
+    WGS_REQUIRE(nchains < (1ll << 32), "partition chains: too many chains for one launch");
+    hipLaunchKernelGGL(chain_walk_kernel, dim3((unsigned)((nchains + 3) / 4)), dim3(256), 0, ctx->stream, w);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // a: the fields common to all slabs (colptr, acol, m, site0, K, P); d_slabs: n_slabs descriptors with

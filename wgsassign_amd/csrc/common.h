@@ -47,6 +47,10 @@ struct wgs_ctx {
     int cus = 0;
     void *ws = nullptr;      // grow-only device workspace (assignment outputs / pointer tables)
     size_t ws_bytes = 0;
+    // per-context state that must not be shared between contexts on different devices
+    bool log_table_ready = false;               // the log table of assign_kernels.hip is uploaded to this device
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // bracket the scoring kernels of the last wgs_assign / wgs_score_*
+    float last_assign_ms = 0.0f;
 };
 // Device workspace of at least `bytes` (256-byte aligned); contents are not preserved across calls.
 int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out);
@@ -138,6 +142,54 @@ struct PartsSlab {     // one population slab inside the single exact-partition 
 };
 int launch_parts_exact(wgs_ctx *ctx, const AssignArgs &a, const PartsSlab *d_slabs, int n_slabs, int total_blocks,
                        const float *d_carry, float *d_parts);
+
+// ---- scoring: all n x K sums in one launch over a table of population slabs ----------------------
+// A launch scores the individuals [row_lo, row_hi) (file order; all of them in the common case).  The
+// work unit of a wavefront is (pair group, block): NP pairs of slab columns x one BLOCK of
+// WGS_BLOCK_TILES tiles (4096 SNPs).  Its float64 sums over the block are STORED to S[block][cell]
+// (cell = individual * K + population) -- one writer per element, no atomics, so the n x K sums
+// (S added over blocks in block order) are reproducible bit for bit.  The same block structure
+// carries the exact partition chains (see chain_cand_kernel).
+constexpr int WGS_BLOCK_TILES = 64;            // tiles per block: 4096 SNPs
+struct ScoreSlab {
+    const float4 *slab;
+    const int32_t *members;        // slab column -> global individual
+    int32_t npairs, ncols;
+    int32_t pair0;                 // first pair holding a scored column
+    int32_t npg;                   // pair groups (NP pairs each) holding scored columns
+    int32_t pg0;                   // first launch-wide pair-group index of this slab
+    int32_t col_lo, col_hi;        // scored columns [col_lo, col_hi)
+};
+struct ScoreArgs {
+    const ScoreSlab *slabs;        // device
+    int32_t n_slabs, total_pg;
+    const float *const *colptr;    // device: [n*K] per-(individual, k) vectors, or nullptr
+    const float *const *acol;      // device: [K] shared vectors
+    int64_t m, site0, cells;       // cells = n * K
+    int32_t K, P, period;          // period = P / gcd(64, P): tiles t and t + period give a lane the same label
+    int32_t nblocks;
+    double *S;                     // device: [nblocks][cells] block sums, then exclusive prefixes
+    const double *start;           // device: [cells] sum over the preceding SNP shards (or nullptr)
+    uint32_t *cand;                // device: [cells * P][nblocks] packed block functions
+};
+struct WalkArgs {
+    const uint32_t *cand;          // [chains][nblocks]
+    const float *carry;            // [chains] running values after the preceding shards, or nullptr
+    float *parts;                  // [chains] out
+    const int32_t *group_of, *col_of, *npairs;   // per individual / per slab (wgs_beagle tables)
+    float4 *const *base;
+    const float *const *colptr, *const *acol;
+    int64_t m, site0;
+    int32_t n, K, P, nblocks, row_lo, row_hi;
+    int32_t *n_serial;             // device counter: blocks that took the literal serial loop (or nullptr)
+};
+int score_pairs_per_wave(int K);               // NP of the sweep for K populations (depends on the register batch KB)
+int chain_pairs_per_wave(int K, bool per_ind); // NP of the chain kernel (the slab table must be built for it)
+int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode);
+int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix);
+size_t chain_cand_lds_bytes(int K, int P, bool per_ind);
+int launch_chain_cand(wgs_ctx *ctx, const ScoreArgs &a);
+int launch_chain_walk(wgs_ctx *ctx, const WalkArgs &w);
 int launch_log_mismatch(wgs_ctx *ctx, unsigned int b0, unsigned int b1, unsigned long long *d_count, unsigned int *d_first);
 int launch_log_values(wgs_ctx *ctx, const float *d_x, float *d_out, int64_t n, int use_libm);
 int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *vec, int64_t m, int mode);

@@ -12,8 +12,6 @@
 //   lanes process the same individual at the same time, so the leave-one-out skip and the
 //   column bound are wave-uniform branches.  Loads for the next U pairs are issued before the
 //   current U pairs are consumed (register double buffer).
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -617,25 +615,13 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     const int64_t blocks = tgroups * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
     dim3 grid((unsigned)blocks);
-    static const int env_variant = getenv("WGS_EM_VARIANT") ? atoi(getenv("WGS_EM_VARIANT")) : 0;   // tuning experiments
-    const int variant = shared_slabs ? 5 : (env_variant == 5 ? 0 : env_variant);   // 5 = temporal loads + XCD-aware order
-#define WGS_EM_LAUNCH(M, UU, NTT) hipLaunchKernelGGL((em_sweep_kernel<M, UU, NTT>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m)
+    // U = 4 pairs per register buffer; nontemporal loads when every slab byte is used once (measured best of
+    // U in {2, 4, 8} x {temporal, nontemporal}), temporal loads + XCD-aware order when fits share slabs
+#define WGS_EM_LAUNCH(M, NTT) hipLaunchKernelGGL((em_sweep_kernel<M, 4, NTT>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m)
     if (mode == WGS_MODE_EXACT) {
-        switch (variant) {
-            case 2: WGS_EM_LAUNCH(WGS_MODE_EXACT, 8, false); break;
-            case 3: WGS_EM_LAUNCH(WGS_MODE_EXACT, 8, true); break;
-            case 4: WGS_EM_LAUNCH(WGS_MODE_EXACT, 2, false); break;
-            case 5: WGS_EM_LAUNCH(WGS_MODE_EXACT, 4, false); break;
-            default: WGS_EM_LAUNCH(WGS_MODE_EXACT, 4, true); break;      // measured best: U = 4, nontemporal loads
-        }
+        if (shared_slabs) WGS_EM_LAUNCH(WGS_MODE_EXACT, false); else WGS_EM_LAUNCH(WGS_MODE_EXACT, true);
     } else {
-        switch (variant) {
-            case 2: WGS_EM_LAUNCH(WGS_MODE_FAST, 8, false); break;
-            case 3: WGS_EM_LAUNCH(WGS_MODE_FAST, 8, true); break;
-            case 4: WGS_EM_LAUNCH(WGS_MODE_FAST, 2, false); break;
-            case 5: WGS_EM_LAUNCH(WGS_MODE_FAST, 4, false); break;
-            default: WGS_EM_LAUNCH(WGS_MODE_FAST, 4, true); break;
-        }
+        if (shared_slabs) WGS_EM_LAUNCH(WGS_MODE_FAST, false); else WGS_EM_LAUNCH(WGS_MODE_FAST, true);
     }
 #undef WGS_EM_LAUNCH
     HIP_TRY(hipGetLastError());

@@ -129,7 +129,10 @@ static bool parse_line(const wgs_reader *r, const Line &ln, float *out, std::str
     if (!next(tb, te)) return false;
     site->assign(tb, te);                                  // reader_cy.pyx:56-57
     if (!next(tb, te) || !next(tb, te)) return false;      // allele1, allele2 (reader_cy.pyx:59-60)
-    for (int i = 0; i < r->gl_cols; ++i) {
+    // a header whose GL column count is not a multiple of 3 leaves a partial individual: the reference
+    // parses those columns but only keeps the first 2 * (n // 3) values of each row (reader_cy.pyx:48-49,
+    // 71-75), so they are not read at all here -- every row is exactly 2 * n_inds floats
+    for (int i = 0; i < 3 * r->n_inds; ++i) {
         if (!next(tb, te)) return false;
         if ((i + 1) % 3 != 0) *out++ = (float)parse_double(tb, te);   // reader_cy.pyx:62-66
     }

@@ -199,7 +199,7 @@ class EMBatch:
     index) when >= 0 -- the leave-one-out re-fit of glassy.py:65-78.
     """
 
-    GUARD = 0.25   # relative half-width of the band in which the exact serial chain decides
+    GUARD = 0.0    # floor of the band in which the exact serial chain decides (see guard_band)
 
     def __init__(self, beagle, groups, skips=None, mode=None):
         self.b = beagle
@@ -265,6 +265,12 @@ class EMBatch:
         check(_lib.load().wgs_em_get_f(self._h, int(fit), f32p(out)))
         return out
 
+    def get_f_range(self, fit, row0, nrows, previous=False):
+        """Rows [row0, row0+nrows) of the current (or previous-iteration) frequencies of a fit."""
+        out = np.empty(int(nrows), dtype=np.float32)
+        check(_lib.load().wgs_em_get_f_range(self._h, int(fit), int(bool(previous)), int(row0), int(nrows), f32p(out)))
+        return out
+
     def set_f(self, fit, f):
         f = _as_f32c(f, "f")
         check(_lib.load().wgs_em_set_f(self._h, int(fit), f32p(f)))
@@ -290,7 +296,18 @@ class EMBatch:
             pass
 
 
-def decide_converged(ssq, m_total, tole, guard):
+def guard_band(m_total, guard=0.0):
+    """Relative half-width of the band around tole^2 * m in which the float64 sum cannot decide for the
+    reference's SERIAL FLOAT32 sum (emMAF_cy.pyx:30-31).  Every one of the m additions rounds by at most
+    half an ulp of its result, i.e. by <= F * 2^-24 with F the final float32 sum, so
+    |S - F| <= m * 2^-24 * F rigorously (S: exact sum): the band must grow with m -- at 10^7 SNPs it is
+    +-0.6, from 1.7*10^7 SNPs on the float32 sum may sit arbitrarily far BELOW the exact one (small terms
+    are absorbed) and only the upper edge remains.  `guard` is a floor (tests force the chain with 1e9);
+    1e-6 covers the float32 divide by m and the float32 rounding of m itself."""
+    return max(float(guard), float(m_total) * 2.0 ** -24) + 1e-6
+
+
+def decide_converged(ssq, m_total, tole, guard=0.0):
     """Classify a float64 sum of squared differences against the reference's test
     `sqrt(float32_serial_sum / float32(m)) < tole` (emMAF_cy.pyx:26-33, emMAF.py:22-23):
     returns +1 converged, -1 not converged, 0 too close to call (needs the exact chain).
@@ -298,9 +315,11 @@ def decide_converged(ssq, m_total, tole, guard):
     if ssq != ssq or not tole > 0:
         return -1
     thresh = tole * tole * float(m_total)
-    if ssq <= thresh * (1.0 - guard):
+    g = guard_band(m_total, guard)
+    # F <= S / (1 - g) (g < 1) and F >= S / (1 + g)
+    if g < 1.0 and ssq < thresh * (1.0 - g):
         return 1
-    if ssq >= thresh * (1.0 + guard):
+    if ssq >= thresh * (1.0 + g):
         return -1
     return 0
 
@@ -357,27 +376,31 @@ def run_em(em, max_iter, tole, comm=None, m_total=None):
     return iters
 
 
+def _colptr_arg(colptr, n, K):
+    if colptr is None:
+        return None, None
+    arr = np.ascontiguousarray(colptr, dtype=np.uint64)
+    if arr.shape != (n, K):
+        raise ValueError("colptr must be (n, K)")
+    return arr, arr.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
+
+
 def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
     """All n x K assignment log-likelihood sums in one sweep (glassy.py:18-44 / 87-109).
 
     Returns (out (n, K) float64, parts (n*P, K) float64 or None), already summed over ranks.
     colptr: optional (n, K) array of device addresses (per-individual frequency vectors).
+    P > 1 also returns float64 partition sums (the WGSASSIGN_PARTS=fast path; the reference's serial
+    float32 partition sums come from partition_sums_exact / Score).
     """
     mode = default_mode() if mode is None else mode
     n, K = beagle.n, afset.K
     out = np.zeros((n, K), dtype=np.float64)
     parts = np.zeros((n * P, K), dtype=np.float64) if P > 1 else None
-    cp = None
-    if colptr is not None:
-        arr = np.ascontiguousarray(colptr, dtype=np.uint64)
-        if arr.shape != (n, K):
-            raise ValueError("colptr must be (n, K)")
-        cp = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
+    _keep, cp = _colptr_arg(colptr, n, K)
     check(_lib.load().wgs_assign(beagle.handle, afset.handle, cp, int(P), mode, f64p(out),
                                  f64p(parts) if parts is not None else None))
-    ms = ctypes.c_float()
-    check(_lib.load().wgs_assign_last_ms(ctypes.byref(ms)))
-    assign.last_ms = ms.value
+    assign.last_ms = last_assign_ms(beagle.ctx)
     if comm is not None and comm.world > 1:
         out = comm.allreduce_sum(out)
         if parts is not None:
@@ -385,15 +408,104 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
     return out, parts
 
 
-def partition_sums_exact(beagle, afset, colptr=None, P=1, comm=None):
+def last_assign_ms(ctx):
+    """Kernel time of the context's last scoring call (HIP events on its stream)."""
+    ms = ctypes.c_float()
+    check(_lib.load().wgs_assign_last_ms(ctx.handle, ctypes.byref(ms)))
+    return ms.value
+
+
+MAX_BLOCK_PARALLEL_PARTS = 64     # beyond this the chains are many and short: literal one-lane chains
+
+
+class Score:
+    """The scoring step of glassy.py:31-42 / 92-109 on device-resident data (wgs_score): the n x K float64
+    sums of the individuals [rows) in one reproducible sweep, and the reference's serial float32
+    partition sums (utils.py:147-149) from block functions prepared in parallel on every SNP shard."""
+
+    def __init__(self, beagle, afset, colptr=None, rows=None):
+        self.b, self.K, self.n = beagle, afset.K, beagle.n
+        lo, hi = (0, self.n) if rows is None else (int(rows[0]), int(rows[1]))
+        self.rows = (lo, hi)
+        self._keep, cp = _colptr_arg(colptr, self.n, self.K)
+        h = ctypes.c_void_p()
+        check(_lib.load().wgs_score_create(beagle.handle, afset.handle, cp, lo, hi, ctypes.byref(h)))
+        self._h = h
+        self.local = None
+        self.ms = {}
+
+    def sums(self, mode=None, comm=None):
+        """(n, K) float64 sums over all SNPs (all ranks); rows outside `rows` are 0."""
+        mode = default_mode() if mode is None else mode
+        out = np.zeros((self.n, self.K), dtype=np.float64)
+        check(_lib.load().wgs_score_sums(self._h, mode, f64p(out)))
+        self.ms["sweep"] = last_assign_ms(self.b.ctx)
+        self.local, self.mode = out, mode
+        if comm is not None and comm.world > 1:
+            # every rank's totals: rank r needs the sum over the shards before it to predict its chains
+            slots = np.zeros((comm.world,) + out.shape)
+            slots[comm.rank] = out
+            self.by_rank = comm.allreduce_sum(slots)
+            return self.by_rank.sum(axis=0)
+        self.by_rank = out[None]
+        return out
+
+    def parts_exact(self, P, comm=None):
+        """(n*P, K) float32: utils.partition_loglikes for every (individual, population), bit-exact.
+        Needs sums(MODE_EXACT) first.  Every rank prepares its block functions at once; only the walk
+        (milliseconds) follows the previous shard's float32 carries."""
+        if self.local is None or self.mode != MODE_EXACT:
+            self.sums(MODE_EXACT, comm)
+        lib = _lib.load()
+        world = comm.world if comm is not None else 1
+        rank = comm.rank if comm is not None else 0
+        start = np.ascontiguousarray(self.by_rank[:rank].sum(axis=0)) if rank > 0 else None
+        check(lib.wgs_score_chains_prepare(self._h, int(P), f64p(start) if start is not None else None))
+        self.ms["chains"] = last_assign_ms(self.b.ctx)
+        parts = np.zeros((self.n * P, self.K), dtype=np.float32)
+        carry = None
+        for r in range(world):
+            mine = np.zeros((self.n * P, self.K), dtype=np.float64)
+            if r == rank:
+                check(lib.wgs_score_chains_walk(self._h, f32p(carry) if carry is not None else None, f32p(parts)))
+                self.ms["walk"] = last_assign_ms(self.b.ctx)
+                mine = parts.astype(np.float64)
+            if world > 1:
+                mine = comm.allreduce_sum(mine)      # only rank r contributes: a broadcast of its float32 values
+                carry = np.ascontiguousarray(mine.astype(np.float32))
+        return carry if world > 1 else parts
+
+    def serial_blocks(self):
+        """(blocks redone with the literal serial loop, (chain, block) pairs walked) of the last walk."""
+        tot = ctypes.c_int64()
+        k = _lib.load().wgs_score_last_serial_blocks(self._h, ctypes.byref(tot))
+        return k, tot.value
+
+    def close(self):
+        if self._h:
+            _lib.load().wgs_score_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def partition_sums_exact(beagle, afset, colptr=None, P=1, comm=None, literal=False):
     """utils.partition_loglikes for all n x K pairs, bit-exact (serial float32 per partition in site
     order).  With SNP shards the float32 carries travel from rank to rank in SNP order.
-    Returns (n*P, K) float32."""
+    Returns (n*P, K) float32.  literal=True (or P > 64) uses one GPU lane per chain -- the slow
+    cross-check of the block-parallel chains."""
     n, K = beagle.n, afset.K
-    cp = None
-    if colptr is not None:
-        arr = np.ascontiguousarray(colptr, dtype=np.uint64)
-        cp = arr.ctypes.data_as(ctypes.POINTER(ctypes.c_void_p))
+    if not literal and P <= MAX_BLOCK_PARALLEL_PARTS:
+        sc = Score(beagle, afset, colptr)
+        try:
+            return sc.parts_exact(P, comm)
+        finally:
+            sc.close()
+    _keep, cp = _colptr_arg(colptr, n, K)
     lib = _lib.load()
     world = comm.world if comm is not None else 1
     rank = comm.rank if comm is not None else 0
@@ -402,8 +514,8 @@ def partition_sums_exact(beagle, afset, colptr=None, P=1, comm=None):
     for r in range(world):
         mine = np.zeros((n * P, K), dtype=np.float64)
         if r == rank:
-            check(lib.wgs_assign_parts_exact(beagle.handle, afset.handle, cp, int(P),
-                                             f32p(carry) if carry is not None else None, f32p(parts)))
+            check(lib.wgs_debug_parts_exact_literal(beagle.handle, afset.handle, cp, int(P),
+                                                    f32p(carry) if carry is not None else None, f32p(parts)))
             mine = parts.astype(np.float64)
         if world > 1:
             mine = comm.allreduce_sum(mine)      # only rank r contributes: a broadcast of its float32 values

@@ -3,7 +3,7 @@ import numpy as np
 
 import os
 
-from .device import AFSet, DeviceBeagle, EMBatch, assign, partition_sums_exact
+from .device import MAX_BLOCK_PARALLEL_PARTS, AFSet, DeviceBeagle, EMBatch, Score, assign, partition_sums_exact
 
 
 def assignLL(L, af, t=1):
@@ -67,21 +67,64 @@ def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1,
     return logl, logl_parts
 
 
+def loo_column_table(afset, em, group_of, i0, i1):
+    """(n, K) table of device addresses for scoring individuals [i0, i1): individual i is scored against
+    its own re-fit (fit i - i0 of `em`) and, for every other population, the re-fit of the most recent
+    earlier individual of that population, else the column of `afset` (glassy.py:87-105, the sticky
+    overwrite).  Rows outside [i0, i1) hold valid placeholders."""
+    n, k = len(group_of), afset.K
+    cur = [afset.col_dev(j) for j in range(k)]
+    colptr = np.empty((n, k), dtype=np.uint64)
+    colptr[:] = cur
+    for i in range(i0, i1):
+        cur[group_of[i]] = em.f_dev(i - i0)
+        colptr[i] = cur
+    return colptr
+
+
+def score_loo_batch(scored, afset, em, group_of, i0, i1, P=1, exact_parts=True, comm=None, timings=None):
+    """Scoring step of glassy.py:92-109 for individuals [i0, i1) whose converged, clamped re-fits are the
+    fits of `em`: returns (sums (n, K) float64, partition sums (n*P, K) or None).  Only rows [i0, i1) are
+    computed (a batch scores its own individuals); the other rows are 0."""
+    colptr = loo_column_table(afset, em, group_of, i0, i1)
+    if not exact_parts:
+        if P == 1:
+            sc = Score(scored, afset, colptr, rows=(i0, i1))
+            o = sc.sums(comm=comm)
+            sc.close()
+            return o, None
+        return assign(scored, afset, colptr=colptr, P=P, comm=comm)      # float64 partition sums (WGSASSIGN_PARTS=fast)
+    # sums over all sites in float64 (np.sum(dtype=float), glassy.py:101); partition sums literally as
+    # utils.py:147-149 accumulates them (serial float32) -- for P == 1 too (glassy.py:108-109)
+    from ._lib import MODE_EXACT
+    if P > MAX_BLOCK_PARALLEL_PARTS:
+        o, _ = assign(scored, afset, colptr=colptr, P=1, comm=comm)
+        return o, partition_sums_exact(scored, afset, colptr=colptr, P=P, comm=comm)
+    sc = Score(scored, afset, colptr, rows=(i0, i1))
+    o = sc.sums(MODE_EXACT, comm)
+    pr = sc.parts_exact(P, comm)
+    if timings is not None:
+        for k, v in sc.ms.items():
+            timings[k + "_ms"] = timings.get(k + "_ms", 0.0) + v
+        timings["serial_blocks"] = sc.serial_blocks()
+    sc.close()
+    return o, pr
+
+
 def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None, verbose=True, timings=None,
-               need_parts=True):
+               need_parts=True, inspect=None):
     """The body of loo() on device-resident matrices: `beagle` holds the GLs the frequencies are
     re-estimated from, `scored` the GLs that are scored (the same object unless a downsampled
     matrix is given), both with population slabs `group_of`.  `af` (m, K) float32 is mutated like
-    glassy.py:87-89 does.  With `comm`, SNPs are sharded over ranks (af is this rank's shard)."""
+    glassy.py:87-89 does.  With `comm`, SNPs are sharded over ranks (af is this rank's shard).
+    inspect(em, i0, i1), if given, is called with each batch's converged and clamped fits."""
     import time
     n, k = beagle.n, af.shape[1]
     counts = np.bincount(group_of, minlength=k)
     # The n re-fits need 2 float32 vectors + the per-tile partial sums each (~8.2 bytes per SNP and fit).
     # They run as ONE batch when that fits the free device memory, else in file-order batches: the
     # "current" columns (afset) carry the sticky overwrite from batch to batch.
-    free_bytes, _ = beagle.ctx.mem_info()
-    per_fit = int(beagle.m * 8.2) + 4096
-    batch = int(os.environ.get("WGSASSIGN_LOO_BATCH", max(1, min(n, int(0.8 * free_bytes) // per_fit))))
+    batch = loo_batch_size(beagle, n, comm)
     exact_parts = os.environ.get("WGSASSIGN_PARTS", "exact") != "fast" and (need_parts or P > 1)
     afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
     out = np.zeros((n, k), dtype=np.float64)
@@ -99,22 +142,9 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
             if verbose and iters[i] > 0:
                 print("EM (MAF) converged at iteration: " + str(int(iters[i])))
             em.clamp(i - i0, int(counts[group_of[i]]) - 1)
-        # column table: individual i is scored against its own re-fit and, for every other population,
-        # the re-fit of the most recent earlier individual of that population (glassy.py:87-105);
-        # individuals outside this batch get valid placeholders and their rows are ignored
-        cur = [afset.col_dev(j) for j in range(k)]
-        colptr = np.empty((n, k), dtype=np.uint64)
-        colptr[:] = cur
-        for i in range(i0, i1):
-            cur[group_of[i]] = em.f_dev(i - i0)
-            colptr[i] = cur
-        if exact_parts:
-            # sums over all sites in float64 (np.sum(dtype=float), glassy.py:101); partition sums literally
-            # as utils.py:147-149 accumulates them (serial float32) -- for P == 1 too (glassy.py:108-109)
-            o, _ = assign(scored, afset, colptr=colptr, P=1, comm=comm)
-            pr = partition_sums_exact(scored, afset, colptr=colptr, P=P, comm=comm)
-        else:
-            o, pr = assign(scored, afset, colptr=colptr, P=P, comm=comm)
+        if inspect is not None:
+            inspect(em, i0, i1)
+        o, pr = score_loo_batch(scored, afset, em, group_of, i0, i1, P, exact_parts, comm, timings)
         out[i0:i1] = o[i0:i1]
         if parts is not None and pr is not None:
             parts[i0 * P:i1 * P] = pr[i0 * P:i1 * P]
@@ -134,3 +164,18 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
         logl = out.astype(np.float32)
         logl_parts = parts.astype(np.float32) if parts is not None else logl.copy()
     return logl, logl_parts
+
+
+def loo_batch_size(beagle, n, comm=None):
+    """Number of leave-one-out re-fits per EM batch: what fits the free device memory (or
+    WGSASSIGN_LOO_BATCH), agreed across SNP-shard ranks -- every rank must build batches of the same
+    fits or the per-iteration all-reduces stop matching -- by taking the minimum over ranks."""
+    free_bytes, _ = beagle.ctx.mem_info()
+    per_fit = int(beagle.m * 8.2) + 4096
+    batch = int(os.environ.get("WGSASSIGN_LOO_BATCH", max(1, min(n, int(0.8 * free_bytes) // per_fit))))
+    batch = max(1, min(n, batch))
+    if comm is not None and comm.world > 1:
+        slots = np.zeros(comm.world)
+        slots[comm.rank] = batch
+        batch = int(np.min(comm.allreduce_sum(slots)))
+    return batch
