@@ -117,10 +117,21 @@ int wgs_em_last_sweep_ms(wgs_em *em, float *ms);
  * the frequencies of their last update -- emMAF.py:23-25 `break`s after the update. */
 int wgs_em_set_active(wgs_em *em, int32_t fit, int active);
 int wgs_em_n_active(wgs_em *em);
-/* The driver loop of emMAF.py:20-26 (step, decide `diff < tole`, freeze) is host code above
- * this ABI: wgsassign_amd/device.py:EMBatch.run.  It needs, per iteration, the all-reduced
- * sums of wgs_em_step and -- only when sum/m is within a guard band of tole^2 -- the exact
- * serial chain of wgs_em_rmse_chain handed from SNP shard to SNP shard in rank order. */
+/* emMAF.emMAF(L, iter, tole, t) -- emMAF.py:15-27 -- for EVERY fit of the batch in one call: update,
+ * `rmse1d(f, f_prev) < tole` -> stop (after the update), at most max_iter updates.  iters_out[j] = the
+ * 1-based iteration at which fit j converged, 0 if max_iter was exhausted (the reference prints nothing
+ * then).  m_total = SNPs of ALL shards (the metric divides by it); comm = the RCCL communicator of the
+ * SNP shards or NULL for one shard.  Iterations are enqueued one ahead of the host: a device kernel
+ * decides the clear cases from the (all-reduced) float64 sums; only sums within the band
+ * max(guard_floor, m_total * 2^-24) of tole^2 * m_total -- where the reference's serial float32 sum can
+ * fall on either side -- go through the exact chain (wgs_em_rmse_chain's, batched over fits, carries
+ * handed from shard to shard in rank order).  Identical iteration counts and frequencies to the
+ * step-by-step protocol of wgsassign_amd/device.py:run_em (kept for communicators other than RCCL). */
+typedef struct wgs_comm wgs_comm;
+int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm, double guard_floor,
+               int32_t *iters_out);
+/* Iterations enqueued / batched exact-chain resolutions / wall seconds of the last wgs_em_fit. */
+int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds);
 /* Clamp fit j's frequencies to [lo, hi] the way WGSassign.py:236-240 does (float32 compares,
  * NaN untouched). */
 int wgs_em_clamp(wgs_em *em, int32_t fit, float lo, float hi);
@@ -182,6 +193,17 @@ void wgs_score_destroy(wgs_score *sc);
 int wgs_score_sums(wgs_score *sc, int mode, double *out);
 int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start);
 int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out);
+/* glassy.loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L, num_partitions) -- glassy.py:47-112 -- in one
+ * call on device-resident data: per individual (file order) the re-fit of its population without it
+ * (wgs_em_fit, a batch of individuals at once), the clamp with n_pop - 1, the never-restored overwrite of
+ * the population's column of `a` (in: full-population estimates, out: each population's last re-fit), the
+ * K float64 sums and -- when parts_out is given -- the serial float32 partition sums.
+ * scored: the matrix that is scored (NULL = b).  batch: re-fits per EM batch (0 = what fits the free
+ * device memory, agreed across ranks).  ll_out: host float64 [n*K]; parts_out: host float32 [n*P*K] or
+ * NULL; iters_out: [n] convergence iterations of the re-fits (0 = max_iter exhausted). */
+int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, double tole, int64_t m_total,
+            wgs_comm *comm, int32_t P, int32_t batch, int mode, double *ll_out, float *parts_out, int32_t *iters_out);
+
 /* Test hooks: (chain, block) pairs of the last walk that took the literal serial loop / walked in all;
  * the literal one-lane-per-chain kernel behind wgs_assign_parts_exact, whatever P. */
 int wgs_score_last_serial_blocks(wgs_score *sc, int64_t *total_blocks);
@@ -192,10 +214,10 @@ int wgs_debug_parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *cons
  * The one collective of the sharded path -- a sum all-reduce of a few float64 over xGMI -- without
  * a tensor framework: librccl is dlopen'ed on first use.  Rank 0 creates the 128-byte unique id,
  * the host side distributes it (wgsassign_amd/comm.py: TCP on MASTER_ADDR), every rank inits. */
-typedef struct wgs_comm wgs_comm;
 int wgs_comm_unique_id(uint8_t *id128);
 int wgs_comm_init(wgs_ctx *ctx, const uint8_t *id128, int rank, int world, wgs_comm **out);
 void wgs_comm_destroy(wgs_comm *c);
+int wgs_comm_rank(wgs_comm *c, int *rank, int *world);
 /* In-place sum of n float64 in device memory, enqueued on the context's stream (pairs with wgs_em_step_dev). */
 int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n);
 /* Same for a host buffer (staged through the device); returns when the result is back. */

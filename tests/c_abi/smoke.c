@@ -82,7 +82,46 @@ int main(void)
             fprintf(stderr, "log-likelihood %d not negative/finite: %g\n", i, out[i]);
             return 1;
         }
-    printf("C ABI smoke OK: f[0]=%.6f ssq=%.6g logl[0][0]=%.4f\n", f[0], ssq[0], out[0]);
+    /* the whole of emMAF.emMAF for both populations in one call: fresh batch, run to convergence */
+    wgs_em *em2 = NULL;
+    int32_t iters[K] = {0, 0};
+    CHECK(wgs_em_create(b, K, fit_group, NULL, WGS_MODE_EXACT, &em2));
+    CHECK(wgs_em_fit(em2, 200, 1e-4, M, NULL, 0.0, iters));
+    if (iters[0] < 2 || iters[0] > 200 || iters[1] < 2 || iters[1] > 200) {
+        fprintf(stderr, "wgs_em_fit: implausible iteration counts %d %d\n", iters[0], iters[1]);
+        return 1;
+    }
+    static float fa[M], fb[M];
+    CHECK(wgs_em_get_f(em2, 0, fa));
+    CHECK(wgs_em_get_f_range(em2, 0, 1, 0, M, fb));
+    double d2 = 0.0, rm = 0.0;
+    for (int i = 0; i < M; ++i) d2 += (double)(fa[i] - fb[i]) * (double)(fa[i] - fb[i]);
+    CHECK(wgs_rmse1d(ctx, fa, fb, M, &rm));
+    if (!(rm < 1e-4) || fabs(rm - sqrt(d2 / M)) > 1e-3 * rm) {
+        fprintf(stderr, "wgs_em_fit stopped at rmse %g (float64 estimate %g)\n", rm, sqrt(d2 / M));
+        return 1;
+    }
+    /* glassy.loo in one call: N re-fits, sticky columns, scores and exact partition sums */
+    double loo[N * K];
+    float parts[N * 2 * K];
+    int32_t loo_iters[N];
+    for (int k = 0; k < K; ++k) {
+        CHECK(wgs_em_clamp(em2, k, 1.0f / 8.0f, 7.0f / 8.0f));
+        CHECK(wgs_afset_set_column_from_em(af, k, em2, k));
+    }
+    CHECK(wgs_loo(b, NULL, af, 200, 1e-4, M, NULL, 2, 0, WGS_MODE_EXACT, loo, parts, loo_iters));
+    for (int i = 0; i < N; ++i)
+        for (int k = 0; k < K; ++k) {
+            const double tot = (double)parts[(i * 2 + 0) * K + k] + (double)parts[(i * 2 + 1) * K + k];
+            if (!(loo[i * K + k] < 0.0) || fabs(tot - loo[i * K + k]) > 1e-4 * fabs(tot) || loo_iters[i] < 1) {
+                fprintf(stderr, "wgs_loo: individual %d population %d: sum %g, partitions %g, iterations %d\n", i, k,
+                        loo[i * K + k], tot, loo_iters[i]);
+                return 1;
+            }
+        }
+    printf("C ABI smoke OK: f[0]=%.6f ssq=%.6g logl[0][0]=%.4f fit iterations %d/%d loo[0][0]=%.4f\n", f[0], ssq[0], out[0],
+           iters[0], iters[1], loo[0]);
+    wgs_em_destroy(em2);
     wgs_afset_destroy(af);
     wgs_em_destroy(em);
     wgs_beagle_destroy(b);

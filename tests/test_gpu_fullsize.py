@@ -166,12 +166,13 @@ def test_config4_loo_2M_x_500_K8(wg, oracle):
             oracle.emMAF_update(Lp, f, 8)
         assert same(oracle.clamp(f, int(counts[group_of[i]]) - 1), cols[i]), i
     # (b) scoring with those columns on the window: oracle vs a second device run built from the rows
-    ll_o, parts_o = oracle.loo_score(rows, np.ascontiguousarray(af0[r0:r0 + nr]), cols, group_of, 8, P, site0=r0)
+    A0 = af0[r0:r0 + nr].copy()          # (a row slice is already contiguous: ascontiguousarray would alias af0)
+    ll_o, parts_o = oracle.loo_score(rows, A0.copy(), cols, group_of, 8, P, site0=r0)
     bw = dev.DeviceBeagle.from_host(rows, group_of, K, site0=r0)
     emw = dev.EMBatch(bw, group_of, np.arange(n, dtype=np.int32))
     for i in range(n):
         emw.set_f(i, cols[i])
-    afw = dev.AFSet.from_host(np.ascontiguousarray(af0[r0:r0 + nr]))
+    afw = dev.AFSet.from_host(A0)
     o, pr = wg.glassy.score_loo_batch(bw, afw, emw, group_of, 0, n, P)
     assert nearly_all_identical(o.astype(np.float32), ll_o) and same(pr, parts_o)
     for x in (afw, emw, bw):

@@ -86,6 +86,10 @@ def clean(stdout):
     """Program output without the launcher's noise: gloo prints a banner per rank and torchrun may
     emit a blank line before the first program line."""
     lines = [l for l in stdout.splitlines() if "[Gloo]" not in l and "connected peer ranks" not in l]   # ranks interleave
+    # the two ranks' gloo banners can interleave mid-line and leave a fragment ("1") of their own: the program's
+    # output starts at its banner line
+    if "WGSassign" in lines:
+        lines = lines[lines.index("WGSassign"):]
     while lines and lines[0] == "":
         lines.pop(0)
     return lines

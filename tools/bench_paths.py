@@ -41,7 +41,8 @@ def main():
     ctx.sync()
     t_fit = time.perf_counter() - t0
     res["reference_af_fit"] = {"seconds": round(t_fit, 4), "iters": [int(x) for x in iters],
-                               "snp_updates_per_s": float(m) * float(np.sum(iters)) / t_fit}
+                               "snp_updates_per_s": float(m) * float(np.sum(iters)) / t_fit,
+                               "iterations_enqueued, chain_batches, seconds_in_wgs_em_fit": list(em.fit_stats())}
     t0 = time.perf_counter()
     c = em.rmse_chain(0, 0.0)
     res["rmse_chain"] = {"seconds": round(time.perf_counter() - t0, 5), "diff": device.chain_diff(c, m)}
@@ -59,16 +60,25 @@ def main():
                        float(np.mean(np.argmax(out, axis=1) == group_of))}
     afs.close()
     if a.loo:
-        tm = {}
+        tm, af0 = {}, af.copy()
         t0 = time.perf_counter()
         ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, a.partitions, verbose=False, timings=tm,
                                       need_parts=a.partitions > 1 or a.exact_parts)      # as the command line does
-        res["loo"] = {"seconds": round(time.perf_counter() - t0, 3), "em_seconds": round(tm["em_seconds"], 3),
-                      "score_seconds": round(tm["score_seconds"], 3), "fits": n,
+        res["loo"] = {"seconds": round(time.perf_counter() - t0, 3), "fits": n,
                       "iters_min_max": [int(tm["iters"].min()), int(tm["iters"].max())],
-                      "accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of)),
-                      "score_kernels_ms": {k: round(v, 3) for k, v in tm.items() if k.endswith("_ms")},
-                      "chain_blocks_serial_of_walked": tm.get("serial_blocks")}
+                      "accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of)), "one_call": bool(tm.get("one_call"))}
+        # the same through the step-wise entry points, for the breakdown (EM batch / scoring kernels)
+        os.environ["WGSASSIGN_LOO"] = "python"
+        tm2, af2 = {}, af0.copy()
+        t0 = time.perf_counter()
+        ll2, parts2 = glassy.loo_device(b, b, af2, group_of, 200, 1e-4, a.partitions, verbose=False, timings=tm2,
+                                        need_parts=a.partitions > 1 or a.exact_parts)
+        res["loo_stepwise"] = {"seconds": round(time.perf_counter() - t0, 3), "em_seconds": round(tm2["em_seconds"], 3),
+                               "score_seconds": round(tm2["score_seconds"], 3),
+                               "score_kernels_ms": {k: round(v, 3) for k, v in tm2.items() if k.endswith("_ms")},
+                               "chain_blocks_serial_of_walked": tm2.get("serial_blocks"),
+                               "identical_to_one_call": bool(ll.tobytes() == ll2.tobytes() and parts.tobytes() == parts2.tobytes()
+                                                             and af.tobytes() == af2.tobytes())}
     print(json.dumps(res))
 
 

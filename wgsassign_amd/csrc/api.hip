@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 
 #include "common.h"
@@ -293,6 +294,18 @@ struct wgs_em {
     std::vector<int32_t> last;            // fits swept by the last step
     int last_chain_serial_blocks = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the sweep kernel(s) of the last step
+    // wgs_em_fit: device-side fit states, two-slot pinned rings for the one-iteration lookahead
+    int32_t *d_state = nullptr;           // [n_fits] EM_ACTIVE / EM_CONVERGED / EM_UNDECIDED
+    FitDesc *d_descs2[2] = {nullptr, nullptr}, *h_descs2[2] = {nullptr, nullptr};
+    int32_t *h_state[2] = {nullptr, nullptr}, *h_setstate = nullptr;
+    double *d_ssq2 = nullptr;             // [n_fits] sums of the iteration in flight
+    hipEvent_t ev_it[2] = {nullptr, nullptr};
+    ChainJob *d_jobs = nullptr, *h_jobs = nullptr;
+    float *d_chain_out = nullptr, *h_chain_out = nullptr;     // [n_fits] carries | [n_fits] serial-block counts
+    void *d_chain_batch = nullptr;
+    size_t chain_batch_jobs = 0;
+    double fit_seconds = 0.0;
+    int fit_iterations = 0, fit_chain_batches = 0;
 };
 
 void wgs_em_destroy(wgs_em *em)
@@ -310,6 +323,16 @@ void wgs_em_destroy(wgs_em *em)
     if (em->d_chain_work) (void)hipFree(em->d_chain_work);
     if (em->ev0) (void)hipEventDestroy(em->ev0);
     if (em->ev1) (void)hipEventDestroy(em->ev1);
+    for (int i = 0; i < 2; ++i) {
+        if (em->d_descs2[i]) (void)hipFree(em->d_descs2[i]);
+        if (em->h_descs2[i]) (void)hipHostFree(em->h_descs2[i]);
+        if (em->h_state[i]) (void)hipHostFree(em->h_state[i]);
+        if (em->ev_it[i]) (void)hipEventDestroy(em->ev_it[i]);
+    }
+    for (void *p : {(void *)em->d_state, (void *)em->d_ssq2, (void *)em->d_jobs, (void *)em->d_chain_out, em->d_chain_batch})
+        if (p) (void)hipFree(p);
+    for (void *p : {(void *)em->h_jobs, (void *)em->h_chain_out, (void *)em->h_setstate})
+        if (p) (void)hipHostFree(p);
     delete em;
 }
 
@@ -392,6 +415,7 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
         d.ncols = s.ncols;
         d.skip = em->skip_local[j];
         d.n_eff = em->n_eff[j];
+        d.state = nullptr;
         em->last.push_back(j);
     }
     HIP_TRY(hipMemsetAsync(ssq_dev, 0, sizeof(double) * em->n_fits, ctx->stream));
@@ -452,6 +476,227 @@ int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out)
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     *carry_out = host[0];
     memcpy(&em->last_chain_serial_blocks, &host[1], sizeof(int));
+    return 0;
+}
+
+/* ---- emMAF.py:15-27 for every fit of the batch in ONE call ------------------------------------------
+ * The host enqueues iteration t (sweep, sum reduction, [RCCL all-reduce], decision kernel, state readback)
+ * BEFORE it reads the decisions of iteration t-1, so the GPU never waits for the host:
+ *   - the decision kernel settles the clear cases on the device (EM_CONVERGED / EM_ACTIVE) and parks the
+ *     fits whose float64 sum lies in the guard band (EM_UNDECIDED);
+ *   - a sweep skips every fit that is not EM_ACTIVE, so a fit that converged at t-1 keeps the frequencies of
+ *     update t-1 (emMAF.py:23-25 breaks after the update) and a parked fit keeps both vectors its exact
+ *     chain needs;
+ *   - the host, one iteration behind, resolves parked fits with the exact serial float32 chain (all of them
+ *     in one batched launch; across SNP shards the float32 carries travel in rank order) and either
+ *     finishes them or re-activates them -- such a fit simply runs its next sweep one iteration later.
+ * Decisions use only all-reduced sums, so every rank takes the same path. */
+static int em_fit_alloc(wgs_em *em)
+{
+    if (em->d_state) return 0;
+    const size_t n = (size_t)em->n_fits;
+    HIP_TRY(hipMalloc(&em->d_state, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&em->d_ssq2, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&em->d_jobs, sizeof(ChainJob) * n));
+    HIP_TRY(hipMalloc(&em->d_chain_out, sizeof(float) * 2 * n));
+    HIP_TRY(hipHostMalloc(&em->h_jobs, sizeof(ChainJob) * n, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&em->h_chain_out, sizeof(float) * 2 * n, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&em->h_setstate, sizeof(int32_t) * n, hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc(&em->d_descs2[i], sizeof(FitDesc) * n));
+        HIP_TRY(hipHostMalloc(&em->h_descs2[i], sizeof(FitDesc) * n, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&em->ev_it[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+/* Exact chains of `fits` (all at once): converged[i] = the reference's `diff < tole` for fits[i]. */
+static int em_resolve_chains(wgs_em *em, const std::vector<int32_t> &fits, double tole, int64_t m_total, wgs_comm *comm,
+                             std::vector<char> &converged)
+{
+    wgs_ctx *ctx = em->b->ctx;
+    const int nj = (int)fits.size();
+    converged.assign(nj, 0);
+    if (nj == 0) return 0;
+    const size_t per = rmse_chain_workspace_bytes(em->b->m);
+    if ((size_t)nj > em->chain_batch_jobs) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (em->d_chain_batch) (void)hipFree(em->d_chain_batch);
+        em->d_chain_batch = nullptr;
+        em->chain_batch_jobs = 0;
+        const size_t want = std::min<size_t>((size_t)em->n_fits, std::max<size_t>((size_t)nj, 16));
+        HIP_TRY(hipMalloc(&em->d_chain_batch, per * want));
+        em->chain_batch_jobs = want;
+    }
+    int world = 1, rank = 0;
+    if (comm) wgs_comm_rank(comm, &rank, &world);
+    std::vector<float> carry(nj, 0.0f);
+    std::vector<double> hop(nj);
+    for (int r = 0; r < world; ++r) {
+        std::fill(hop.begin(), hop.end(), 0.0);
+        if (r == rank) {
+            for (int i = 0; i < nj; ++i) {
+                const int j = fits[i];
+                em->h_jobs[i] = ChainJob{em_f(em, j, em->cur[j]), em_f(em, j, em->cur[j] ^ 1), carry[i]};
+            }
+            HIP_TRY(hipMemcpyAsync(em->d_jobs, em->h_jobs, sizeof(ChainJob) * nj, hipMemcpyHostToDevice, ctx->stream));
+            if (launch_rmse_chain_batch(ctx, em->d_jobs, nj, em->b->m, em->d_chain_out, em->d_chain_batch,
+                                        reinterpret_cast<int *>(em->d_chain_out + em->n_fits)))
+                return 1;
+            HIP_TRY(hipMemcpyAsync(em->h_chain_out, em->d_chain_out, sizeof(float) * nj, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            for (int i = 0; i < nj; ++i) hop[i] = (double)em->h_chain_out[i];
+        }
+        if (world > 1 && wgs_comm_allreduce_f64(comm, hop.data(), nj)) return 1;   // only rank r contributes: a broadcast
+        for (int i = 0; i < nj; ++i) carry[i] = (float)hop[i];
+    }
+    ++em->fit_chain_batches;
+    for (int i = 0; i < nj; ++i) {
+        const float res = carry[i] / (float)m_total;         // emMAF_cy.pyx:32
+        converged[i] = sqrt((double)res) < tole;             // emMAF_cy.pyx:33, emMAF.py:23
+    }
+    return 0;
+}
+
+int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm, double guard_floor, int32_t *iters_out)
+{
+    WGS_REQUIRE(em && iters_out, "null argument");
+    WGS_REQUIRE(m_total >= em->b->m, "m_total (%lld) is smaller than this shard (%lld SNPs)", (long long)m_total, (long long)em->b->m);
+    wgs_ctx *ctx = em->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (em_fit_alloc(em)) return 1;
+    const int n = em->n_fits;
+    const int64_t ntiles = wgs_ntiles(em->b->m);
+    // the band of device.py: guard_band / decide_converged
+    double lo = -1.0, hi = -INFINITY;                        // tole <= 0 or NaN: `diff < tole` never holds
+    if (tole > 0) {
+        const double thresh = tole * tole * (double)m_total;
+        const double g = std::max(guard_floor, (double)m_total * 0x1p-24) + 1e-6;
+        lo = g < 1.0 ? thresh * (1.0 - g) : -1.0;
+        hi = thresh * (1.0 + g);
+    }
+    std::vector<char> fin(n, 0), skipped(n, 0);
+    std::vector<int32_t> sweeps(n, 0), init(n), ran, parked, lists[2];
+    for (int j = 0; j < n; ++j) {
+        iters_out[j] = 0;
+        fin[j] = !em->active[j];
+        init[j] = em->active[j] ? EM_ACTIVE : EM_CONVERGED;
+    }
+    HIP_TRY(hipMemcpyAsync(em->d_state, init.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    em->fit_iterations = em->fit_chain_batches = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    bool launched_prev = false;
+    for (int t = 1;; ++t) {
+        const int slot = t & 1;
+        // Who ran at t-1 is known now: its list minus the fits found finished or parked when the decisions
+        // of t-2 were read (those sweeps returned at once).
+        ran.clear();
+        for (int j : lists[slot ^ 1]) {
+            if (skipped[j]) continue;
+            ++sweeps[j];
+            em->cur[j] ^= 1;                                 // the new frequencies are current; 1-cur holds f_prev
+            ran.push_back(j);
+        }
+        std::fill(skipped.begin(), skipped.end(), 0);
+        // ---- enqueue iteration t (fits that turn out to have converged at t-1 return at once)
+        std::vector<int32_t> &L = lists[slot];
+        L.clear();
+        for (int j = 0; j < n; ++j)
+            if (!fin[j] && sweeps[j] < max_iter) L.push_back(j);
+        if (!L.empty()) {
+            std::vector<char> seen(em->b->n_groups, 0);
+            bool shared = false;
+            FitDesc *H = em->h_descs2[slot];
+            for (size_t i = 0; i < L.size(); ++i) {
+                const int j = L[i];
+                const Slab &s = em->b->slabs[em->group[j]];
+                FitDesc &d = H[i];
+                d.slab = s.base;
+                d.f_old = em_f(em, j, em->cur[j]);
+                d.f_new = em_f(em, j, em->cur[j] ^ 1);
+                d.ssq = em->d_ssq2 + j;
+                d.ssq_part = em->d_part + (size_t)j * ntiles;
+                d.npairs = s.npairs;
+                d.ncols = s.ncols;
+                d.skip = em->skip_local[j];
+                d.n_eff = em->n_eff[j];
+                d.state = em->d_state + j;
+                shared = shared || seen[em->group[j]];
+                seen[em->group[j]] = 1;
+            }
+            HIP_TRY(hipMemcpyAsync(em->d_descs2[slot], H, sizeof(FitDesc) * L.size(), hipMemcpyHostToDevice, ctx->stream));
+            const int64_t per_fit = (ntiles + 3) / 4 + 8;
+            const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
+            for (size_t off = 0; off < L.size(); off += max_fits) {
+                const int cnt = (int)std::min<size_t>(max_fits, L.size() - off);
+                if (launch_em_sweep(ctx, em->d_descs2[slot] + off, cnt, em->b->m, em->mode, shared)) return 1;
+            }
+            for (size_t off = 0; off < L.size(); off += 65535) {
+                const int cnt = (int)std::min<size_t>(65535, L.size() - off);
+                if (launch_ssq_reduce(ctx, em->d_descs2[slot] + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
+            }
+            // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
+            // in the same way on every rank (all ranks take the same decisions).
+            if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, n)) return 1;
+            if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
+            HIP_TRY(hipMemcpyAsync(em->h_state[slot], em->d_state, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipEventRecord(em->ev_it[slot], ctx->stream));
+            ++em->fit_iterations;
+        }
+        // ---- read the decisions of iteration t-1 while the GPU works on iteration t
+        if (launched_prev) {
+            const int ps = slot ^ 1;
+            HIP_TRY(hipEventSynchronize(em->ev_it[ps]));     // also: the pinned descriptors of t-1 have been consumed
+            parked.clear();
+            for (int j : ran) {
+                const int st = em->h_state[ps][j];
+                if (st == EM_CONVERGED) {
+                    fin[j] = 1;
+                    skipped[j] = 1;                          // its sweep t (if enqueued) returned at once
+                    iters_out[j] = sweeps[j];
+                } else if (st == EM_UNDECIDED) {
+                    parked.push_back(j);
+                    skipped[j] = 1;
+                } else if (sweeps[j] >= max_iter) {
+                    fin[j] = 1;                              // exhausted: the reference prints nothing, iters stays 0
+                }
+            }
+            if (!parked.empty()) {
+                std::vector<char> conv;
+                if (em_resolve_chains(em, parked, tole, m_total, comm, conv)) return 1;
+                for (size_t i = 0; i < parked.size(); ++i) {
+                    const int j = parked[i];
+                    if (conv[i]) {
+                        fin[j] = 1;
+                        iters_out[j] = sweeps[j];
+                    } else if (sweeps[j] >= max_iter) {
+                        fin[j] = 1;
+                    }
+                    // stream-ordered behind iteration t (whose sweep must see the fit parked throughout)
+                    em->h_setstate[j] = conv[i] ? EM_CONVERGED : EM_ACTIVE;
+                    HIP_TRY(hipMemcpyAsync(em->d_state + j, em->h_setstate + j, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+                }
+            }
+        }
+        launched_prev = !L.empty();
+        if (!launched_prev) break;                           // nothing in flight: every fit finished or exhausted
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < n; ++j)
+        if (iters_out[j] > 0) em->active[j] = 0;             // frozen, as wgs_em_set_active(j, 0) would
+    em->fit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return 0;
+}
+
+/* Diagnostics of the last wgs_em_fit: iterations enqueued, batched exact-chain resolutions, wall seconds. */
+int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds)
+{
+    WGS_REQUIRE(em, "null argument");
+    if (iterations) *iterations = em->fit_iterations;
+    if (chain_batches) *chain_batches = em->fit_chain_batches;
+    if (seconds) *seconds = em->fit_seconds;
     return 0;
 }
 
@@ -928,6 +1173,125 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
             for (int p = 0; p < P; ++p) t += h[((size_t)i * P + p) * K + k];
             out[(size_t)i * K + k] += t;
         }
+    return 0;
+}
+
+/* ---- glassy.loo -- glassy.py:47-112 -- in one call ---------------------------------------------------
+ * For every individual i (file order): re-fit its population without it (emMAF.py:15-27 via wgs_em_fit, all
+ * individuals of a batch at once), clamp with n_pop - 1 (glassy.py:80-85), OVERWRITE the population's column
+ * (glassy.py:87-89: never restored, so every other column is the re-fit of the most recent earlier individual
+ * of that population), score i against all K columns (float64 sums of the float32 per-site values,
+ * glassy.py:92-105) and, if asked, accumulate the serial float32 partition sums (utils.py:147-149).
+ *   b       the matrix the frequencies are estimated from (population slabs = columns of `a`);
+ *   scored  the matrix that is scored (NULL = b; the downsampled matrix of --loo_downsampled_beagle);
+ *   a       in: the full-population estimates; out: each population's LAST re-fit (glassy.py:89);
+ *   batch   re-fits per EM batch, 0 = what fits the free device memory (agreed across ranks);
+ *   ll_out  host float64 [n*K] (overwritten); parts_out host float32 [n*P*K] or NULL; iters_out [n]. */
+int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm,
+            int32_t P, int32_t batch, int mode, double *ll_out, float *parts_out, int32_t *iters_out)
+{
+    WGS_REQUIRE(b && a && ll_out && iters_out, "null argument");
+    if (!scored) scored = b;
+    WGS_REQUIRE(scored->n == b->n && scored->m == b->m && scored->n_groups == b->n_groups && scored->group_of == b->group_of,
+                "the scored matrix must have the shape and population slabs of the fitted one");
+    WGS_REQUIRE(a->m == b->m && a->K == b->n_groups, "allele frequencies (%lld x %d) do not match the population slabs (%lld x %d)",
+                (long long)a->m, a->K, (long long)b->m, b->n_groups);
+    WGS_REQUIRE(P >= 1, "partition count must be >= 1");
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t n = b->n;
+    const int K = a->K;
+    const size_t cells = (size_t)n * K;
+    int world = 1, rank = 0;
+    if (comm) wgs_comm_rank(comm, &rank, &world);
+    if (batch <= 0) {      // 2 float32 vectors + per-tile partial sums per fit: ~8.2 bytes per SNP and fit
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        const double per_fit = (double)b->m * 8.2 + 4096.0;
+        batch = (int32_t)std::max<double>(1.0, std::min<double>((double)n, 0.8 * (double)free_b / per_fit));
+    }
+    batch = (int32_t)std::min<int64_t>(n, batch);
+    if (world > 1) {       // every rank must run the same batches: the minimum over ranks
+        std::vector<double> slots(world, 0.0);
+        slots[rank] = (double)batch;
+        if (wgs_comm_allreduce_f64(comm, slots.data(), world)) return 1;
+        batch = (int32_t)*std::min_element(slots.begin(), slots.end());
+    }
+    std::vector<int32_t> counts(K, 0);
+    for (int64_t i = 0; i < n; ++i) ++counts[b->group_of[i]];
+    std::fill(ll_out, ll_out + cells, 0.0);
+    if (parts_out) std::fill(parts_out, parts_out + cells * P, 0.0f);
+    std::vector<const float *> colptr(cells), cur(K);
+    std::vector<double> sums(cells), by_rank, start(cells);
+    std::vector<float> parts, carry;
+    std::vector<double> hop;
+    for (int64_t i0 = 0; i0 < n; i0 += batch) {
+        const int64_t i1 = std::min<int64_t>(n, i0 + batch);
+        const int nb = (int)(i1 - i0);
+        std::vector<int32_t> grp(nb), skip(nb);
+        for (int x = 0; x < nb; ++x) grp[x] = b->group_of[i0 + x], skip[x] = (int32_t)(i0 + x);
+        wgs_em *em = nullptr;
+        wgs_score *sc = nullptr;
+        auto guard = on_failure([&] { wgs_score_destroy(sc); wgs_em_destroy(em); });
+        int rc = wgs_em_create(b, nb, grp.data(), skip.data(), mode, &em);
+        if (rc) return rc;
+        if ((rc = wgs_em_fit(em, max_iter, tole, m_total, comm, 0.0, iters_out + i0))) return rc;
+        for (int x = 0; x < nb; ++x) {
+            const int npop = counts[grp[x]] - 1;
+            const double lo = 1.0 / (2.0 * (npop + 1));
+            if ((rc = wgs_em_clamp(em, x, (float)lo, (float)(1.0 - lo)))) return rc;
+        }
+        // glassy.py:87-105: individual i's own re-fit, else the most recent earlier re-fit, else the column of `a`
+        for (int k = 0; k < K; ++k) cur[k] = a->buf + (size_t)k * a->m;
+        for (int64_t i = 0; i < n; ++i)
+            for (int k = 0; k < K; ++k) colptr[(size_t)i * K + k] = cur[k];
+        for (int64_t i = i0; i < i1; ++i) {
+            cur[b->group_of[i]] = wgs_em_f_dev(em, (int32_t)(i - i0));
+            for (int k = 0; k < K; ++k) colptr[(size_t)i * K + k] = cur[k];
+        }
+        if ((rc = wgs_score_create(scored, a, colptr.data(), (int32_t)i0, (int32_t)i1, &sc))) return rc;
+        if ((rc = wgs_score_sums(sc, parts_out ? WGS_MODE_EXACT : mode, sums.data()))) return rc;
+        if (world > 1) {   // every rank's sums: the total, and what precedes each shard (for the chain prediction)
+            by_rank.assign(cells * world, 0.0);
+            std::copy(sums.begin(), sums.end(), by_rank.begin() + cells * rank);
+            if (wgs_comm_allreduce_f64(comm, by_rank.data(), (int64_t)by_rank.size())) return 1;
+            std::fill(sums.begin(), sums.end(), 0.0);
+            std::fill(start.begin(), start.end(), 0.0);
+            for (int r = 0; r < world; ++r)
+                for (size_t c = 0; c < cells; ++c) {
+                    if (r < rank) start[c] += by_rank[cells * r + c];
+                    sums[c] += by_rank[cells * r + c];
+                }
+        }
+        for (size_t c = (size_t)i0 * K; c < (size_t)i1 * K; ++c) ll_out[c] = sums[c];
+        if (parts_out) {
+            if ((rc = wgs_score_chains_prepare(sc, P, world > 1 && rank > 0 ? start.data() : nullptr))) return rc;
+            parts.assign(cells * P, 0.0f);
+            carry.clear();
+            for (int r = 0; r < world; ++r) {
+                if (r == rank && (rc = wgs_score_chains_walk(sc, carry.empty() ? nullptr : carry.data(), parts.data()))) return rc;
+                if (world > 1) {                             // rank r's float32 values to everyone (exact in float64)
+                    hop.assign(cells * P, 0.0);
+                    if (r == rank)
+                        for (size_t c = 0; c < cells * P; ++c) hop[c] = (double)parts[c];
+                    if (wgs_comm_allreduce_f64(comm, hop.data(), (int64_t)hop.size())) return 1;
+                    carry.resize(cells * P);
+                    for (size_t c = 0; c < cells * P; ++c) carry[c] = (float)hop[c];
+                }
+            }
+            const std::vector<float> &fin = world > 1 ? carry : parts;
+            for (size_t c = (size_t)i0 * P * K; c < (size_t)i1 * P * K; ++c) parts_out[c] = fin[c];
+        }
+        // the last re-fit of each population in this batch becomes the current column
+        std::vector<int32_t> last(K, -1);
+        for (int x = 0; x < nb; ++x) last[grp[x]] = x;
+        for (int k = 0; k < K; ++k)
+            if (last[k] >= 0 && (rc = wgs_afset_set_column_from_em(a, k, em, last[k]))) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        guard.dismiss();
+        wgs_score_destroy(sc);
+        wgs_em_destroy(em);
+    }
     return 0;
 }
 

@@ -99,6 +99,13 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     int32_t npairs, ncols;
     int32_t skip;      // local column left out (LOO) or -1
     int32_t n_eff;     // ncols - (skip >= 0)
+    const int32_t *state;  // device: fit state (EM_ACTIVE / EM_CONVERGED / EM_UNDECIDED) or nullptr = always sweep
+};
+enum { EM_ACTIVE = 0, EM_CONVERGED = 1, EM_UNDECIDED = 2 };
+// One exact convergence chain (emMAF_cy.pyx:30-31 over this shard): float32 running sum of (a-b)^2 from carry_in.
+struct ChainJob {
+    const float *a, *b;
+    float carry_in;
 };
 
 struct FisherDesc {    // one population of the --ne_obs sweep
@@ -115,6 +122,8 @@ int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, 
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode, bool shared_slabs);
 int ssq_reduce_chunks(void);
 int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2);
+// state[fit] of every listed fit that swept: ssq < lo -> EM_CONVERGED, ssq >= hi (or NaN) -> EM_ACTIVE, else EM_UNDECIDED
+int launch_em_decide(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, double lo, double hi);
 int launch_div_check(wgs_ctx *ctx, unsigned long long seed, unsigned long long per_thread, unsigned long long *d_mismatch);
 int launch_fill(wgs_ctx *ctx, float *p, int64_t count, float v);
 int launch_clamp(wgs_ctx *ctx, float *p, int64_t count, float lo, float hi);
@@ -122,6 +131,8 @@ int launch_rmse_chain_serial(wgs_ctx *ctx, const float *a, const float *b, int64
 size_t rmse_chain_workspace_bytes(int64_t m);
 int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out, void *work,
                       int *d_serial);
+// n_jobs chains at once (device array of jobs): d_out[j] / d_serial[j]; work: n_jobs * rmse_chain_workspace_bytes(m)
+int launch_rmse_chain_batch(wgs_ctx *ctx, const ChainJob *d_jobs, int n_jobs, int64_t m, float *d_out, void *work, int *d_serial);
 
 struct AssignArgs {
     const float4 *slab;

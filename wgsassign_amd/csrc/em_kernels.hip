@@ -110,6 +110,9 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
         tgroup = (int64_t)(j / (unsigned)n_fits) * 8 + xcd;
     }
     const FitDesc fd = fits[fit];
+    // a fit whose convergence was decided (or is being decided) on the device by the previous iteration's
+    // em_decide_kernel is skipped: the host enqueues sweeps one iteration ahead of what it has read back
+    if (fd.state && *fd.state != EM_ACTIVE) return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t tile = tgroup * WAVES + wave;
     const int64_t row0 = tile * 64;
@@ -220,6 +223,21 @@ __global__ __launch_bounds__(64) void ssq_reduce2_kernel(const FitDesc *__restri
     if (threadIdx.x == 0) *fits[blockIdx.x].ssq = v;
 }
 
+// emMAF.py:22-23 on the device for the clear cases: the float64 sum S decides `diff < tole` unless it lies in
+// the band [lo, hi) around tole^2 * m in which the reference's serial float32 sum may fall on either side
+// (device.py: guard_band); those fits are parked as EM_UNDECIDED for the exact chain.  Fits that did not
+// sweep (state != EM_ACTIVE) keep their state.  NaN never converges (NaN < tole is False).
+__global__ void em_decide_kernel(const FitDesc *__restrict__ fits, int n_fits, double lo, double hi)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_fits) return;
+    const FitDesc fd = fits[j];
+    int32_t *st = const_cast<int32_t *>(fd.state);
+    if (!st || *st != EM_ACTIVE) return;
+    const double s = *fd.ssq;
+    *st = (s != s || s >= hi) ? EM_ACTIVE : (s < lo ? EM_CONVERGED : EM_UNDECIDED);
+}
+
 __global__ void fill_kernel(float *p, int64_t count, float v)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -293,10 +311,13 @@ __device__ __forceinline__ float sqdiff(const float *a, const float *b, int64_t 
     return d * d;
 }
 
-__global__ __launch_bounds__(256) void rmse_block_sum_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t m,
-                                                            double *__restrict__ S)
+// All chain kernels take a device array of jobs; blockIdx.y selects the job (one fit's pair of vectors), and
+// every per-block array (S, expo, cand) is laid out [job][block].
+__global__ __launch_bounds__(256) void rmse_block_sum_kernel(const ChainJob *__restrict__ jobs, int64_t m, double *__restrict__ S_all)
 {
     __shared__ double red[256];
+    const float *__restrict__ a = jobs[blockIdx.y].a, *__restrict__ b = jobs[blockIdx.y].b;
+    double *__restrict__ S = S_all + (size_t)blockIdx.y * gridDim.x;
     const int64_t base = (int64_t)blockIdx.x * RB;
     double acc = 0.0;
     for (int k = 0; k < RB / 256; ++k) {
@@ -314,9 +335,13 @@ __global__ __launch_bounds__(256) void rmse_block_sum_kernel(const float *__rest
 
 // expo[b] = biased float32 exponent predicted for the running sum at the start of block b
 // (0: unknown -> serial; -1: the block adds only zeros -> the sum passes through unchanged).
-__global__ __launch_bounds__(1024) void rmse_predict_kernel(const double *__restrict__ S, int nblocks, float carry, int *__restrict__ expo)
+__global__ __launch_bounds__(1024) void rmse_predict_kernel(const double *__restrict__ S_all, int nblocks, const ChainJob *__restrict__ jobs,
+                                                            int *__restrict__ expo_all)
 {
     __shared__ double part[1024];
+    const double *__restrict__ S = S_all + (size_t)blockIdx.x * nblocks;
+    int *__restrict__ expo = expo_all + (size_t)blockIdx.x * nblocks;
+    const float carry = jobs[blockIdx.x].carry_in;
     const int per = (nblocks + 1023) / 1024;
     const int b0 = threadIdx.x * per;
     double acc = 0.0;
@@ -379,10 +404,13 @@ __device__ __forceinline__ void chain_step(unsigned int dbits, int be, long long
 }
 
 // cand[b][c][p], c = 0,1,2 for biased exponents expo[b]-1, expo[b], expo[b]+1.
-__global__ __launch_bounds__(256) void rmse_candidates_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t m,
-                                                             const int *__restrict__ expo, long long *__restrict__ cand)
+__global__ __launch_bounds__(256) void rmse_candidates_kernel(const ChainJob *__restrict__ jobs, int64_t m, const int *__restrict__ expo_all,
+                                                             long long *__restrict__ cand_all)
 {
     __shared__ long long sh[256][6];
+    const float *__restrict__ a = jobs[blockIdx.y].a, *__restrict__ b = jobs[blockIdx.y].b;
+    const int *__restrict__ expo = expo_all + (size_t)blockIdx.y * gridDim.x;
+    long long *__restrict__ cand = cand_all + (size_t)blockIdx.y * gridDim.x * 6;
     const int e = expo[blockIdx.x];
     long long D[6] = {0, 0, 0, 0, 0, 0};
     if (e > 0) {
@@ -424,13 +452,17 @@ __global__ __launch_bounds__(256) void rmse_candidates_kernel(const float *__res
 
 // One wavefront walks the blocks in order.  All 64 lanes hold the same running value (uniform
 // control flow), so the serial fallback of a block can stage its 4096 squares in LDS cooperatively.
-__global__ __launch_bounds__(64) void rmse_walk_kernel(const float *__restrict__ a, const float *__restrict__ b, int64_t m,
-                                                       const int *__restrict__ expo, const long long *__restrict__ cand, int nblocks,
-                                                       float carry, float *out, int *n_serial)
+__global__ __launch_bounds__(64) void rmse_walk_kernel(const ChainJob *__restrict__ jobs, int64_t m, const int *__restrict__ expo_all,
+                                                       const long long *__restrict__ cand_all, int nblocks, float *out_all, int *n_serial_all)
 {
     __shared__ float sq[RB];
     const int lane = threadIdx.x;
-    float res = carry;
+    const float *__restrict__ a = jobs[blockIdx.x].a, *__restrict__ b = jobs[blockIdx.x].b;
+    const int *__restrict__ expo = expo_all + (size_t)blockIdx.x * nblocks;
+    const long long *__restrict__ cand = cand_all + (size_t)blockIdx.x * nblocks * 6;
+    float *out = out_all + blockIdx.x;
+    int *n_serial = n_serial_all ? n_serial_all + blockIdx.x : nullptr;
+    float res = jobs[blockIdx.x].carry_in;
     int serial = 0;
     for (int blk = 0; blk < nblocks; ++blk) {
         const int e = expo[blk];
@@ -686,6 +718,14 @@ int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int6
     return 0;
 }
 
+int launch_em_decide(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, double lo, double hi)
+{
+    if (n_fits <= 0) return 0;
+    hipLaunchKernelGGL(em_decide_kernel, dim3((unsigned)((n_fits + 255) / 256)), dim3(256), 0, ctx->stream, d_descs, n_fits, lo, hi);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_fill(wgs_ctx *ctx, float *p, int64_t count, float v)
 {
     if (count <= 0) return 0;
@@ -716,11 +756,30 @@ int launch_rmse_chain_serial(wgs_ctx *ctx, const float *a, const float *b, int64
 size_t rmse_chain_workspace_bytes(int64_t m)
 {
     const size_t nb = (size_t)((m + RB - 1) / RB);
-    return nb * (sizeof(double) + sizeof(int) + 6 * sizeof(long long)) + 64;
+    return ((nb * (sizeof(double) + sizeof(int) + 6 * sizeof(long long)) + 7) & ~(size_t)7) + 64;   // + one ChainJob
 }
 
-// work: rmse_chain_workspace_bytes(m) bytes of device memory; d_serial (may be null) receives the
-// number of blocks that took the literal serial loop.
+// work: n_jobs * rmse_chain_workspace_bytes(m) bytes of device memory (the first sizeof(ChainJob) * n_jobs bytes
+// of each call's job table live at its end); d_serial (may be null) receives per job the number of blocks that
+// took the literal serial loop.
+int launch_rmse_chain_batch(wgs_ctx *ctx, const ChainJob *d_jobs, int n_jobs, int64_t m, float *d_out, void *work, int *d_serial)
+{
+    if (n_jobs <= 0) return 0;
+    WGS_REQUIRE(m > 0, "empty chain");
+    WGS_REQUIRE(n_jobs <= 65535, "too many convergence chains in one batch");
+    const int nb = (int)((m + RB - 1) / RB);
+    long long *cand = reinterpret_cast<long long *>(work);
+    double *S = reinterpret_cast<double *>(cand + (size_t)n_jobs * nb * 6);
+    int *expo = reinterpret_cast<int *>(S + (size_t)n_jobs * nb);
+    hipLaunchKernelGGL(rmse_block_sum_kernel, dim3(nb, n_jobs), dim3(256), 0, ctx->stream, d_jobs, m, S);
+    hipLaunchKernelGGL(rmse_predict_kernel, dim3(n_jobs), dim3(1024), 0, ctx->stream, S, nb, d_jobs, expo);
+    hipLaunchKernelGGL(rmse_candidates_kernel, dim3(nb, n_jobs), dim3(256), 0, ctx->stream, d_jobs, m, expo, cand);
+    hipLaunchKernelGGL(rmse_walk_kernel, dim3(n_jobs), dim3(64), 0, ctx->stream, d_jobs, m, expo, cand, nb, d_out, d_serial);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// One chain; the job record is kept in the 64 spare bytes at the end of `work` (rmse_chain_workspace_bytes).
 int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out, void *work,
                       int *d_serial)
 {
@@ -729,14 +788,9 @@ int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, f
         HIP_TRY(hipGetLastError());
         return 0;
     }
-    const int nb = (int)((m + RB - 1) / RB);
-    long long *cand = reinterpret_cast<long long *>(work);
-    double *S = reinterpret_cast<double *>(cand + (size_t)nb * 6);
-    int *expo = reinterpret_cast<int *>(S + nb);
-    hipLaunchKernelGGL(rmse_block_sum_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, m, S);
-    hipLaunchKernelGGL(rmse_predict_kernel, dim3(1), dim3(1024), 0, ctx->stream, S, nb, carry_in, expo);
-    hipLaunchKernelGGL(rmse_candidates_kernel, dim3(nb), dim3(256), 0, ctx->stream, a, b, m, expo, cand);
-    hipLaunchKernelGGL(rmse_walk_kernel, dim3(1), dim3(64), 0, ctx->stream, a, b, m, expo, cand, nb, carry_in, d_out, d_serial);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    ChainJob job{a, b, carry_in};
+    ChainJob *d_job = reinterpret_cast<ChainJob *>(reinterpret_cast<char *>(work) + rmse_chain_workspace_bytes(m) - 64);
+    HIP_TRY(hipMemcpyAsync(d_job, &job, sizeof job, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));        // `job` is a local
+    return launch_rmse_chain_batch(ctx, d_job, 1, m, d_out, work, d_serial);
 }

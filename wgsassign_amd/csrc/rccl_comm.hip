@@ -101,6 +101,14 @@ int wgs_comm_init(wgs_ctx *ctx, const uint8_t *id128, int rank, int world, wgs_c
     return 0;
 }
 
+int wgs_comm_rank(wgs_comm *c, int *rank, int *world)
+{
+    WGS_REQUIRE(c, "null argument");
+    if (rank) *rank = c->rank;
+    if (world) *world = c->world;
+    return 0;
+}
+
 void wgs_comm_destroy(wgs_comm *c)
 {
     if (!c) return;

@@ -281,8 +281,31 @@ class EMBatch:
     # ---- the driver loop of emMAF.py:20-26, for all fits at once
     def run(self, max_iter, tole, comm=None, m_total=None):
         """Returns iters (n_fits,), the 1-based iteration at which each fit met `diff < tole`
-        (0: max_iter exhausted -- the reference prints nothing then)."""
+        (0: max_iter exhausted -- the reference prints nothing then).  One C call (wgs_em_fit: iterations
+        enqueued ahead of the host, decisions on the device) for one shard or RCCL shards; the
+        step-by-step protocol of run_em for the other communicators (gloo / socket rehearsals) or when
+        WGSASSIGN_EM_LOOP=python."""
+        native = comm is None or comm.world == 1 or getattr(comm, "handle", None) is not None
+        if native and os.environ.get("WGSASSIGN_EM_LOOP", "c") != "python":
+            return self.fit(max_iter, tole, comm, m_total)
         return run_em(self, max_iter, tole, comm, m_total)
+
+    def fit(self, max_iter, tole, comm=None, m_total=None):
+        """wgs_em_fit: emMAF.py:15-27 for every fit in one call."""
+        lib = _lib.load()
+        handle = getattr(comm, "handle", None) if comm is not None and comm.world > 1 else None
+        if m_total is None:
+            m_total = int(comm.allreduce_sum(np.array([float(self.b.m)]))[0]) if handle is not None else self.b.m
+        iters = np.zeros(self.n_fits, dtype=np.int32)
+        check(lib.wgs_em_fit(self._h, int(max_iter), float(tole), int(m_total), handle, float(self.GUARD), i32p(iters)))
+        self.active = self.active & (iters == 0)
+        return iters
+
+    def fit_stats(self):
+        """(iterations enqueued, batched exact-chain resolutions, wall seconds) of the last fit()."""
+        it, ch, sec = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
+        check(_lib.load().wgs_em_fit_stats(self._h, ctypes.byref(it), ctypes.byref(ch), ctypes.byref(sec)))
+        return it.value, ch.value, sec.value
 
     def close(self):
         if self._h:

@@ -121,11 +121,41 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
     import time
     n, k = beagle.n, af.shape[1]
     counts = np.bincount(group_of, minlength=k)
+    exact_parts = os.environ.get("WGSASSIGN_PARTS", "exact") != "fast" and (need_parts or P > 1)
+    handle = getattr(comm, "handle", None) if comm is not None and comm.world > 1 else None
+    one_call = (comm is None or comm.world == 1 or handle is not None) and inspect is None \
+        and (exact_parts or P == 1) and P <= MAX_BLOCK_PARALLEL_PARTS and os.environ.get("WGSASSIGN_LOO", "c") != "python"
+    if one_call:
+        # the whole of glassy.py:65-109 behind one C entry (wgs_loo); the Python orchestration below does the
+        # same through the step-wise entry points and serves the other communicators (gloo / socket)
+        import ctypes
+        from . import _lib
+        from .device import default_mode
+        t0 = time.perf_counter()
+        afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
+        m_total = int(comm.allreduce_sum(np.array([float(beagle.m)]))[0]) if handle is not None else beagle.m
+        out = np.zeros((n, k), dtype=np.float64)
+        parts = np.zeros((n * P, k), dtype=np.float32) if exact_parts else None
+        iters = np.zeros(n, dtype=np.int32)
+        _lib.check(_lib.load().wgs_loo(beagle.handle, scored.handle if scored is not beagle else None, afset.handle,
+                                       int(maf_iter), float(maf_tole), m_total, handle, P,
+                                       int(os.environ.get("WGSASSIGN_LOO_BATCH", 0)), default_mode(), _lib.f64p(out),
+                                       _lib.f32p(parts) if parts is not None else None, _lib.i32p(iters)))
+        if verbose:
+            for i in range(n):
+                if iters[i] > 0:
+                    print("EM (MAF) converged at iteration: " + str(int(iters[i])))
+        af[:, :] = afset.to_host()
+        afset.close()
+        if timings is not None:
+            timings.update(seconds=time.perf_counter() - t0, iters=iters, one_call=True)
+        with np.errstate(over="ignore"):
+            logl = out.astype(np.float32)
+        return logl, (parts if parts is not None else logl.copy())
     # The n re-fits need 2 float32 vectors + the per-tile partial sums each (~8.2 bytes per SNP and fit).
     # They run as ONE batch when that fits the free device memory, else in file-order batches: the
     # "current" columns (afset) carry the sticky overwrite from batch to batch.
     batch = loo_batch_size(beagle, n, comm)
-    exact_parts = os.environ.get("WGSASSIGN_PARTS", "exact") != "fast" and (need_parts or P > 1)
     afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
     out = np.zeros((n, k), dtype=np.float64)
     parts = np.zeros((n * P, k), dtype=np.float64 if not exact_parts else np.float32) if (P > 1 or exact_parts) else None
