@@ -223,7 +223,12 @@ def main():
                 "kernel": "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_snp": 8 * n + 8 * K}
 
-    roofline["traffic"], roofline["traffic_source"] = pmc_traffic(m, n, K, args.mode)
+    pmc = committed_pmc(m, n, K, args.mode)
+    roofline["traffic"], roofline["traffic_source"] = pmc.get("em_traffic"), pmc.get("source")
+    if pmc.get("em_valu_busy_frac") is not None:
+        # the exact-mode sweep sits on the FP64 issue roof as well: share of cycles the vector units were busy
+        roofline["valu_busy_frac"] = round(pmc["em_valu_busy_frac"], 4)
+        roofline["effective_clock_ghz"] = round(pmc["em_clock_ghz"], 3)
 
     extra = {"gl_pair_terms_per_s": value * n_call, "synth_seconds": round(t_gen, 2),
              "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
@@ -259,7 +264,14 @@ def main():
                            "terms_per_s": m_total * float(n) * K / t_as,
                            "kernel_ms": round(as_ms, 3),
                            "hbm_frac": round((8.0 * n + 4.0 * K) * m / (as_ms * 1e-3) / HBM_PEAK, 4) if as_ms > 0 else None,
+                           "kernel": "score_sweep_kernel<%s> + block_prefix_kernel (one launch over all population slabs)" % args.mode,
                            "checksum": float(np.sum(out))}
+        if pmc.get("assign_valu_busy_frac") is not None and pmc.get("assign_insts_valu"):
+            # bound: FP64 vector issue (one double log per term), not HBM.  valu_frac = SQ_ACTIVE_INST_VALU * 4 /
+            # (1024 SIMDs * GRBM_GUI_ACTIVE / 8) from the committed rocprofv3 PMC pass of this workload
+            extra["assign"].update({"bound": "valu_fp64_issue", "valu_frac": round(pmc["assign_valu_busy_frac"], 4),
+                                    "valu_insts_per_term": round(pmc["assign_insts_valu"] * 64.0 / (float(m) * n * K), 2),
+                                    "traffic": pmc.get("assign_traffic"), "pmc_source": pmc.get("source")})
         afs.close()
 
     cpu = None
@@ -285,12 +297,13 @@ def main():
             dist.destroy_process_group()
 
 
-def pmc_traffic(m, n, K, mode):
-    """HBM bytes per EM-sweep launch from the committed rocprofv3 PMC passes of this workload
-    (profiles/*/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction applied);
-    None when no committed measurement matches the workload being run."""
+def committed_pmc(m, n, K, mode):
+    """Counters of the EM sweep and the scoring sweep from the committed rocprofv3 PMC passes of THIS workload
+    (profiles/*/pmc_summary.json, written by tools/summarize_profile.py: traffic = (2*FETCH_SIZE + WRITE_SIZE)
+    * 1024 with the gfx950 correction, valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE
+    / 8)); the newest matching profile wins, {} when none matches the workload being run."""
     import glob
-    best = (None, None)
+    best = {}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
         try:
             d = json.load(open(f))
@@ -298,9 +311,18 @@ def pmc_traffic(m, n, K, mode):
             continue
         if d.get("bench_config") != {"snps_per_gpu": m, "n": n, "K": K, "mode": mode}:
             continue
+        cur = {"source": os.path.relpath(f, ROOT)}
         for k, e in d.get("kernels", {}).items():
-            if "em_sweep_kernel" in k and "traffic_bytes_per_launch" in e:
-                best = (e["traffic_bytes_per_launch"], os.path.relpath(f, ROOT))
+            if "em_sweep_kernel<%d" % (0 if mode == "exact" else 1) in k:
+                cur["em_traffic"] = e.get("traffic_bytes_per_launch")
+                cur["em_valu_busy_frac"] = e.get("valu_busy_frac")
+                cur["em_clock_ghz"] = e.get("effective_clock_ghz")
+            if "score_sweep_kernel" in k:           # one launch scores the whole matrix
+                cur["assign_traffic"] = e.get("traffic_bytes_per_launch")
+                cur["assign_valu_busy_frac"] = e.get("valu_busy_frac")
+                cur["assign_insts_valu"] = e.get("SQ_INSTS_VALU", {}).get("mean")
+        if cur.get("em_traffic") is not None:
+            best = cur
     return best
 
 

@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # substrings of the kernel names whose counters are kept (every kernel of the hot path)
-KERNELS = ("em_sweep", "em_decide", "assign_", "parts_", "chain_", "ssq_reduce", "rmse", "fisher_", "block_reduce")
+KERNELS = ("em_sweep", "em_decide", "assign_", "score_", "parts_", "chain_", "ssq_reduce", "rmse", "fisher_", "block_prefix")
 
 
 def main():
@@ -27,6 +27,10 @@ def main():
     kt = glob.glob(os.path.join(ROOT, "gpurun_out", prefix + "_kt", "*", "*_kernel_stats.csv"))
     if kt:
         shutil.copy(kt[0], os.path.join(out, "kernel_stats.csv"))
+        # effective clock per kernel needs its duration: keep the mean duration beside the counters
+        durations = {r["Name"].strip('"'): float(r["AverageNs"]) for r in csv.DictReader(open(kt[0]))}
+    else:
+        durations = {}
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
     for sub in ("fetch", "write", "sq", "sq2"):
         for f in glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (prefix, sub), "*", "*_counter_collection.csv")):
@@ -41,6 +45,16 @@ def main():
         e = {c: {"dispatches": len(v), "mean": sum(v) / len(v)} for c, v in cs.items()}
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             e["traffic_bytes_per_launch"] = (2 * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024
+        if "SQ_ACTIVE_INST_VALU" in cs and "GRBM_GUI_ACTIVE" in cs:
+            # SQ_ACTIVE_INST_VALU counts quad-cycles over all SIMDs; GRBM_GUI_ACTIVE sums the 8 XCDs' cycles
+            # (MI355X_MICROARCH.md: PMC units); 256 CUs x 4 SIMDs
+            cycles = e["GRBM_GUI_ACTIVE"]["mean"] / 8.0
+            e["valu_busy_frac"] = e["SQ_ACTIVE_INST_VALU"]["mean"] * 4.0 / (1024.0 * cycles)
+            e["valu_cycles_per_instruction"] = e["SQ_ACTIVE_INST_VALU"]["mean"] * 4.0 / e["SQ_INSTS_VALU"]["mean"] if "SQ_INSTS_VALU" in cs else None
+        if k in durations:
+            e["avg_duration_ms_kernel_trace"] = durations[k] / 1e6
+            if "GRBM_GUI_ACTIVE" in cs:
+                e["effective_clock_ghz"] = e["GRBM_GUI_ACTIVE"]["mean"] / 8.0 / durations[k]
         summary["kernels"][k] = e
     json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1)[:3000])
