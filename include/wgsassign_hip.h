@@ -261,6 +261,16 @@ int wgs_reader_skip_names(wgs_reader *r, int64_t max_rows, int64_t *nrows);
 const char *wgs_reader_chunk_sites(wgs_reader *r, int64_t *bytes);
 /* Number of data lines (sites) of a gzipped Beagle file: one inflate pass, no parsing. */
 int wgs_reader_count_sites(const char *path, int64_t *sites);
+/* The same pass can leave an INDEX behind (index_path): header fields, the site count and at most max_points
+ * access points about span_bytes of text apart (deflate-block boundaries with their 32 KiB dictionaries; member
+ * boundaries of BGZF / concatenated gzip need none), and the site names, '\n'-terminated (names_path) -- so that
+ * one pass per file serves the count, the names-only pass of the downsampled-LOO site masks and every rank's
+ * start position.  wgs_reader_open_indexed returns a reader whose next row is first_row without inflating what
+ * precedes the access point before it: a rank that owns a later SNP range reads only its own range. */
+int wgs_reader_build_index(const char *path, const char *index_path, const char *names_path, int64_t span_bytes,
+                           int32_t max_points, int64_t *sites);
+int wgs_reader_index_sites(const char *path, const char *index_path, int64_t *sites);
+int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t first_row, int threads, wgs_reader **out);
 
 /* Test hooks for the convergence chain: wgs_rmse1d's value through the literal one-lane serial
  * kernel (serial != 0) or through the block-parallel exact emulation, reporting the number of

@@ -132,3 +132,94 @@ def test_speed_report(tmp_path):
     assert Ln.tobytes() == L.tobytes() and len(sites) == 20_000
     print("native reader: %.0f sites/s at n=100 (%d threads)" % (20_000 / t_native, min(len(os.sched_getaffinity(0)), 16)))
     assert 20_000 / t_native > 30_500      # the reference's readBeagle: 30.5 k sites/s at n=100
+
+
+# ------------------------------------------------------------------ random access (wgs_reader_build_index)
+def _bgzf_like(path, text, block=7000):
+    """Concatenated gzip members (what bgzip / ANGSD's BGZF writer produce: one member per <= 64 KiB block)."""
+    data = text.encode()
+    with open(path, "wb") as fh:
+        for i in range(0, len(data), block):
+            fh.write(gzip.compress(data[i:i + block], compresslevel=6))
+
+
+def _text_of(L, blank_lines=False, final_newline=True):
+    m, n = L.shape[0], L.shape[1] // 2
+    head = "marker\tallele1\tallele2\t" + "\t".join("I%d\tI%d\tI%d" % (i, i, i) for i in range(n))
+    lines = [head]
+    for s in range(m):
+        vals = []
+        for i in range(n):
+            g0, g1 = L[s, 2 * i], L[s, 2 * i + 1]
+            vals += ["%.6f" % g0, "%.6f" % g1, "%.6f" % max(0.0, 1 - g0 - g1)]
+        lines.append("ctg%d_%d\t0\t1\t" % (s % 7, s + 1) + "\t".join(vals))
+        if blank_lines and s % 97 == 5:
+            lines.append("")
+    return "\n".join(lines) + ("\n" if final_newline else "")
+
+
+@pytest.mark.parametrize("layout", ["plain", "members", "plain_no_final_newline_blank_lines"])
+def test_indexed_open_starts_at_any_row(tmp_path, monkeypatch, layout):
+    """An index built in one pass lets a reader start at ANY row and return exactly the rows a from-the-start
+    reader returns there: plain gzip (access points at deflate-block boundaries, 32 KiB dictionaries), concatenated
+    members (BGZF-like: member starts need no dictionary), blank lines and a missing final newline."""
+    import ctypes
+    from wgsassign_amd import _lib, reader_cy
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    m, n = 2500, 11
+    L, _ = synth.make_beagle(m, n, 2, seed=31)
+    text = _text_of(L, blank_lines="blank" in layout, final_newline="no_final" not in layout)
+    p = str(tmp_path / ("x_%s.beagle.gz" % layout))
+    if layout == "members":
+        _bgzf_like(p, text)
+    else:
+        with gzip.open(p, "wt", newline="", compresslevel=6) as fh:
+            fh.write(text)
+    lib = _lib.load()
+    idx = str(tmp_path / "i.idx")
+    nam = str(tmp_path / "i.names")
+    sites = ctypes.c_int64()
+    _lib.check(lib.wgs_reader_build_index(p.encode(), idx.encode(), nam.encode(), 40_000, 1000, ctypes.byref(sites)))
+    assert sites.value == m == reader_cy.count_sites(p)
+    names = open(nam).read().split("\n")[:-1]
+    assert names == ["ctg%d_%d" % (s % 7, s + 1) for s in range(m)]
+    assert os.path.getsize(idx) >= 2 * 32768 or layout == "members"         # access points with dictionaries were recorded
+    for first in [0, 1, 2, 63, 64, 500, 1234, 2498, 2499]:
+        with reader_cy.BeagleStream(p, threads=2, index=idx, first_row=first) as st:
+            assert st.n == n and st.sample_names == ["I%d" % i for i in range(n)]
+            rows, sn = next(st.chunks(max_rows=40))
+        k = min(40, m - first)
+        assert rows.shape[0] == k and sn == names[first:first + k], first
+        assert rows.tobytes() == L[first:first + k].tobytes(), first
+    # an index of another file (or of an older version of this one) is refused
+    os.utime(p, (1, 1))
+    with pytest.raises(ValueError, match="is not an index of"):
+        reader_cy.BeagleStream(p, index=idx, first_row=3)
+
+
+def test_ensure_index_once_and_names_pass(tmp_path, monkeypatch):
+    """read_site_names + the per-rank readers make ONE inflate pass over the file between them (the index
+    pass); later opens reuse the cached index."""
+    from wgsassign_amd import reader_cy
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path / "cache"))
+    os.makedirs(tmp_path / "cache")
+    L, _ = synth.make_beagle(900, 5, 1, seed=4)
+    p = str(tmp_path / "y.beagle.gz")
+    write_beagle(p, L)
+    samples, names = reader_cy.read_site_names(p)
+    assert samples == ["Ind%d" % i for i in range(5)] and names == ["chr1_%d" % (s + 1) for s in range(900)]
+    idx, nam = reader_cy.index_paths(p)
+    stamp = os.path.getmtime(idx)
+    time.sleep(0.05)
+    i2, _, sites = reader_cy.ensure_index(p)
+    assert i2 == idx and sites == 900 and os.path.getmtime(idx) == stamp          # not rebuilt
+    got = [r.copy() for r, _ in reader_cy.prefetched(reader_cy.BeagleStream(p, index=idx, first_row=450).chunks(max_rows=100))]
+    assert np.concatenate(got).tobytes() == L[450:].tobytes()
+    # errors inside the background producer reach the consumer
+    def boom():
+        yield 1
+        raise RuntimeError("inside")
+    it = reader_cy.prefetched(boom())
+    assert next(it) == 1
+    with pytest.raises(RuntimeError, match="inside"):
+        next(it)

@@ -86,8 +86,8 @@ def _run(args, comm):
         # WGSassign.py:172-198 with names-only passes: every rank derives the same two site masks, then
         # parses only its range of the KEPT sites of each file
         assert os.path.isfile(args.loo_downsampled_beagle), "Downsampled beagle file doesn't exist!"
-        sample_names, names_ref = reader_cy.read_site_names(args.beagle)
-        sample_names_ds, names_ds = reader_cy.read_site_names(args.loo_downsampled_beagle)
+        sample_names, names_ref = reader_cy.read_site_names(args.beagle, comm)
+        sample_names_ds, names_ds = reader_cy.read_site_names(args.loo_downsampled_beagle, comm)
         n = len(sample_names)
         say("Loaded " + str(len(names_ref)) + " sites and " + str(n) + " individuals.")
         if root:
@@ -110,12 +110,12 @@ def _run(args, comm):
         if kept_ref != [x for x, k in zip(names_ds, keep_ds) if k]:
             raise ValueError("Site names in full and downsampled Beagle do not match after filtering.")
         beagle, _, site_names, m = reader_cy.stream_to_device(args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank,
-                                                              world=comm.world, keep=keep_ref)
+                                                              world=comm.world, keep=keep_ref, comm=comm)
         scored, _, _, _ = reader_cy.stream_to_device(args.loo_downsampled_beagle, group_of, n_groups, ctx=ctx,
-                                                     rank=comm.rank, world=comm.world, keep=keep_ds)
+                                                     rank=comm.rank, world=comm.world, keep=keep_ds, comm=comm)
     else:
         beagle, sample_names, site_names, m = reader_cy.stream_to_device(
-            args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank, world=comm.world)
+            args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank, world=comm.world, comm=comm)
         n = beagle.n
         say("Loaded " + str(m) + " sites and " + str(n) + " individuals.")
         ends = comm.allgather_object((site_names[:4], site_names[-4:]))

@@ -83,6 +83,9 @@ SIGNATURES = {
     "wgs_reader_skip_names": (c_int, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "wgs_reader_chunk_sites": (c_vp, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_reader_count_sites": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
+    "wgs_reader_build_index": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_i64, c_i32, ctypes.POINTER(c_i64)]),
+    "wgs_reader_index_sites": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(c_i64)]),
+    "wgs_reader_open_indexed": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_i64, c_int, ctypes.POINTER(c_vp)]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),
     "wgs_em_last_chain_serial_blocks": (c_int, [c_vp]),
     "wgs_debug_div_mismatch": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),

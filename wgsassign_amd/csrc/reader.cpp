@@ -14,10 +14,13 @@
 // of ten, one correctly rounded division -- identical to strtod for such inputs); anything else
 // (exponents, inf/nan, hex) goes through strtod itself.
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -78,8 +81,114 @@ struct Line {
 
 }  // namespace
 
+namespace {
+
+// ---- gzip input with random access ------------------------------------------------------------------
+// A gzip stream can only be inflated from its start -- unless one keeps, for chosen deflate-block
+// boundaries, the 32 KiB of output that precede them (the dictionary the next block may refer to).
+// wgs_reader_build_index makes ONE inflate pass over the file, counting the data lines (sites) and
+// recording such access points (every `span` bytes of output; at the start of a gzip member -- BGZF
+// files have one per 64 KiB -- no dictionary is needed); a reader opened from the index starts at the
+// access point before its first row, so a rank that owns a later SNP range no longer inflates the
+// ranges before it.
+constexpr size_t GZ_WIN = 32768;
+
+struct AccessPoint {
+    uint64_t in = 0;            // compressed offset of the first byte not yet consumed
+    uint64_t out = 0;           // uncompressed offset
+    int64_t lines_before = 0;   // non-blank lines (header included) completed before `out`
+    uint8_t bits = 0;           // bits of byte in-1 that belong to the next block (0: byte aligned)
+    uint8_t content = 0;        // the line in progress at `out` already holds a non-delimiter character
+    uint8_t at_line_start = 0;  // `out` is the first byte of a line
+    uint8_t member_start = 0;   // a gzip member header starts at `in` (no dictionary needed)
+    std::vector<unsigned char> window;   // GZ_WIN bytes of output before `out` (empty at a member start)
+};
+
+struct GzSource {
+    FILE *fp = nullptr;
+    z_stream z;
+    bool z_live = false, raw = false, eof = false;
+    std::vector<unsigned char> in;
+
+    ~GzSource() { close(); }
+    void close()
+    {
+        if (z_live) inflateEnd(&z);
+        z_live = false;
+        if (fp) fclose(fp);
+        fp = nullptr;
+    }
+    bool refill()
+    {
+        if (z.avail_in != 0) return true;
+        const size_t got = fread(in.data(), 1, in.size(), fp);
+        z.next_in = in.data();
+        z.avail_in = (unsigned)got;
+        return got != 0;
+    }
+    // from the first byte (ap == nullptr) or from an access point
+    bool open(const char *path, const AccessPoint *ap)
+    {
+        close();
+        fp = fopen(path, "rb");
+        if (!fp) return false;
+        in.resize(4u << 20);
+        memset(&z, 0, sizeof z);
+        eof = false;
+        raw = ap && !ap->member_start;
+        if (inflateInit2(&z, raw ? -15 : 15 + 32) != Z_OK) return false;
+        z_live = true;
+        if (!ap) return true;
+        if (fseeko(fp, (off_t)(ap->in - (ap->bits ? 1 : 0)), SEEK_SET) != 0) return false;
+        if (ap->bits) {
+            const int c = getc(fp);
+            if (c == EOF) return false;
+            if (inflatePrime(&z, ap->bits, c >> (8 - ap->bits)) != Z_OK) return false;
+        }
+        if (raw && inflateSetDictionary(&z, ap->window.data(), (unsigned)ap->window.size()) != Z_OK) return false;
+        return true;
+    }
+    // up to `cap` bytes of output; 0 at the end of the file, -1 on a corrupt stream
+    long read(char *dst, size_t cap)
+    {
+        if (eof) return 0;
+        z.next_out = reinterpret_cast<unsigned char *>(dst);
+        z.avail_out = (unsigned)std::min<size_t>(cap, 1u << 30);
+        const unsigned want = z.avail_out;
+        while (z.avail_out != 0) {
+            if (!refill()) {
+                eof = true;             // input exhausted (a truncated last member ends the data like gzread's EOF)
+                break;
+            }
+            const int ret = inflate(&z, Z_NO_FLUSH);
+            if (ret == Z_STREAM_END) {  // end of a gzip member: another one may follow (concatenated gzip, BGZF)
+                if (raw) {              // raw inflate leaves the 8-byte CRC32 + ISIZE trailer in the input
+                    for (int skip = 8; skip > 0;) {
+                        if (!refill()) break;
+                        const unsigned k = std::min<unsigned>((unsigned)skip, z.avail_in);
+                        z.next_in += k;
+                        z.avail_in -= k;
+                        skip -= (int)k;
+                    }
+                    raw = false;
+                }
+                if (!refill()) {
+                    eof = true;
+                    break;
+                }
+                if (inflateReset2(&z, 15 + 32) != Z_OK) return -1;
+            } else if (ret != Z_OK && ret != Z_BUF_ERROR) {
+                return -1;
+            }
+        }
+        return (long)(want - z.avail_out);
+    }
+};
+
+}  // namespace
+
 struct wgs_reader {
-    gzFile gz = nullptr;
+    GzSource src;
     std::vector<std::string> samples;
     int gl_cols = 0;   // GL columns in the header (3 per individual)
     int n_inds = 0;
@@ -101,8 +210,7 @@ static bool fill(wgs_reader *r)
     }
     if (r->len == r->buf.size()) r->buf.resize(r->buf.size() * 2);   // a single line longer than the buffer
     while (!r->eof && r->len < r->buf.size()) {
-        const int want = (int)std::min<size_t>(r->buf.size() - r->len, 1u << 30);
-        const int got = gzread(r->gz, r->buf.data() + r->len, (unsigned)want);
+        const long got = r->src.read(r->buf.data() + r->len, r->buf.size() - r->len);
         if (got < 0) return false;
         if (got == 0) {
             r->eof = true;
@@ -113,6 +221,7 @@ static bool fill(wgs_reader *r)
     return true;
 }
 
+namespace {
 // Parse one data line into out[0 .. 2*n_inds); returns false when the line is short.
 static bool parse_line(const wgs_reader *r, const Line &ln, float *out, std::string *site)
 {
@@ -139,6 +248,24 @@ static bool parse_line(const wgs_reader *r, const Line &ln, float *out, std::str
     return true;
 }
 
+// Header line (reader_cy.pyx:35-49): tokens after the first three are GL columns, every third names a sample.
+void parse_header(const char *p, const char *hend, std::vector<std::string> &samples, int &gl_cols)
+{
+    int tok = 0;
+    samples.clear();
+    while (p < hend) {
+        while (p < hend && is_delim(*p)) ++p;
+        if (p >= hend) break;
+        const char *tb = p;
+        while (p < hend && !is_delim(*p)) ++p;
+        ++tok;
+        if (tok > 3 && (tok - 3) % 3 == 1) samples.emplace_back(tb, p);
+    }
+    gl_cols = tok > 3 ? tok - 3 : 0;
+}
+
+}  // namespace
+
 extern "C" {
 
 int wgs_reader_open(const char *path, int threads, wgs_reader **out)
@@ -147,54 +274,422 @@ int wgs_reader_open(const char *path, int threads, wgs_reader **out)
         wgs_set_error("null argument");
         return 2;
     }
-    gzFile gz = gzopen(path, "rb");
-    if (!gz) {
+    wgs_reader *r = new wgs_reader();
+    if (!r->src.open(path, nullptr)) {
         wgs_set_error("cannot open Beagle file %s", path);
+        delete r;
         return 2;
     }
-    gzbuffer(gz, 1u << 20);
-    wgs_reader *r = new wgs_reader();
-    r->gz = gz;
     r->threads = threads > 0 ? threads : 1;
     r->buf.resize(64u << 20);
     if (!fill(r)) {
         wgs_set_error("read error in %s", path);
-        gzclose(gz);
         delete r;
         return 1;
     }
-    // header line (reader_cy.pyx:35-49)
     const char *nl = (const char *)memchr(r->buf.data(), '\n', r->len);
     while (!nl && !r->eof) {
         if (!fill(r)) break;
         nl = (const char *)memchr(r->buf.data(), '\n', r->len);
     }
     const char *hend = nl ? nl : r->buf.data() + r->len;
-    const char *p = r->buf.data();
-    int tok = 0;
-    while (p < hend) {
-        while (p < hend && is_delim(*p)) ++p;
-        if (p >= hend) break;
-        const char *tb = p;
-        while (p < hend && !is_delim(*p)) ++p;
-        ++tok;
-        if (tok > 3) {
-            const int c = tok - 3;
-            if (c % 3 == 1) r->samples.emplace_back(tb, p);
-        }
-    }
-    r->gl_cols = tok > 3 ? tok - 3 : 0;
+    parse_header(r->buf.data(), hend, r->samples, r->gl_cols);
     r->n_inds = r->gl_cols / 3;
     r->pos = nl ? (size_t)(nl - r->buf.data()) + 1 : r->len;
     *out = r;
     return 0;
 }
 
-void wgs_reader_close(wgs_reader *r)
+void wgs_reader_close(wgs_reader *r) { delete r; }
+
+}  // extern "C"
+
+namespace {
+
+// Line bookkeeping of the index pass over consecutive pieces of output: non-blank lines completed, whether
+// the line in progress has content, optional capture of every data line's first token (the site name).
+struct LineScan {
+    int64_t lines = 0;          // non-blank lines completed (the header is line 0)
+    bool content = false, at_line_start = true, in_name = false, name_done = false;
+    std::string header, *names = nullptr;
+    bool header_done = false;
+
+    void feed(const unsigned char *p, size_t n)
+    {
+        const unsigned char *e = p + n;
+        while (p < e) {
+            if (!header_done) {                      // keep the header line verbatim
+                const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(e - p));
+                header.append((const char *)p, (size_t)((nl ? nl : e) - p));
+                if (!nl) return;
+                header_done = true;
+                lines += 1;                          // the header counts as a line even when empty
+                content = false;
+                at_line_start = true;
+                p = nl + 1;
+                continue;
+            }
+            if (!content) {                          // look for the first non-delimiter of the line
+                while (p < e && *p != '\n' && is_delim((char)*p)) ++p, at_line_start = false;
+                if (p == e) return;
+                if (*p == '\n') {                    // blank line: not counted
+                    at_line_start = true;
+                    ++p;
+                    continue;
+                }
+                content = true;
+                at_line_start = false;
+                in_name = names != nullptr;
+                name_done = false;
+            }
+            if (in_name) {
+                const unsigned char *t = p;
+                while (t < e && !is_delim((char)*t)) ++t;
+                names->append((const char *)p, (size_t)(t - p));
+                p = t;
+                if (p == e) return;
+                names->push_back('\n');
+                in_name = false;
+            }
+            const unsigned char *nl = (const unsigned char *)memchr(p, '\n', (size_t)(e - p));
+            if (!nl) return;
+            lines += 1;
+            content = false;
+            at_line_start = true;
+            p = nl + 1;
+        }
+    }
+    void finish()
+    {
+        if (!header_done) {
+            header_done = true;
+            lines += 1;
+        } else if (content) {
+            if (in_name) names->push_back('\n');
+            lines += 1;                              // last line without a newline
+        }
+        content = false;
+    }
+};
+
+struct BeagleIndex {
+    uint64_t file_size = 0, mtime = 0;
+    int64_t sites = 0;
+    int32_t gl_cols = 0;
+    std::vector<std::string> samples;
+    std::vector<AccessPoint> points;
+};
+
+bool file_identity(const char *path, uint64_t &size, uint64_t &mtime)
 {
-    if (!r) return;
-    if (r->gz) gzclose(r->gz);
-    delete r;
+    struct stat st;
+    if (stat(path, &st) != 0) return false;
+    size = (uint64_t)st.st_size;
+    mtime = (uint64_t)st.st_mtime;
+    return true;
+}
+
+// One inflate pass: count the sites, read the header, record access points every `span` output bytes.
+int scan_file(const char *path, int64_t span, BeagleIndex &idx, std::string *names)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) {
+        wgs_set_error("cannot open Beagle file %s", path);
+        return 2;
+    }
+    file_identity(path, idx.file_size, idx.mtime);
+    std::vector<unsigned char> in(4u << 20), win(GZ_WIN);
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 15 + 32) != Z_OK) {
+        fclose(fp);
+        wgs_set_error("zlib initialisation failed");
+        return 1;
+    }
+    LineScan ls;
+    ls.names = names;
+    uint64_t totin = 0, totout = 0, last = 0;
+    bool member_start = true, bad = false;
+    z.avail_out = 0;
+    auto add_point = [&](bool at_member) {
+        AccessPoint ap;
+        ap.in = totin;
+        ap.out = totout;
+        ap.lines_before = ls.lines;
+        ap.content = ls.content;
+        ap.at_line_start = ls.at_line_start;
+        ap.member_start = at_member;
+        ap.bits = at_member ? 0 : (uint8_t)(z.data_type & 7);
+        if (!at_member) {                            // the GZ_WIN bytes before `out`, oldest first
+            ap.window.resize(GZ_WIN);
+            const size_t left = z.avail_out;         // free space at the end of the circular window
+            memcpy(ap.window.data(), win.data() + (GZ_WIN - left), left);
+            memcpy(ap.window.data() + left, win.data(), GZ_WIN - left);
+        }
+        idx.points.push_back(std::move(ap));
+        last = totout;
+    };
+    for (;;) {
+        if (z.avail_in == 0) {
+            const size_t got = fread(in.data(), 1, in.size(), fp);
+            if (got == 0) break;
+            z.next_in = in.data();
+            z.avail_in = (unsigned)got;
+        }
+        if (member_start && span > 0 && totout - last >= (uint64_t)span && totout > 0) add_point(true);
+        member_start = false;
+        if (z.avail_out == 0) {
+            z.avail_out = (unsigned)GZ_WIN;
+            z.next_out = win.data();
+        }
+        const unsigned char *produced_at = z.next_out;
+        const unsigned in0 = z.avail_in, out0 = z.avail_out;
+        const int ret = inflate(&z, Z_BLOCK);
+        totin += in0 - z.avail_in;
+        totout += out0 - z.avail_out;
+        ls.feed(produced_at, out0 - z.avail_out);
+        if (ret == Z_STREAM_END) {                   // next gzip member, if any
+            if (z.avail_in == 0) {
+                const size_t got = fread(in.data(), 1, in.size(), fp);
+                z.next_in = in.data();
+                z.avail_in = (unsigned)got;
+                if (got == 0) break;
+            }
+            if (inflateReset2(&z, 15 + 32) != Z_OK) {
+                bad = true;
+                break;
+            }
+            member_start = true;
+            continue;
+        }
+        if (ret != Z_OK && ret != Z_BUF_ERROR) {
+            bad = true;
+            break;
+        }
+        // at the end of a deflate block that is not the last of its member
+        if (span > 0 && (z.data_type & 128) && !(z.data_type & 64) && totout - last >= (uint64_t)span && totout >= GZ_WIN)
+            add_point(false);
+    }
+    inflateEnd(&z);
+    fclose(fp);
+    if (bad) {
+        wgs_set_error("read error in %s (corrupt gzip stream)", path);
+        return 1;
+    }
+    ls.finish();
+    idx.sites = ls.lines > 0 ? ls.lines - 1 : 0;     // minus the header line
+    parse_header(ls.header.data(), ls.header.data() + ls.header.size(), idx.samples, idx.gl_cols);
+    return 0;
+}
+
+template <typename T>
+void put(FILE *f, const T &v) { fwrite(&v, sizeof v, 1, f); }
+template <typename T>
+bool get(FILE *f, T &v) { return fread(&v, sizeof v, 1, f) == 1; }
+
+const char kIndexMagic[8] = {'W', 'G', 'S', 'I', 'D', 'X', '1', 0};
+
+bool save_index(const char *path, const BeagleIndex &idx)
+{
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return false;
+    fwrite(kIndexMagic, 1, 8, f);
+    put(f, idx.file_size);
+    put(f, idx.mtime);
+    put(f, idx.sites);
+    put(f, idx.gl_cols);
+    const int32_t ns = (int32_t)idx.samples.size(), np = (int32_t)idx.points.size();
+    put(f, ns);
+    for (const auto &s : idx.samples) {
+        const int32_t l = (int32_t)s.size();
+        put(f, l);
+        fwrite(s.data(), 1, s.size(), f);
+    }
+    put(f, np);
+    for (const auto &a : idx.points) {
+        put(f, a.in);
+        put(f, a.out);
+        put(f, a.lines_before);
+        put(f, a.bits);
+        put(f, a.content);
+        put(f, a.at_line_start);
+        put(f, a.member_start);
+        if (!a.member_start) fwrite(a.window.data(), 1, GZ_WIN, f);
+    }
+    const bool ok = !ferror(f);
+    fclose(f);
+    return ok && rename(tmp.c_str(), path) == 0;     // atomic: readers never see a partial index
+}
+
+bool load_index(const char *path, BeagleIndex &idx)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    char magic[8];
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kIndexMagic, 8) == 0;
+    int32_t ns = 0, np = 0;
+    ok = ok && get(f, idx.file_size) && get(f, idx.mtime) && get(f, idx.sites) && get(f, idx.gl_cols) && get(f, ns) && ns >= 0;
+    for (int i = 0; ok && i < ns; ++i) {
+        int32_t l = 0;
+        ok = get(f, l) && l >= 0 && l < (1 << 20);
+        if (!ok) break;
+        std::string s((size_t)l, '\0');
+        ok = fread(&s[0], 1, (size_t)l, f) == (size_t)l;
+        idx.samples.push_back(std::move(s));
+    }
+    ok = ok && get(f, np) && np >= 0;
+    for (int i = 0; ok && i < np; ++i) {
+        AccessPoint a;
+        ok = get(f, a.in) && get(f, a.out) && get(f, a.lines_before) && get(f, a.bits) && get(f, a.content) &&
+             get(f, a.at_line_start) && get(f, a.member_start);
+        if (ok && !a.member_start) {
+            a.window.resize(GZ_WIN);
+            ok = fread(a.window.data(), 1, GZ_WIN, f) == GZ_WIN;
+        }
+        if (ok) idx.points.push_back(std::move(a));
+    }
+    fclose(f);
+    return ok;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* ONE inflate pass over a gzipped Beagle file: counts its sites, and (index_path != NULL) writes an index --
+ * header fields plus at most max_points access points, about `span_bytes` of text apart -- from which
+ * wgs_reader_open_indexed starts at any row without inflating what precedes it; names_path != NULL also
+ * receives every site name, '\n'-terminated (the names-only pass of the downsampled-LOO site masks). */
+int wgs_reader_build_index(const char *path, const char *index_path, const char *names_path, int64_t span_bytes, int32_t max_points,
+                           int64_t *sites)
+{
+    if (!path || !sites) {
+        wgs_set_error("null argument");
+        return 2;
+    }
+    BeagleIndex idx;
+    std::string names;
+    const int rc = scan_file(path, index_path ? std::max<int64_t>(span_bytes, (int64_t)GZ_WIN) : 0, idx, names_path ? &names : nullptr);
+    if (rc) return rc;
+    *sites = idx.sites;
+    if (index_path) {
+        if (max_points > 0 && (int64_t)idx.points.size() > max_points) {       // thin out evenly
+            std::vector<AccessPoint> keep;
+            const double step = (double)idx.points.size() / max_points;
+            for (int i = 0; i < max_points; ++i) keep.push_back(std::move(idx.points[(size_t)(i * step)]));
+            idx.points.swap(keep);
+        }
+        if (!save_index(index_path, idx)) {
+            wgs_set_error("cannot write the Beagle index %s", index_path);
+            return 1;
+        }
+    }
+    if (names_path) {
+        FILE *f = fopen(names_path, "wb");
+        if (!f || fwrite(names.data(), 1, names.size(), f) != names.size()) {
+            if (f) fclose(f);
+            wgs_set_error("cannot write the site names to %s", names_path);
+            return 1;
+        }
+        fclose(f);
+    }
+    return 0;
+}
+
+/* Sites of the file an index was built for (after checking that it still describes `path`: size and mtime). */
+int wgs_reader_index_sites(const char *path, const char *index_path, int64_t *sites)
+{
+    if (!path || !index_path || !sites) {
+        wgs_set_error("null argument");
+        return 2;
+    }
+    BeagleIndex idx;
+    uint64_t size = 0, mtime = 0;
+    if (!load_index(index_path, idx) || !file_identity(path, size, mtime) || size != idx.file_size || mtime != idx.mtime) {
+        wgs_set_error("%s is not an index of %s", index_path, path);
+        return 2;
+    }
+    *sites = idx.sites;
+    return 0;
+}
+
+/* A reader positioned so that the next row it returns is `first_row` (0-based site index): it starts inflating
+ * at the last access point at or before that row and skips the few lines in between without parsing. */
+int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t first_row, int threads, wgs_reader **out)
+{
+    if (!path || !index_path || !out || first_row < 0) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    BeagleIndex idx;
+    uint64_t size = 0, mtime = 0;
+    if (!load_index(index_path, idx) || !file_identity(path, size, mtime) || size != idx.file_size || mtime != idx.mtime) {
+        wgs_set_error("%s is not an index of %s", index_path, path);
+        return 2;
+    }
+    // data row r is non-blank line r + 1; an access point serves it when lines_before <= r + 1 (it may sit inside
+    // line lines_before, whose remainder is then skipped: that costs one more line of margin)
+    const AccessPoint *best = nullptr;
+    for (const auto &a : idx.points) {
+        const int64_t first_full = a.lines_before + (a.at_line_start ? 0 : 1);
+        if (first_full <= first_row + 1 && (!best || a.out > best->out)) best = &a;
+    }
+    wgs_reader *r = new wgs_reader();
+    r->samples = idx.samples;
+    r->gl_cols = idx.gl_cols;
+    r->n_inds = idx.gl_cols / 3;
+    r->threads = threads > 0 ? threads : 1;
+    r->buf.resize(64u << 20);
+    if (!r->src.open(path, best)) {
+        wgs_set_error("cannot open Beagle file %s at its access point", path);
+        delete r;
+        return 2;
+    }
+    int64_t line = 0;            // non-blank line index of the next complete line in the buffer
+    if (best) {
+        if (!fill(r)) {
+            wgs_set_error("read error in %s", path);
+            delete r;
+            return 1;
+        }
+        line = best->lines_before;
+        if (!best->at_line_start) {                      // drop the tail of the line the access point sits in
+            bool content = best->content;
+            for (;;) {
+                const char *b = r->buf.data() + r->pos;
+                const char *nl = (const char *)memchr(b, '\n', r->len - r->pos);
+                const char *e = nl ? nl : r->buf.data() + r->len;
+                for (const char *t = b; t < e && !content; ++t) content = !is_delim(*t);
+                r->pos = (size_t)(e - r->buf.data()) + (nl ? 1 : 0);
+                if (nl || r->eof) break;
+                if (!fill(r)) {
+                    wgs_set_error("read error in %s", path);
+                    delete r;
+                    return 1;
+                }
+                if (r->eof && r->pos >= r->len) break;
+            }
+            line += content ? 1 : 0;
+        }
+    } else {
+        line = 0;                                        // from the first byte: the header is line 0
+    }
+    // skip whole lines up to the wanted row (line index first_row + 1); from the start that includes the header
+    int64_t to_skip = first_row + 1 - line, got = 0;
+    if (to_skip < 0) {
+        wgs_set_error("index of %s is inconsistent", path);
+        delete r;
+        return 1;
+    }
+    if (to_skip > 0 && (wgs_reader_skip(r, to_skip, &got) != 0 || got != to_skip)) {
+        if (got != to_skip) wgs_set_error("Beagle file %s is shorter than its index says", path);
+        delete r;
+        return 1;
+    }
+    r->lines_read = first_row;
+    *out = r;
+    return 0;
 }
 
 int wgs_reader_n_individuals(wgs_reader *r) { return r ? r->n_inds : 0; }
@@ -327,44 +822,7 @@ static int skip_impl(wgs_reader *r, int64_t max_rows, int64_t *nrows, bool names
     return 0;
 }
 
-int wgs_reader_count_sites(const char *path, int64_t *sites)
-{
-    if (!path || !sites) {
-        wgs_set_error("null argument");
-        return 2;
-    }
-    gzFile gz = gzopen(path, "rb");
-    if (!gz) {
-        wgs_set_error("cannot open Beagle file %s", path);
-        return 2;
-    }
-    gzbuffer(gz, 1u << 20);
-    std::vector<char> buf(16u << 20);
-    int64_t lines = 0;
-    bool content = false;   // the current line holds a non-delimiter character
-    for (;;) {
-        const int got = gzread(gz, buf.data(), (unsigned)buf.size());
-        if (got < 0) {
-            gzclose(gz);
-            wgs_set_error("read error in %s", path);
-            return 1;
-        }
-        if (got == 0) break;
-        for (int i = 0; i < got; ++i) {
-            const char c = buf[i];
-            if (c == '\n') {
-                lines += content;
-                content = false;
-            } else if (!is_delim(c)) {
-                content = true;
-            }
-        }
-    }
-    lines += content;
-    gzclose(gz);
-    *sites = lines > 0 ? lines - 1 : 0;   // minus the header line
-    return 0;
-}
+int wgs_reader_count_sites(const char *path, int64_t *sites) { return wgs_reader_build_index(path, nullptr, nullptr, 0, 0, sites); }
 
 const char *wgs_reader_chunk_sites(wgs_reader *r, int64_t *bytes)
 {

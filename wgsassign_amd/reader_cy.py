@@ -7,22 +7,40 @@ atof(token) rounded to float32.
 """
 import ctypes
 import gzip
+import hashlib
 import os
+import queue
+import tempfile
+import threading
 
 import numpy as np
 
 from . import _lib
 
+INDEX_SPAN_BYTES = 64 << 20       # text between two access points of the index
+INDEX_MAX_POINTS = 4096
+
 
 class BeagleStream:
     """Chunked reader: iterate (rows float32 (k, 2n), site_names list) until the file ends."""
 
-    def __init__(self, path, threads=None):
+    def __init__(self, path, threads=None, index=None, first_row=0):
+        """From the first site, or -- given the index of wgs_reader_build_index -- positioned at `first_row`
+        without inflating the file up to there."""
         lib = _lib.load()
         if threads is None:
             threads = min(len(os.sched_getaffinity(0)), 16)
         h = ctypes.c_void_p()
-        _lib.check(lib.wgs_reader_open(os.fsencode(path), int(threads), ctypes.byref(h)))
+        if index is None:
+            _lib.check(lib.wgs_reader_open(os.fsencode(path), int(threads), ctypes.byref(h)))
+            if first_row:
+                got = ctypes.c_int64()
+                _lib.check(lib.wgs_reader_skip(h, int(first_row), ctypes.byref(got)))
+                if got.value != first_row:
+                    raise RuntimeError("Beagle file shorter than counted")
+        else:
+            _lib.check(lib.wgs_reader_open_indexed(os.fsencode(path), os.fsencode(index), int(first_row), int(threads),
+                                                   ctypes.byref(h)))
         self._h = h
         self.n = lib.wgs_reader_n_individuals(h)
         self.sample_names = [lib.wgs_reader_sample_name(h, i).decode() for i in range(self.n)]
@@ -76,20 +94,74 @@ def count_sites(path):
     return n.value
 
 
-def read_site_names(path, chunk=1 << 20):
-    """(sample_names, site_names) of a Beagle file without parsing any likelihood (inflate-bound)."""
+def index_paths(path):
+    """Where the index (and the site-name list) of a Beagle file are cached: the temporary directory
+    (WGSASSIGN_INDEX_DIR overrides it), keyed by the file's absolute path, size and modification time."""
+    st = os.stat(path)
+    key = hashlib.sha1(("%s|%d|%d" % (os.path.abspath(path), st.st_size, int(st.st_mtime))).encode()).hexdigest()[:20]
+    base = os.path.join(os.environ.get("WGSASSIGN_INDEX_DIR", tempfile.gettempdir()), "wgsassign_" + key)
+    return base + ".idx", base + ".names"
+
+
+def ensure_index(path, comm=None, names=False):
+    """ONE inflate pass per file and node: the first rank counts the sites, records the access points (and the
+    site names when asked) next to each other in the index cache; the other ranks wait and read the result.
+    Returns (index_path, names_path or None, sites)."""
     lib = _lib.load()
-    names = []
-    with BeagleStream(path, threads=1) as st:
-        while True:
-            got = ctypes.c_int64()
-            _lib.check(lib.wgs_reader_skip_names(st._h, chunk, ctypes.byref(got)))
-            if got.value == 0:
-                break
-            nbytes = ctypes.c_int64()
-            ptr = lib.wgs_reader_chunk_sites(st._h, ctypes.byref(nbytes))
-            names.extend(ctypes.string_at(ptr, nbytes.value).decode().split("\n")[:-1])
-        return list(st.sample_names), names
+    idx, nam = index_paths(path)
+    rank = comm.rank if comm is not None else 0
+
+    def valid():
+        n = ctypes.c_int64()
+        ok = os.path.exists(idx) and lib.wgs_reader_index_sites(os.fsencode(path), os.fsencode(idx), ctypes.byref(n)) == 0
+        return (ok and (not names or os.path.exists(nam))), n.value
+
+    ok, sites = valid()
+    if rank == 0 and not ok:
+        n = ctypes.c_int64()
+        _lib.check(lib.wgs_reader_build_index(os.fsencode(path), os.fsencode(idx), os.fsencode(nam) if names else None,
+                                              INDEX_SPAN_BYTES, INDEX_MAX_POINTS, ctypes.byref(n)))
+    if comm is not None and comm.world > 1:
+        comm.barrier()
+    ok, sites = valid()
+    if not ok:
+        raise RuntimeError("the index of %s could not be built or read (%s)" % (path, idx))
+    return idx, (nam if names else None), sites
+
+
+def read_site_names(path, comm=None):
+    """(sample_names, site_names) of a Beagle file without parsing any likelihood: the names come out of the
+    same single inflate pass that counts the sites and builds the index."""
+    idx, nam, _ = ensure_index(path, comm, names=True)
+    with BeagleStream(path, threads=1, index=idx, first_row=0) as st:
+        samples = list(st.sample_names)
+    with open(nam, "rb") as fh:
+        names = fh.read().decode().split("\n")[:-1]
+    return samples, names
+
+
+def prefetched(gen, depth=1):
+    """Run a generator one item ahead in a background thread: the next chunk is inflated and parsed (native code,
+    GIL released) while the caller uploads the current one."""
+    q = queue.Queue(maxsize=depth)
+    done = object()
+
+    def work():
+        try:
+            for item in gen:
+                q.put(item)
+            q.put(done)
+        except BaseException as e:      # hand the error to the consumer
+            q.put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    while True:
+        item = q.get()
+        if item is done:
+            return
+        if isinstance(item, BaseException):
+            raise item
+        yield item
 
 
 def readBeagle(beagle):
@@ -125,22 +197,23 @@ def readBeagle_py(beagle):
 
 
 def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, rank=0, world=1, m_total=None,
-                     keep=None):
-    """Two passes over the file: count the sites, then parse chunk by chunk straight into the
-    device slabs -- host memory stays bounded by one chunk (the reference holds two
-    full copies).  With world > 1 this rank skips to its contiguous SNP range
-    (comm.shard_range) and parses only that.  group_of may be a callable(sample_names) ->
-    (group_of, n_groups).  keep (bool array over the file's sites, e.g. the site mask of
-    utils.filter_sites_to_common) restricts the matrix to the kept sites; shard ranges then count
-    kept sites.  Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
+                     keep=None, comm=None):
+    """The file goes chunk by chunk straight into the device slabs -- host memory stays bounded by two chunks
+    (the reference holds two full copies).  One indexing pass per file and node (ensure_index)
+    counts the sites; with world > 1 every rank then starts at the access point before its contiguous SNP range
+    (comm.shard_range) and inflates and parses only that range, the next chunk being prepared while the current
+    one is uploaded.  group_of may be a callable(sample_names) -> (group_of, n_groups).  keep (bool array over the
+    file's sites, e.g. the site mask of utils.filter_sites_to_common) restricts the matrix to the kept sites;
+    shard ranges then count kept sites.  Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
     from .comm import shard_range
     from .device import DeviceBeagle
+    index, _, m_file = ensure_index(path, comm)
     if keep is not None:
         keep = np.asarray(keep, dtype=bool)
         kept_rows = np.flatnonzero(keep)
         m_total = len(kept_rows)
     elif m_total is None:
-        m_total = count_sites(path)
+        m_total = m_file
     lo, hi = shard_range(m_total, rank, world)
     # file rows [r0, r1) cover this rank's (kept) sites
     if keep is None:
@@ -149,16 +222,14 @@ def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, ra
         r0, r1 = int(kept_rows[lo]), int(kept_rows[hi - 1]) + 1
     else:
         r0 = r1 = 0
-    with BeagleStream(path, threads) as st:
+    if hi <= lo:
+        raise ValueError("fewer sites (%d) than ranks (%d): nothing to shard" % (m_total, world))
+    with BeagleStream(path, threads, index=index, first_row=r0) as st:
         if callable(group_of):
             group_of, n_groups = group_of(list(st.sample_names))
-        if hi <= lo:
-            raise ValueError("fewer sites (%d) than ranks (%d): nothing to shard" % (m_total, world))
         beagle = DeviceBeagle(hi - lo, st.n, group_of, n_groups, site0=lo, ctx=ctx)
-        if st.skip(r0) != r0:
-            raise RuntimeError("Beagle file shorter than counted")
         row0, frow, site_names = 0, r0, []
-        for rows, names in st.chunks(limit=r1 - r0):
+        for rows, names in prefetched(st.chunks(limit=r1 - r0)):
             if keep is not None:
                 sel = keep[frow:frow + rows.shape[0]]
                 frow += rows.shape[0]
