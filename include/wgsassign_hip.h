@@ -19,8 +19,9 @@
  *   - arithmetic mode: WGS_MODE_EXACT reproduces the reference's rounding sequence operation
  *     by operation (double products rounded to float32, float32 (p0+p1)+p2, serial float32
  *     accumulation over individuals in file order) and is bit-identical to the reference for
- *     allele frequencies and EM iteration counts; WGS_MODE_FAST evaluates each term in float32
- *     and is within ~1e-6 relative (documented in DESIGN.md).
+ *     allele frequencies and EM iteration counts; WGS_MODE_FAST evaluates each term in float32: the
+ *     n x K sums stay within 1.2e-7 relative at full size, the EM frequencies drift up to 7e-6 at 10M SNPs
+ *     (iteration counts unchanged) -- see DESIGN.md; the host side only ever defaults to EXACT.
  */
 #ifndef WGSASSIGN_HIP_H
 #define WGSASSIGN_HIP_H
@@ -199,10 +200,12 @@ int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out
  * the population's column of `a` (in: full-population estimates, out: each population's last re-fit), the
  * K float64 sums and -- when parts_out is given -- the serial float32 partition sums.
  * scored: the matrix that is scored (NULL = b).  batch: re-fits per EM batch (0 = what fits the free
- * device memory, agreed across ranks).  ll_out: host float64 [n*K]; parts_out: host float32 [n*P*K] or
+ * device memory, agreed across ranks).  em_mode / score_mode: arithmetic of the re-fits and of the sums
+ * (the partition sums are always exact).  ll_out: host float64 [n*K]; parts_out: host float32 [n*P*K] or
  * NULL; iters_out: [n] convergence iterations of the re-fits (0 = max_iter exhausted). */
 int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, double tole, int64_t m_total,
-            wgs_comm *comm, int32_t P, int32_t batch, int mode, double *ll_out, float *parts_out, int32_t *iters_out);
+            wgs_comm *comm, int32_t P, int32_t batch, int em_mode, int score_mode, double *ll_out, float *parts_out,
+            int32_t *iters_out);
 
 /* Test hooks: (chain, block) pairs of the last walk that took the literal serial loop / walked in all;
  * the literal one-lane-per-chain kernel behind wgs_assign_parts_exact, whatever P. */

@@ -109,7 +109,7 @@ int main(void)
         CHECK(wgs_em_clamp(em2, k, 1.0f / 8.0f, 7.0f / 8.0f));
         CHECK(wgs_afset_set_column_from_em(af, k, em2, k));
     }
-    CHECK(wgs_loo(b, NULL, af, 200, 1e-4, M, NULL, 2, 0, WGS_MODE_EXACT, loo, parts, loo_iters));
+    CHECK(wgs_loo(b, NULL, af, 200, 1e-4, M, NULL, 2, 0, WGS_MODE_EXACT, WGS_MODE_EXACT, loo, parts, loo_iters));
     for (int i = 0; i < N; ++i)
         for (int k = 0; k < K; ++k) {
             const double tot = (double)parts[(i * 2 + 0) * K + k] + (double)parts[(i * 2 + 1) * K + k];

@@ -122,7 +122,7 @@ def test_native_communicator_handle_in_the_c_loops(wg, golden):
     afs = dev.AFSet.from_host(fit["pop_af"].copy())
     n, K, P = b.n, 5, 3
     ll, parts, it = np.zeros((n, K)), np.zeros((n * P, K), dtype=np.float32), np.zeros(n, dtype=np.int32)
-    _lib.check(_lib.load().wgs_loo(b.handle, None, afs.handle, 200, 1e-4, b.m, c.handle, P, 30, 0, _lib.f64p(ll),
+    _lib.check(_lib.load().wgs_loo(b.handle, None, afs.handle, 200, 1e-4, b.m, c.handle, P, 30, 0, 0, _lib.f64p(ll),
                                    _lib.f32p(parts), _lib.i32p(it)))
     assert same(parts, g["parts_P3"]) and same(afs.to_host(), g["af_after_P3"]) and it.min() > 0
     afs.close()

@@ -1188,7 +1188,7 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
  *   batch   re-fits per EM batch, 0 = what fits the free device memory (agreed across ranks);
  *   ll_out  host float64 [n*K] (overwritten); parts_out host float32 [n*P*K] or NULL; iters_out [n]. */
 int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm,
-            int32_t P, int32_t batch, int mode, double *ll_out, float *parts_out, int32_t *iters_out)
+            int32_t P, int32_t batch, int em_mode, int score_mode, double *ll_out, float *parts_out, int32_t *iters_out)
 {
     WGS_REQUIRE(b && a && ll_out && iters_out, "null argument");
     if (!scored) scored = b;
@@ -1233,7 +1233,7 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
         wgs_em *em = nullptr;
         wgs_score *sc = nullptr;
         auto guard = on_failure([&] { wgs_score_destroy(sc); wgs_em_destroy(em); });
-        int rc = wgs_em_create(b, nb, grp.data(), skip.data(), mode, &em);
+        int rc = wgs_em_create(b, nb, grp.data(), skip.data(), em_mode, &em);
         if (rc) return rc;
         if ((rc = wgs_em_fit(em, max_iter, tole, m_total, comm, 0.0, iters_out + i0))) return rc;
         for (int x = 0; x < nb; ++x) {
@@ -1250,7 +1250,7 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
             for (int k = 0; k < K; ++k) colptr[(size_t)i * K + k] = cur[k];
         }
         if ((rc = wgs_score_create(scored, a, colptr.data(), (int32_t)i0, (int32_t)i1, &sc))) return rc;
-        if ((rc = wgs_score_sums(sc, parts_out ? WGS_MODE_EXACT : mode, sums.data()))) return rc;
+        if ((rc = wgs_score_sums(sc, parts_out ? WGS_MODE_EXACT : score_mode, sums.data()))) return rc;
         if (world > 1) {   // every rank's sums: the total, and what precedes each shard (for the chain prediction)
             by_rank.assign(cells * world, 0.0);
             std::copy(sums.begin(), sums.end(), by_rank.begin() + cells * rank);

@@ -4,9 +4,11 @@ Host code is Python/NumPy; all arithmetic of the hot path runs in the HIP kernel
 include/wgsassign_hip.h.  SNP sharding over ranks needs exactly one collective (a sum
 all-reduce of a few float64), supplied by a `comm` object (wgsassign_amd/comm.py).
 """
+import atexit
 import ctypes
 import math
 import os
+import weakref
 
 import numpy as np
 
@@ -14,13 +16,41 @@ from . import _lib
 from ._lib import MODE_EXACT, MODE_FAST, check, f32p, f64p, i32p
 
 _default_ctx = None
+_live = weakref.WeakSet()       # device objects that still own library handles
+
+
+@atexit.register
+def _close_all():
+    """Release every device object before the interpreter tears modules down: children (scores, EM batches)
+    before the matrices they refer to, so no destructor runs against a freed parent or an unloaded library."""
+    order = {"Score": 0, "EMBatch": 1, "AFSet": 2, "DeviceBeagle": 3}
+    for obj in sorted(list(_live), key=lambda o: order.get(type(o).__name__, 9)):
+        try:
+            obj.close()
+        except Exception:
+            pass
+
+
+
+def _mode_from(var):
+    m = os.environ.get(var, "exact").lower()
+    if m not in ("exact", "fast"):
+        raise ValueError("%s must be 'exact' or 'fast', got %r" % (var, m))
+    return MODE_EXACT if m == "exact" else MODE_FAST
 
 
 def default_mode():
-    m = os.environ.get("WGSASSIGN_MODE", "exact").lower()
-    if m not in ("exact", "fast"):
-        raise ValueError("WGSASSIGN_MODE must be 'exact' or 'fast', got %r" % m)
-    return MODE_EXACT if m == "exact" else MODE_FAST
+    """Arithmetic of the SCORING sweep (WGSASSIGN_MODE): exact (default; per-site values bit-identical to the
+    reference) or fast (float32 evaluation, hardware log: n x K sums within 1.2e-7 relative of exact at 10M x 1000 x
+    K=10 and 2M x 500 x K=8 -- tools/check_fast_mode.py -- inside the 1e-6 bar, 2.9x faster)."""
+    return _mode_from("WGSASSIGN_MODE")
+
+
+def default_em_mode():
+    """Arithmetic of the EM update (WGSASSIGN_EM_MODE, default exact).  The float32 update keeps the reference's
+    iteration counts but its frequencies drift up to 7e-6 relative at 10M SNPs (0.1 % of them beyond 1e-6): outside
+    the 1e-6 bar, so it is an explicit opt-in and never implied by WGSASSIGN_MODE=fast."""
+    return _mode_from("WGSASSIGN_EM_MODE")
 
 
 def _as_f32c(a, name):
@@ -103,6 +133,7 @@ class DeviceBeagle:
         h = ctypes.c_void_p()
         check(_lib.load().wgs_beagle_create(self.ctx.handle, self.m, self.n, gp, n_groups, self.site0, ctypes.byref(h)))
         self._h = h
+        _live.add(self)
 
     @classmethod
     def from_host(cls, L, group_of=None, n_groups=1, site0=0, ctx=None):
@@ -157,6 +188,7 @@ class AFSet:
         h = ctypes.c_void_p()
         check(_lib.load().wgs_afset_create(self.ctx.handle, self.m, self.K, ctypes.byref(h)))
         self._h = h
+        _live.add(self)
 
     @classmethod
     def from_host(cls, A, ctx=None):
@@ -204,12 +236,13 @@ class EMBatch:
     def __init__(self, beagle, groups, skips=None, mode=None):
         self.b = beagle
         self.n_fits = len(groups)
-        self.mode = default_mode() if mode is None else mode
+        self.mode = default_em_mode() if mode is None else mode
         g = np.ascontiguousarray(groups, dtype=np.int32)
         s = np.ascontiguousarray(skips if skips is not None else np.full(self.n_fits, -1), dtype=np.int32)
         h = ctypes.c_void_p()
         check(_lib.load().wgs_em_create(beagle.handle, self.n_fits, i32p(g), i32p(s), self.mode, ctypes.byref(h)))
         self._h = h
+        _live.add(self)
         self.active = np.ones(self.n_fits, dtype=bool)
 
     @property
@@ -454,6 +487,7 @@ class Score:
         h = ctypes.c_void_p()
         check(_lib.load().wgs_score_create(beagle.handle, afset.handle, cp, lo, hi, ctypes.byref(h)))
         self._h = h
+        _live.add(self)
         self.local = None
         self.ms = {}
 

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .device import default_mode, get_context
+from .device import default_em_mode, get_context
 
 _CNAMES = {"float64": "double", "float32": "float", "int32": "int", "int64": "long", "int16": "short",
            "int8": "signed char", "uint8": "unsigned char", "uint16": "unsigned short", "uint32": "unsigned int",
@@ -41,7 +41,7 @@ def emMAF_update(L, f, t=1):
         return None
     if L.shape[1] != 2 * n:
         L = np.ascontiguousarray(L[:, :2 * n])
-    _lib.check(_lib.load().wgs_emmaf_update(get_context().handle, _lib.f32p(L), m, n, _lib.f32p(f), default_mode()))
+    _lib.check(_lib.load().wgs_emmaf_update(get_context().handle, _lib.f32p(L), m, n, _lib.f32p(f), default_em_mode()))
     return None
 
 

@@ -130,7 +130,7 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
         # same through the step-wise entry points and serves the other communicators (gloo / socket)
         import ctypes
         from . import _lib
-        from .device import default_mode
+        from .device import default_em_mode, default_mode
         t0 = time.perf_counter()
         afset = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32))
         m_total = int(comm.allreduce_sum(np.array([float(beagle.m)]))[0]) if handle is not None else beagle.m
@@ -139,7 +139,7 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
         iters = np.zeros(n, dtype=np.int32)
         _lib.check(_lib.load().wgs_loo(beagle.handle, scored.handle if scored is not beagle else None, afset.handle,
                                        int(maf_iter), float(maf_tole), m_total, handle, P,
-                                       int(os.environ.get("WGSASSIGN_LOO_BATCH", 0)), default_mode(), _lib.f64p(out),
+                                       int(os.environ.get("WGSASSIGN_LOO_BATCH", 0)), default_em_mode(), default_mode(), _lib.f64p(out),
                                        _lib.f32p(parts) if parts is not None else None, _lib.i32p(iters)))
         if verbose:
             for i in range(n):
