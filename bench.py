@@ -80,9 +80,24 @@ def launch_ranks(n_ranks, fixed_env):
             if kind:
                 env["WGSASSIGN_COMM"] = kind
                 env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 7 * attempt)      # a fresh side-channel port
-            out = None if env["RANK"] == "0" else subprocess.DEVNULL
-            procs.append(subprocess.Popen(argv, env=env, stdout=out))
+            # rank 0's stdout is filtered: only the JSON line goes to this process's stdout (librccl prints a version
+            # banner on stdout when its communicator initialises); everything else is passed on to stderr
+            out = subprocess.PIPE if env["RANK"] == "0" else subprocess.DEVNULL
+            procs.append(subprocess.Popen(argv, env=env, stdout=out, text=True))
+        pumps = []
+        for p in procs:
+            if p.stdout is not None:
+                def pump(stream=p.stdout):
+                    for line in stream:
+                        dst = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+                        dst.write(line)
+                        dst.flush()
+                th = threading.Thread(target=pump, daemon=True)
+                th.start()
+                pumps.append(th)
         codes = [p.wait() for p in procs]
+        for th in pumps:
+            th.join(10)
         if all(c == 0 for c in codes):
             return 0
         if any(c == COMM_INIT_FAILED for c in codes) and not kind and os.environ.get("WGSASSIGN_COMM", "rccl") == "rccl":
@@ -196,21 +211,30 @@ def main():
         slots[rank] = x
         return float(np.max(comm.allreduce_sum(slots)))
 
-    def step():
-        # sweep kernel -> (N > 1: RCCL all-reduce of the K sums, enqueued behind it) -> one readback:
-        # exactly what EMBatch.run does per EM iteration
-        return em.step_reduced(comm if use_dist else None)
+    # A step = one EM iteration of the production loop.  With one shard or RCCL shards that loop is wgs_em_fit
+    # (device.EMBatch.fit): per iteration the sweep, the sum reduction, [the RCCL all-reduce of the K sums, enqueued
+    # behind it], the device-side convergence decision and the state readback, enqueued one iteration ahead of the
+    # host.  tole = 0 never converges, so fit(K, 0.0) runs EXACTLY K iterations.  Other communicators (socket, gloo)
+    # take the step-by-step protocol: sweep -> host all-reduce -> one readback per iteration.
+    pipelined = not use_dist or getattr(comm, "handle", None) is not None
 
-    for _ in range(args.warmup):
-        step()
-    kernel_ms = []
+    def run_steps(k):
+        if pipelined:
+            em.fit(k, 0.0, comm if use_dist else None, m_total)
+            return em.fit_stats()[3] / max(1, k)
+        ms = []
+        for _ in range(k):
+            em.step_reduced(comm)
+            ms.append(em.last_sweep_ms())
+        return float(np.mean(ms)) if ms else 0.0
+
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ssq = step()
-        kernel_ms.append(em.last_sweep_ms())
+    kernel_ms = [run_steps(args.steps)]
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    ssq = em.step_reduced(comm if use_dist else None)       # untimed: the sums after warmup + steps + 1 updates
     ms_per_step = elapsed / args.steps * 1e3
     value = K * m_total * args.steps / elapsed          # per-population SNP-updates/s, whole job
 
@@ -293,7 +317,8 @@ def main():
                 "dtype": "f64" if args.mode == "exact" else "f32", "data": "synthetic",
                 "config": {"workload": "synthetic Beagle %d SNPs x %d ind, K=%d, --get_reference_af EM sweep (+ --get_pop_like sweep), SNP-sharded over %d GPU(s)"
                                        % (m_total, n, K, world), "mode": args.mode, "snps_per_gpu": m,
-                           "gl_bytes_per_gpu": beagle.nbytes(), "comm": comm_note},
+                           "gl_bytes_per_gpu": beagle.nbytes(), "comm": comm_note,
+                           "step": "wgs_em_fit iteration (enqueued ahead of the host)" if pipelined else "sweep + host all-reduce + readback"},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
     em.close()

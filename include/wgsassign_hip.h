@@ -131,8 +131,9 @@ int wgs_em_n_active(wgs_em *em);
 typedef struct wgs_comm wgs_comm;
 int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm, double guard_floor,
                int32_t *iters_out);
-/* Iterations enqueued / batched exact-chain resolutions / wall seconds of the last wgs_em_fit. */
-int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds);
+/* Iterations enqueued / batched exact-chain resolutions / wall seconds of the last wgs_em_fit, and the summed
+ * duration in ms of its sweep kernels (HIP events recorded on the context's stream around every sweep). */
+int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds, double *sweep_ms);
 /* Clamp fit j's frequencies to [lo, hi] the way WGSassign.py:236-240 does (float32 compares,
  * NaN untouched). */
 int wgs_em_clamp(wgs_em *em, int32_t fit, float lo, float hi);

@@ -44,7 +44,8 @@ def test_c_loop_equals_python_loop(wg, monkeypatch, guard):
         iters = em.run(200, 1e-4)
         res[loop] = (iters.copy(), np.stack([em.get_f(j) for j in range(n + K)]), em.active.copy())
         if loop == "c":
-            launched, batches, seconds = em.fit_stats()
+            launched, batches, seconds, sweep_ms = em.fit_stats()
+            assert 0 < sweep_ms < seconds * 1e3
             # one iteration of lookahead; a parked fit sweeps every other iteration
             assert launched >= iters.max() + 1 and (launched >= 2 * iters.max() if guard > 1 else launched <= iters.max() + 4)
             assert (batches >= iters.max()) if guard > 1 else (batches <= 6)

@@ -42,7 +42,7 @@ def main():
     t_fit = time.perf_counter() - t0
     res["reference_af_fit"] = {"seconds": round(t_fit, 4), "iters": [int(x) for x in iters],
                                "snp_updates_per_s": float(m) * float(np.sum(iters)) / t_fit,
-                               "iterations_enqueued, chain_batches, seconds_in_wgs_em_fit": list(em.fit_stats())}
+                               "iterations_enqueued, chain_batches, seconds_in_wgs_em_fit, sweep_kernels_ms": list(em.fit_stats())}
     t0 = time.perf_counter()
     c = em.rmse_chain(0, 0.0)
     res["rmse_chain"] = {"seconds": round(time.perf_counter() - t0, 5), "diff": device.chain_diff(c, m)}

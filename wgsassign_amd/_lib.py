@@ -47,7 +47,7 @@ SIGNATURES = {
     "wgs_em_step_dev": (c_int, [c_vp, c_vp]),
     "wgs_em_rmse_chain": (c_int, [c_vp, c_i32, ctypes.c_float, c_f32p]),
     "wgs_em_fit": (c_int, [c_vp, c_i32, ctypes.c_double, c_i64, c_vp, ctypes.c_double, c_i32p]),
-    "wgs_em_fit_stats": (c_int, [c_vp, c_i32p, c_i32p, c_f64p]),
+    "wgs_em_fit_stats": (c_int, [c_vp, c_i32p, c_i32p, c_f64p, c_f64p]),
     "wgs_comm_rank": (c_int, [c_vp, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "wgs_em_last_sweep_ms": (c_int, [c_vp, c_f32p]),
     "wgs_em_set_active": (c_int, [c_vp, c_i32, c_int]),

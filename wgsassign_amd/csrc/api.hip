@@ -300,6 +300,8 @@ struct wgs_em {
     int32_t *h_state[2] = {nullptr, nullptr}, *h_setstate = nullptr;
     double *d_ssq2 = nullptr;             // [n_fits] sums of the iteration in flight
     hipEvent_t ev_it[2] = {nullptr, nullptr};
+    hipEvent_t ev_sw0[2] = {nullptr, nullptr}, ev_sw1[2] = {nullptr, nullptr};   // bracket the sweep kernel(s) of a slot
+    double fit_sweep_ms = 0.0;            // summed sweep-kernel time of the last wgs_em_fit (HIP events)
     ChainJob *d_jobs = nullptr, *h_jobs = nullptr;
     float *d_chain_out = nullptr, *h_chain_out = nullptr;     // [n_fits] carries | [n_fits] serial-block counts
     void *d_chain_batch = nullptr;
@@ -328,6 +330,8 @@ void wgs_em_destroy(wgs_em *em)
         if (em->h_descs2[i]) (void)hipHostFree(em->h_descs2[i]);
         if (em->h_state[i]) (void)hipHostFree(em->h_state[i]);
         if (em->ev_it[i]) (void)hipEventDestroy(em->ev_it[i]);
+        if (em->ev_sw0[i]) (void)hipEventDestroy(em->ev_sw0[i]);
+        if (em->ev_sw1[i]) (void)hipEventDestroy(em->ev_sw1[i]);
     }
     for (void *p : {(void *)em->d_state, (void *)em->d_ssq2, (void *)em->d_jobs, (void *)em->d_chain_out, em->d_chain_batch})
         if (p) (void)hipFree(p);
@@ -507,6 +511,8 @@ static int em_fit_alloc(wgs_em *em)
         HIP_TRY(hipHostMalloc(&em->h_descs2[i], sizeof(FitDesc) * n, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&em->ev_it[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&em->ev_sw0[i]));
+        HIP_TRY(hipEventCreate(&em->ev_sw1[i]));
     }
     return 0;
 }
@@ -586,6 +592,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     HIP_TRY(hipMemcpyAsync(em->d_state, init.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     em->fit_iterations = em->fit_chain_batches = 0;
+    em->fit_sweep_ms = 0.0;
     const auto t_begin = std::chrono::steady_clock::now();
     bool launched_prev = false;
     for (int t = 1;; ++t) {
@@ -629,10 +636,12 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
             HIP_TRY(hipMemcpyAsync(em->d_descs2[slot], H, sizeof(FitDesc) * L.size(), hipMemcpyHostToDevice, ctx->stream));
             const int64_t per_fit = (ntiles + 3) / 4 + 8;
             const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
+            HIP_TRY(hipEventRecord(em->ev_sw0[slot], ctx->stream));
             for (size_t off = 0; off < L.size(); off += max_fits) {
                 const int cnt = (int)std::min<size_t>(max_fits, L.size() - off);
                 if (launch_em_sweep(ctx, em->d_descs2[slot] + off, cnt, em->b->m, em->mode, shared)) return 1;
             }
+            HIP_TRY(hipEventRecord(em->ev_sw1[slot], ctx->stream));
             for (size_t off = 0; off < L.size(); off += 65535) {
                 const int cnt = (int)std::min<size_t>(65535, L.size() - off);
                 if (launch_ssq_reduce(ctx, em->d_descs2[slot] + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
@@ -649,6 +658,8 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         if (launched_prev) {
             const int ps = slot ^ 1;
             HIP_TRY(hipEventSynchronize(em->ev_it[ps]));     // also: the pinned descriptors of t-1 have been consumed
+            float sweep_ms = 0.0f;
+            if (hipEventElapsedTime(&sweep_ms, em->ev_sw0[ps], em->ev_sw1[ps]) == hipSuccess) em->fit_sweep_ms += sweep_ms;
             parked.clear();
             for (int j : ran) {
                 const int st = em->h_state[ps][j];
@@ -690,13 +701,15 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     return 0;
 }
 
-/* Diagnostics of the last wgs_em_fit: iterations enqueued, batched exact-chain resolutions, wall seconds. */
-int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds)
+/* Diagnostics of the last wgs_em_fit: iterations enqueued, batched exact-chain resolutions, wall seconds, and the
+ * summed duration of its sweep kernels (HIP events on the context's stream around each iteration's sweep). */
+int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds, double *sweep_ms)
 {
     WGS_REQUIRE(em, "null argument");
     if (iterations) *iterations = em->fit_iterations;
     if (chain_batches) *chain_batches = em->fit_chain_batches;
     if (seconds) *seconds = em->fit_seconds;
+    if (sweep_ms) *sweep_ms = em->fit_sweep_ms;
     return 0;
 }
 

@@ -326,7 +326,8 @@ class EMBatch:
     def fit(self, max_iter, tole, comm=None, m_total=None):
         """wgs_em_fit: emMAF.py:15-27 for every fit in one call."""
         lib = _lib.load()
-        handle = getattr(comm, "handle", None) if comm is not None and comm.world > 1 else None
+        forced = comm is not None and getattr(comm, "force_device", False)     # bench.py: rehearse the collective on one GPU
+        handle = getattr(comm, "handle", None) if comm is not None and (comm.world > 1 or forced) else None
         if m_total is None:
             m_total = int(comm.allreduce_sum(np.array([float(self.b.m)]))[0]) if handle is not None else self.b.m
         iters = np.zeros(self.n_fits, dtype=np.int32)
@@ -335,10 +336,10 @@ class EMBatch:
         return iters
 
     def fit_stats(self):
-        """(iterations enqueued, batched exact-chain resolutions, wall seconds) of the last fit()."""
-        it, ch, sec = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double()
-        check(_lib.load().wgs_em_fit_stats(self._h, ctypes.byref(it), ctypes.byref(ch), ctypes.byref(sec)))
-        return it.value, ch.value, sec.value
+        """(iterations enqueued, batched exact-chain resolutions, wall seconds, summed sweep-kernel ms) of the last fit()."""
+        it, ch, sec, ms = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_double(), ctypes.c_double()
+        check(_lib.load().wgs_em_fit_stats(self._h, ctypes.byref(it), ctypes.byref(ch), ctypes.byref(sec), ctypes.byref(ms)))
+        return it.value, ch.value, sec.value, ms.value
 
     def close(self):
         if self._h:
