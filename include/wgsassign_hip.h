@@ -288,6 +288,9 @@ int wgs_em_last_chain_serial_blocks(wgs_em *em);
  * 2^20 x per_thread pseudo-random EM-shaped operand pairs whose quotient differs bitwise from the
  * compiler's IEEE double divide. */
 int wgs_debug_div_mismatch(wgs_ctx *ctx, uint64_t seed, uint64_t per_thread, uint64_t *mismatch);
+/* ... and the accuracy of its once-refined reciprocal: the largest relative error over ALL 2^23 float32 mantissas of
+ * the denominator at binary exponent `exponent` (its exactness argument needs < 2^-48; see em_kernels.hip). */
+int wgs_debug_rcp_error(wgs_ctx *ctx, int exponent, double *max_rel);
 
 /* Test hooks for the assignment kernel's double-precision log of float32 arguments
  * (csrc/assign_kernels.hip: log_f32arg): number of float32 bit patterns in [b0, b1) whose

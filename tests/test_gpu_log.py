@@ -94,3 +94,14 @@ def test_em_divide_is_ieee_exact(dev):
     bad = ctypes.c_uint64(123)
     _lib.check(lib.wgs_debug_div_mismatch(ctx.handle, 20260313, 4096, ctypes.byref(bad)))
     assert bad.value == 0, bad.value
+
+
+def test_em_divide_reciprocal_bound_exhaustive(dev):
+    """div_exact uses ONE Newton refinement of v_rcp_f64.  Its exactness argument (csrc/em_kernels.hip) needs the
+    refined reciprocal within 2^-48 of 1/den: checked here for EVERY float32 mantissa of the denominator (2^23 values),
+    at exponents from float32-denormal sums to the largest possible sum."""
+    lib, ctx, _lib = dev
+    for exponent in (-149, -126, -100, -30, -1, 0, 1, 2):
+        worst = ctypes.c_double(-1.0)
+        _lib.check(lib.wgs_debug_rcp_error(ctx.handle, exponent, ctypes.byref(worst)))
+        assert 0 <= worst.value < 2.0 ** -48, (exponent, worst.value)

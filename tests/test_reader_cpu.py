@@ -223,3 +223,87 @@ def test_ensure_index_once_and_names_pass(tmp_path, monkeypatch):
     assert next(it) == 1
     with pytest.raises(RuntimeError, match="inside"):
         next(it)
+
+
+def test_header_with_a_partial_individual(tmp_path):
+    """A header whose GL column count is not a multiple of 3: the reference keeps n = c // 3 individuals and the first
+    2n values of each row (reader_cy.pyx:48-49, 71-75).  Every parsed row is exactly 2n floats -- the extra columns are
+    not written anywhere (they used to spill into the next row and past the end of the last one)."""
+    from wgsassign_amd import reader_cy
+    n, m = 3, 200
+    rng = np.random.default_rng(3)
+    head = "marker\tallele1\tallele2\t" + "\t".join("S%d" % (i // 3) for i in range(3 * n + 2))     # 11 GL columns
+    vals = np.round(rng.random((m, 3 * n + 2)), 6)
+    p = str(tmp_path / "odd.beagle.gz")
+    with gzip.open(p, "wt") as fh:
+        fh.write(head + "\n")
+        for s in range(m):
+            fh.write("c_%d\tA\tC\t" % s + "\t".join("%.6f" % v for v in vals[s]) + "\n")
+    guard = np.full((m + 1, 2 * n), -7.0, dtype=np.float32)
+    with reader_cy.BeagleStream(p, threads=4) as st:
+        assert st.n == n and st.sample_names == ["S0", "S1", "S2"]             # the complete individuals
+        import ctypes
+        from wgsassign_amd import _lib
+        got = ctypes.c_int64()
+        _lib.check(_lib.load().wgs_reader_next(st._h, _lib.f32p(guard), m, ctypes.byref(got)))
+    assert got.value == m and np.all(guard[m] == -7.0)                           # nothing written past the last row
+    want = np.stack([vals[:, 3 * i + j] for i in range(n) for j in (0, 1)], axis=1).astype(np.float32)
+    assert guard[:m].tobytes() == want.tobytes()
+
+
+def _bgzf_write(path, text, block=60000):
+    """A real BGZF file (htslib layout): gzip members with the 'BC' extra subfield announcing their size, raw deflate
+    payload, CRC32 + ISIZE trailer, and the empty end-of-file marker block."""
+    import struct
+    import zlib
+    data = text.encode()
+    with open(path, "wb") as fh:
+        for i in list(range(0, len(data), block)) + [None]:
+            chunk = b"" if i is None else data[i:i + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            payload = co.compress(chunk) + co.flush()
+            bsize = 12 + 6 + len(payload) + 8
+            fh.write(b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) +
+                     b"BC" + struct.pack("<HH", 2, bsize - 1) + payload +
+                     struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+@pytest.mark.parametrize("variant", ["normal", "no_final_newline_blank_lines"])
+def test_bgzf_parallel_index_and_block_parallel_inflate(tmp_path, monkeypatch, variant):
+    """BGZF input (what ANGSD writes): the index pass inflates the blocks on all host threads and finds the same site
+    count, header and line numbers as the serial pass over the same text; readers opened at any row inflate their
+    blocks in parallel and return the same rows; gzip itself reads the file as ordinary multi-member gzip."""
+    import ctypes
+    from wgsassign_amd import _lib, reader_cy
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    m, n = 4000, 9
+    L, _ = synth.make_beagle(m, n, 2, seed=77)
+    text = _text_of(L, blank_lines="blank" in variant, final_newline="no_final" not in variant)
+    p = str(tmp_path / "b.beagle.gz")
+    _bgzf_write(p, text)
+    assert gzip.open(p, "rt").read() == text
+    lib = _lib.load()
+    idx = str(tmp_path / "b.idx")
+    sites = ctypes.c_int64()
+    _lib.check(lib.wgs_reader_build_index(p.encode(), idx.encode(), None, 100_000, 4096, ctypes.byref(sites)))
+    assert sites.value == m
+    assert os.path.getsize(idx) < 20_000                      # block starts need no 32 KiB dictionaries
+    names = ["ctg%d_%d" % (s % 7, s + 1) for s in range(m)]
+    for first in [0, 1, 190, 191, 192, 1000, 2047, 3999]:
+        with reader_cy.BeagleStream(p, threads=3, index=idx, first_row=first) as st:
+            assert st.n == n
+            got = list(st.chunks(max_rows=700))
+        rows = np.concatenate([r for r, _ in got])
+        sn = [x for _, ns in got for x in ns]
+        assert rows.tobytes() == L[first:].tobytes() and sn == names[first:], first
+    # without an index: from the start, block-parallel
+    Lr, samples, sites_r = reader_cy.readBeagle(p)
+    assert Lr.tobytes() == L.tobytes() and sites_r == names and samples == ["I%d" % i for i in range(n)]
+    # the names pass takes the serial route and agrees
+    s2, n2 = reader_cy.read_site_names(p)
+    assert n2 == names and s2 == samples
+    # a truncated file is an error, not a silent short read
+    cut = str(tmp_path / "cut.beagle.gz")
+    open(cut, "wb").write(open(p, "rb").read()[:-5000])
+    with pytest.raises(RuntimeError):
+        reader_cy.readBeagle(cut)

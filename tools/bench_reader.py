@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--inds", type=int, default=2000)
     ap.add_argument("--sites", type=int, default=3000)
     ap.add_argument("--device", action="store_true")
+    ap.add_argument("--bgzf", action="store_true", help="write the file as BGZF (what ANGSD produces) instead of plain gzip")
     a = ap.parse_args()
     n, m = a.inds, a.sites
     rng = np.random.default_rng(1)
@@ -30,7 +31,37 @@ def main():
     path = os.path.join(d, "bench.beagle.gz")
     head = "marker\tallele1\tallele2\t" + "\t".join("I%d\tI%d\tI%d" % (i, i, i) for i in range(n))
     text_bytes = 0
-    with gzip.open(path, "wt", compresslevel=6) as fh:
+    import struct
+    import zlib
+
+    class Bgzf:
+        """minimal BGZF writer: 60 kB blocks, 'BC' size subfield, end marker"""
+        def __init__(self, path):
+            self.fh, self.buf = open(path, "wb"), b""
+
+        def block(self, chunk):
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            payload = co.compress(chunk) + co.flush()
+            self.fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" +
+                          struct.pack("<HH", 2, 12 + 6 + len(payload) + 8 - 1) + payload +
+                          struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+        def write(self, text):
+            self.buf += text.encode()
+            while len(self.buf) >= 60000:
+                self.block(self.buf[:60000])
+                self.buf = self.buf[60000:]
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            if self.buf:
+                self.block(self.buf)
+            self.block(b"")
+            self.fh.close()
+
+    with (Bgzf(path) if a.bgzf else gzip.open(path, "wt", compresslevel=6)) as fh:
         fh.write(head + "\n")
         for s in range(m):
             g = rng.dirichlet((0.6, 0.6, 0.6), size=n)
@@ -38,7 +69,7 @@ def main():
             text_bytes += len(line)
             fh.write(line)
     res = {"individuals": n, "sites": m, "text_MB": round(text_bytes / 1e6, 1), "gz_MB": round(os.path.getsize(path) / 1e6, 1),
-           "threads": min(len(os.sched_getaffinity(0)), 16)}
+           "threads": min(len(os.sched_getaffinity(0)), 16), "format": "bgzf" if a.bgzf else "gzip"}
     t0 = time.perf_counter()
     idx, _, sites = reader_cy.ensure_index(path)
     t = time.perf_counter() - t0

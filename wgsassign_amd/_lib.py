@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwgsassign_hip.so")
+LIB_PATH = os.environ.get("WGSASSIGN_LIB_PATH") or os.path.join(_HERE, "libwgsassign_hip.so")   # override: experimental builds
 
 MODE_EXACT = 0
 MODE_FAST = 1
@@ -88,6 +88,7 @@ SIGNATURES = {
     "wgs_reader_open_indexed": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_i64, c_int, ctypes.POINTER(c_vp)]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),
     "wgs_em_last_chain_serial_blocks": (c_int, [c_vp]),
+    "wgs_debug_rcp_error": (c_int, [c_vp, c_int, c_f64p]),
     "wgs_debug_div_mismatch": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(ctypes.c_uint64)]),
     "wgs_debug_log_mismatch": (c_int, [c_vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32)]),
     "wgs_debug_log_values": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_int]),

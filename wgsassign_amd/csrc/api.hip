@@ -1519,6 +1519,23 @@ int wgs_debug_div_mismatch(wgs_ctx *ctx, uint64_t seed, uint64_t per_thread, uin
     return 0;
 }
 
+/* Largest relative error of the once-refined reciprocal of div_exact over all 2^23 float32 mantissas of the
+ * denominator scaled by 2^exponent (the bound its exactness argument rests on: < 2^-48). */
+int wgs_debug_rcp_error(wgs_ctx *ctx, int exponent, double *max_rel)
+{
+    WGS_REQUIRE(ctx && max_rel, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, 256, &ws)) return 1;
+    unsigned long long *d = reinterpret_cast<unsigned long long *>(ws), h = 0;
+    HIP_TRY(hipMemsetAsync(d, 0, sizeof h, ctx->stream));
+    if (launch_rcp_error(ctx, exponent, d)) return 1;
+    HIP_TRY(hipMemcpyAsync(&h, d, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    memcpy(max_rel, &h, sizeof h);
+    return 0;
+}
+
 int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first)
 {
     WGS_REQUIRE(ctx && count && first, "null argument");

@@ -571,7 +571,7 @@ constexpr int WALK_CHUNK = 1024;
 __global__ __launch_bounds__(256) void chain_walk_kernel(WalkArgs W)
 {
     __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
-    __shared__ float sq_all[4][WALK_CHUNK];
+    __shared__ __attribute__((aligned(16))) float sq_all[4][WALK_CHUNK];
     const double2 *tab = load_log_table(tab_lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void chain_walk_kernel(WalkArgs W)
             const int64_t first = lo + (((p - (W.site0 + lo)) % W.P) + W.P) % W.P;
             for (int64_t c0 = first; c0 < hi; c0 += (int64_t)WALK_CHUNK * W.P) {
                 int cnt = 0;
-#pragma unroll 4
+#pragma unroll 8
                 for (int r = 0; r < WALK_CHUNK / 64; ++r) {
                     const int64_t s = c0 + (int64_t)(r * 64 + lane) * W.P;
                     float v = 0.0f;
@@ -629,7 +629,18 @@ __global__ __launch_bounds__(256) void chain_walk_kernel(WalkArgs W)
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                for (int t = 0; t < cnt; ++t) res = res + sq[t];          // float32 += float32, site order
+                // float32 += float32 in site order.  The adds are one dependent chain; the LDS reads are not:
+                // 16 values per batch of four ds_read_b128, so their latency is paid once per batch, not per add
+                int t = 0;
+                for (; t + 16 <= cnt; t += 16) {
+                    const float4 a = *reinterpret_cast<const float4 *>(sq + t), b = *reinterpret_cast<const float4 *>(sq + t + 4);
+                    const float4 c = *reinterpret_cast<const float4 *>(sq + t + 8), d = *reinterpret_cast<const float4 *>(sq + t + 12);
+                    res = res + a.x; res = res + a.y; res = res + a.z; res = res + a.w;
+                    res = res + b.x; res = res + b.y; res = res + b.z; res = res + b.w;
+                    res = res + c.x; res = res + c.y; res = res + c.z; res = res + c.w;
+                    res = res + d.x; res = res + d.y; res = res + d.z; res = res + d.w;
+                }
+                for (; t < cnt; ++t) res = res + sq[t];
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -795,6 +806,9 @@ int launch_log_values(wgs_ctx *ctx, const float *d_x, float *d_out, int64_t n, i
 // KB = populations per register batch: the batch size with the fewest passes over K, then the least padding
 static int pick_kb(int K)
 {
+#ifdef WGS_EXPERIMENT_KB10     // experiment: K = 10 in ONE register pass (halves the GL traffic of the sweep)
+    if (K == 10) return 10;
+#endif
     int best = 4, best_cost = 1 << 30;
     for (int kb = 4; kb <= 8; ++kb) {
         const int passes = (K + kb - 1) / kb;
@@ -837,8 +851,14 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
     }
 }
 
+#ifdef WGS_EXPERIMENT_KB10
+#define WGS_KB10_CASE(X) case 10: X(10, 1); break;
+#else
+#define WGS_KB10_CASE(X)
+#endif
 #define WGS_FOR_KB_NP(X, K)                \
     switch (pick_kb(K)) {                  \
+        WGS_KB10_CASE(X)                   \
         case 4: X(4, 2); break;            \
         case 5: X(5, 2); break;            \
         case 6: X(6, 2); break;            \

@@ -124,6 +124,7 @@ int ssq_reduce_chunks(void);
 int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2);
 // state[fit] of every listed fit that swept: ssq < lo -> EM_CONVERGED, ssq >= hi (or NaN) -> EM_ACTIVE, else EM_UNDECIDED
 int launch_em_decide(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, double lo, double hi);
+int launch_rcp_error(wgs_ctx *ctx, int exponent, unsigned long long *d_max_bits);
 int launch_div_check(wgs_ctx *ctx, unsigned long long seed, unsigned long long per_thread, unsigned long long *d_mismatch);
 int launch_fill(wgs_ctx *ctx, float *p, int64_t count, float v);
 int launch_clamp(wgs_ctx *ctx, float *p, int64_t count, float lo, float hi);

@@ -36,25 +36,33 @@ struct SnpState {
     float ff, omff, ff2;              // fast-mode float copies
 };
 
-// Correctly rounded double quotient num/den for den = a float32 value (or 0) and 0 <= num:
-// the same Newton-Raphson core LLVM emits for an IEEE f64 divide (v_rcp_f64 seed, two
-// refinements, quotient, one residual correction), minus the v_div_scale range scaling that
-// operands of this magnitude never need; v_div_fixup keeps the 0/0, x/0 and NaN results of `/`.
+// Correctly rounded double quotient num/den for den = a float32 value widened to double (or 0) and num >= 0.
+// v_rcp_f64 seed (measured 2^-24.4 relative), ONE Newton refinement (r within 2^-48.7 of 1/den: checked for every
+// float32 mantissa of den, tests/test_gpu_log.py), q0 = RN(num * r), residual fma, one correction, v_div_fixup for
+// the 0/0, x/0 and NaN results of `/`.  Why one refinement suffices where a general IEEE divide needs two:
+//   * before its rounding the corrected quotient fma(rem, r, q0) is within q * 2^-97 of num/den (the residual is known
+//     to 2^-53 relative, the reciprocal to 2^-48.7, and the correction itself is only q * 2^-48.6 large);
+//   * den has 24 significant bits and num at most 53, so num/den is never closer than q * 2^-78 to the midpoint of two
+//     doubles (and never on one): with num = A * 2^a, den = B * 2^b, midpoint M * 2^u (M odd, 54 bits),
+//     |num - den * M 2^u| is a non-zero multiple of 2^(b+u), i.e. >= 2^(a-25), and dividing by den < 2^(b+24)
+//     leaves >= 2^(a-b-49) = q * 2^-78;
+// so the final rounding lands on the correctly rounded quotient -- the same bits as the compiler's IEEE divide
+// (wgs_debug_div_mismatch: 0 of 8.6e9 EM-shaped operand pairs), with two fewer FP64 instructions per term and
+// without the v_div_scale range scaling these operands never need.
+__device__ __forceinline__ double refined_rcp(double den)
+{
+    double r = __builtin_amdgcn_rcp(den);
+    const double e = __builtin_fma(-den, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 __device__ __forceinline__ double div_exact(double num, double den)
 {
-#ifdef WGS_PLAIN_DIVIDE
-    return num / den;
-#else
-    double r = __builtin_amdgcn_rcp(den);
-    double e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
+    const double r = refined_rcp(den);
     double q = num * r;
     const double rem = __builtin_fma(-den, q, num);
     q = __builtin_fma(rem, r, q);
     return __builtin_amdgcn_div_fixup(q, den, num);
-#endif
 }
 
 // One (SNP, individual) term of emMAF_cy.pyx:19-22, exact rounding sequence:
@@ -636,7 +644,26 @@ __global__ void div_check_kernel(unsigned long long seed, unsigned long long per
     if (bad) atomicAdd(mismatch, bad);
 }
 
+// Test hook: the largest relative error of refined_rcp over EVERY float32 mantissa (2^23 denominators) at the given
+// binary exponent, against the correctly rounded 1/den (IEEE divide), as the ordered integer image of the double.
+__global__ void rcp_error_kernel(int exponent, unsigned long long *max_bits)
+{
+    const unsigned int mant = blockIdx.x * blockDim.x + threadIdx.x;      // 2^23 threads
+    if (mant >= (1u << 23)) return;
+    const double den = __builtin_ldexp((double)__uint_as_float(0x3F800000u | mant), exponent);
+    const double exact = 1.0 / den;
+    const double err = __builtin_fabs(refined_rcp(den) - exact) / exact;
+    atomicMax(max_bits, (unsigned long long)__double_as_longlong(err));
+}
+
 }  // namespace
+
+int launch_rcp_error(wgs_ctx *ctx, int exponent, unsigned long long *d_max_bits)
+{
+    hipLaunchKernelGGL(rcp_error_kernel, dim3((1u << 23) / 256), dim3(256), 0, ctx->stream, exponent, d_max_bits);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
 
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode, bool shared_slabs)
 {

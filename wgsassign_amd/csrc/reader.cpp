@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -104,11 +105,58 @@ struct AccessPoint {
     std::vector<unsigned char> window;   // GZ_WIN bytes of output before `out` (empty at a member start)
 };
 
+// BGZF (bgzip, htslib -- what ANGSD writes): a series of gzip members of at most 64 KiB, each announcing its own
+// compressed size in a 'BC' extra subfield and its uncompressed size in the trailer, so the blocks can be found
+// without inflating anything and inflated independently, in parallel.
+struct BgzfBlock {
+    uint64_t off = 0;       // file offset of the member
+    uint32_t csize = 0;     // whole member, header and trailer included
+    uint32_t hdr = 0;       // bytes before the deflate data
+    uint32_t isize = 0;     // uncompressed bytes
+};
+
+// Parses the member header at p (n bytes available): 0 = not BGZF, -1 = need more bytes, else the member size.
+inline long bgzf_member_size(const unsigned char *p, size_t n, uint32_t *hdr)
+{
+    if (n < 12) return -1;
+    if (p[0] != 31 || p[1] != 139 || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = p[10] | ((size_t)p[11] << 8);
+    if (n < 12 + xlen) return -1;
+    for (size_t q = 12; q + 4 <= 12 + xlen;) {
+        const size_t slen = p[q + 2] | ((size_t)p[q + 3] << 8);
+        if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) {
+            if ((p[3] & ~4) != 0) return 0;      // names / comments / header CRC: not what bgzip writes
+            *hdr = (uint32_t)(12 + xlen);
+            return (long)(p[q + 4] | ((size_t)p[q + 5] << 8)) + 1;
+        }
+        q += 4 + slen;
+    }
+    return 0;
+}
+
+// Inflate one BGZF member (raw deflate between header and trailer) into out[0 .. isize).
+inline bool bgzf_inflate(z_stream &z, const unsigned char *member, const BgzfBlock &b, unsigned char *out)
+{
+    if (b.isize == 0) return true;
+    if (inflateReset(&z) != Z_OK) return false;
+    z.next_in = const_cast<unsigned char *>(member) + b.hdr;
+    z.avail_in = b.csize - b.hdr - 8;
+    z.next_out = out;
+    z.avail_out = b.isize;
+    return inflate(&z, Z_FINISH) == Z_STREAM_END && z.avail_out == 0;
+}
+
 struct GzSource {
     FILE *fp = nullptr;
     z_stream z;
     bool z_live = false, raw = false, eof = false;
     std::vector<unsigned char> in;
+    // BGZF mode
+    bool bgzf = false;
+    int threads = 1;
+    std::vector<unsigned char> cbuf;
+    size_t clen = 0, cpos = 0;
+    std::vector<BgzfBlock> batch;
 
     ~GzSource() { close(); }
     void close()
@@ -148,10 +196,100 @@ struct GzSource {
         if (raw && inflateSetDictionary(&z, ap->window.data(), (unsigned)ap->window.size()) != Z_OK) return false;
         return true;
     }
+    // After open() at the start of a member: switch to parallel block inflation if the file is BGZF from here on
+    // (checked block by block as they are read; a non-BGZF member later is an error, such files do not exist).
+    void try_bgzf(int nthreads)
+    {
+        if (raw) return;
+        const off_t here = ftello(fp);
+        unsigned char head[64];
+        const size_t got = fread(head, 1, sizeof head, fp);
+        fseeko(fp, here, SEEK_SET);
+        uint32_t hdr = 0;
+        if (bgzf_member_size(head, got, &hdr) > 0) {
+            bgzf = true;
+            threads = nthreads > 0 ? nthreads : 1;
+            cbuf.resize(32u << 20);
+            clen = cpos = 0;
+        }
+    }
+    long read_bgzf(char *dst, size_t cap)
+    {
+        for (;;) {
+            // whole members available in cbuf[cpos, clen) that fit into `cap`
+            batch.clear();
+            size_t p = cpos, out = 0;
+            bool need_more = false;
+            while (p < clen) {
+                uint32_t hdr = 0;
+                const long sz = bgzf_member_size(cbuf.data() + p, clen - p, &hdr);
+                if (sz == 0) return -1;
+                if (sz < 0 || p + (size_t)sz > clen) {
+                    need_more = true;
+                    break;
+                }
+                BgzfBlock b;
+                b.off = p;
+                b.csize = (uint32_t)sz;
+                b.hdr = hdr;
+                const unsigned char *t = cbuf.data() + p + sz - 4;
+                b.isize = t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+                if (b.isize > 65536 || b.csize < hdr + 8) return -1;
+                if (out + b.isize > cap) break;
+                batch.push_back(b);
+                out += b.isize;
+                p += (size_t)sz;
+            }
+            if (!batch.empty()) {
+                std::vector<size_t> ooff(batch.size());
+                size_t acc = 0;
+                for (size_t i = 0; i < batch.size(); ++i) ooff[i] = acc, acc += batch[i].isize;
+                const int T = (int)std::min<size_t>((size_t)threads, batch.size());
+                std::vector<char> ok(T, 1);
+                auto work = [&](int t) {
+                    z_stream zz;
+                    memset(&zz, 0, sizeof zz);
+                    if (inflateInit2(&zz, -15) != Z_OK) {
+                        ok[t] = 0;
+                        return;
+                    }
+                    for (size_t i = (size_t)t; i < batch.size(); i += (size_t)T)
+                        if (!bgzf_inflate(zz, cbuf.data() + batch[i].off, batch[i], reinterpret_cast<unsigned char *>(dst) + ooff[i])) ok[t] = 0;
+                    inflateEnd(&zz);
+                };
+                if (T <= 1) {
+                    work(0);
+                } else {
+                    std::vector<std::thread> th;
+                    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+                    for (auto &x : th) x.join();
+                }
+                for (char c : ok)
+                    if (!c) return -1;
+                cpos = p;
+                if (acc > 0) return (long)acc;
+                continue;                            // only empty members (the BGZF end marker): look further
+            }
+            if (!need_more && p < clen) return -2;   // the next member does not fit into `cap`
+            // refill the compressed staging buffer
+            if (cpos > 0) {
+                memmove(cbuf.data(), cbuf.data() + cpos, clen - cpos);
+                clen -= cpos;
+                cpos = 0;
+            }
+            const size_t got = fread(cbuf.data() + clen, 1, cbuf.size() - clen, fp);
+            clen += got;
+            if (got == 0) {
+                eof = true;
+                return clen == 0 ? 0 : -1;           // trailing bytes that are not a whole member
+            }
+        }
+    }
     // up to `cap` bytes of output; 0 at the end of the file, -1 on a corrupt stream
     long read(char *dst, size_t cap)
     {
         if (eof) return 0;
+        if (bgzf) return read_bgzf(dst, cap);
         z.next_out = reinterpret_cast<unsigned char *>(dst);
         z.avail_out = (unsigned)std::min<size_t>(cap, 1u << 30);
         const unsigned want = z.avail_out;
@@ -208,9 +346,11 @@ static bool fill(wgs_reader *r)
         r->len -= r->pos;
         r->pos = 0;
     }
-    if (r->len == r->buf.size()) r->buf.resize(r->buf.size() * 2);   // a single line longer than the buffer
+    // a single line longer than the buffer (in BGZF mode a whole 64 KiB block must fit behind the tail)
+    if (r->buf.size() - r->len < (r->src.bgzf ? 65536u : 1u)) r->buf.resize(r->buf.size() * 2);
     while (!r->eof && r->len < r->buf.size()) {
         const long got = r->src.read(r->buf.data() + r->len, r->buf.size() - r->len);
+        if (got == -2) break;                                 // BGZF: the next block does not fit any more; enough for now
         if (got < 0) return false;
         if (got == 0) {
             r->eof = true;
@@ -281,6 +421,7 @@ int wgs_reader_open(const char *path, int threads, wgs_reader **out)
         return 2;
     }
     r->threads = threads > 0 ? threads : 1;
+    r->src.try_bgzf(r->threads);
     r->buf.resize(64u << 20);
     if (!fill(r)) {
         wgs_set_error("read error in %s", path);
@@ -482,6 +623,196 @@ int scan_file(const char *path, int64_t span, BeagleIndex &idx, std::string *nam
     return 0;
 }
 
+// ---- the same pass for BGZF files, in parallel -----------------------------------------------------------------
+// The block table (offsets, compressed and uncompressed sizes) comes from hopping over the member headers and
+// trailers -- nothing is inflated for it.  Worker threads then inflate disjoint ranges of blocks and summarise each:
+// where its first newline is, whether there is text before it, how many non-blank lines end after it, and what is
+// left open at its end.  A serial pass over the summaries (a few words per 64 KiB of input) turns them into global
+// line numbers; access points are block starts (no dictionaries).
+struct BlockLines {
+    uint8_t has_nl = 0;             // the block contains a newline
+    uint8_t content_before = 0;     // non-delimiter text before the first newline (or anywhere, if there is none)
+    uint8_t content_after = 0;      // non-delimiter text after the last newline
+    uint8_t last_is_nl = 0;         // the block ends with a newline
+    int32_t lines_after_first = 0;  // non-blank lines that start AND end inside the block
+};
+
+bool bgzf_block_table(const char *path, std::vector<BgzfBlock> &blocks)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return false;
+    const int fd = fileno(fp);
+    uint64_t off = 0;
+    unsigned char head[512], tail[4];
+    bool ok = true;
+    for (;;) {
+        const ssize_t got = pread(fd, head, sizeof head, (off_t)off);
+        if (got == 0) break;
+        uint32_t hdr = 0;
+        const long sz = got > 0 ? bgzf_member_size(head, (size_t)got, &hdr) : 0;
+        if (sz <= 0 || pread(fd, tail, 4, (off_t)(off + (uint64_t)sz - 4)) != 4) {
+            ok = false;
+            break;
+        }
+        BgzfBlock b;
+        b.off = off;
+        b.csize = (uint32_t)sz;
+        b.hdr = hdr;
+        b.isize = tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        if (b.isize > 65536 || b.csize < hdr + 8) {
+            ok = false;
+            break;
+        }
+        blocks.push_back(b);
+        off += (uint64_t)sz;
+    }
+    fclose(fp);
+    return ok && !blocks.empty();
+}
+
+void summarise_block(const unsigned char *p, size_t n, BlockLines &bl)
+{
+    const unsigned char *e = p + n;
+    const unsigned char *nl = (const unsigned char *)memchr(p, '\n', n);
+    const unsigned char *seg_end = nl ? nl : e;
+    for (const unsigned char *t = p; t < seg_end && !bl.content_before; ++t) bl.content_before = !is_delim((char)*t);
+    if (!nl) return;
+    bl.has_nl = 1;
+    const unsigned char *q = nl + 1;
+    for (;;) {
+        const unsigned char *nx = (const unsigned char *)memchr(q, '\n', (size_t)(e - q));
+        const unsigned char *end = nx ? nx : e;
+        bool content = false;
+        for (const unsigned char *t = q; t < end && !content; ++t) content = !is_delim((char)*t);
+        if (!nx) {
+            bl.content_after = content;
+            break;
+        }
+        bl.lines_after_first += content;
+        q = nx + 1;
+    }
+    bl.last_is_nl = n > 0 && p[n - 1] == '\n';
+}
+
+// Returns 0 on success, -1 when the file is not (entirely) BGZF -- the caller then takes the serial pass.
+int scan_file_bgzf(const char *path, int64_t span, int threads, BeagleIndex &idx)
+{
+    std::vector<BgzfBlock> blocks;
+    if (!bgzf_block_table(path, blocks)) return -1;
+    file_identity(path, idx.file_size, idx.mtime);
+    const size_t nb = blocks.size();
+    std::vector<BlockLines> sum(nb);
+    std::string header;
+    // the header line: inflate serially from the first block until its newline
+    {
+        FILE *fp = fopen(path, "rb");
+        if (!fp) return -1;
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (inflateInit2(&z, -15) != Z_OK) {
+            fclose(fp);
+            return -1;
+        }
+        std::vector<unsigned char> cb(65536 + 1024), ob(65536);
+        for (size_t i = 0; i < nb; ++i) {
+            if (pread(fileno(fp), cb.data(), blocks[i].csize, (off_t)blocks[i].off) != (ssize_t)blocks[i].csize) break;
+            BgzfBlock b = blocks[i];
+            b.off = 0;
+            if (!bgzf_inflate(z, cb.data(), b, ob.data())) break;
+            const unsigned char *nl = (const unsigned char *)memchr(ob.data(), '\n', b.isize);
+            header.append((const char *)ob.data(), nl ? (size_t)(nl - ob.data()) : b.isize);
+            if (nl) break;
+        }
+        inflateEnd(&z);
+        fclose(fp);
+    }
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)(threads > 0 ? threads : 1), nb));
+    std::vector<char> ok(T, 1);
+    auto work = [&](int t) {
+        FILE *fp = fopen(path, "rb");
+        z_stream z;
+        memset(&z, 0, sizeof z);
+        if (!fp || inflateInit2(&z, -15) != Z_OK) {
+            ok[t] = 0;
+            if (fp) fclose(fp);
+            return;
+        }
+        const int fd = fileno(fp);
+        const size_t b0 = nb * (size_t)t / (size_t)T, b1 = nb * (size_t)(t + 1) / (size_t)T;
+        std::vector<unsigned char> cb(8u << 20), ob(65536);
+        for (size_t i = b0; i < b1 && ok[t];) {
+            // read a run of consecutive blocks with one pread
+            size_t j = i, bytes = 0;
+            while (j < b1 && bytes + blocks[j].csize <= cb.size()) bytes += blocks[j++].csize;
+            if (pread(fd, cb.data(), bytes, (off_t)blocks[i].off) != (ssize_t)bytes) {
+                ok[t] = 0;
+                break;
+            }
+            size_t at = 0;
+            for (; i < j; ++i) {
+                BgzfBlock b = blocks[i];
+                b.off = 0;
+                if (!bgzf_inflate(z, cb.data() + at, b, ob.data())) {
+                    ok[t] = 0;
+                    break;
+                }
+                summarise_block(ob.data(), b.isize, sum[i]);
+                at += b.csize;
+            }
+        }
+        inflateEnd(&z);
+        fclose(fp);
+    };
+    if (T <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    for (char c : ok)
+        if (!c) {
+            wgs_set_error("read error in %s (corrupt BGZF block)", path);
+            return 1;
+        }
+    // serial pass over the summaries: line numbers at every block start
+    int64_t lines = 0;              // non-blank lines completed
+    bool content = false, at_line_start = true, header_done = false;
+    uint64_t out = 0, last = 0;
+    for (size_t i = 0; i < nb; ++i) {
+        const BlockLines &bl = sum[i];
+        if (span > 0 && out > 0 && out - last >= (uint64_t)span && blocks[i].isize > 0 && header_done) {
+            AccessPoint ap;
+            ap.in = blocks[i].off;
+            ap.out = out;
+            ap.lines_before = lines;
+            ap.content = content;
+            ap.at_line_start = at_line_start;
+            ap.member_start = 1;
+            idx.points.push_back(std::move(ap));
+            last = out;
+        }
+        if (blocks[i].isize == 0) continue;
+        if (bl.has_nl) {
+            // the header counts as a line even when it is empty (LineScan); every other line only when non-blank
+            lines += !header_done ? 1 : (content || bl.content_before);
+            header_done = true;
+            lines += bl.lines_after_first;
+            content = bl.content_after;
+            at_line_start = bl.last_is_nl;
+        } else {
+            content = content || bl.content_before;
+            at_line_start = false;
+        }
+        out += blocks[i].isize;
+    }
+    if (!header_done) lines += 1;
+    else if (content) lines += 1;   // last line without a newline
+    idx.sites = lines > 0 ? lines - 1 : 0;
+    parse_header(header.data(), header.data() + header.size(), idx.samples, idx.gl_cols);
+    return 0;
+}
+
 template <typename T>
 void put(FILE *f, const T &v) { fwrite(&v, sizeof v, 1, f); }
 template <typename T>
@@ -570,7 +901,13 @@ int wgs_reader_build_index(const char *path, const char *index_path, const char 
     }
     BeagleIndex idx;
     std::string names;
-    const int rc = scan_file(path, index_path ? std::max<int64_t>(span_bytes, (int64_t)GZ_WIN) : 0, idx, names_path ? &names : nullptr);
+    const int64_t span = index_path ? std::max<int64_t>(span_bytes, (int64_t)GZ_WIN) : 0;
+    // BGZF input (what ANGSD writes): blocks are independent -> all host threads; site names need the serial pass
+    int rc = names_path ? -1 : scan_file_bgzf(path, span, (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u), idx);
+    if (rc < 0) {
+        idx = BeagleIndex();
+        rc = scan_file(path, span, idx, names_path ? &names : nullptr);
+    }
     if (rc) return rc;
     *sites = idx.sites;
     if (index_path) {
@@ -646,6 +983,7 @@ int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t fi
         delete r;
         return 2;
     }
+    if (!best || best->member_start) r->src.try_bgzf(r->threads);
     int64_t line = 0;            // non-blank line index of the next complete line in the buffer
     if (best) {
         if (!fill(r)) {
