@@ -286,6 +286,8 @@ struct wgs_em {
     float *fbuf[2] = {nullptr, nullptr};  // 2 x n_fits x m
     FitDesc *d_descs = nullptr;
     FitDesc *h_descs = nullptr;           // pinned
+    int32_t *d_groups = nullptr, *h_groups = nullptr;         // (first, count) pairs of the fit-group sweep, step path
+    int32_t *d_groups2[2] = {nullptr, nullptr}, *h_groups2[2] = {nullptr, nullptr};   // ... wgs_em_fit slots
     double *d_ssq = nullptr;
     double *d_part = nullptr;             // n_fits x ntiles per-tile partial sums
     double *d_part2 = nullptr;            // n_fits x ssq_reduce_chunks() slice sums
@@ -318,6 +320,12 @@ void wgs_em_destroy(wgs_em *em)
         if (em->fbuf[i]) (void)hipFree(em->fbuf[i]);
     if (em->d_descs) (void)hipFree(em->d_descs);
     if (em->h_descs) (void)hipHostFree(em->h_descs);
+    if (em->d_groups) (void)hipFree(em->d_groups);
+    if (em->h_groups) (void)hipHostFree(em->h_groups);
+    for (int i = 0; i < 2; ++i) {
+        if (em->d_groups2[i]) (void)hipFree(em->d_groups2[i]);
+        if (em->h_groups2[i]) (void)hipHostFree(em->h_groups2[i]);
+    }
     if (em->d_ssq) (void)hipFree(em->d_ssq);
     if (em->d_part) (void)hipFree(em->d_part);
     if (em->d_part2) (void)hipFree(em->d_part2);
@@ -391,6 +399,8 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     HIP_TRY(hipEventCreate(&em->ev0));
     HIP_TRY(hipEventCreate(&em->ev1));
     HIP_TRY(hipHostMalloc(&em->h_descs, sizeof(FitDesc) * n_fits, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&em->d_groups, sizeof(int32_t) * 2 * n_fits));
+    HIP_TRY(hipHostMalloc(&em->h_groups, sizeof(int32_t) * 2 * n_fits, hipHostMallocDefault));
     if (launch_fill(b->ctx, em->fbuf[0], (int64_t)n_fits * b->m, 0.25f)) return 1;   // emMAF.py:17-18
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     guard.dismiss();
@@ -400,56 +410,89 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
 
 static float *em_f(wgs_em *em, int fit, int which) { return em->fbuf[which] + (size_t)fit * em->b->m; }
 
+/* Enqueue one sweep (+ the fixed-order reduction of its sums) for the fits in `list`: descriptors into the pinned
+ * array H and from there to D.  Fits of different populations stream their slabs once (nontemporal loads); when
+ * several fits share a slab (leave-one-out batches) they are ordered by slab and swept in groups of up to
+ * em_fits_per_group() per wavefront (group table Hg -> Dg), which share the tile's loads and conversions.
+ * ssq_base[j] receives fit j's sum; state_base (device, may be NULL) holds the fit states a sweep honours. */
+static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDesc *H, FitDesc *D, int32_t *Hg, int32_t *Dg,
+                            double *ssq_base, int32_t *state_base, hipEvent_t ev0, hipEvent_t ev1)
+{
+    wgs_ctx *ctx = em->b->ctx;
+    const int64_t ntiles = wgs_ntiles(em->b->m);
+    std::vector<int32_t> order(list);
+    std::vector<char> seen(em->b->n_groups, 0);
+    bool shared = false;
+    for (int j : order) {
+        shared = shared || seen[em->group[j]];
+        seen[em->group[j]] = 1;
+    }
+    if (shared) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return em->group[x] < em->group[y]; });
+    for (size_t i = 0; i < order.size(); ++i) {
+        const int j = order[i];
+        const Slab &s = em->b->slabs[em->group[j]];
+        FitDesc &d = H[i];
+        d.slab = s.base;
+        d.f_old = em_f(em, j, em->cur[j]);
+        d.f_new = em_f(em, j, em->cur[j] ^ 1);
+        d.ssq = ssq_base + j;
+        d.ssq_part = em->d_part + (size_t)j * ntiles;
+        d.npairs = s.npairs;
+        d.ncols = s.ncols;
+        d.skip = em->skip_local[j];
+        d.n_eff = em->n_eff[j];
+        d.state = state_base ? state_base + j : nullptr;
+    }
+    // H (pinned) stays untouched until the caller has waited for this sweep
+    HIP_TRY(hipMemcpyAsync(D, H, sizeof(FitDesc) * order.size(), hipMemcpyHostToDevice, ctx->stream));
+    int32_t n_groups = 0;
+    if (shared) {
+        const int fg = em_fits_per_group();
+        for (size_t i = 0; i < order.size();) {
+            size_t k = i + 1;
+            while (k < order.size() && (int)(k - i) < fg && em->group[order[k]] == em->group[order[i]]) ++k;
+            Hg[2 * n_groups] = (int32_t)i;
+            Hg[2 * n_groups + 1] = (int32_t)(k - i);
+            ++n_groups;
+            i = k;
+        }
+        HIP_TRY(hipMemcpyAsync(Dg, Hg, sizeof(int32_t) * 2 * n_groups, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (ev0) HIP_TRY(hipEventRecord(ev0, ctx->stream));
+    const int64_t per_unit = ((ntiles + 3) / 4 + 7) / 8 * 8 + 8;       // workgroups per fit / per group: slices stay below 2^31
+    const size_t max_units = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_unit);
+    if (shared) {
+        for (size_t off = 0; off < (size_t)n_groups; off += max_units) {
+            const int cnt = (int)std::min<size_t>(max_units, (size_t)n_groups - off);
+            if (launch_em_sweep_groups(ctx, D, Dg + 2 * off, cnt, em->b->m, em->mode)) return 1;
+        }
+    } else {
+        for (size_t off = 0; off < order.size(); off += max_units) {
+            const int cnt = (int)std::min<size_t>(max_units, order.size() - off);
+            if (launch_em_sweep(ctx, D + off, cnt, em->b->m, em->mode, false)) return 1;
+        }
+    }
+    if (ev1) HIP_TRY(hipEventRecord(ev1, ctx->stream));
+    for (size_t off = 0; off < order.size(); off += 65535) {
+        const int cnt = (int)std::min<size_t>(65535, order.size() - off);
+        if (launch_ssq_reduce(ctx, D + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
+    }
+    return 0;
+}
+
 int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
 {
     WGS_REQUIRE(em && ssq_dev, "null argument");
     wgs_ctx *ctx = em->b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     em->last.clear();
-    for (int j = 0; j < em->n_fits; ++j) {
-        if (!em->active[j]) continue;
-        const Slab &s = em->b->slabs[em->group[j]];
-        FitDesc &d = em->h_descs[em->last.size()];
-        d.slab = s.base;
-        d.f_old = em_f(em, j, em->cur[j]);
-        d.f_new = em_f(em, j, em->cur[j] ^ 1);
-        d.ssq = ssq_dev + j;
-        d.ssq_part = em->d_part + (size_t)j * wgs_ntiles(em->b->m);
-        d.npairs = s.npairs;
-        d.ncols = s.ncols;
-        d.skip = em->skip_local[j];
-        d.n_eff = em->n_eff[j];
-        d.state = nullptr;
-        em->last.push_back(j);
-    }
+    for (int j = 0; j < em->n_fits; ++j)
+        if (em->active[j]) em->last.push_back(j);
     HIP_TRY(hipMemsetAsync(ssq_dev, 0, sizeof(double) * em->n_fits, ctx->stream));
     if (em->last.empty()) return 0;
-    // h_descs (pinned) stays untouched until the next step, which the caller only starts after
+    // h_descs / h_groups (pinned) stay untouched until the next step, which the caller only starts after
     // consuming this step's sums
-    HIP_TRY(hipMemcpyAsync(em->d_descs, em->h_descs, sizeof(FitDesc) * em->last.size(), hipMemcpyHostToDevice, ctx->stream));
-    // launch in slices of <= 65535 fits (grid.y limit)
-    HIP_TRY(hipEventRecord(em->ev0, ctx->stream));
-    {
-        // slices keep one launch below 2^31 workgroups
-        const int64_t per_fit = (wgs_ntiles(em->b->m) + 3) / 4 + 8;
-        const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
-        // several fits on one slab (leave-one-out): cacheable loads + XCD-aware order; else streaming
-        std::vector<char> seen(em->b->n_groups, 0);
-        bool shared = false;
-        for (int j : em->last) {
-            shared = shared || seen[em->group[j]];
-            seen[em->group[j]] = 1;
-        }
-        for (size_t off = 0; off < em->last.size(); off += max_fits) {
-            const int cnt = (int)std::min<size_t>(max_fits, em->last.size() - off);
-            if (launch_em_sweep(ctx, em->d_descs + off, cnt, em->b->m, em->mode, shared)) return 1;
-        }
-    }
-    HIP_TRY(hipEventRecord(em->ev1, ctx->stream));
-    for (size_t off = 0; off < em->last.size(); off += 65535) {
-        const int cnt = (int)std::min<size_t>(65535, em->last.size() - off);
-        if (launch_ssq_reduce(ctx, em->d_descs + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
-    }
+    if (em_enqueue_sweep(em, em->last, em->h_descs, em->d_descs, em->h_groups, em->d_groups, ssq_dev, nullptr, em->ev0, em->ev1)) return 1;
     for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
     return 0;
 }
@@ -501,6 +544,7 @@ static int em_fit_alloc(wgs_em *em)
     const size_t n = (size_t)em->n_fits;
     HIP_TRY(hipMalloc(&em->d_state, sizeof(int32_t) * n));
     HIP_TRY(hipMalloc(&em->d_ssq2, sizeof(double) * n));
+    HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * n));
     HIP_TRY(hipMalloc(&em->d_jobs, sizeof(ChainJob) * n));
     HIP_TRY(hipMalloc(&em->d_chain_out, sizeof(float) * 2 * n));
     HIP_TRY(hipHostMalloc(&em->h_jobs, sizeof(ChainJob) * n, hipHostMallocDefault));
@@ -509,6 +553,8 @@ static int em_fit_alloc(wgs_em *em)
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipMalloc(&em->d_descs2[i], sizeof(FitDesc) * n));
         HIP_TRY(hipHostMalloc(&em->h_descs2[i], sizeof(FitDesc) * n, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&em->d_groups2[i], sizeof(int32_t) * 2 * n));
+        HIP_TRY(hipHostMalloc(&em->h_groups2[i], sizeof(int32_t) * 2 * n, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&em->ev_it[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&em->ev_sw0[i]));
@@ -573,7 +619,6 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     HIP_TRY(hipSetDevice(ctx->device));
     if (em_fit_alloc(em)) return 1;
     const int n = em->n_fits;
-    const int64_t ntiles = wgs_ntiles(em->b->m);
     // the band of device.py: guard_band / decide_converged
     double lo = -1.0, hi = -INFINITY;                        // tole <= 0 or NaN: `diff < tole` never holds
     if (tole > 0) {
@@ -613,39 +658,9 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         for (int j = 0; j < n; ++j)
             if (!fin[j] && sweeps[j] < max_iter) L.push_back(j);
         if (!L.empty()) {
-            std::vector<char> seen(em->b->n_groups, 0);
-            bool shared = false;
-            FitDesc *H = em->h_descs2[slot];
-            for (size_t i = 0; i < L.size(); ++i) {
-                const int j = L[i];
-                const Slab &s = em->b->slabs[em->group[j]];
-                FitDesc &d = H[i];
-                d.slab = s.base;
-                d.f_old = em_f(em, j, em->cur[j]);
-                d.f_new = em_f(em, j, em->cur[j] ^ 1);
-                d.ssq = em->d_ssq2 + j;
-                d.ssq_part = em->d_part + (size_t)j * ntiles;
-                d.npairs = s.npairs;
-                d.ncols = s.ncols;
-                d.skip = em->skip_local[j];
-                d.n_eff = em->n_eff[j];
-                d.state = em->d_state + j;
-                shared = shared || seen[em->group[j]];
-                seen[em->group[j]] = 1;
-            }
-            HIP_TRY(hipMemcpyAsync(em->d_descs2[slot], H, sizeof(FitDesc) * L.size(), hipMemcpyHostToDevice, ctx->stream));
-            const int64_t per_fit = (ntiles + 3) / 4 + 8;
-            const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
-            HIP_TRY(hipEventRecord(em->ev_sw0[slot], ctx->stream));
-            for (size_t off = 0; off < L.size(); off += max_fits) {
-                const int cnt = (int)std::min<size_t>(max_fits, L.size() - off);
-                if (launch_em_sweep(ctx, em->d_descs2[slot] + off, cnt, em->b->m, em->mode, shared)) return 1;
-            }
-            HIP_TRY(hipEventRecord(em->ev_sw1[slot], ctx->stream));
-            for (size_t off = 0; off < L.size(); off += 65535) {
-                const int cnt = (int)std::min<size_t>(65535, L.size() - off);
-                if (launch_ssq_reduce(ctx, em->d_descs2[slot] + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
-            }
+            if (em_enqueue_sweep(em, L, em->h_descs2[slot], em->d_descs2[slot], em->h_groups2[slot], em->d_groups2[slot], em->d_ssq2,
+                                 em->d_state, em->ev_sw0[slot], em->ev_sw1[slot]))
+                return 1;
             // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
             // in the same way on every rank (all ranks take the same decisions).
             if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, n)) return 1;

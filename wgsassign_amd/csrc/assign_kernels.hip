@@ -30,7 +30,18 @@ namespace {
 __device__ double2 wgs_log_table_dev[WGS_LOG_N];
 constexpr int WGS_LOG_REP = 16;   // LDS copies of the table (see load_log_table)
 
-__device__ __forceinline__ double log_f32arg(double x, const double2 *tab)
+// c8 = -0.125, the leading polynomial coefficient, handed in by the hot loops from a VGPR pair they keep alive
+// (log_c8()): the first Horner step then is ONE v_fma_f64 with a register and a scalar constant, instead of a
+// v_mov_b64 of 1/7 into the accumulator of a v_fmac_f64 for every term (two non-inline constants do not fit one
+// instruction's constant bus).
+__device__ __forceinline__ double log_c8()
+{
+    double c = -0.125;
+    asm volatile("" : "+v"(c));
+    return c;
+}
+
+__device__ __forceinline__ double log_f32arg(double x, const double2 *tab, double c8 = -0.125)
 {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
     const unsigned int hi = (unsigned int)(bits >> 32), lo = (unsigned int)bits;
@@ -44,7 +55,7 @@ __device__ __forceinline__ double log_f32arg(double x, const double2 *tab)
     const double w = __builtin_fma(kd, WGS_LN2HI, t.y);    // kd*Ln2hi is exact
     const double hi_ = w + r;
     const double lo_ = __builtin_fma(kd, WGS_LN2LO, (w - hi_) + r);
-    double q = __builtin_fma(r, -0.125, 1.0 / 7.0);        // log1p(r) = r + r^2 * q(r)
+    double q = __builtin_fma(r, c8, 1.0 / 7.0);            // log1p(r) = r + r^2 * q(r)
     q = __builtin_fma(r, q, -1.0 / 6.0);
     q = __builtin_fma(r, q, 0.2);
     q = __builtin_fma(r, q, -0.25);
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(256, (PER_IND || KB * NP > 10) ? 2 : WGS_SWEEP_MIN_
     const float4 *slab = w.sl.slab;
     const int npairs = w.sl.npairs;
     const int64_t t0 = w.t0, t1 = w.t1;
+    const double c8 = log_c8();
 
     for (int kb = 0; kb < A.K; kb += KB) {
         constexpr int NA = PER_IND ? NP * 2 * KB : KB;
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256, (PER_IND || KB * NP > 10) ? 2 : WGS_SWEEP_MIN_
                                 if (!fin) acc[q][h][j] += (double)__builtin_amdgcn_logf(s);
                             } else {
                                 plain = plain && fin;
-                                acc[q][h][j] += (double)(float)log_f32arg((double)s, tab);
+                                acc[q][h][j] += (double)(float)log_f32arg((double)s, tab, c8);
                             }
                         } else {
                             acc[q][h][j] += (double)site_ll_fast(gl[h][0], gl[h][1], g2f, a);
@@ -432,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void chain_cand_kernel(ScoreArgs A)
     const int64_t t0 = w.t0, t1 = w.t1;
     const int P = A.P, period = A.period;
     const double invP = 1.0 / (double)P;
+    const double c8 = log_c8();
     constexpr int CW = NP * 2 * KB;
     unsigned *wD = cand_lds + (size_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 2 * CW * P;
     unsigned *wF = wD + CW * P;
@@ -516,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void chain_cand_kernel(ScoreArgs A)
                             // v = the float32 the reference stores for this site -- unless s is 0, negative or
                             // NaN (log_f32arg is not defined there): such a lane marks its blocks instead
                             plain = plain && __builtin_isfpclass(s, FP_POS_FINITE);
-                            const float v = (float)log_f32arg((double)s, tab);
+                            const float v = (float)log_f32arg((double)s, tab, c8);
                             const float mag = -v;                               // >= 0 for every likelihood <= 1
                             const float r = (X0[q][h][j] + mag) - X0[q][h][j];  // RN(mag / u) * u on the predicted grid
                             acc[q][h][j] += r;                                  // exact while the block stays in the binade

@@ -120,6 +120,8 @@ int launch_fisher_ind_sites(wgs_ctx *ctx, const float4 *slab, const int32_t *d_c
 int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, const float *th, double *out, int64_t m,
                       int npairs, int ncols);
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode, bool shared_slabs);
+int em_fits_per_group(void);
+int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
 int ssq_reduce_chunks(void);
 int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2);
 // state[fit] of every listed fit that swept: ssq < lo -> EM_CONVERGED, ssq >= hi (or NaN) -> EM_ACTIVE, else EM_UNDECIDED

@@ -95,6 +95,19 @@ __device__ __forceinline__ void term_fast(float g0, float g1, const SnpState &st
     tmp = tmp + num * __builtin_amdgcn_rcpf(2.0f * s);
 }
 
+// The same two terms with the per-(SNP, individual) part hoisted: g0, g1 widened to double and g2 = (1-g0)-g1 do
+// not depend on the fit, so leave-one-out fits of one population that walk a tile together share them.
+__device__ __forceinline__ void term_exact_shared(double g0d, double g1d, double g2d, const SnpState &st, float &tmp)
+{
+    const float p0 = (float)((g0d * st.omf) * st.omf);
+    const float p1 = (float)((g1d * st.fd2) * st.omf);
+    const float p2 = (float)((g2d * st.fd) * st.fd);
+    const float s = (p0 + p1) + p2;
+    const double num = __builtin_fma(2.0, (double)p2, (double)p1);
+    const double q = div_exact(num, (double)s);
+    tmp = (float)__builtin_fma(0.5, q, (double)tmp);
+}
+
 // NT = nontemporal slab loads (each byte is used once: fits of different populations);
 // NT = false + XCD-aware workgroup order when several fits share slabs (leave-one-out).
 template <int MODE, int U, bool NT>
@@ -196,6 +209,116 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
     if (lane == 0) fd.ssq_part[tile] = sq;
+}
+
+// Leave-one-out batches: up to FG fits of ONE population slab per wavefront.  They read the same tile, so its GL
+// loads, the float->double conversions and g2 = (1-g0)-g1 are done once for all of them (4 of the 29 FP64-rate
+// instructions of a term; the re-fits are bound by FP64 issue, not by memory), each fit keeping its own serial
+// float32 accumulation.  groups[g] = (first descriptor, count) into `fits`, all of one slab.  Same XCD-aware
+// workgroup order as em_sweep_kernel<.., NT = false>, with groups in the place of fits.
+constexpr int FG = 4;
+
+template <int MODE, int U>
+__global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDesc *__restrict__ fits, const int2 *__restrict__ groups,
+                                                                     int n_groups, int64_t m)
+{
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const int grp = (int)(j % (unsigned)n_groups);
+    const int64_t tgroup = (int64_t)(j / (unsigned)n_groups) * 8 + xcd;
+    const int2 gd = groups[grp];
+    FitDesc fd[FG];
+    bool on[FG];
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < FG; ++f) {
+        on[f] = f < gd.y;
+        fd[f] = fits[gd.x + (on[f] ? f : 0)];
+        if (on[f] && fd[f].state && *fd[f].state != EM_ACTIVE) on[f] = false;     // decided on the device: skip (see em_sweep_kernel)
+        any = any || on[f];
+    }
+    if (!any) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = tgroup * WAVES + wave;
+    const int64_t row0 = tile * 64;
+    if (row0 >= m) return;
+    const int64_t my_row = row0 + lane;
+    const int64_t my_row_c = my_row < m ? my_row : m - 1;
+    SnpState st[FG];
+    float f_old[FG], tmp[FG];
+#pragma unroll
+    for (int f = 0; f < FG; ++f) {
+        f_old[f] = ((gf32_ptr)fd[f].f_old)[my_row_c];
+        st[f].fd = (double)f_old[f];
+        st[f].omf = 1.0 - st[f].fd;
+        st[f].fd2 = 2.0 * st[f].fd;
+        st[f].ff = f_old[f];
+        st[f].omff = 1.0f - f_old[f];
+        st[f].ff2 = 2.0f * f_old[f];
+        tmp[f] = 0.0f;
+    }
+    const int npairs = fd[0].npairs, ncols = fd[0].ncols;
+    gf4_ptr src = (gf4_ptr)fd[0].slab + tile * npairs * 64 + lane;
+    const int last = npairs - 1;
+    f4 cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = ldg<false>(src + (u < last ? u : last) * 64);
+    // one individual (g0, g1) for every fit that is on and does not leave it out
+    auto individual = [&](float g0, float g1, int col, bool checked) {
+        if (MODE == WGS_MODE_EXACT) {
+            const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
+#pragma unroll
+            for (int f = 0; f < FG; ++f)
+                if (on[f] && (!checked || col != fd[f].skip)) term_exact_shared(g0d, g1d, g2d, st[f], tmp[f]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < FG; ++f)
+                if (on[f] && (!checked || col != fd[f].skip)) term_fast(g0, g1, st[f], tmp[f]);
+        }
+    };
+    for (int p0 = 0; p0 < npairs; p0 += U) {
+        if (p0 + U < npairs) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int pp = p0 + U + u;
+                nxt[u] = ldg<false>(src + (pp < last ? pp : last) * 64);
+            }
+        }
+        bool plain = 2 * (p0 + U) <= ncols;
+#pragma unroll
+        for (int f = 0; f < FG; ++f) plain = plain && (!on[f] || fd[f].skip < 2 * p0 || fd[f].skip >= 2 * (p0 + U));
+        if (plain) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f4 v = cur[u];
+                individual(v.x, v.y, 0, false);
+                individual(v.z, v.w, 0, false);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const f4 v = cur[u];
+                const int ia = 2 * (p0 + u), ib = ia + 1;
+                if (ia < ncols) individual(v.x, v.y, ia, true);
+                if (ib < ncols) individual(v.z, v.w, ib, true);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+#pragma unroll
+    for (int f = 0; f < FG; ++f) {
+        if (!on[f]) continue;                                // wave-uniform
+        const float f_new = tmp[f] / (float)fd[f].n_eff;     // emMAF_cy.pyx:23 (float32 divide)
+        double sq = 0.0;
+        if (my_row < m) {
+            ((gf32_wptr)fd[f].f_new)[my_row] = f_new;
+            const float d = f_new - f_old[f];                // emMAF_cy.pyx:31, float32
+            sq = (double)(d * d);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if (lane == 0) fd[f].ssq_part[tile] = sq;
+    }
 }
 
 // ssq[fit] = sum over tiles of the per-tile partials, in a fixed summation order (reproducible):
@@ -683,6 +806,25 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
         if (shared_slabs) WGS_EM_LAUNCH(WGS_MODE_FAST, false); else WGS_EM_LAUNCH(WGS_MODE_FAST, true);
     }
 #undef WGS_EM_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int em_fits_per_group(void) { return FG; }
+
+// d_groups: n_groups (first, count) pairs into d_descs, every group's fits on one slab (leave-one-out batches)
+int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode)
+{
+    if (n_groups <= 0 || m <= 0) return 0;
+    const int64_t tiles = (m + 63) / 64;
+    const int64_t tgroups = ((tiles + WAVES - 1) / WAVES + 7) / 8 * 8;          // the XCD-aware order covers whole groups of 8
+    const int64_t blocks = tgroups * n_groups;
+    WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
+    const int2 *g = reinterpret_cast<const int2 *>(d_groups);
+    if (mode == WGS_MODE_EXACT)
+        hipLaunchKernelGGL((em_sweep_group_kernel<WGS_MODE_EXACT, 4>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, ctx->stream, d_descs, g, n_groups, m);
+    else
+        hipLaunchKernelGGL((em_sweep_group_kernel<WGS_MODE_FAST, 4>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, ctx->stream, d_descs, g, n_groups, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
