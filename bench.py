@@ -336,6 +336,7 @@ def committed_pmc(m, n, K, mode):
     * 1024 with the gfx950 correction, valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE
     / 8)); the newest matching profile wins, {} when none matches the workload being run."""
     import glob
+    import re
     best = {}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
         try:
@@ -350,7 +351,9 @@ def committed_pmc(m, n, K, mode):
                 cur["em_traffic"] = e.get("traffic_bytes_per_launch")
                 cur["em_valu_busy_frac"] = e.get("valu_busy_frac")
                 cur["em_clock_ghz"] = e.get("effective_clock_ghz")
-            if "score_sweep_kernel" in k:           # one launch scores the whole matrix
+            sk = re.search(r"score_sweep_kernel<(\d+), (\d+), (\d+), (true|false)>", k)
+            if sk and int(sk.group(3)) == (0 if mode == "exact" else 1) and sk.group(4) == "false":
+                # ONE launch scores the whole matrix (template arguments: KB, NP, MODE, PER_IND)
                 cur["assign_traffic"] = e.get("traffic_bytes_per_launch")
                 cur["assign_valu_busy_frac"] = e.get("valu_busy_frac")
                 cur["assign_insts_valu"] = e.get("SQ_INSTS_VALU", {}).get("mean")

@@ -58,6 +58,28 @@ def make_beagle(m, n, K, seed=SEED, depth=2.0, interleave=False):
     return np.ascontiguousarray(L), IDs
 
 
+def make_beagle_for_labels(m, labels, K, seed=SEED, depth=2.0):
+    """Like make_beagle, for an arbitrary assignment of individuals to K DIFFERENTIATED populations (labels[i] in
+    0..K-1, any sizes, any order): a scoring kernel that mixes up frequency columns gives visibly different sums."""
+    labels = np.asarray(labels)
+    n = len(labels)
+    rng = np.random.Generator(np.random.PCG64(seed + 7919 * m + 104729 * n + K))
+    p_anc = rng.beta(0.8, 0.8, size=m)
+    p_pop = np.clip(p_anc[:, None] + rng.normal(0.0, 0.12, size=(m, K)), 0.01, 0.99)
+    geno = rng.binomial(2, p_pop[:, labels])
+    d = rng.poisson(depth, size=(m, n))
+    e = 0.01
+    alt = rng.binomial(d, np.array([e, 0.5, 1.0 - e])[geno])
+    ref = d - alt
+    l0, l1, l2 = (1 - e) ** ref * e ** alt, 0.5 ** d, (1 - e) ** alt * e ** ref
+    tot = l0 + l1 + l2
+    L = np.empty((m, 2 * n), dtype=np.float32)
+    L[:, 0::2] = np.round(l0 / tot, 6).astype(np.float32)
+    L[:, 1::2] = np.round(l1 / tot, 6).astype(np.float32)
+    IDs = np.array([["Ind%d" % i, "pop%02d" % labels[i]] for i in range(n)], dtype=str)
+    return np.ascontiguousarray(L), IDs
+
+
 def digest(a):
     """sha256[:16] of the array bytes (same convention as BASELINE.md section 2)."""
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

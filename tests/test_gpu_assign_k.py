@@ -1,9 +1,10 @@
 """Assignment / leave-one-out scoring kernels at the population counts the BASELINE configs launch.
 
-`launch_assign` (csrc/assign_kernels.hip) batches the K populations into register batches of KB:
-K=6 -> KB=6, K=7 -> 7, K=8 -> 8 (config 4), K=10 -> two passes of 5 (config 3), K=13 -> two passes
-of 7 with a padded slot, K=20 -> three passes of 7 with a padded slot (config 5); NP = 2 individual
-pairs per wave for KB <= 6, 1 above.  Every one of them is held to the oracle here, in both
+The scoring sweep (csrc/assign_kernels.hip) batches the K populations into register batches of KB <= 10:
+K=6 -> KB=6, K=7 -> 7, K=8 -> 8 (config 4), K=9 -> 9, K=10 -> 10 (config 3, one pass), K=13 -> two passes of 7 with
+a padded slot, K=17 -> two passes of 9 with a padded slot, K=20 -> two passes of 10 (config 5); NP = 2 individual
+pairs per wave for KB <= 6, 1 above.  The chain kernel of the exact partition sums stays at KB <= 8 (K=10 -> two
+passes of 5, K=20 -> three of 7).  Every one of them is held to the oracle here, in both
 modes: shared frequency columns (glassy.py:31-42, --get_pop_like) and per-individual columns
 (glassy.py:92-109, --loo), with odd population sizes and SNP counts that are not multiples of 64.
 """
@@ -18,17 +19,21 @@ from test_gpu_parity import close, nearly_all_identical, quiet, same, same_nan, 
 
 pytestmark = pytest.mark.gpu
 
-KS = [6, 7, 8, 10, 13, 20]
+KS = [6, 7, 8, 9, 10, 13, 17, 20]
 
 
 def odd_populations(K, rng):
-    """Population sizes 1..7 with both parities, individuals interleaved in file order."""
+    """Population labels: sizes 2..7 with both parities, individuals interleaved in file order."""
     sizes = [int(x) for x in rng.integers(2, 8, size=K)]
     sizes[0], sizes[-1] = 3, 5
     labels = np.repeat(np.arange(K), sizes)
     rng.shuffle(labels)
-    IDs = np.array([["Ind%d" % i, "pop%02d" % labels[i]] for i in range(len(labels))], dtype=str)
-    return IDs
+    return labels
+
+
+def structured(m, K, rng, seed):
+    """Genotype likelihoods drawn from K DIFFERENTIATED populations (a kernel that confuses columns cannot pass)."""
+    return synth.make_beagle_for_labels(m, odd_populations(K, rng), K, seed=seed)
 
 
 @pytest.fixture(scope="module")
@@ -46,9 +51,9 @@ def wg():
 @pytest.mark.parametrize("K", KS)
 def test_assign_shared_columns_against_oracle(wg, oracle, K):
     rng = np.random.default_rng(500 + K)
-    IDs = odd_populations(K, rng)
-    n, m = len(IDs), 1000 + 37 * K + 1
-    L, _ = synth.make_beagle(m, n, 1, seed=4000 + K)
+    m = 1000 + 37 * K + 1
+    L, IDs = structured(m, K, rng, 4000 + K)
+    n = len(IDs)
     pops_o, af_o, _, iters_o = oracle.fit_reference_af(L, IDs, t=4)
     (pops, af, iters), _ = quiet(wg.emMAF.emMAF_populations, L, IDs, 200, 1e-4)
     assert list(iters) == list(iters_o) and same(af, af_o)
@@ -74,9 +79,9 @@ def test_assign_shared_columns_against_oracle(wg, oracle, K):
 @pytest.mark.parametrize("K", KS)
 def test_loo_per_individual_columns_against_oracle(wg, oracle, K, P):
     rng = np.random.default_rng(900 + K)
-    IDs = odd_populations(K, rng)
-    n, m = len(IDs), 600 + 29 * K + 3
-    L, _ = synth.make_beagle(m, n, 1, seed=5000 + K)
+    m = 600 + 29 * K + 3
+    L, IDs = structured(m, K, rng, 5000 + K)
+    n = len(IDs)
     _, af_o, _, _ = oracle.fit_reference_af(L, IDs, t=4)
     af1, af2 = af_o.copy(), af_o.copy()
     with np.errstate(all="ignore"):
@@ -93,9 +98,9 @@ def test_fast_partition_kernel_large_K(wg, oracle, monkeypatch, K):
     partition sums, within the reference's own float32 accumulation noise."""
     monkeypatch.setenv("WGSASSIGN_PARTS", "fast")
     rng = np.random.default_rng(1300 + K)
-    IDs = odd_populations(K, rng)
-    n, m = len(IDs), 777
-    L, _ = synth.make_beagle(m, n, 1, seed=6000 + K)
+    m = 777
+    L, IDs = structured(m, K, rng, 6000 + K)
+    n = len(IDs)
     _, af_o, _, _ = oracle.fit_reference_af(L, IDs, t=4)
     af1, af2 = af_o.copy(), af_o.copy()
     with np.errstate(all="ignore"):

@@ -408,10 +408,9 @@ def test_random_small_shapes_against_oracle(wg, oracle):
         K = int(rng.integers(1, 5))
         n = int(rng.integers(K, 4 * K + 3))
         P = int(rng.choice([1, 2, 3, 7]))
-        L, _ = synth.make_beagle(m, n, 1, seed=1000 + case)
         labels = rng.integers(0, K, size=n)
         labels[:K] = np.arange(K)                      # every population non-empty
-        IDs = np.array([["Ind%d" % i, "p%d" % labels[i]] for i in range(n)], dtype=str)
+        L, IDs = synth.make_beagle_for_labels(m, labels, K, seed=1000 + case)      # differentiated populations
         with np.errstate(all="ignore"):
             pops_o, af_o, _, iters_o = oracle.fit_reference_af(L, IDs, t=2)
             (pops, af, iters), _ = quiet(wg.emMAF.emMAF_populations, L, IDs, 200, 1e-4)

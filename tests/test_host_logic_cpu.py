@@ -229,3 +229,17 @@ def test_reference_import_paths_resolve():
     assert emMAF_cy.emMAF_update.__module__ == "wgsassign_amd.emMAF_cy" and callable(glassy_cy.loglike)
     assert callable(reader_cy.readBeagle) and callable(utils.write_ass_mats) and callable(fisher.fisher_obs)
     assert cli.parser.prog == "WGSassign" and callable(cli.main)
+
+
+def test_console_script_declared_like_the_reference():
+    """setup.py:47-50 of the reference installs `WGSassign=WGSassign.WGSassign:main`; pyproject.toml declares the same
+    script name on this build's main(), and the alias package keeps the reference's module path importable."""
+    import importlib
+    import tomli
+    meta = tomli.load(open(os.path.join(ROOT, "pyproject.toml"), "rb"))
+    target = meta["project"]["scripts"]["WGSassign"]
+    mod, func = target.split(":")
+    assert callable(getattr(importlib.import_module(mod), func))
+    assert set(meta["tool"]["setuptools"]["packages"]) == {"wgsassign_amd", "WGSassign"}
+    import WGSassign.WGSassign as ref_path
+    assert ref_path.main is getattr(importlib.import_module(mod), func)

@@ -24,7 +24,12 @@ def main():
     prefix, name, config = sys.argv[1], sys.argv[2], sys.argv[3]
     out = os.path.join(ROOT, "profiles", name)
     os.makedirs(out, exist_ok=True)
-    kt = glob.glob(os.path.join(ROOT, "gpurun_out", prefix + "_kt", "*", "*_kernel_stats.csv"))
+    def newest(pattern):
+        """gpurun merges every call's files into the same directories: only the most recent run counts"""
+        found = sorted(glob.glob(pattern), key=os.path.getmtime)
+        return found[-1:]
+
+    kt = newest(os.path.join(ROOT, "gpurun_out", prefix + "_kt", "*", "*_kernel_stats.csv"))
     if kt:
         shutil.copy(kt[0], os.path.join(out, "kernel_stats.csv"))
         # effective clock per kernel needs its duration: keep the mean duration beside the counters
@@ -33,7 +38,7 @@ def main():
         durations = {}
     counters = collections.defaultdict(lambda: collections.defaultdict(list))
     for sub in ("fetch", "write", "sq", "sq2"):
-        for f in glob.glob(os.path.join(ROOT, "gpurun_out", "%s_%s" % (prefix, sub), "*", "*_counter_collection.csv")):
+        for f in newest(os.path.join(ROOT, "gpurun_out", "%s_%s" % (prefix, sub), "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(f)):
                 k = r["Kernel_Name"]
                 if any(t in k for t in KERNELS):

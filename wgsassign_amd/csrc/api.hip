@@ -469,7 +469,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     } else {
         for (size_t off = 0; off < order.size(); off += max_units) {
             const int cnt = (int)std::min<size_t>(max_units, order.size() - off);
-            if (launch_em_sweep(ctx, D + off, cnt, em->b->m, em->mode, false)) return 1;
+            if (launch_em_sweep(ctx, D + off, cnt, em->b->m, em->mode)) return 1;
         }
     }
     if (ev1) HIP_TRY(hipEventRecord(ev1, ctx->stream));

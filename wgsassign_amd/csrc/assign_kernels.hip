@@ -252,7 +252,7 @@ __device__ __forceinline__ bool decode_wave(const ScoreArgs &A, WaveWork<NP> &w)
 #define WGS_SWEEP_MIN_BLOCKS 3
 #endif
 template <int KB, int NP, int MODE, bool PER_IND>
-__global__ __launch_bounds__(256, (PER_IND || KB * NP > 10) ? 2 : WGS_SWEEP_MIN_BLOCKS) void score_sweep_kernel(ScoreArgs A)
+__global__ __launch_bounds__(256, (PER_IND || KB * NP > 10 || KB > 8) ? 2 : WGS_SWEEP_MIN_BLOCKS) void score_sweep_kernel(ScoreArgs A)
 {
     __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
     const double2 *tab = load_log_table(tab_lds);
@@ -816,14 +816,14 @@ int launch_log_values(wgs_ctx *ctx, const float *d_x, float *d_out, int64_t n, i
     return 0;
 }
 
-// KB = populations per register batch: the batch size with the fewest passes over K, then the least padding
-static int pick_kb(int K)
+// KB = populations per register batch: the batch size with the fewest passes over K, then the least padding.
+// Every pass re-reads the block's GLs, so K <= 10 is ONE pass (HBM traffic = algorithmic bytes) and K = 20 two;
+// KB = 9, 10 run one pair per wave at 2 waves/SIMD (measured equal to two passes of 5 in exact mode -- the kernel is
+// bound by FP64 issue either way -- and 11 % faster in float32 mode).
+static int pick_kb(int K, int kb_max = 10)
 {
-#ifdef WGS_EXPERIMENT_KB10     // experiment: K = 10 in ONE register pass (halves the GL traffic of the sweep)
-    if (K == 10) return 10;
-#endif
     int best = 4, best_cost = 1 << 30;
-    for (int kb = 4; kb <= 8; ++kb) {
+    for (int kb = 4; kb <= kb_max; ++kb) {
         const int passes = (K + kb - 1) / kb;
         const int cost = passes * 1000 + passes * kb - K;
         if (cost < best_cost) best_cost = cost, best = kb;
@@ -832,11 +832,13 @@ static int pick_kb(int K)
 }
 
 // NP = 2 pairs per wave halves the per-tile frequency loads/conversions per term (measured 174 -> 150 ms at
-// K = 10, KB = 5); for KB >= 7 it only costs occupancy (KB = 10 in one pass measured slower than two of 5).
+// K = 10, KB = 5); for KB >= 7 the accumulators leave no room for it.
 int score_pairs_per_wave(int K) { return pick_kb(K) <= 6 ? 2 : 1; }
 // The chain kernel keeps three float32 per (cell, lane) instead of one float64; with per-individual columns
 // its pointer and frequency tables leave room for one pair only.
-int chain_pairs_per_wave(int K, bool per_ind) { return per_ind ? 1 : score_pairs_per_wave(K); }
+// It stays with batches of at most 8 populations (9 and 10 would spill).
+static int pick_kb_chain(int K) { return pick_kb(K, 8); }
+int chain_pairs_per_wave(int K, bool per_ind) { return per_ind ? 1 : (pick_kb_chain(K) <= 6 ? 2 : 1); }
 
 // The float64 partition sums of WGSASSIGN_PARTS=fast (P > 1): lane <-> individual pair, one slab per launch.
 int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
@@ -855,7 +857,7 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
     a.tiles_per_wave = (int32_t)(tpw > 0x7fffffff ? 0x7fffffff : tpw);
     const int64_t waves = (ntiles + a.tiles_per_wave - 1) / a.tiles_per_wave;
     dim3 grid((unsigned)((waves + 3) / 4), (unsigned)pairblocks);
-    switch (pick_kb(a.K)) {
+    switch (pick_kb(a.K, 8)) {
         case 4: return launch_assign_kb<4>(ctx, a, mode, grid);
         case 5: return launch_assign_kb<5>(ctx, a, mode, grid);
         case 6: return launch_assign_kb<6>(ctx, a, mode, grid);
@@ -864,19 +866,15 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
     }
 }
 
-#ifdef WGS_EXPERIMENT_KB10
-#define WGS_KB10_CASE(X) case 10: X(10, 1); break;
-#else
-#define WGS_KB10_CASE(X)
-#endif
 #define WGS_FOR_KB_NP(X, K)                \
     switch (pick_kb(K)) {                  \
-        WGS_KB10_CASE(X)                   \
         case 4: X(4, 2); break;            \
         case 5: X(5, 2); break;            \
         case 6: X(6, 2); break;            \
         case 7: X(7, 1); break;            \
-        default: X(8, 1); break;           \
+        case 8: X(8, 1); break;            \
+        case 9: X(9, 1); break;            \
+        default: X(10, 1); break;          \
     }
 
 int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode)
@@ -914,7 +912,7 @@ int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, dou
 
 size_t chain_cand_lds_bytes(int K, int P, bool per_ind)
 {
-    const int kb = pick_kb(K), np = chain_pairs_per_wave(K, per_ind);
+    const int kb = pick_kb_chain(K), np = chain_pairs_per_wave(K, per_ind);
     return (size_t)4 * 2 * (np * 2 * kb) * P * sizeof(unsigned);
 }
 
@@ -933,7 +931,13 @@ int launch_chain_cand(wgs_ctx *ctx, const ScoreArgs &a)
         if (per_ind) hipLaunchKernelGGL((chain_cand_kernel<KB, 1, true>), grid, dim3(256), lds, ctx->stream, a);      \
         else hipLaunchKernelGGL((chain_cand_kernel<KB, NP, false>), grid, dim3(256), lds, ctx->stream, a);            \
     } while (0)
-    WGS_FOR_KB_NP(WGS_CAND, a.K)
+    switch (pick_kb_chain(a.K)) {
+        case 4: WGS_CAND(4, 2); break;
+        case 5: WGS_CAND(5, 2); break;
+        case 6: WGS_CAND(6, 2); break;
+        case 7: WGS_CAND(7, 1); break;
+        default: WGS_CAND(8, 1); break;
+    }
 #undef WGS_CAND
     HIP_TRY(hipGetLastError());
     return 0;

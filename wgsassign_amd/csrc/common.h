@@ -119,7 +119,7 @@ int launch_fisher_ind_sites(wgs_ctx *ctx, const float4 *slab, const int32_t *d_c
                             int npairs, int count);
 int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, const float *th, double *out, int64_t m,
                       int npairs, int ncols);
-int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode, bool shared_slabs);
+int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
 int ssq_reduce_chunks(void);

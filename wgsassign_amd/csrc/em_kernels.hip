@@ -108,28 +108,15 @@ __device__ __forceinline__ void term_exact_shared(double g0d, double g1d, double
     tmp = (float)__builtin_fma(0.5, q, (double)tmp);
 }
 
-// NT = nontemporal slab loads (each byte is used once: fits of different populations);
-// NT = false + XCD-aware workgroup order when several fits share slabs (leave-one-out).
-template <int MODE, int U, bool NT>
+// One fit per wavefront, nontemporal slab loads (each byte is used once: fits of different populations; fits that
+// share a slab -- leave-one-out -- run em_sweep_group_kernel below).
+template <int MODE, int U>
 __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m)
 {
-    // Fit index varies fastest across workgroups: leave-one-out fits of one population read the
-    // SAME slab tiles, so consecutive workgroups hit in L2 / Infinity Cache instead of re-streaming
-    // the slab from HBM once per fit.  (Fits of different populations just interleave K streams.)
-    // In the shared (NT == false) case the order is also XCD-aware: workgroups are dealt round-robin
-    // over the 8 XCDs (blockIdx % 8 labels the XCD), so tile group = 8 * (j / n_fits) + blockIdx % 8
-    // keeps ALL fits of a tile group on one XCD and its tiles enter one L2 once, not eight.  A wrong
-    // guess about placement costs speed only.
-    int fit;
-    int64_t tgroup;
-    if (NT) {
-        fit = (int)(blockIdx.x % (unsigned)n_fits);
-        tgroup = blockIdx.x / (unsigned)n_fits;
-    } else {
-        const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        fit = (int)(j % (unsigned)n_fits);
-        tgroup = (int64_t)(j / (unsigned)n_fits) * 8 + xcd;
-    }
+    constexpr bool NT = true;
+    // Fit index varies fastest across workgroups: the K fits interleave K streams over the slabs.
+    const int fit = (int)(blockIdx.x % (unsigned)n_fits);
+    const int64_t tgroup = blockIdx.x / (unsigned)n_fits;
     const FitDesc fd = fits[fit];
     // a fit whose convergence was decided (or is being decided) on the device by the previous iteration's
     // em_decide_kernel is skipped: the host enqueues sweeps one iteration ahead of what it has read back
@@ -214,8 +201,10 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
 // Leave-one-out batches: up to FG fits of ONE population slab per wavefront.  They read the same tile, so its GL
 // loads, the float->double conversions and g2 = (1-g0)-g1 are done once for all of them (4 of the 29 FP64-rate
 // instructions of a term; the re-fits are bound by FP64 issue, not by memory), each fit keeping its own serial
-// float32 accumulation.  groups[g] = (first descriptor, count) into `fits`, all of one slab.  Same XCD-aware
-// workgroup order as em_sweep_kernel<.., NT = false>, with groups in the place of fits.
+// float32 accumulation.  groups[g] = (first descriptor, count) into `fits`, all of one slab.  The loads are
+// cacheable and the workgroup order is XCD-aware: workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8
+// labels the XCD), so tile group = 8 * (j / n_groups) + blockIdx % 8 keeps ALL groups of a tile group on one XCD
+// and its tiles enter one L2 once, not eight times.  A wrong guess about placement costs speed only.
 constexpr int FG = 4;
 
 template <int MODE, int U>
@@ -788,24 +777,20 @@ int launch_rcp_error(wgs_ctx *ctx, int exponent, unsigned long long *d_max_bits)
     return 0;
 }
 
-int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode, bool shared_slabs)
+// Fits of different populations: every slab byte is used once -> nontemporal loads, fit index fastest.
+// (U = 4 pairs per register buffer measured best of {2, 4, 8}; fits that SHARE a slab go through
+// launch_em_sweep_groups.)
+int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode)
 {
     if (n_fits <= 0 || m <= 0) return 0;
     const int64_t tiles = (m + 63) / 64;
-    int64_t tgroups = (tiles + WAVES - 1) / WAVES;
-    if (shared_slabs) tgroups = (tgroups + 7) / 8 * 8;          // XCD-aware order covers whole groups of 8
-    const int64_t blocks = tgroups * n_fits;
+    const int64_t blocks = (tiles + WAVES - 1) / WAVES * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
     dim3 grid((unsigned)blocks);
-    // U = 4 pairs per register buffer; nontemporal loads when every slab byte is used once (measured best of
-    // U in {2, 4, 8} x {temporal, nontemporal}), temporal loads + XCD-aware order when fits share slabs
-#define WGS_EM_LAUNCH(M, NTT) hipLaunchKernelGGL((em_sweep_kernel<M, 4, NTT>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m)
-    if (mode == WGS_MODE_EXACT) {
-        if (shared_slabs) WGS_EM_LAUNCH(WGS_MODE_EXACT, false); else WGS_EM_LAUNCH(WGS_MODE_EXACT, true);
-    } else {
-        if (shared_slabs) WGS_EM_LAUNCH(WGS_MODE_FAST, false); else WGS_EM_LAUNCH(WGS_MODE_FAST, true);
-    }
-#undef WGS_EM_LAUNCH
+    if (mode == WGS_MODE_EXACT)
+        hipLaunchKernelGGL((em_sweep_kernel<WGS_MODE_EXACT, 4>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
+    else
+        hipLaunchKernelGGL((em_sweep_kernel<WGS_MODE_FAST, 4>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
     HIP_TRY(hipGetLastError());
     return 0;
 }
