@@ -186,3 +186,59 @@ def test_native_rccl_single_rank():
     assert np.array_equal(c.allreduce_sum(big), big)
     c.barrier()
     c.close()
+
+
+def test_cli_three_ranks_on_a_bgzf_file_equal_one_process(tmp_path, oracle):
+    """A generated BGZF Beagle file (what ANGSD writes) through the command line: three ranks over the TCP-star
+    communicator (no torch; all on the one GPU) each open the file at the access point of their own SNP range and
+    produce, bit for bit, the files of the single-process run -- which in turn match the oracle on the parsed matrix."""
+    import gzip
+    import numpy as np
+    import synth
+    from test_reader_cpu import _bgzf_write
+    m, K = 30_011, 6
+    rng = np.random.default_rng(12)
+    labels = np.repeat(np.arange(K), [5, 6, 7, 4, 8, 6])
+    rng.shuffle(labels)
+    L, IDs = synth.make_beagle_for_labels(m, labels, K, seed=404)
+    n = len(IDs)
+    head = "marker\tallele1\tallele2\t" + "\t".join("%s\t%s\t%s" % (x, x, x) for x in IDs[:, 0])
+    lines = [head]
+    for s in range(m):
+        vals = []
+        for i in range(n):
+            g0, g1 = L[s, 2 * i], L[s, 2 * i + 1]
+            vals += ["%.6f" % g0, "%.6f" % g1, "%.6f" % max(0.0, 1 - g0 - g1)]
+        lines.append("chr%d_%d\t0\t1\t" % (s % 3, s + 1) + "\t".join(vals))
+    beagle = str(tmp_path / "gen.beagle.gz")
+    _bgzf_write(beagle, "\n".join(lines) + "\n")
+    ids = str(tmp_path / "ids.txt")
+    np.savetxt(ids, IDs, fmt="%s", delimiter="\t")
+    env0 = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env0.update(PYTHONPATH=ROOT, WGSASSIGN_DEVICE="0", WGSASSIGN_INDEX_DIR=str(tmp_path))
+    args = ["-m", "wgsassign_amd.WGSassign", "--beagle", beagle, "--pop_af_IDs", ids, "--get_reference_af", "--loo",
+            "--partition_sites", "2"]
+    one = subprocess.run([sys.executable] + args + ["--out", "one"], cwd=tmp_path, env=env0, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-3000:]
+    port = free_port()
+    procs = []
+    for r in range(3):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   WGSASSIGN_COMM="socket")
+        procs.append(subprocess.Popen([sys.executable] + args + ["--out", "three"], cwd=tmp_path, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+    assert outs[0].replace("three.", "one.") == one.stdout and outs[1].strip() == "" and outs[2].strip() == ""
+    for suffix in (".pop_af.npy", ".pop_names.txt", ".pop_like_LOO.tsv"):
+        assert (tmp_path / ("three" + suffix)).read_bytes() == (tmp_path / ("one" + suffix)).read_bytes(), suffix
+    assert gzip.open(tmp_path / "three.pop_like_LOO_partitions_2.tsv.gz", "rt").read() == \
+        gzip.open(tmp_path / "one.pop_like_LOO_partitions_2.tsv.gz", "rt").read()
+    # ... and the single-process files are the oracle's
+    pops, af_o, _, iters_o = oracle.fit_reference_af(L, IDs, t=8)
+    assert np.load(tmp_path / "one.pop_af.npy").tobytes() == af_o.tobytes()
+    assert [l for l in one.stdout.splitlines() if l.startswith("EM (MAF)")][:K] == ["EM (MAF) converged at iteration: %d" % i for i in iters_o]
+    loo_o, parts_o = oracle.loo(L, af_o.copy(), IDs, 8, 200, 1e-4, None, 2)
+    rows = [l.split("\t") for l in gzip.open(tmp_path / "one.pop_like_LOO_partitions_2.tsv.gz", "rt").read().strip().split("\n")][1:]
+    assert [["%.6f" % v for v in row] for row in parts_o] == [r[3:] for r in rows]
