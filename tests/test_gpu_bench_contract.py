@@ -63,3 +63,24 @@ def test_bench_failure_of_a_rank_propagates(tmp_path):
                         "--steps", "1", "--warmup", "0", "--no-cpu", "--no-assign"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WGSASSIGN_DEVICE="0", WGSASSIGN_COMM="socket"))
     assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_under_torchrun(tmp_path):
+    """The driver's documented multi-GPU launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (here N = 2 on the one GPU, all-reduce over the TCP
+    star): every rank process supervises one worker, rank 0's JSON line is the only stdout line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(WGSASSIGN_DEVICE="0", WGSASSIGN_COMM="socket")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--snps", "200000", "--inds", "100",
+                        "--pops", "5", "--steps", "3", "--warmup", "1", "--no-cpu", "--no-assign"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["snps_per_gpu"] == 100000
