@@ -84,3 +84,19 @@ def test_bench_under_torchrun(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["snps_per_gpu"] == 100000
+
+
+def test_rccl_init_failure_falls_back_to_the_tcp_all_reduce():
+    """Default communicator (the library's RCCL one) with two ranks on ONE GPU: RCCL refuses the duplicate device, the
+    ranks agree over the TCP star to keep the socket all-reduce, the run completes and says so -- the failure path a
+    mis-configured multi-GPU node would take (librccl's stdout banner must not reach the JSON consumer)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                                 "WGSASSIGN_COMM", "WGSASSIGN_BACKEND")}
+    env.update(WGSASSIGN_DEVICE="0", WGS_BENCH_INIT_TIMEOUT="90")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--snps", "200000", "--inds", "100", "--pops", "5",
+                        "--steps", "3", "--warmup", "1", "--no-cpu", "--no-assign"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and "RCCL init failed" in d["config"]["comm"] and d["config"]["comm"].startswith("socket all-reduce")
