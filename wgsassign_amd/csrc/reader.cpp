@@ -539,7 +539,11 @@ int scan_file(const char *path, int64_t span, BeagleIndex &idx, std::string *nam
         return 2;
     }
     file_identity(path, idx.file_size, idx.mtime);
-    std::vector<unsigned char> in(4u << 20), win(GZ_WIN);
+    // Output goes into 1 MiB laps of a buffer whose first GZ_WIN bytes always hold the 32 KiB that precede the lap
+    // (copied there when a lap starts), so the dictionary of an access point is the GZ_WIN bytes before next_out,
+    // contiguous -- and inflate is called per megabyte or deflate block, not per 32 KiB.
+    constexpr size_t LAP = 1u << 20;
+    std::vector<unsigned char> in(4u << 20), win(GZ_WIN + LAP);
     z_stream z;
     memset(&z, 0, sizeof z);
     if (inflateInit2(&z, 15 + 32) != Z_OK) {
@@ -561,12 +565,7 @@ int scan_file(const char *path, int64_t span, BeagleIndex &idx, std::string *nam
         ap.at_line_start = ls.at_line_start;
         ap.member_start = at_member;
         ap.bits = at_member ? 0 : (uint8_t)(z.data_type & 7);
-        if (!at_member) {                            // the GZ_WIN bytes before `out`, oldest first
-            ap.window.resize(GZ_WIN);
-            const size_t left = z.avail_out;         // free space at the end of the circular window
-            memcpy(ap.window.data(), win.data() + (GZ_WIN - left), left);
-            memcpy(ap.window.data() + left, win.data(), GZ_WIN - left);
-        }
+        if (!at_member) ap.window.assign(z.next_out - GZ_WIN, z.next_out);       // the GZ_WIN bytes before `out`
         idx.points.push_back(std::move(ap));
         last = totout;
     };
@@ -579,9 +578,10 @@ int scan_file(const char *path, int64_t span, BeagleIndex &idx, std::string *nam
         }
         if (member_start && span > 0 && totout - last >= (uint64_t)span && totout > 0) add_point(true);
         member_start = false;
-        if (z.avail_out == 0) {
-            z.avail_out = (unsigned)GZ_WIN;
-            z.next_out = win.data();
+        if (z.avail_out == 0) {                      // new lap: keep the last GZ_WIN bytes in front of it
+            if (totout > 0) memmove(win.data(), z.next_out - GZ_WIN, GZ_WIN);
+            z.avail_out = (unsigned)LAP;
+            z.next_out = win.data() + GZ_WIN;
         }
         const unsigned char *produced_at = z.next_out;
         const unsigned in0 = z.avail_in, out0 = z.avail_out;
