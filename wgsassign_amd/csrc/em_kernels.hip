@@ -12,6 +12,8 @@
 //   lanes process the same individual at the same time, so the leave-one-out skip and the
 //   column bound are wave-uniform branches.  Loads for the next U pairs are issued before the
 //   current U pairs are consumed (register double buffer).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -56,14 +58,21 @@ __device__ __forceinline__ double refined_rcp(double den)
     return __builtin_fma(r, e, r);
 }
 
+// FIXUP = false leaves out v_div_fixup: correct whenever den is a positive finite float32 (subnormals included: as
+// doubles they are normal and num/den stays far inside the double range) and num is finite -- the hot loops check
+// exactly that per buffer (one v_cmp_class per term, ANDed in scalar registers) and redo the rare buffer that holds
+// a sum of 0, NaN or inf with FIXUP = true, which is what produces the reference's 0/0 -> NaN.
+template <bool FIXUP = true>
 __device__ __forceinline__ double div_exact(double num, double den)
 {
     const double r = refined_rcp(den);
     double q = num * r;
     const double rem = __builtin_fma(-den, q, num);
     q = __builtin_fma(rem, r, q);
-    return __builtin_amdgcn_div_fixup(q, den, num);
+    return FIXUP ? __builtin_amdgcn_div_fixup(q, den, num) : q;
 }
+
+constexpr unsigned FP_POS_FINITE_NONZERO = 0x0100 | 0x0080;     // +normal | +subnormal
 
 // One (SNP, individual) term of emMAF_cy.pyx:19-22, exact rounding sequence:
 //   p0 = (float)(((double)g0*(1.0-f))*(1.0-f))
@@ -72,16 +81,27 @@ __device__ __forceinline__ double div_exact(double num, double den)
 //   tmp = (float)((double)tmp + ((double)p1 + 2.0*(double)p2) / (2.0*(double)((p0+p1)+p2)))
 // Scalings by 2 are exact, so 2.0*p2 + p1 is one fma and x/(2s) == 0.5*(x/s) folds into the
 // accumulation's fma: every remaining operation is one rounding of the reference's expression.
-__device__ __forceinline__ void term_exact(float g0, float g1, const SnpState &st, float &tmp)
+// (g0d, g1d, g2d = g0, g1 widened to double and (1-g0)-g1: they do not depend on the fit, so leave-one-out fits of one
+// population that walk a tile together share them.)  FIXUP = false: see div_exact; `ok` collects whether every sum
+// was a positive finite number.
+template <bool FIXUP>
+__device__ __forceinline__ void term_exact_shared(double g0d, double g1d, double g2d, const SnpState &st, float &tmp, bool &ok)
 {
-    const double g0d = (double)g0, g1d = (double)g1;
     const float p0 = (float)((g0d * st.omf) * st.omf);
     const float p1 = (float)((g1d * st.fd2) * st.omf);
-    const float p2 = (float)((((1.0 - g0d) - g1d) * st.fd) * st.fd);
+    const float p2 = (float)((g2d * st.fd) * st.fd);
     const float s = (p0 + p1) + p2;
+    if (!FIXUP) ok = ok && __builtin_isfpclass(s, FP_POS_FINITE_NONZERO);
     const double num = __builtin_fma(2.0, (double)p2, (double)p1);
-    const double q = div_exact(num, (double)s);
+    const double q = div_exact<FIXUP>(num, (double)s);
     tmp = (float)__builtin_fma(0.5, q, (double)tmp);
+}
+
+template <bool FIXUP>
+__device__ __forceinline__ void term_exact(float g0, float g1, const SnpState &st, float &tmp, bool &ok)
+{
+    const double g0d = (double)g0, g1d = (double)g1;
+    term_exact_shared<FIXUP>(g0d, g1d, (1.0 - g0d) - g1d, st, tmp, ok);
 }
 
 // Fast mode: the same expression evaluated in float32 (one reciprocal), same accumulation order.
@@ -93,19 +113,6 @@ __device__ __forceinline__ void term_fast(float g0, float g1, const SnpState &st
     const float s = (p0 + p1) + p2;
     const float num = p1 + 2.0f * p2;
     tmp = tmp + num * __builtin_amdgcn_rcpf(2.0f * s);
-}
-
-// The same two terms with the per-(SNP, individual) part hoisted: g0, g1 widened to double and g2 = (1-g0)-g1 do
-// not depend on the fit, so leave-one-out fits of one population that walk a tile together share them.
-__device__ __forceinline__ void term_exact_shared(double g0d, double g1d, double g2d, const SnpState &st, float &tmp)
-{
-    const float p0 = (float)((g0d * st.omf) * st.omf);
-    const float p1 = (float)((g1d * st.fd2) * st.omf);
-    const float p2 = (float)((g2d * st.fd) * st.fd);
-    const float s = (p0 + p1) + p2;
-    const double num = __builtin_fma(2.0, (double)p2, (double)p1);
-    const double q = div_exact(num, (double)s);
-    tmp = (float)__builtin_fma(0.5, q, (double)tmp);
 }
 
 // One fit per wavefront, nontemporal slab loads (each byte is used once: fits of different populations; fits that
@@ -144,6 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = ldg<NT>(src + (u < last ? u : last) * 64);   // clamped: tail re-reads hit cache
     float tmp = 0.0f;
+    bool dummy_ok = true;            // the checked (tail / left-out) buffers always use the fixup
     for (int p0 = 0; p0 < npairs; p0 += U) {
         if (p0 + U < npairs) {                   // one wave-uniform branch per buffer, loads unconditional
 #pragma unroll
@@ -156,13 +164,28 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
         // the left-out individual (LOO) or the odd tail checks each individual (wave-uniform)
         const bool plain = 2 * (p0 + U) <= fd.ncols && (fd.skip < 2 * p0 || fd.skip >= 2 * (p0 + U));
         if (plain) {
+            if (MODE == WGS_MODE_EXACT) {
+                const float tmp0 = tmp;
+                bool ok = true;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const f4 v = cur[u];
-                if (MODE == WGS_MODE_EXACT) {
-                    term_exact(v.x, v.y, st, tmp);
-                    term_exact(v.z, v.w, st, tmp);
-                } else {
+                for (int u = 0; u < U; ++u) {
+                    const f4 v = cur[u];
+                    term_exact<false>(v.x, v.y, st, tmp, ok);
+                    term_exact<false>(v.z, v.w, st, tmp, ok);
+                }
+                if (!__all(ok)) {                // a sum of 0, NaN or inf somewhere in this buffer: redo it with the fixup
+                    tmp = tmp0;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const f4 v = cur[u];
+                        term_exact<true>(v.x, v.y, st, tmp, ok);
+                        term_exact<true>(v.z, v.w, st, tmp, ok);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const f4 v = cur[u];
                     term_fast(v.x, v.y, st, tmp);
                     term_fast(v.z, v.w, st, tmp);
                 }
@@ -173,10 +196,10 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_kernel(const FitDesc *__r
                 const f4 v = cur[u];
                 const int ia = 2 * (p0 + u), ib = ia + 1;
                 if (ia < fd.ncols && ia != fd.skip) {
-                    if (MODE == WGS_MODE_EXACT) term_exact(v.x, v.y, st, tmp); else term_fast(v.x, v.y, st, tmp);
+                    if (MODE == WGS_MODE_EXACT) term_exact<true>(v.x, v.y, st, tmp, dummy_ok); else term_fast(v.x, v.y, st, tmp);
                 }
                 if (ib < fd.ncols && ib != fd.skip) {
-                    if (MODE == WGS_MODE_EXACT) term_exact(v.z, v.w, st, tmp); else term_fast(v.z, v.w, st, tmp);
+                    if (MODE == WGS_MODE_EXACT) term_exact<true>(v.z, v.w, st, tmp, dummy_ok); else term_fast(v.z, v.w, st, tmp);
                 }
             }
         }
@@ -251,13 +274,16 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDes
     f4 cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = ldg<false>(src + (u < last ? u : last) * 64);
-    // one individual (g0, g1) for every fit that is on and does not leave it out
+    // one individual (g0, g1) for every fit that is on and does not leave it out.  (The fixup-free divide of the
+    // single-fit kernel does not pay here: with four accumulators to save and a second copy of the body the kernel
+    // measured 8 % slower.)
+    bool ok = true;
     auto individual = [&](float g0, float g1, int col, bool checked) {
         if (MODE == WGS_MODE_EXACT) {
             const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
 #pragma unroll
             for (int f = 0; f < FG; ++f)
-                if (on[f] && (!checked || col != fd[f].skip)) term_exact_shared(g0d, g1d, g2d, st[f], tmp[f]);
+                if (on[f] && (!checked || col != fd[f].skip)) term_exact_shared<true>(g0d, g1d, g2d, st[f], tmp[f], ok);
         } else {
 #pragma unroll
             for (int f = 0; f < FG; ++f)
