@@ -162,3 +162,16 @@ def test_sums_are_reproducible_and_mode_fast_close(dev, oracle):
     assert np.max(np.abs(f1 - a1) / np.abs(a1)) < 1e-6
     afs.close()
     b.close()
+
+
+def test_random_shapes_against_the_literal_kernel():
+    """tools/stress_chains.py, 16 random cases (shapes up to 10^6 SNPs, K <= 20, P <= 64, site0 beyond 2^33, carries,
+    per-individual columns, injected -inf / NaN / constant columns / missing-data runs): 0 mismatches."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_chains.py"), "16", "2026"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "16 cases, 0 mismatches" in r.stdout
