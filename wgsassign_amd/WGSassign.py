@@ -115,7 +115,7 @@ def _run(args, comm):
                                                      rank=comm.rank, world=comm.world, keep=keep_ds, comm=comm)
     else:
         beagle, sample_names, site_names, m = reader_cy.stream_to_device(
-            args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank, world=comm.world, comm=comm)
+            args.beagle, group_of, n_groups, ctx=ctx, rank=comm.rank, world=comm.world, comm=comm, names="ends")
         n = beagle.n
         say("Loaded " + str(m) + " sites and " + str(n) + " individuals.")
         ends = comm.allgather_object((site_names[:4], site_names[-4:]))

@@ -197,14 +197,16 @@ def readBeagle_py(beagle):
 
 
 def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, rank=0, world=1, m_total=None,
-                     keep=None, comm=None):
+                     keep=None, comm=None, names="all"):
     """The file goes chunk by chunk straight into the device slabs -- host memory stays bounded by two chunks
     (the reference holds two full copies).  One indexing pass per file and node (ensure_index)
     counts the sites; with world > 1 every rank then starts at the access point before its contiguous SNP range
     (comm.shard_range) and inflates and parses only that range, the next chunk being prepared while the current
     one is uploaded.  group_of may be a callable(sample_names) -> (group_of, n_groups).  keep (bool array over the
     file's sites, e.g. the site mask of utils.filter_sites_to_common) restricts the matrix to the kept sites;
-    shard ranges then count kept sites.  Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
+    shard ranges then count kept sites.  names="ends" keeps only the first and last four site names of the range
+    (all the command line prints; a Python list of 50M names would cost gigabytes and minutes).
+    Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
     from .comm import shard_range
     from .device import DeviceBeagle
     index, _, m_file = ensure_index(path, comm)
@@ -228,7 +230,7 @@ def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, ra
         if callable(group_of):
             group_of, n_groups = group_of(list(st.sample_names))
         beagle = DeviceBeagle(hi - lo, st.n, group_of, n_groups, site0=lo, ctx=ctx)
-        row0, frow, site_names = 0, r0, []
+        row0, frow, site_names, tail, names_mode = 0, r0, [], [], names
         for rows, names in prefetched(st.chunks(limit=r1 - r0)):
             if keep is not None:
                 sel = keep[frow:frow + rows.shape[0]]
@@ -238,7 +240,14 @@ def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, ra
             if rows.shape[0]:
                 beagle.upload_rows(np.ascontiguousarray(rows), row0)
             row0 += rows.shape[0]
-            site_names.extend(names)
+            if names_mode == "all":
+                site_names.extend(names)
+            else:
+                if len(site_names) < 4:
+                    site_names = (site_names + names)[:4]
+                tail = (tail + names)[-4:]
+        if names_mode != "all" and row0 > 4:
+            site_names = site_names + tail         # [:4] are the first four names of the range, [-4:] the last four
         if row0 != hi - lo:
             raise RuntimeError("Beagle file changed while reading: expected %d sites, parsed %d" % (hi - lo, row0))
         return beagle, list(st.sample_names), site_names, m_total
