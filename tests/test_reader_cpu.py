@@ -66,13 +66,16 @@ def test_awkward_tokens_and_line_ends(tmp_path):
     no final newline."""
     from wgsassign_amd import reader_cy
     toks = ["1e-3", "0.1234567890123456789", "+0.5", "-0.25", "nan", "inf", ".5", "5.", "1E2", "0.000001",
-            "0.3333333333333333", "123456789012345678", "0x1p-2", "  0.75"]
+            "0.3333333333333333", "123456789012345678", "0x1p-2", "  0.75",
+            # eight characters like ANGSD's d.dddddd, but not that format -- and the format itself between them
+            "1.5e-003", "0.333333", "00.12345", "-0.12345", "9.999999", "0.1234567", "0.12345", "1.000000"]
     vals = " \t".join(t.strip() for t in toks)
     n = len(toks) // 2
     head = "marker allele1 allele2 " + " ".join("S%d S%d S%d" % (i, i, i) for i in range(n))
     row = lambda name: name + "\tA\tC\t" + "\t".join(
         "%s\t%s\t0.0" % (toks[2 * i].strip(), toks[2 * i + 1].strip()) for i in range(n))
-    text = head + "\r\n" + row("s1") + "\r\n\r\n" + row("s2") + "\n" + row("s3")      # no final newline
+    row2 = row("s2").replace("\t", " \t")                                          # two delimiters between tokens
+    text = head + "\r\n" + row("s1") + "\r\n\r\n" + row2 + "\n" + row("s3")        # no final newline
     p = str(tmp_path / "b.beagle.gz")
     with gzip.open(p, "wt", newline="") as fh:
         fh.write(text)
@@ -191,6 +194,23 @@ def test_indexed_open_starts_at_any_row(tmp_path, monkeypatch, layout):
         k = min(40, m - first)
         assert rows.shape[0] == k and sn == names[first:first + k], first
         assert rows.tobytes() == L[first:first + k].tobytes(), first
+    # whole ranges: the stretches between access points are inflated in parallel, `threads` at a time, the one after
+    # the last point by the serial stream -- the same rows and names as one stream from the first byte
+    for first, threads in [(0, 4), (1234, 3), (2400, 16), (0, 1)]:
+        with reader_cy.BeagleStream(p, threads=threads, index=idx, first_row=first) as st:
+            got = list(st.chunks(max_rows=333))
+        assert np.concatenate([r for r, _ in got]).tobytes() == L[first:].tobytes(), (first, threads)
+        assert [x for _, ns in got for x in ns] == names[first:], (first, threads)
+    # a file cut short after its index was built (same size and mtime faked): an error, not a short read
+    if layout == "plain":
+        cut = str(tmp_path / "cut.beagle.gz")
+        raw = open(p, "rb").read()
+        open(cut, "wb").write(raw[:len(raw) // 2] + bytes(len(raw) - len(raw) // 2))
+        st_p = os.stat(p)
+        os.utime(cut, (st_p.st_atime, st_p.st_mtime))
+        with pytest.raises(RuntimeError):
+            with reader_cy.BeagleStream(cut, threads=4, index=idx, first_row=0) as st:
+                list(st.chunks(max_rows=333))
     # an index of another file (or of an older version of this one) is refused
     os.utime(p, (1, 1))
     with pytest.raises(ValueError, match="is not an index of"):
@@ -302,6 +322,19 @@ def test_bgzf_parallel_index_and_block_parallel_inflate(tmp_path, monkeypatch, v
     # the names pass takes the serial route and agrees
     s2, n2 = reader_cy.read_site_names(p)
     assert n2 == names and s2 == samples
+    # blocks are inflated by libdeflate when its shared library is installed, by zlib otherwise (or on request): same matrix
+    if variant == "normal":
+        import subprocess
+        import sys
+        from conftest import ROOT
+        code = ("import sys, hashlib; sys.path.insert(0, %r); from wgsassign_amd import reader_cy; "
+                "L, _, s = reader_cy.readBeagle(%r); print(hashlib.sha1(L.tobytes()).hexdigest(), len(s))" % (ROOT, p))
+        import hashlib
+        for backend in ("zlib", "libdeflate"):
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, WGSASSIGN_INFLATE=backend))
+            assert r.returncode == 0, r.stderr[-2000:]
+            assert r.stdout.split() == [hashlib.sha1(L.tobytes()).hexdigest(), str(m)], backend
     # a truncated file is an error, not a silent short read
     cut = str(tmp_path / "cut.beagle.gz")
     open(cut, "wb").write(open(p, "rb").read()[:-5000])

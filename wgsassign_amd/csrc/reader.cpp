@@ -13,6 +13,7 @@
 // most 15 significant digits and no exponent take the exact fast path (integer mantissa / power
 // of ten, one correctly rounded division -- identical to strtod for such inputs); anything else
 // (exponents, inf/nan, hex) goes through strtod itself.
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -76,6 +77,25 @@ inline double parse_double(const char *p, const char *e)
     return strtod(s.c_str(), nullptr);
 }
 
+// The token almost every Beagle file consists of: "d.dddddd" (ANGSD prints %f) followed by a delimiter or the end of
+// the line.  Eight bytes are checked and converted at once: XOR with "0.000000" leaves the digit values (and 0 for the
+// point), the pairwise multiply-adds of the usual eight-digit trick give d0 d2 .. d7 0 = 10 * mantissa, and the value is
+// that integer / 1e7 -- one correctly rounded division of two exactly representable numbers, i.e. strtod's result.
+inline bool parse_f6(const char *p, const char *e, double *v)
+{
+    if (e - p < 8 || (e - p > 8 && !is_delim(p[8]))) return false;
+    uint64_t w;
+    memcpy(&w, p, 8);
+    uint64_t d = w ^ 0x3030303030302E30ull;
+    if ((((d + 0x7676767676767676ull) | d) & 0x8080808080808080ull) || (d & 0xFF00ull)) return false;
+    d = (d >> 8) | (d & 0xFF);                               // first digit, then the six decimals, then 0
+    d = d * 10 + (d >> 8);
+    const uint64_t mask = 0x000000FF000000FFull;
+    d = (((d & mask) * (100 + (1000000ull << 32))) + (((d >> 16) & mask) * (1 + (10000ull << 32)))) >> 32;
+    *v = (double)(uint32_t)d / 1e7;
+    return true;
+}
+
 struct Line {
     const char *begin, *end;   // without the newline
 };
@@ -134,17 +154,64 @@ inline long bgzf_member_size(const unsigned char *p, size_t n, uint32_t *hdr)
     return 0;
 }
 
-// Inflate one BGZF member (raw deflate between header and trailer) into out[0 .. isize).
-inline bool bgzf_inflate(z_stream &z, const unsigned char *member, const BgzfBlock &b, unsigned char *out)
+// Whole-buffer inflate of BGZF members.  libdeflate does that 2-3x faster than zlib; this image ships its shared
+// library (libdeflate.so.0, 1.10) without the header, hence the three prototypes and dlopen.  Without the library, or
+// with WGSASSIGN_INFLATE=zlib: zlib's raw inflate.  Neither checks the member's CRC32 (gzread does; a corrupt block
+// that still inflates to ISIZE bytes would show up as unparsable text).
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    void (*release)(void *) = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    bool ok = false;
+    LibDeflate()
+    {
+        const char *want = getenv("WGSASSIGN_INFLATE");
+        if (want && strcmp(want, "zlib") == 0) return;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        alloc = reinterpret_cast<void *(*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+        release = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_decompressor"));
+        decompress = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(dlsym(h, "libdeflate_deflate_decompress"));
+        ok = alloc && release && decompress;
+    }
+};
+inline const LibDeflate &libdeflate()
 {
-    if (b.isize == 0) return true;
-    if (inflateReset(&z) != Z_OK) return false;
-    z.next_in = const_cast<unsigned char *>(member) + b.hdr;
-    z.avail_in = b.csize - b.hdr - 8;
-    z.next_out = out;
-    z.avail_out = b.isize;
-    return inflate(&z, Z_FINISH) == Z_STREAM_END && z.avail_out == 0;
+    static const LibDeflate L;
+    return L;
 }
+
+struct BlockInflater {
+    z_stream z;
+    bool z_live = false;
+    void *ld = nullptr;
+    BlockInflater() { memset(&z, 0, sizeof z); }
+    BlockInflater(const BlockInflater &) = delete;
+    BlockInflater &operator=(const BlockInflater &) = delete;
+    ~BlockInflater()
+    {
+        if (ld) libdeflate().release(ld);
+        if (z_live) inflateEnd(&z);
+    }
+    bool init()
+    {
+        if (libdeflate().ok && (ld = libdeflate().alloc()) != nullptr) return true;
+        z_live = inflateInit2(&z, -15) == Z_OK;
+        return z_live;
+    }
+    // one member (raw deflate between its header and trailer) into out[0 .. isize)
+    bool run(const unsigned char *member, const BgzfBlock &b, unsigned char *out)
+    {
+        if (b.isize == 0) return true;
+        if (ld) return libdeflate().decompress(ld, member + b.hdr, b.csize - b.hdr - 8, out, b.isize, nullptr) == 0;
+        if (inflateReset(&z) != Z_OK) return false;
+        z.next_in = const_cast<unsigned char *>(member) + b.hdr;
+        z.avail_in = b.csize - b.hdr - 8;
+        z.next_out = out;
+        z.avail_out = b.isize;
+        return inflate(&z, Z_FINISH) == Z_STREAM_END && z.avail_out == 0;
+    }
+};
 
 struct GzSource {
     FILE *fp = nullptr;
@@ -157,6 +224,13 @@ struct GzSource {
     std::vector<unsigned char> cbuf;
     size_t clen = 0, cpos = 0;
     std::vector<BgzfBlock> batch;
+    // segmented mode: a plain-gzip file read through its index -- the stretches between consecutive access points
+    // are inflated independently, each from its own 32 KiB dictionary, `threads` at a time (BGZF blocks, megabytes long)
+    bool segmented = false;
+    std::string seg_path;
+    std::vector<AccessPoint> segs;   // stretch i = output [segs[i].out, segs[i+1].out); the last point runs to the end
+    size_t seg_next = 0;
+    size_t in_bytes = 4u << 20;      // compressed staging buffer of the serial stream
 
     ~GzSource() { close(); }
     void close()
@@ -180,7 +254,7 @@ struct GzSource {
         close();
         fp = fopen(path, "rb");
         if (!fp) return false;
-        in.resize(4u << 20);
+        in.resize(in_bytes);
         memset(&z, 0, sizeof z);
         eof = false;
         raw = ap && !ap->member_start;
@@ -247,15 +321,13 @@ struct GzSource {
                 const int T = (int)std::min<size_t>((size_t)threads, batch.size());
                 std::vector<char> ok(T, 1);
                 auto work = [&](int t) {
-                    z_stream zz;
-                    memset(&zz, 0, sizeof zz);
-                    if (inflateInit2(&zz, -15) != Z_OK) {
+                    BlockInflater inf;
+                    if (!inf.init()) {
                         ok[t] = 0;
                         return;
                     }
                     for (size_t i = (size_t)t; i < batch.size(); i += (size_t)T)
-                        if (!bgzf_inflate(zz, cbuf.data() + batch[i].off, batch[i], reinterpret_cast<unsigned char *>(dst) + ooff[i])) ok[t] = 0;
-                    inflateEnd(&zz);
+                        if (!inf.run(cbuf.data() + batch[i].off, batch[i], reinterpret_cast<unsigned char *>(dst) + ooff[i])) ok[t] = 0;
                 };
                 if (T <= 1) {
                     work(0);
@@ -285,9 +357,90 @@ struct GzSource {
             }
         }
     }
-    // up to `cap` bytes of output; 0 at the end of the file, -1 on a corrupt stream
+    static constexpr size_t SEG_BATCH_MAX = 512u << 20;      // text inflated by one batch of stretches
+    void use_segments(const char *path, std::vector<AccessPoint> points, int nthreads)
+    {
+        if (bgzf || points.size() < 2 || nthreads < 2) return;
+        segmented = true;
+        seg_path = path;
+        segs = std::move(points);
+        seg_next = 0;
+        threads = nthreads;
+    }
+    size_t seg_len(size_t i) const { return (size_t)(segs[i + 1].out - segs[i].out); }
+    // room the next read() needs at least / would like to have
+    size_t min_room() const
+    {
+        if (bgzf) return 65536;
+        if (segmented && seg_next + 1 < segs.size()) return std::max<size_t>(seg_len(seg_next), 1);
+        return 1;
+    }
+    size_t want_room() const
+    {
+        if (!segmented) return min_room();
+        size_t total = 0;
+        for (size_t c = 0; c < (size_t)threads && seg_next + c + 1 < segs.size(); ++c) {
+            if (c > 0 && total + seg_len(seg_next + c) > SEG_BATCH_MAX) break;
+            total += seg_len(seg_next + c);
+        }
+        return std::max<size_t>(total, 1);
+    }
+    // -3: no whole stretch is left (the one after the last access point has no known end) -- the serial stream,
+    // reopened at that point, takes over
+    long read_segments(char *dst, size_t cap)
+    {
+        for (;;) {
+            if (seg_next + 1 >= segs.size()) {
+                segmented = false;
+                const AccessPoint last = std::move(segs[seg_next]);
+                segs.clear();
+                return open(seg_path.c_str(), &last) ? -3 : -1;
+            }
+            size_t c = 0, total = 0;
+            while (c < (size_t)threads && seg_next + c + 1 < segs.size()) {
+                const size_t len = seg_len(seg_next + c);
+                if (total + len > cap || (c > 0 && total + len > SEG_BATCH_MAX)) break;
+                total += len;
+                ++c;
+            }
+            if (c == 0) return -2;
+            std::vector<size_t> ooff(c);
+            for (size_t i = 0, acc = 0; i < c; ++i) ooff[i] = acc, acc += seg_len(seg_next + i);
+            std::vector<char> ok(c, 1);
+            auto work = [&](size_t i) {
+                GzSource s;
+                s.in_bytes = 1u << 20;
+                const size_t len = seg_len(seg_next + i);
+                size_t got = 0;
+                if (!s.open(seg_path.c_str(), &segs[seg_next + i])) ok[i] = 0;
+                while (ok[i] && got < len) {
+                    const long k = s.read(dst + ooff[i] + got, len - got);
+                    if (k <= 0) ok[i] = 0;       // the file ends before the index says it does
+                    else got += (size_t)k;
+                }
+            };
+            if (c == 1) {
+                work(0);
+            } else {
+                std::vector<std::thread> th;
+                for (size_t i = 0; i < c; ++i) th.emplace_back(work, i);
+                for (auto &x : th) x.join();
+            }
+            for (char f : ok)
+                if (!f) return -1;
+            for (size_t i = 0; i < c; ++i) std::vector<unsigned char>().swap(segs[seg_next + i].window);   // done with it
+            seg_next += c;
+            if (total > 0) return (long)total;
+        }
+    }
+    // up to `cap` bytes of output; 0 at the end of the file, -1 on a corrupt stream, -2: the next unit (BGZF block,
+    // stretch between access points) does not fit into `cap`
     long read(char *dst, size_t cap)
     {
+        if (segmented) {
+            const long k = read_segments(dst, cap);
+            if (k != -3) return k;
+        }
         if (eof) return 0;
         if (bgzf) return read_bgzf(dst, cap);
         z.next_out = reinterpret_cast<unsigned char *>(dst);
@@ -325,12 +478,33 @@ struct GzSource {
 
 }  // namespace
 
+// Text buffer that grows without being zero-filled (std::vector's resize would touch every new page).
+struct TextBuf {
+    char *p = nullptr;
+    size_t n = 0;
+    ~TextBuf() { free(p); }
+    TextBuf() = default;
+    TextBuf(const TextBuf &) = delete;
+    TextBuf &operator=(const TextBuf &) = delete;
+    char *data() const { return p; }
+    size_t size() const { return n; }
+    bool resize(size_t want)
+    {
+        if (want <= n) return true;
+        char *q = (char *)realloc(p, want);
+        if (!q) return false;
+        p = q;
+        n = want;
+        return true;
+    }
+};
+
 struct wgs_reader {
     GzSource src;
     std::vector<std::string> samples;
     int gl_cols = 0;   // GL columns in the header (3 per individual)
     int n_inds = 0;
-    std::vector<char> buf;
+    TextBuf buf;
     size_t len = 0, pos = 0;
     bool eof = false;
     std::string chunk_sites;   // '\n'-joined site names of the last chunk
@@ -346,17 +520,21 @@ static bool fill(wgs_reader *r)
         r->len -= r->pos;
         r->pos = 0;
     }
-    // a single line longer than the buffer (in BGZF mode a whole 64 KiB block must fit behind the tail)
-    if (r->buf.size() - r->len < (r->src.bgzf ? 65536u : 1u)) r->buf.resize(r->buf.size() * 2);
+    // a single line longer than the buffer; a whole 64 KiB BGZF block, or one batch of stretches between access
+    // points, must fit behind the tail
+    const size_t want = r->src.want_room();
+    if (r->buf.size() - r->len < want && !r->buf.resize(r->src.segmented ? r->len + want : r->buf.size() * 2)) return false;
     while (!r->eof && r->len < r->buf.size()) {
+        const bool batch = r->src.segmented;
         const long got = r->src.read(r->buf.data() + r->len, r->buf.size() - r->len);
-        if (got == -2) break;                                 // BGZF: the next block does not fit any more; enough for now
+        if (got == -2) break;                                 // the next block does not fit any more; enough for now
         if (got < 0) return false;
         if (got == 0) {
             r->eof = true;
             break;
         }
         r->len += (size_t)got;
+        if (batch) break;                                     // one parallel batch per call (a second would be a partial one)
     }
     return true;
 }
@@ -381,9 +559,25 @@ static bool parse_line(const wgs_reader *r, const Line &ln, float *out, std::str
     // a header whose GL column count is not a multiple of 3 leaves a partial individual: the reference
     // parses those columns but only keeps the first 2 * (n // 3) values of each row (reader_cy.pyx:48-49,
     // 71-75), so they are not read at all here -- every row is exactly 2 * n_inds floats
-    for (int i = 0; i < 3 * r->n_inds; ++i) {
-        if (!next(tb, te)) return false;
-        if ((i + 1) % 3 != 0) *out++ = (float)parse_double(tb, te);   // reader_cy.pyx:62-66
+    for (int i = 0; i < r->n_inds; ++i) {
+        // fast path: "\td.dddddd\td.dddddd\t<anything>" -- one delimiter, two fixed-format values, the third skipped
+        if (e - p >= 19 && is_delim(p[0])) {
+            double a, b;
+            if (parse_f6(p + 1, e, &a) && parse_f6(p + 10, e, &b)) {
+                const char *q = p + 19;
+                while (q < e && !is_delim(*q)) ++q;
+                if (q > p + 19) {                                         // the third value is there
+                    *out++ = (float)a;
+                    *out++ = (float)b;
+                    p = q;
+                    continue;
+                }
+            }
+        }
+        for (int j = 0; j < 3; ++j) {
+            if (!next(tb, te)) return false;
+            if (j < 2) *out++ = (float)parse_double(tb, te);              // reader_cy.pyx:62-66
+        }
     }
     return true;
 }
@@ -422,7 +616,11 @@ int wgs_reader_open(const char *path, int threads, wgs_reader **out)
     }
     r->threads = threads > 0 ? threads : 1;
     r->src.try_bgzf(r->threads);
-    r->buf.resize(64u << 20);
+    if (!r->buf.resize(64u << 20)) {
+        wgs_set_error("out of memory");
+        delete r;
+        return 1;
+    }
     if (!fill(r)) {
         wgs_set_error("read error in %s", path);
         delete r;
@@ -707,9 +905,8 @@ int scan_file_bgzf(const char *path, int64_t span, int threads, BeagleIndex &idx
     {
         FILE *fp = fopen(path, "rb");
         if (!fp) return -1;
-        z_stream z;
-        memset(&z, 0, sizeof z);
-        if (inflateInit2(&z, -15) != Z_OK) {
+        BlockInflater inf;
+        if (!inf.init()) {
             fclose(fp);
             return -1;
         }
@@ -718,21 +915,19 @@ int scan_file_bgzf(const char *path, int64_t span, int threads, BeagleIndex &idx
             if (pread(fileno(fp), cb.data(), blocks[i].csize, (off_t)blocks[i].off) != (ssize_t)blocks[i].csize) break;
             BgzfBlock b = blocks[i];
             b.off = 0;
-            if (!bgzf_inflate(z, cb.data(), b, ob.data())) break;
+            if (!inf.run(cb.data(), b, ob.data())) break;
             const unsigned char *nl = (const unsigned char *)memchr(ob.data(), '\n', b.isize);
             header.append((const char *)ob.data(), nl ? (size_t)(nl - ob.data()) : b.isize);
             if (nl) break;
         }
-        inflateEnd(&z);
         fclose(fp);
     }
     const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)(threads > 0 ? threads : 1), nb));
     std::vector<char> ok(T, 1);
     auto work = [&](int t) {
         FILE *fp = fopen(path, "rb");
-        z_stream z;
-        memset(&z, 0, sizeof z);
-        if (!fp || inflateInit2(&z, -15) != Z_OK) {
+        BlockInflater inf;
+        if (!fp || !inf.init()) {
             ok[t] = 0;
             if (fp) fclose(fp);
             return;
@@ -752,7 +947,7 @@ int scan_file_bgzf(const char *path, int64_t span, int threads, BeagleIndex &idx
             for (; i < j; ++i) {
                 BgzfBlock b = blocks[i];
                 b.off = 0;
-                if (!bgzf_inflate(z, cb.data() + at, b, ob.data())) {
+                if (!inf.run(cb.data() + at, b, ob.data())) {
                     ok[t] = 0;
                     break;
                 }
@@ -760,7 +955,6 @@ int scan_file_bgzf(const char *path, int64_t span, int threads, BeagleIndex &idx
                 at += b.csize;
             }
         }
-        inflateEnd(&z);
         fclose(fp);
     };
     if (T <= 1) {
@@ -977,23 +1171,45 @@ int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t fi
     r->gl_cols = idx.gl_cols;
     r->n_inds = idx.gl_cols / 3;
     r->threads = threads > 0 ? threads : 1;
-    r->buf.resize(64u << 20);
+    if (!r->buf.resize(64u << 20)) {
+        wgs_set_error("out of memory");
+        delete r;
+        return 1;
+    }
     if (!r->src.open(path, best)) {
         wgs_set_error("cannot open Beagle file %s at its access point", path);
         delete r;
         return 2;
     }
     if (!best || best->member_start) r->src.try_bgzf(r->threads);
+    const bool have_best = best != nullptr;
+    const int64_t best_lines = best ? best->lines_before : 0;
+    const bool best_line_start = best ? best->at_line_start != 0 : true, best_content = best ? best->content != 0 : false;
+    if (!r->src.bgzf && r->threads > 1) {                    // plain gzip: inflate the stretches between access points in parallel
+        std::vector<AccessPoint> segs;
+        if (best) {
+            segs.push_back(*best);
+        } else {
+            AccessPoint start;
+            start.member_start = 1;
+            start.at_line_start = 1;
+            segs.push_back(start);
+        }
+        for (auto &a : idx.points)
+            if (a.out > segs.back().out) segs.push_back(std::move(a));   // idx.points (and `best`) are spent from here on
+        best = nullptr;
+        r->src.use_segments(path, std::move(segs), r->threads);
+    }
     int64_t line = 0;            // non-blank line index of the next complete line in the buffer
-    if (best) {
+    if (have_best) {
         if (!fill(r)) {
             wgs_set_error("read error in %s", path);
             delete r;
             return 1;
         }
-        line = best->lines_before;
-        if (!best->at_line_start) {                      // drop the tail of the line the access point sits in
-            bool content = best->content;
+        line = best_lines;
+        if (!best_line_start) {                          // drop the tail of the line the access point sits in
+            bool content = best_content;
             for (;;) {
                 const char *b = r->buf.data() + r->pos;
                 const char *nl = (const char *)memchr(b, '\n', r->len - r->pos);

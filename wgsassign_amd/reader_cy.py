@@ -17,7 +17,7 @@ import numpy as np
 
 from . import _lib
 
-INDEX_SPAN_BYTES = 64 << 20       # text between two access points of the index
+INDEX_SPAN_BYTES = 16 << 20       # text between two access points of the index (= one unit of parallel inflate)
 INDEX_MAX_POINTS = 4096
 
 
