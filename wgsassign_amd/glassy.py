@@ -56,6 +56,9 @@ def loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L=None, num_partitions=1,
     print(str(n) + " individuals to assign to " + str(k) + " populations")
     if downsampled_L is not None:
         print("Using downsampled GLs for likelihood evaluation in LOO assignment.")
+    if m == 0 or n == 0:
+        # glassy.py:65-109 over no SNPs: every re-fit and every per-site vector is empty, np.sum([]) = 0.0
+        return np.zeros((n, k), dtype=np.float32), np.zeros((n * P, k), dtype=np.float32)
     pops = np.unique(IDs[:, 1])
     group_of = np.searchsorted(pops, IDs[:n, 1]).astype(np.int32)
     beagle = DeviceBeagle.from_host(L, group_of, len(pops))
