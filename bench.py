@@ -77,6 +77,7 @@ def launch_ranks(n_ranks, fixed_env):
         procs = []
         for env_r in fixed_env:
             env = dict(os.environ, **env_r)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs between processes on this host driver
             if kind:
                 env["WGSASSIGN_COMM"] = kind
                 env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 7 * attempt)      # a fresh side-channel port

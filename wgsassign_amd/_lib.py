@@ -115,6 +115,8 @@ def load():
             raise RuntimeError(
                 "wgsassign_amd: %s is missing. Build it with `python -m wgsassign_amd.build` "
                 "(needs hipcc). There is no CPU fallback." % LIB_PATH)
+        # RCCL between processes needs dmabuf IPC on this host driver; the runtime reads this at its first HIP call
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)   # AttributeError if the .so does not export it
