@@ -202,6 +202,26 @@ def test_write_ass_mats_matches_reference_text(golden, tmp_path):
     assert gzip.open(outz, "rt").read() == str(cli["parts_tsv"])
     with pytest.raises(ValueError, match="shape mismatch"):
         utils.write_ass_mats(str(out), loo["loo_P1"][:3], list(fit["samples"]), fit["pops"])
+    # The format is whatever pandas' to_csv(sep="\t", index=False, float_format="%.6f") writes for such a table
+    # (utils.py:96-121): NaN as an empty field (a population of one under LOO), +-inf, names that need quoting.
+    import pandas as pd
+    rng = np.random.default_rng(0)
+    names = ["a b", 'q"uote', "plain", "tab\there", "x,y"]
+    pops = ["north", "so uth", 'w"est']
+    for P, part_col, locs, is_loo in ((1, False, ["north", "north", 'w"est', "so uth", "north"], True), (3, True, None, False),
+                                      (2, True, ["l1", "l2", "l3", "l4", "l5"], False), (1, True, None, False)):
+        mat = (rng.standard_normal((len(names) * P, len(pops))) * 1e5).astype(np.float32)
+        mat[1, 0], mat[2, 1], mat[0, 2], mat[3, 1] = np.nan, np.inf, -np.inf, -0.0
+        cols = {"sample": np.repeat(names, P)}
+        if locs is not None:
+            cols["source_pop" if is_loo else "location"] = np.repeat(locs, P)
+        if part_col:
+            cols["data_part"] = np.tile(np.arange(P), len(names))
+        want = pd.concat([pd.DataFrame(cols), pd.DataFrame(mat, columns=pops)], axis=1).to_csv(sep="\t", index=False, float_format="%.6f")
+        with contextlib.redirect_stdout(io.StringIO()):
+            utils.write_ass_mats(str(out), mat, names, pops, partition_count=P, print_part_column=part_col, sample_locations=locs,
+                                 doing_LOO=is_loo)
+        assert out.read_text() == want, (P, part_col)
 
 
 def test_cli_flags_and_refusals(tmp_path):

@@ -1,5 +1,5 @@
 """Host-side helpers around the hot path: drop-in for the reference's `utils.py`
-(site masks, partition sums, assignment-matrix writer).  Pure NumPy/pandas, no device work."""
+(site masks, partition sums, assignment-matrix writer).  Pure NumPy, no device work."""
 import gzip
 
 import numpy as np
@@ -47,12 +47,16 @@ def partition_loglikes(per_site_ll, partition_count):
 
 def write_ass_mats(filename, loglike_mat, sample_names, pop_names, partition_count=1, print_part_column=True,
                    sample_locations=None, doing_LOO=False):
-    """utils.py:49-123: tab-separated assignment matrix, `%.6f`, gzipped when the name ends in .gz.
-    Columns: sample, [source_pop|location], [data_part], one per population."""
-    import pandas as pd
+    """utils.py:49-123: tab-separated assignment matrix, gzipped when the name ends in .gz.  One row per
+    (sample, partition) in sample-major order; columns: sample, [source_pop | location], [data_part], then one
+    per population.  The reference assembles a DataFrame and calls to_csv(sep="\t", float_format="%.6f"); the
+    same bytes are written here row by row through the csv module (which is what to_csv drives): values as
+    %.6f, NaN as an empty field, minimal quoting."""
+    import csv
     n_ind, K = len(sample_names), len(pop_names)
-    if loglike_mat.shape != (n_ind * partition_count, K):
-        raise ValueError(f"loglike_mat shape mismatch: expected {(n_ind * partition_count, K)}, got {loglike_mat.shape}")
+    values = np.asarray(loglike_mat)
+    if values.shape != (n_ind * partition_count, K):
+        raise ValueError(f"loglike_mat shape mismatch: expected {(n_ind * partition_count, K)}, got {values.shape}")
     if not print_part_column and partition_count != 1:
         raise ValueError("print_part_column=False is only allowed if partition_count == 1")
     if sample_locations is not None:
@@ -60,15 +64,18 @@ def write_ass_mats(filename, loglike_mat, sample_names, pop_names, partition_cou
             raise ValueError("Length of sample_locations does not match sample_names")
         if doing_LOO and not set(sample_locations).issubset(set(pop_names)):
             raise ValueError("sample_locations contains values not in pop_names (required for LOO mode)")
-    cols = {"sample": np.repeat(sample_names, partition_count)}
+    header = ["sample"]
     if sample_locations is not None:
-        cols["source_pop" if doing_LOO is True else "location"] = np.repeat(sample_locations, partition_count)
+        header.append("source_pop" if doing_LOO is True else "location")
     if print_part_column:
-        cols["data_part"] = np.tile(np.arange(partition_count), n_ind)
-    df = pd.concat([pd.DataFrame(cols), pd.DataFrame(loglike_mat, columns=pop_names)], axis=1)
-    if filename.endswith(".gz"):
-        with gzip.open(filename, "wt") as fh:
-            df.to_csv(fh, sep="\t", index=False, float_format="%.6f")
-    else:
-        df.to_csv(filename, sep="\t", index=False, float_format="%.6f")
+        header.append("data_part")
+    opener = gzip.open if filename.endswith(".gz") else open
+    with opener(filename, "wt", newline="") as fh:
+        out = csv.writer(fh, delimiter="\t", lineterminator="\n")
+        out.writerow(header + [str(p) for p in pop_names])
+        for i in range(n_ind):
+            lead = [sample_names[i]] + ([sample_locations[i]] if sample_locations is not None else [])
+            for part in range(partition_count):
+                row = values[i * partition_count + part]
+                out.writerow(lead + ([part] if print_part_column else []) + ["" if v != v else "%.6f" % v for v in row])
     print(f"Wrote assignment matrix to {filename}")
