@@ -121,6 +121,51 @@ def test_config3_10M_x_1000_K10(wg, oracle):
     assert nearly_all_identical(out_sum.astype(np.float32), out_full.astype(np.float32), frac=0.999)
 
 
+def test_config3_get_pop_like_shape_one_slab_beyond_2_pow_32(wg, oracle):
+    """The --get_pop_like shape of configs[2]: ALL 1000 individuals in ONE slab (no population labels are known when
+    only a frequency file is given), 10M SNPs -> 5.0e9 float4 elements, i.e. element indices beyond 2^32.  Checked at a
+    row window near the END of the slab (tile 154 687 of 156 250: element index 4.95e9): the EM update with
+    n_call = 1000 and the assignment sums of the window equal the oracle on the downloaded rows; the full sums are
+    additive over two SNP shards."""
+    dev = wg.device
+    m, n, K = 10_000_000, 1000, 10
+    one = np.zeros(n, dtype=np.int32)
+    b = dev.DeviceBeagle(m, n, one, 1)
+    b.synth(synth.SEED, 2.0)
+    assert b.nbytes() == 80_000_000_000
+    r0, nr = 9_900_017, 640
+    assert (r0 // 64) * (n // 2) * 64 > 2 ** 32
+    rows = b.download_rows(r0, nr)
+    em = dev.EMBatch(b, np.zeros(1, dtype=np.int32))
+    for _ in range(2):
+        em.step()
+    f_dev = em.get_f(0)
+    f = np.full(nr, 0.25, dtype=np.float32)
+    for _ in range(2):
+        oracle.emMAF_update(rows, f, 8)
+    assert same(f, f_dev[r0:r0 + nr])                                     # n_call = 1000 in one fit
+    em.close()
+    # K frequency columns spread around the fitted one
+    A = np.clip(f_dev[:, None] + np.linspace(-0.2, 0.2, K, dtype=np.float32)[None, :], 0.01, 0.99).astype(np.float32)
+    afs = dev.AFSet.from_host(A)
+    out_full, _ = dev.assign(b, afs)
+    assert out_full.shape == (n, K) and np.all(np.isfinite(out_full)) and np.all(out_full < 0)
+    window_assign_check(dev, oracle, b, afs, r0, 512, one, 1)
+    afs.close()
+    b.close()
+    half = 6_000_000 + 33
+    out_sum = np.zeros_like(out_full)
+    for lo, hi in ((0, half), (half, m)):
+        bs = dev.DeviceBeagle(hi - lo, n, one, 1, site0=lo)
+        bs.synth(synth.SEED, 2.0)
+        a_s = dev.AFSet.from_host(np.ascontiguousarray(A[lo:hi]))
+        o, _ = dev.assign(bs, a_s)
+        out_sum += o
+        a_s.close()
+        bs.close()
+    assert np.max(np.abs(out_sum - out_full) / np.abs(out_full)) < 1e-12
+
+
 def test_config4_loo_2M_x_500_K8(wg, oracle):
     """configs[3]: 2M SNPs x 500 individuals, K=8, --loo --partition_sites 3 at full size through
     glassy.loo_device: 500 leave-one-out re-fits, scoring with per-individual columns (KB=8), exact
