@@ -20,8 +20,11 @@ def print_sample_and_site_summary(sample_names, site_names):
 
 
 def site_mask(site_names, site_names_target):
-    """Boolean keep-mask of utils.py:30-33 (bit-exact: membership of each site in the target)."""
-    return np.isin(np.array(site_names), list(set(site_names_target)))
+    """Boolean keep-mask of utils.py:30-33 (bit-exact: membership of each site in the target).  The reference's
+    np.isin sorts both string arrays (6 s at 2M sites); a hash set gives the same booleans in 0.5 s."""
+    target = set(site_names_target.tolist() if isinstance(site_names_target, np.ndarray) else site_names_target)
+    names = site_names.tolist() if isinstance(site_names, np.ndarray) else site_names
+    return np.fromiter((x in target for x in names), dtype=bool, count=len(names))
 
 
 def filter_sites_to_common(L, site_names, site_names_target):
