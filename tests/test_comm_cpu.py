@@ -129,3 +129,25 @@ def test_unpack_array_refuses_object_dtype():
     head = json.dumps({"dtype": "|O", "shape": [1]}).encode()
     with pytest.raises(RuntimeError):
         comm._unpack_array(struct.pack("<i", len(head)) + head + b"\0" * 8)
+
+
+def test_launch_local_ranks_env_stdout_and_failure(tmp_path, capfd):
+    """`WGSassign --gpus N` starts its ranks through comm.launch_local_ranks: every rank sees RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_*, only rank 0 reaches stdout, a failing rank ends the others and its status is returned."""
+    import sys
+    import time
+    from wgsassign_amd import comm
+    code = ("import os, sys; r = os.environ['RANK']; "
+            "open(os.path.join(%r, 'r' + r), 'w').write(' '.join(os.environ[k] for k in "
+            "('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY'))); print('out of rank', r)" % str(tmp_path))
+    assert comm.launch_local_ranks(3, [sys.executable, "-c", code]) == 0
+    seen = [open(tmp_path / ("r%d" % r)).read().split() for r in range(3)]
+    assert [s[:4] for s in seen] == [[str(r), str(r), "3", "127.0.0.1"] for r in range(3)]
+    assert len({s[4] for s in seen}) == 1 and all(s[5] == "0" for s in seen)
+    out = capfd.readouterr().out
+    assert out.strip().splitlines() == ["out of rank 0"]
+    # rank 1 fails at once, the others would run for a minute: ended, status 7 returned promptly
+    code = "import os, sys, time; sys.exit(7) if os.environ['RANK'] == '1' else time.sleep(60)"
+    t0 = time.time()
+    assert comm.launch_local_ranks(3, [sys.executable, "-c", code]) == 7
+    assert time.time() - t0 < 20

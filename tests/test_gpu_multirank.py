@@ -172,6 +172,34 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     assert clean(r.stdout) == str(g["stdout_like"]).replace("<TMP>/", "").splitlines()
 
 
+def test_cli_gpus_flag_starts_its_own_ranks(tmp_path, golden):
+    """`WGSassign --gpus 2` (no torchrun): the command line starts one process per rank itself; here both on the one
+    GPU over the TCP all-reduce.  Same files and stdout as the reference CLI run recorded in tests/golden."""
+    import gzip
+    import numpy as np
+    from conftest import GOLDEN
+    g = golden("amre_cli.npz")
+    data = os.path.join(GOLDEN, "data")
+    env = dict(os.environ, WGSASSIGN_COMM="socket", WGSASSIGN_DEVICE="0", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "wgsassign_amd.WGSassign", "--gpus", "2",
+                        "--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),
+                        "--pop_af_IDs", os.path.join(data, "amre.breeding.ind85.reference_k5.IDs.txt"),
+                        "--get_reference_af", "--loo", "--partition_sites", "3", "--out", "ref", "--threads", "2"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert np.load(tmp_path / "ref.pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
+    assert clean(r.stdout) == str(g["stdout_ref"]).replace("<TMP>/", "").splitlines()
+    assert gzip.open(tmp_path / "ref.pop_like_LOO_partitions_3.tsv.gz", "rt").read() == str(g["parts_tsv"])
+    assert "\t-gpus 2\n" in (tmp_path / "ref.args").read_text()
+    # a rank that fails takes the run down with its status (here: an unreadable Beagle file on every rank)
+    r = subprocess.run([sys.executable, "-m", "wgsassign_amd.WGSassign", "--gpus", "2", "--beagle", str(tmp_path / "missing.beagle.gz"),
+                        "--pop_af_IDs", os.path.join(data, "amre.breeding.ind85.reference_k5.IDs.txt"), "--get_reference_af", "--out", "bad"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+
+
 def test_native_rccl_single_rank():
     """The library's own RCCL communicator (dlopen'ed librccl, no torch): with one rank the all-reduce
     is the identity -- exercises loading, unique id, init, the stream-ordered collective, destroy."""

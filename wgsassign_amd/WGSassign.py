@@ -37,6 +37,9 @@ parser.add_argument("--partition_sites", type=int, metavar="INT", default=1,
                          "log-likelihoods for each subset.")
 parser.add_argument("--ne_obs", action="store_true",
                     help="Estimate population and individuals effective sample sizes")
+parser.add_argument("--gpus", metavar="INT", type=int, default=1,
+                    help="MI355X build: shard the SNPs over INT GPUs of this node, one process per GPU "
+                         "(not needed under torchrun or any launcher that sets RANK / WORLD_SIZE)")
 # recognised but not provided by this build (out of the hot-path scope)
 for _flag in ("--get_assignment_z_score", "--get_reference_z_score", "--single_read_threshold",
               "--get_em_mix", "--get_mcmc_mix"):
@@ -217,8 +220,14 @@ def main(argv=None):
     if len(sys.argv) < 2 and argv is None:
         parser.print_help()
         sys.exit()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU, started here before anything touches the device; they come back through this function
+        # with RANK / WORLD_SIZE set
+        from .comm import launch_local_ranks
+        sys.exit(launch_local_ranks(args.gpus, [sys.executable, "-m", "wgsassign_amd.WGSassign"] +
+                                    list(sys.argv[1:] if argv is None else argv)))
     from .comm import init_from_env
-    comm = init_from_env()          # LocalComm outside torchrun; one rank per GPU under it
+    comm = init_from_env()          # LocalComm for one process; one rank per GPU under --gpus N / torchrun
     root = comm.rank == 0
     if root:
         print("WGSassign")

@@ -409,6 +409,51 @@ def init_from_env(ctx=None):
     return TorchComm(device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
 
+def launch_local_ranks(n, argv, env=None, poll=0.05):
+    """Start `argv` n times as ranks 0 .. n-1 of this node -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT set, a free port chosen -- and wait for them: what `WGSassign --gpus N` does instead of asking for
+    torchrun.  Rank 0 writes to this process's stdout, the others only to stderr.  The caller must not have touched
+    the GPU (children are separate processes; nothing is exec'ed).  When a rank fails the others are ended; returns
+    the first non-zero exit status, else 0."""
+    import socket
+    import subprocess
+    import time
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ if env is None else env)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                 MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(argv, env=e, stdout=None if r == 0 else subprocess.DEVNULL))
+    status = 0
+    try:
+        left = set(range(n))
+        while left:
+            for r in sorted(left):
+                rc = procs[r].poll()
+                if rc is None:
+                    continue
+                left.discard(r)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 1
+            if status != 0:
+                break
+            time.sleep(poll)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return status
+
+
 def shard_range(m_total, rank, world):
     """Contiguous SNP range [lo, hi) of `rank`: GPU g owns [g*m/G, (g+1)*m/G)."""
     lo = (m_total * rank) // world
