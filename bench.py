@@ -412,9 +412,9 @@ def cpu_baseline(beagle, group_of, K, ms, seconds=12.0):
     return {"value": K * ms * sweeps / el, "unit": "SNP-updates/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
             "assign_value": assign_snps_per_s, "assign_unit": "SNPs/s (all n x K terms of a SNP = 1)",
             "sample": "first %d SNPs x %d ind of the same synthetic matrix, K=%d populations, %d sweeps in %.1f s "
-                      "(OpenMP threads=%d; per-population gather %.2f s not included); assignment leg: %d of the %d (individual, "
-                      "population) scans timed, %.2f ms each" %
-                      (ms, beagle.n, K, sweeps, el, threads, t_gather, pairs, beagle.n * K, t_pair * 1e3)}
+                      "(OpenMP threads=%d; per-population gather %.2f s not included); assignment leg: %d (individual, population) "
+                      "scans over the sample timed, %.2f ms each, of the %d a full matrix needs" %
+                      (ms, beagle.n, K, sweeps, el, threads, t_gather, pairs, t_pair * 1e3, beagle.n * K)}
 
 
 if __name__ == "__main__":
