@@ -96,6 +96,17 @@ def launch_ranks(n_ranks, fixed_env):
                 th = threading.Thread(target=pump, daemon=True)
                 th.start()
                 pumps.append(th)
+        # wait for all ranks; once one has failed the others (possibly stuck in a collective with it) get 15 s, then are ended
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.time()
+            if failed_at is not None and time.time() - failed_at > 15.0:
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                failed_at = float("inf")
+            time.sleep(0.05)
         codes = [p.wait() for p in procs]
         for th in pumps:
             th.join(10)
@@ -105,7 +116,7 @@ def launch_ranks(n_ranks, fixed_env):
             print("bench.py: RCCL communicator did not initialise (exit 75); restarting the ranks over the socket all-reduce",
                   file=sys.stderr, flush=True)
             continue
-        return next(c for c in codes if c != 0)
+        return next((c for c in codes if c > 0), 1)       # a rank's own status rather than the -SIGTERM of the ones ended here
     return 1
 
 
