@@ -92,6 +92,21 @@ def test_loo_per_individual_columns_against_oracle(wg, oracle, K, P):
     assert same_nan(af2, af1), (K, P)                # the sticky column overwrite
 
 
+def test_loo_with_more_partitions_than_the_block_parallel_chains_take(wg, oracle):
+    """--partition_sites 100 (> 64: the leave-one-out falls back from the single C call to the step-by-step driver and
+    the one-lane-per-chain kernel): same bits as the oracle's np.add.at sums, same sticky columns."""
+    K, P = 6, 100
+    rng = np.random.default_rng(77)
+    L, IDs = structured(1500, K, rng, 7100)
+    _, af_o, _, _ = oracle.fit_reference_af(L, IDs, t=4)
+    af1, af2 = af_o.copy(), af_o.copy()
+    with np.errstate(all="ignore"):
+        loo_o, parts_o = oracle.loo(L, af1, IDs, 4, 200, 1e-4, None, P)
+        (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 200, 1e-4, None, P)
+    assert parts.shape == (len(IDs) * P, K)
+    assert nearly_all_identical(loo, loo_o) and same_nan(parts, parts_o) and same_nan(af2, af1)
+
+
 @pytest.mark.parametrize("K", [8, 10, 13])
 def test_fast_partition_kernel_large_K(wg, oracle, monkeypatch, K):
     """WGSASSIGN_PARTS=fast routes P > 1 through assign_kernel<KB> (lane <-> individual pair): float64

@@ -39,7 +39,7 @@ def oracle_parts(oracle, L, A, P, site0=0, carry=None):
     return out
 
 
-@pytest.mark.parametrize("P", [1, 2, 3, 7, 10, 64])
+@pytest.mark.parametrize("P", [1, 2, 3, 7, 10, 64, 65, 100])       # beyond 64 partitions: the one-lane chains
 def test_chains_match_literal_kernel_and_oracle(dev, oracle, P):
     m, n, K = 40_000 + 37, 14, 3
     L, IDs = synth.make_beagle(m, n, K, seed=70 + P)
