@@ -2,7 +2,7 @@
 
 The scoring sweep (csrc/assign_kernels.hip) batches the K populations into register batches of KB <= 10:
 K=6 -> KB=6, K=7 -> 7, K=8 -> 8 (config 4), K=9 -> 9, K=10 -> 10 (config 3, one pass), K=13 -> two passes of 7 with
-a padded slot, K=17 -> two passes of 9 with a padded slot, K=20 -> two passes of 10 (config 5); NP = 2 individual
+a padded slot, K=17 -> two passes of 9 with a padded slot, K=20 -> two passes of 10 (config 5), K=23 -> three of 8, K=33 -> four of 9; NP = 2 individual
 pairs per wave for KB <= 6, 1 above.  The chain kernel of the exact partition sums stays at KB <= 8 (K=10 -> two
 passes of 5, K=20 -> three of 7).  Every one of them is held to the oracle here, in both
 modes: shared frequency columns (glassy.py:31-42, --get_pop_like) and per-individual columns
@@ -19,7 +19,7 @@ from test_gpu_parity import close, nearly_all_identical, quiet, same, same_nan, 
 
 pytestmark = pytest.mark.gpu
 
-KS = [6, 7, 8, 9, 10, 13, 17, 20]
+KS = [6, 7, 8, 9, 10, 13, 17, 20, 23, 33]
 
 
 def odd_populations(K, rng):
