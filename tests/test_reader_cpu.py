@@ -340,3 +340,16 @@ def test_bgzf_parallel_index_and_block_parallel_inflate(tmp_path, monkeypatch, v
     open(cut, "wb").write(open(p, "rb").read()[:-5000])
     with pytest.raises(RuntimeError):
         reader_cy.readBeagle(cut)
+
+
+def test_reader_clean_under_address_and_thread_sanitizers():
+    """csrc/reader.cpp is host code with worker threads (parallel parse, BGZF blocks, gzip stretches between access
+    points): tools/reader_sanitize.sh builds it with -fsanitize=address,undefined and with -fsanitize=thread and drives
+    the index pass, indexed opens at several rows and thread counts, and full reads whose checksums must agree."""
+    import subprocess
+    from conftest import ROOT
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "reader_sanitize.sh"), "3000", "20"], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "clean under ASan+UBSan and TSan" in r.stdout and r.stdout.count("\nok\n") == 8
+    assert "ERROR: AddressSanitizer" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr
