@@ -245,6 +245,9 @@ int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum);
 /* The per-site float32 values themselves for individuals [i0, i0+count) of ONE population
  * (rows_out[(i - i0) * m + s]), so the host can apply np.mean to each row exactly as fisher.py:59. */
 int wgs_fisher_ind_sites(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *rows_out);
+/* ... and np.mean of each of those rows formed on the device exactly as NumPy forms it (pairwise float32 sum, float64
+ * division, float32 result): means_out[i - i0], fisher.py:59 without moving the rows to the host. */
+int wgs_fisher_ind_means(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *means_out);
 
 /* ------------------------------------------------------------------ streamed Beagle reader (host)
  * reader_cy.readBeagle(path) -- reader_cy.pyx:16-77 -- as a chunked native reader: gzip inflate,

@@ -122,3 +122,26 @@ def test_fast_partition_kernel_large_K(wg, oracle, monkeypatch, K):
         loo_o, parts_o = oracle.loo(L, af1, IDs, 4, 200, 1e-4, None, 3)
         (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 200, 1e-4, None, 3)
     assert close(loo, loo_o) and close(parts, parts_o, RTOL_PARTS) and same_nan(af2, af1)
+
+
+@pytest.mark.parametrize("m, n, K", [(1501, 40, 6), (8192 + 77, 26, 5), (70_001, 30, 10), (300_000, 24, 8)])
+def test_sums_are_numpys_own_float64_sums(wg, oracle, m, n, K):
+    """glassy.py:38 stores np.sum(vec, dtype=float): NumPy adds, chunk of 8192 sites after chunk, the chunk's pairwise
+    sum to the running float64 total.  block_prefix_kernel adds the device's 4096-site block sums in that order, and
+    inside a block every partial sum of these float32 values is exact in float64 -- so for a matrix that starts at
+    site 0 the float64 sums are NumPy's to the last bit, and every stored float32 equals the oracle's."""
+    labels = np.arange(n) % K
+    L, IDs = synth.make_beagle_for_labels(m, labels, K, seed=m)
+    pops, af, _, _ = oracle.fit_reference_af(L, IDs, t=8)
+    want = oracle.assignLL(L, af.copy(), 8)
+    for group_of, n_groups in ((None, 1), (np.searchsorted(pops, IDs[:, 1]).astype(np.int32), K)):
+        b = wg.device.DeviceBeagle.from_host(L, group_of, n_groups)
+        afs = wg.device.AFSet.from_host(af)
+        out, _ = wg.device.assign(b, afs)
+        afs.close()
+        b.close()
+        assert same(out.astype(np.float32), want), (m, n_groups)
+        for i, k in ((0, 0), (n - 1, K - 1), (n // 2, 1)):
+            vec = np.zeros(m, dtype=np.float32)
+            oracle.loglike(L, af, vec, 4, i, k)
+            assert out[i, k] == np.sum(vec, dtype=float), (m, i, k)

@@ -1514,6 +1514,77 @@ int wgs_fisher_ind_sites(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count,
     return 0;
 }
 
+/* How NumPy sums a contiguous float32 vector of n elements (np.add.reduce behind np.mean, fisher.py:59): the reduction
+ * hands its inner loop at most 8192 elements at a time (the iterator's buffer size -- measured: np.sum equals this
+ * scheme and not one pairwise pass over the whole vector from n = 8193 on; np.setbufsize does not change it), each such
+ * chunk is summed pairwise (em_kernels.hip: pairwise_leaf_kernel) and the chunk sums are added to the running float32
+ * total in order.  The leaves and the order of the additions depend on n alone. */
+namespace {
+struct PairwisePlan {
+    std::vector<int64_t> leaf_lo;
+    std::vector<int32_t> leaf_len, prog;
+};
+void pairwise_plan(int64_t lo, int64_t n, PairwisePlan &p)
+{
+    if (n <= 128) {
+        p.prog.push_back((int32_t)p.leaf_lo.size());
+        p.leaf_lo.push_back(lo);
+        p.leaf_len.push_back((int32_t)n);
+        return;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    pairwise_plan(lo, n2, p);
+    pairwise_plan(lo + n2, n - n2, p);
+    p.prog.push_back(-1);
+}
+}  // namespace
+
+/* fisher.py:52-59 for individuals [i0, i0 + count) of one population slab, entirely on the device:
+ * means_out[i - i0] = np.mean of the individual's float32 per-site terms -- NumPy's pairwise float32 sum, divided by
+ * the count in float64, stored as float32 -- without the count x m matrix ever crossing PCIe. */
+int wgs_fisher_ind_means(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *means_out)
+{
+    WGS_REQUIRE(b && a && means_out && count > 0 && i0 >= 0 && (int64_t)i0 + count <= b->n, "bad argument");
+    WGS_REQUIRE(a->m == b->m && a->K == b->n_groups, "allele frequencies do not match the population slabs");
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int g = b->group_of[i0];
+    std::vector<int32_t> cols(count);
+    for (int j = 0; j < count; ++j) {
+        WGS_REQUIRE(b->group_of[i0 + j] == g, "individuals %d..%d span more than one population", i0, i0 + count - 1);
+        cols[j] = b->col_of[i0 + j];
+    }
+    PairwisePlan plan;
+    for (int64_t lo = 0; lo < b->m; lo += 8192) {            // total = total + pairwise(chunk); the first chunk starts it
+        pairwise_plan(lo, std::min<int64_t>(8192, b->m - lo), plan);
+        if (lo > 0) plan.prog.push_back(-1);
+    }
+    const size_t nleaf = plan.leaf_lo.size(), nprog = plan.prog.size();
+    WGS_REQUIRE(nleaf < (1u << 28), "too many SNPs for one pairwise plan");
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_rows = 0, o_sums = o_rows + up((size_t)count * b->m * sizeof(float)), o_means = o_sums + up((size_t)count * nleaf * sizeof(float)),
+                 o_lo = o_means + up(sizeof(float) * count), o_len = o_lo + up(sizeof(int64_t) * nleaf), o_prog = o_len + up(sizeof(int32_t) * nleaf),
+                 o_cols = o_prog + up(sizeof(int32_t) * nprog), total = o_cols + up(sizeof(int32_t) * count);
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(ctx, total, &ws)) return 1;
+    char *w = reinterpret_cast<char *>(ws);
+    float *d_rows = reinterpret_cast<float *>(w + o_rows), *d_sums = reinterpret_cast<float *>(w + o_sums), *d_means = reinterpret_cast<float *>(w + o_means);
+    int64_t *d_lo = reinterpret_cast<int64_t *>(w + o_lo);
+    int32_t *d_len = reinterpret_cast<int32_t *>(w + o_len), *d_prog = reinterpret_cast<int32_t *>(w + o_prog), *d_cols = reinterpret_cast<int32_t *>(w + o_cols);
+    HIP_TRY(hipMemcpyAsync(d_lo, plan.leaf_lo.data(), sizeof(int64_t) * nleaf, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_len, plan.leaf_len.data(), sizeof(int32_t) * nleaf, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_prog, plan.prog.data(), sizeof(int32_t) * nprog, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), sizeof(int32_t) * count, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));              // the host vectors above go out of use here
+    const Slab &s = b->slabs[g];
+    if (launch_fisher_ind_sites(ctx, s.base, d_cols, a->buf + (size_t)g * a->m, d_rows, b->m, s.npairs, count)) return 1;
+    if (launch_pairwise_mean(ctx, d_rows, count, b->m, d_lo, d_len, (int)nleaf, d_prog, (int)nprog, d_sums, d_means)) return 1;
+    HIP_TRY(hipMemcpyAsync(means_out, d_means, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 /* ------------------------------------------------------------------ test hooks */
 
 /* pairs = 2^20 threads x per_thread operand pairs; *mismatch = results of the kernel's Newton-core

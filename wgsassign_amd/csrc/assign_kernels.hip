@@ -382,8 +382,13 @@ __global__ __launch_bounds__(256, (PER_IND || KB * NP > 10 || KB > 8) ? 2 : WGS_
     }
 }
 
-// out[cell] = sum over blocks of S[block][cell], added in block order (reproducible); with keep_prefix
-// S[block][cell] is replaced by the sum of the blocks before it (what the chain prediction needs).
+// out[cell] = sum over blocks of S[block][cell] in a fixed order (reproducible) -- the order of np.sum(vec, dtype=float)
+// (glassy.py:38): NumPy's reduction hands its inner loop 8192 elements at a time, sums each such chunk pairwise (the top
+// split of a full chunk is 4096 + 4096, i.e. two of the blocks here) and adds the chunk sums to the running total one
+// after the other: total = total + (S[2c] + S[2c+1]).  Inside a block the sweep adds in its own order; that is the same
+// number whenever the partial sums are exact, which 4096 float32 values within 2^14 of each other always are in float64
+// (24 + 14 + 12 bits) -- so for a matrix that starts at site 0 the n x K sums are NumPy's own, not just close to them.
+// With keep_prefix S[block][cell] is replaced by the sum of the blocks before it (what the chain prediction needs).
 __global__ __launch_bounds__(256) void block_prefix_kernel(double *__restrict__ S, int nblocks, int64_t cells, double *__restrict__ out,
                                                            int keep_prefix)
 {
@@ -396,15 +401,23 @@ __global__ __launch_bounds__(256) void block_prefix_kernel(double *__restrict__ 
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = S[(int64_t)(b + u) * cells + cell];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (keep_prefix) S[(int64_t)(b + u) * cells + cell] = run;
-            run += v[u];
+        for (int u = 0; u < 8; u += 2) {
+            if (keep_prefix) {
+                S[(int64_t)(b + u) * cells + cell] = run;
+                S[(int64_t)(b + u + 1) * cells + cell] = run + v[u];
+            }
+            run = run + (v[u] + v[u + 1]);
         }
     }
-    for (; b < nblocks; ++b) {
-        const double v = S[(int64_t)b * cells + cell];
-        if (keep_prefix) S[(int64_t)b * cells + cell] = run;
-        run += v;
+    for (; b < nblocks; b += 2) {
+        const double v0 = S[(int64_t)b * cells + cell];
+        const bool pair = b + 1 < nblocks;
+        const double v1 = pair ? S[(int64_t)(b + 1) * cells + cell] : 0.0;
+        if (keep_prefix) {
+            S[(int64_t)b * cells + cell] = run;
+            if (pair) S[(int64_t)(b + 1) * cells + cell] = run + v0;
+        }
+        run = pair ? run + (v0 + v1) : run + v0;
     }
     out[cell] = run;
 }

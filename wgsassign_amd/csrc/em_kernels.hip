@@ -709,6 +709,61 @@ __global__ __launch_bounds__(256) void fisher_ind_sites_kernel(const float2 *__r
     out[(int64_t)j * m + s] = (float)(((0.5 * (double)term) * thd) * omt);
 }
 
+// ---- np.mean of a float32 row, the way NumPy forms it (fisher.py:59) ---------------------------------------------------
+// NumPy's add.reduce over a contiguous float32 vector adds, chunk after chunk of 8192 elements (api.hip: PairwisePlan), the
+// chunk's pairwise sum (numpy/_core/src/umath/loops_utils.h.src, @TYPE@_pairwise_sum, restated) to the running total: more
+// than 128 elements split into halves, the left one n/2 rounded down to a multiple of 8; a piece of 8..128 elements is summed with EIGHT accumulators r[i % 8], combined as ((r0+r1)+(r2+r3)) +
+// ((r4+r5)+(r6+r7)), the n % 8 leftovers added one by one; fewer than 8 elements are added in order.  The pieces
+// ("leaves") and the order in which their sums are added depend only on the length, so the host lays them out once
+// (api.hip: PairwisePlan); here 8 lanes form a leaf -- lane r IS accumulator r, so the loads are coalesced -- and one
+// thread per row then adds the leaf sums in the plan's order (a stack program: op >= 0 pushes leaf op, -1 adds the two
+// on top).  np.mean divides the float32 sum by the count in float64 and stores float32.
+__global__ __launch_bounds__(256) void pairwise_leaf_kernel(const float *__restrict__ rows, int64_t m, const int64_t *__restrict__ leaf_lo,
+                                                           const int32_t *__restrict__ leaf_len, int nleaf, float *__restrict__ leaf_sums)
+{
+    const int64_t leaf = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const int r = threadIdx.x & 7, j = blockIdx.y;
+    if (leaf >= nleaf) return;                               // the 8 lanes of a leaf leave together
+    const float *a = rows + (int64_t)j * m + leaf_lo[leaf];
+    const int n = leaf_len[leaf];
+    float res;
+    if (n < 8) {
+        res = -0.0f;
+        if (r == 0)
+            for (int i = 0; i < n; ++i) res = res + a[i];
+    } else {
+        const int n8 = n - (n % 8);
+        float acc = a[r];
+        for (int i = 8; i < n8; i += 8) acc = acc + a[i + r];
+        acc = acc + __shfl_xor(acc, 1);                      // r0+r1 | r2+r3 | r4+r5 | r6+r7   (addition commutes: both lanes of a
+        acc = acc + __shfl_xor(acc, 2);                      // (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)  pair hold the same value)
+        res = acc + __shfl_xor(acc, 4);
+        if (r == 0)
+            for (int i = n8; i < n; ++i) res = res + a[i];
+    }
+    if (r == 0) leaf_sums[(int64_t)j * nleaf + leaf] = res;
+}
+
+__global__ __launch_bounds__(64) void pairwise_combine_kernel(const float *__restrict__ leaf_sums, int nleaf, const int32_t *__restrict__ prog,
+                                                             int nprog, int count, int64_t m, float *__restrict__ means)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const float *ls = leaf_sums + (int64_t)j * nleaf;
+    float stack[64];                                         // depth <= log2(m / 64) + 2
+    int sp = 0;
+    for (int p = 0; p < nprog; ++p) {
+        const int op = prog[p];
+        if (op >= 0) {
+            stack[sp++] = ls[op];
+        } else {
+            --sp;
+            stack[sp - 1] = stack[sp - 1] + stack[sp];
+        }
+    }
+    means[j] = (float)((double)stack[0] / (double)m);
+}
+
 // Per individual: sum over this shard's SNPs of its effective-sample-size term (fisher_cy.pyx:41-65,
 // fisher.py:52-59 takes the mean).  lane <-> SNP, wave <-> (pair of individuals, range of tiles).
 __global__ __launch_bounds__(256) void fisher_ind_kernel(const float4 *__restrict__ slab, const int32_t *__restrict__ members,
@@ -867,6 +922,18 @@ int launch_fisher_ind_sites(wgs_ctx *ctx, const float4 *slab, const int32_t *d_c
     dim3 grid((unsigned)((m + 255) / 256), (unsigned)count);
     hipLaunchKernelGGL(fisher_ind_sites_kernel, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const float2 *>(slab), d_cols, th,
                        d_out, m, npairs, count);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m, const int64_t *d_leaf_lo, const int32_t *d_leaf_len,
+                         int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, float *d_means)
+{
+    if (count <= 0 || m <= 0) return 0;
+    dim3 grid((unsigned)(((int64_t)nleaf * 8 + 255) / 256), (unsigned)count);
+    hipLaunchKernelGGL(pairwise_leaf_kernel, grid, dim3(256), 0, ctx->stream, d_rows, m, d_leaf_lo, d_leaf_len, nleaf, d_leaf_sums);
+    hipLaunchKernelGGL(pairwise_combine_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, d_leaf_sums, nleaf, d_prog, nprog,
+                       count, m, d_means);
     HIP_TRY(hipGetLastError());
     return 0;
 }

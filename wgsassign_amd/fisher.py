@@ -29,13 +29,15 @@ def fisher_obs(L, af, IDs, t=1, beagle=None):
     return f_obs, ne_obs
 
 
-def fisher_obs_ind(L, af, IDs, t=1, beagle=None, comm=None, m_total=None, exact_budget_bytes=1 << 30):
+def fisher_obs_ind(L, af, IDs, t=1, beagle=None, comm=None, m_total=None, exact_budget_bytes=8 << 30, host_mean=False):
     """fisher.py:46-60: per individual the mean over SNPs of its effective-sample-size term under
     its own population's frequencies.
 
     Single shard (default): the per-site float32 terms are computed on the device in batches of
-    individuals and np.mean is applied to each row on the host -- the reference's own reduction, so
-    the result is bit-identical.  SNP-sharded (comm given): float64 sums on the device, all-reduced
+    individuals and np.mean of each row is formed there exactly as NumPy forms it (pairwise float32
+    summation, float64 division; csrc/em_kernels.hip: pairwise_leaf_kernel) -- bit-identical to the
+    reference without moving n x m floats over PCIe; host_mean=True downloads the rows and calls np.mean
+    itself (the cross-check).  SNP-sharded (comm given): float64 sums on the device, all-reduced
     (the reference's float32 pairwise mean cannot be split across shards; ~1e-7 relative)."""
     own = beagle is None
     if own:
@@ -49,16 +51,22 @@ def fisher_obs_ind(L, af, IDs, t=1, beagle=None, comm=None, m_total=None, exact_
     else:
         out = np.zeros(beagle.n, dtype=np.float32)
         m, group_of = beagle.m, beagle.group_of
-        batch = int(max(1, min(256, exact_budget_bytes // max(1, 4 * m))))
+        budget = min(exact_budget_bytes, 1 << 30) if host_mean else exact_budget_bytes       # host rows vs device workspace
+        batch = int(max(1, min(256, budget // max(1, 4 * m))))
         i = 0
         while i < beagle.n:
             j = i + 1
             while j < beagle.n and j - i < batch and group_of[j] == group_of[i]:
                 j += 1
-            rows = np.empty((j - i, m), dtype=np.float32)
-            _lib.check(lib.wgs_fisher_ind_sites(beagle.handle, afs.handle, i, j - i, _lib.f32p(rows)))
-            for r in range(j - i):
-                out[i + r] = out[i + r] + np.mean(rows[r])        # fisher.py:59
+            if host_mean:
+                rows = np.empty((j - i, m), dtype=np.float32)
+                _lib.check(lib.wgs_fisher_ind_sites(beagle.handle, afs.handle, i, j - i, _lib.f32p(rows)))
+                for r in range(j - i):
+                    out[i + r] = out[i + r] + np.mean(rows[r])        # fisher.py:59
+            else:
+                means = np.empty(j - i, dtype=np.float32)
+                _lib.check(lib.wgs_fisher_ind_means(beagle.handle, afs.handle, i, j - i, _lib.f32p(means)))
+                out[i:j] = out[i:j] + means                           # 0 + np.mean(...)
             i = j
     afs.close()
     if own:
