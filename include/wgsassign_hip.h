@@ -193,6 +193,8 @@ int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, in
                      wgs_score **out);
 void wgs_score_destroy(wgs_score *sc);
 int wgs_score_sums(wgs_score *sc, int mode, double *out);
+/* ... continued from the SNP shards before this one (NumPy's running total handed from shard to shard): see api.hip. */
+int wgs_score_total_from(wgs_score *sc, const double *carry_in, double *out);
 int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start);
 int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out);
 /* glassy.loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L, num_partitions) -- glassy.py:47-112 -- in one

@@ -51,7 +51,8 @@ def test_bench_self_launches_two_ranks(comm_env):
     lines = [l for l in two.stdout.splitlines() if l.strip() and "[Gloo]" not in l]
     assert len(lines) == 1, two.stdout[-2000:]
     d2 = json.loads(lines[0])
-    assert d2["n_gpus"] == 2 and d2["steps"] == 3 and d2["config"]["snps_per_gpu"] == 100000 and d2["scaling"] == "strong"
+    # rank 0's shard: the cut at 100000 moved down to a multiple of 8192 sites (comm.shard_range)
+    assert d2["n_gpus"] == 2 and d2["steps"] == 3 and d2["config"]["snps_per_gpu"] == 98304 and d2["scaling"] == "strong"
     assert abs(d2["value"] - 5 * 200000 * 3 / (d2["ms_per_step"] * 3e-3)) / d2["value"] < 1e-6
     a, b = np.array(d1["extra"]["ssq_last"]), np.array(d2["extra"]["ssq_last"])
     assert np.all(np.abs(a - b) <= 1e-12 * np.abs(a)), (a, b)      # same sums, shard partials added in rank order
@@ -83,7 +84,7 @@ def test_bench_under_torchrun(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["snps_per_gpu"] == 100000
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["config"]["snps_per_gpu"] == 98304
 
 
 def test_rccl_init_failure_falls_back_to_the_tcp_all_reduce():

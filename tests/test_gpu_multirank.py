@@ -200,6 +200,73 @@ def test_cli_gpus_flag_starts_its_own_ranks(tmp_path, golden):
     assert r.returncode != 0
 
 
+_SUMS_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import synth
+from oracle import oracle
+from wgsassign_amd import device, glassy
+from wgsassign_amd.comm import SocketComm, shard_range
+rank, world = int(sys.argv[1]), 3
+comm = SocketComm(rank, world, "127.0.0.1", {port})
+m, n, K = 100_003, 20, 4
+labels = np.arange(n) % K
+L, IDs = synth.make_beagle_for_labels(m, labels, K, seed=11)
+pops, af, _, _ = oracle.fit_reference_af(L, IDs, t=4)
+group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+lo, hi = shard_range(m, rank, world)
+assert (lo % 8192 == 0 or rank == 0) and (hi % 8192 == 0 or rank == world - 1)
+ctx = device.Context(0)
+b = device.DeviceBeagle.from_host(np.ascontiguousarray(L[lo:hi]), group_of, K, site0=lo, ctx=ctx)
+afs = device.AFSet.from_host(np.ascontiguousarray(af[lo:hi]), ctx=ctx)
+out, _ = device.assign(b, afs, comm=comm)                      # --get_pop_like, SNP-sharded over 3 ranks
+import io, contextlib
+a1 = np.ascontiguousarray(af[lo:hi]).copy()
+with contextlib.redirect_stdout(io.StringIO()):
+    ll, parts = glassy.loo_device(b, b, a1, group_of, 200, 1e-4, 2, comm=comm, verbose=False)      # one C call (wgs_loo)
+os.environ["WGSASSIGN_LOO"] = "python"
+a2 = np.ascontiguousarray(af[lo:hi]).copy()
+with contextlib.redirect_stdout(io.StringIO()):
+    ll_py, parts_py = glassy.loo_device(b, b, a2, group_of, 200, 1e-4, 2, comm=comm, verbose=False) # its Python twin
+ok = ll.tobytes() == ll_py.tobytes() and parts.tobytes() == parts_py.tobytes()
+if rank == 0:                                                 # the same on ONE shard, and NumPy itself
+    bw = device.DeviceBeagle.from_host(L, group_of, K, ctx=ctx)
+    aw = device.AFSet.from_host(af, ctx=ctx)
+    whole, _ = device.assign(bw, aw)
+    ok &= out.tobytes() == whole.tobytes()                    # float64, bit for bit
+    for i, k in ((0, 0), (n - 1, K - 1), (7, 2)):
+        vec = np.zeros(m, dtype=np.float32)
+        oracle.loglike(L, af, vec, 4, i, k)
+        ok &= out[i, k] == np.sum(vec, dtype=float)
+    a3 = af.copy()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ll_w, parts_w = glassy.loo_device(bw, bw, a3, group_of, 200, 1e-4, 2, verbose=False)
+    ok &= ll.tobytes() == ll_w.tobytes() and parts.tobytes() == parts_w.tobytes()
+    with np.errstate(all="ignore"):
+        loo_o, parts_o = oracle.loo(L, af.copy(), IDs, 4, 200, 1e-4, None, 2)
+    ok &= ll.tobytes() == loo_o.tobytes() and parts.tobytes() == parts_o.tobytes()
+print("RANK", rank, "OK" if ok else "FAIL", flush=True)
+comm.barrier()
+sys.exit(0 if ok else 1)
+'''
+
+
+def test_three_ranks_sums_are_the_single_gpu_sums_bit_for_bit(tmp_path):
+    """The n x K float64 sums of a matrix sharded over three ranks (shards cut at multiples of 8192 sites, NumPy's running
+    total handed from shard to shard) equal the one-shard sums and np.sum(vec, dtype=float) itself to the last bit --
+    for --get_pop_like and for --loo (C call and Python twin), whose float32 results then equal the oracle's exactly."""
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(_SUMS_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(3)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+        assert "RANK %d OK" % r in o
+
+
 def test_native_rccl_single_rank():
     """The library's own RCCL communicator (dlopen'ed librccl, no torch): with one rank the all-reduce
     is the identity -- exercises loading, unique id, init, the stream-ordered collective, destroy."""

@@ -122,6 +122,9 @@ def test_shard_range_covers_everything():
             edges = [shard_range(m, r, world) for r in range(world)]
             assert edges[0][0] == 0 and edges[-1][1] == m
             assert all(edges[r][1] == edges[r + 1][0] for r in range(world - 1))
+            if m // world >= 8192:          # long shards are cut at multiples of 8192 sites (NumPy's summation chunks) ...
+                assert all(lo % 8192 == 0 for lo, _ in edges)
+                assert max(hi - lo for lo, hi in edges) - m / world < 2 * 8192          # ... and stay balanced
 
 
 _WORKER = r'''

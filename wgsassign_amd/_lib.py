@@ -97,6 +97,7 @@ SIGNATURES = {
     "wgs_score_create": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_i32, ctypes.POINTER(c_vp)]),
     "wgs_score_destroy": (None, [c_vp]),
     "wgs_score_sums": (c_int, [c_vp, c_int, c_f64p]),
+    "wgs_score_total_from": (c_int, [c_vp, c_f64p, c_f64p]),
     "wgs_score_chains_prepare": (c_int, [c_vp, c_i32, c_f64p]),
     "wgs_score_chains_walk": (c_int, [c_vp, c_f32p, c_f32p]),
     "wgs_loo": (c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_double, c_i64, c_vp, c_i32, c_i32, c_int, c_int, c_f64p, c_f32p, c_i32p]),

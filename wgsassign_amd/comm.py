@@ -454,8 +454,14 @@ def launch_local_ranks(n, argv, env=None, poll=0.05):
     return status
 
 
+SHARD_ALIGN = 8192      # NumPy's reductions work through 8192-element chunks (device.Score.sums)
+
+
 def shard_range(m_total, rank, world):
-    """Contiguous SNP range [lo, hi) of `rank`: GPU g owns [g*m/G, (g+1)*m/G)."""
-    lo = (m_total * rank) // world
-    hi = (m_total * (rank + 1)) // world
-    return lo, hi
+    """Contiguous SNP range [lo, hi) of `rank`: GPU g owns [g*m/G, (g+1)*m/G) -- with the cuts moved down
+    to multiples of 8192 sites when the shards are at least that long, so that every chunk of NumPy's float64
+    summation (glassy.py:38) lies inside one shard and the running total can be handed from shard to shard."""
+    def cut(r):
+        c = (m_total * r) // world
+        return c - c % SHARD_ALIGN if 0 < r < world and m_total // world >= SHARD_ALIGN else c
+    return cut(rank), cut(rank + 1)

@@ -888,7 +888,7 @@ struct wgs_score {
     const float **d_acol = nullptr, **d_colptr = nullptr;
     ScoreSlab *d_slabs[2] = {nullptr, nullptr};      // [0] table of the sweep, [1] table of the chain kernel
     int n_slabs[2] = {0, 0}, total_pg[2] = {0, 0};
-    double *d_S = nullptr, *d_out = nullptr, *d_start = nullptr;
+    double *d_S = nullptr, *d_out = nullptr, *d_start = nullptr, *d_chunks = nullptr;     // d_chunks: [ceil(nblocks/2)][cells]
     uint32_t *d_cand = nullptr;
     float *d_carry = nullptr, *d_parts = nullptr;
     int32_t *d_nserial = nullptr;
@@ -901,7 +901,7 @@ void wgs_score_destroy(wgs_score *sc)
     (void)hipSetDevice(sc->b->ctx->device);
     (void)hipStreamSynchronize(sc->b->ctx->stream);
     void *bufs[] = {sc->d_acol, sc->d_colptr, sc->d_slabs[0], sc->d_slabs[1] == sc->d_slabs[0] ? nullptr : sc->d_slabs[1], sc->d_S,
-                    sc->d_out, sc->d_start, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial};
+                    sc->d_out, sc->d_start, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial, sc->d_chunks};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete sc;
@@ -1020,12 +1020,34 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     HIP_TRY(hipMemsetAsync(sc->d_S, 0, sizeof(double) * (size_t)sc->nblocks * sc->cells, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (launch_score_sweep(ctx, score_args(sc, 0), mode)) return 1;
-    if (launch_block_prefix(ctx, sc->d_S, sc->nblocks, sc->cells, sc->d_out, 1)) return 1;
+    if (!sc->d_chunks && hipMalloc(&sc->d_chunks, sizeof(double) * (size_t)((sc->nblocks + 1) / 2) * sc->cells) != hipSuccess) {
+        wgs_set_error("hipMalloc of the chunk sums failed");
+        return 1;
+    }
+    if (launch_block_prefix(ctx, sc->d_S, sc->nblocks, sc->cells, sc->d_out, 1, sc->d_chunks)) return 1;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, sc->d_out, sizeof(double) * sc->cells, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
     sc->have_prefix = (mode == WGS_MODE_EXACT);
+    return 0;
+}
+
+/* The same sums continued from the SNP shards before this one: out[i*K + k] = (((carry_in + C0) + C1) + ...) over this
+ * shard's 8192-site chunk sums C (kept by wgs_score_sums), i.e. np.sum(vec, dtype=float) of glassy.py:38 carried on in
+ * NumPy's own order when every shard starts at a multiple of 8192 sites (comm.shard_range sees to that).  carry_in (host,
+ * n*K doubles, NULL = zeros) is the value returned for the preceding shard; needs wgs_score_sums first. */
+int wgs_score_total_from(wgs_score *sc, const double *carry_in, double *out)
+{
+    WGS_REQUIRE(sc && out, "null argument");
+    WGS_REQUIRE(sc->d_chunks, "wgs_score_total_from needs wgs_score_sums first");
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!sc->d_start) HIP_TRY(hipMalloc(&sc->d_start, sizeof(double) * sc->cells));
+    if (carry_in) HIP_TRY(hipMemcpyAsync(sc->d_start, carry_in, sizeof(double) * sc->cells, hipMemcpyHostToDevice, ctx->stream));
+    if (launch_chunk_total(ctx, sc->d_chunks, (sc->nblocks + 1) / 2, sc->cells, carry_in ? sc->d_start : nullptr, sc->d_out)) return 1;
+    HIP_TRY(hipMemcpyAsync(out, sc->d_out, sizeof(double) * sc->cells, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -1283,13 +1305,20 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
             by_rank.assign(cells * world, 0.0);
             std::copy(sums.begin(), sums.end(), by_rank.begin() + cells * rank);
             if (wgs_comm_allreduce_f64(comm, by_rank.data(), (int64_t)by_rank.size())) return 1;
-            std::fill(sums.begin(), sums.end(), 0.0);
             std::fill(start.begin(), start.end(), 0.0);
-            for (int r = 0; r < world; ++r)
-                for (size_t c = 0; c < cells; ++c) {
-                    if (r < rank) start[c] += by_rank[cells * r + c];
-                    sums[c] += by_rank[cells * r + c];
+            for (int r = 0; r < rank; ++r)
+                for (size_t c = 0; c < cells; ++c) start[c] += by_rank[cells * r + c];
+            // the totals themselves: np.sum's running float64 total handed from shard to shard in SNP order
+            std::vector<double> run(cells, 0.0);
+            for (int r = 0; r < world; ++r) {
+                if (r == rank) {
+                    if ((rc = wgs_score_total_from(sc, r > 0 ? run.data() : nullptr, sums.data()))) return rc;
+                } else {
+                    std::fill(sums.begin(), sums.end(), 0.0);
                 }
+                if (wgs_comm_allreduce_f64(comm, sums.data(), (int64_t)cells)) return 1;   // only rank r contributes
+                run = sums;
+            }
         }
         for (size_t c = (size_t)i0 * K; c < (size_t)i1 * K; ++c) ll_out[c] = sums[c];
         if (parts_out) {

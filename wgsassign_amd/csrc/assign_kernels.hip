@@ -388,9 +388,11 @@ __global__ __launch_bounds__(256, (PER_IND || KB * NP > 10 || KB > 8) ? 2 : WGS_
 // after the other: total = total + (S[2c] + S[2c+1]).  Inside a block the sweep adds in its own order; that is the same
 // number whenever the partial sums are exact, which 4096 float32 values within 2^14 of each other always are in float64
 // (24 + 14 + 12 bits) -- so for a matrix that starts at site 0 the n x K sums are NumPy's own, not just close to them.
-// With keep_prefix S[block][cell] is replaced by the sum of the blocks before it (what the chain prediction needs).
+// With keep_prefix S[block][cell] is replaced by the sum of the blocks before it (what the chain prediction needs);
+// chunks (may be NULL) receives the chunk sums C[c][cell] = S[2c] + S[2c+1], from which chunk_total_kernel continues a
+// running total handed over by the SNP shard before this one.
 __global__ __launch_bounds__(256) void block_prefix_kernel(double *__restrict__ S, int nblocks, int64_t cells, double *__restrict__ out,
-                                                           int keep_prefix)
+                                                           int keep_prefix, double *__restrict__ chunks)
 {
     const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (cell >= cells) return;
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(256) void block_prefix_kernel(double *__restrict__ 
                 S[(int64_t)(b + u) * cells + cell] = run;
                 S[(int64_t)(b + u + 1) * cells + cell] = run + v[u];
             }
+            if (chunks) chunks[(int64_t)((b + u) >> 1) * cells + cell] = v[u] + v[u + 1];
             run = run + (v[u] + v[u + 1]);
         }
     }
@@ -417,8 +420,20 @@ __global__ __launch_bounds__(256) void block_prefix_kernel(double *__restrict__ 
             S[(int64_t)b * cells + cell] = run;
             if (pair) S[(int64_t)(b + 1) * cells + cell] = run + v0;
         }
+        if (chunks) chunks[(int64_t)(b >> 1) * cells + cell] = pair ? v0 + v1 : v0;
         run = pair ? run + (v0 + v1) : run + v0;
     }
+    out[cell] = run;
+}
+
+// out[cell] = (((carry[cell] + C[0]) + C[1]) + ...): the running float64 total of np.sum continued over this shard's chunks.
+__global__ __launch_bounds__(256) void chunk_total_kernel(const double *__restrict__ chunks, int nchunks, int64_t cells,
+                                                          const double *__restrict__ carry, double *__restrict__ out)
+{
+    const int64_t cell = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= cells) return;
+    double run = carry ? carry[cell] : 0.0;
+    for (int c = 0; c < nchunks; ++c) run = run + chunks[(int64_t)c * cells + cell];
     out[cell] = run;
 }
 
@@ -914,11 +929,19 @@ int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode)
     return 0;
 }
 
-int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix)
+int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix, double *chunks)
 {
     if (cells <= 0) return 0;
     hipLaunchKernelGGL(block_prefix_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, S, nblocks, cells, out,
-                       keep_prefix);
+                       keep_prefix, chunks);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int launch_chunk_total(wgs_ctx *ctx, const double *chunks, int nchunks, int64_t cells, const double *carry, double *out)
+{
+    if (cells <= 0) return 0;
+    hipLaunchKernelGGL(chunk_total_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, ctx->stream, chunks, nchunks, cells, carry, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

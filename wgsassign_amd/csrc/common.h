@@ -202,7 +202,8 @@ struct WalkArgs {
 int score_pairs_per_wave(int K);               // NP of the sweep for K populations (depends on the register batch KB)
 int chain_pairs_per_wave(int K, bool per_ind); // NP of the chain kernel (the slab table must be built for it)
 int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode);
-int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix);
+int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix, double *chunks);
+int launch_chunk_total(wgs_ctx *ctx, const double *chunks, int nchunks, int64_t cells, const double *carry, double *out);
 size_t chain_cand_lds_bytes(int K, int P, bool per_ind);
 int launch_chain_cand(wgs_ctx *ctx, const ScoreArgs &a);
 int launch_chain_walk(wgs_ctx *ctx, const WalkArgs &w);

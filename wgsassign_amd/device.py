@@ -452,6 +452,14 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
     """
     mode = default_mode() if mode is None else mode
     n, K = beagle.n, afset.K
+    if P == 1 and comm is not None and comm.world > 1:       # the totals in NumPy's order across the shards (Score.sums)
+        sc = Score(beagle, afset, colptr)
+        try:
+            out = sc.sums(mode, comm)
+            assign.last_ms = sc.ms["sweep"]
+            return out, None
+        finally:
+            sc.close()
     out = np.zeros((n, K), dtype=np.float64)
     parts = np.zeros((n * P, K), dtype=np.float64) if P > 1 else None
     _keep, cp = _colptr_arg(colptr, n, K)
@@ -504,7 +512,15 @@ class Score:
             slots = np.zeros((comm.world,) + out.shape)
             slots[comm.rank] = out
             self.by_rank = comm.allreduce_sum(slots)
-            return self.by_rank.sum(axis=0)
+            # the totals: np.sum's running float64 total (glassy.py:38) handed from shard to shard in SNP order, each
+            # shard continuing it over its own 8192-site chunk sums (shard_range aligns the shards to such chunks)
+            run = None
+            for r in range(comm.world):
+                mine = np.zeros_like(out)
+                if r == comm.rank:
+                    check(_lib.load().wgs_score_total_from(self._h, f64p(run) if run is not None else None, f64p(mine)))
+                run = np.ascontiguousarray(comm.allreduce_sum(mine))      # only rank r contributes: a broadcast
+            return run
         self.by_rank = out[None]
         return out
 
