@@ -250,6 +250,9 @@ int wgs_fisher_ind_sites(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count,
 /* ... and np.mean of each of those rows formed on the device exactly as NumPy forms it (pairwise float32 sum, float64
  * division, float32 result): means_out[i - i0], fisher.py:59 without moving the rows to the host. */
 int wgs_fisher_ind_means(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *means_out);
+/* ... over SNP shards: NumPy's running float32 total after this shard, continued from the one before (carry_in, NULL on the
+ * first shard); the last shard's totals / number of sites (float64 division) are the means. */
+int wgs_fisher_ind_sums(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, const float *carry_in, float *sums_out);
 
 /* ------------------------------------------------------------------ streamed Beagle reader (host)
  * reader_cy.readBeagle(path) -- reader_cy.pyx:16-77 -- as a chunked native reader: gzip inflate,

@@ -158,8 +158,7 @@ def test_cli_two_ranks_matches_single_process(tmp_path, golden):
     assert np.load(tmp_path / "ne.fisher_obs.npy").tobytes() == gf["f_obs"].tobytes()
     assert np.load(tmp_path / "ne.ne_obs.npy").tobytes() == gf["ne_obs"].tobytes()
     assert (tmp_path / "ne.ne_obs.txt").read_text() == str(gf["ne_obs_txt"])
-    got = np.loadtxt(tmp_path / "ne.ne_ind.txt")
-    assert np.all(np.abs(got - gf["ne_ind"]) <= 1e-6 * np.abs(gf["ne_ind"]) + 1e-7)
+    assert (tmp_path / "ne.ne_ind.txt").read_text() == str(gf["ne_ind_txt"])      # np.mean's running total crosses the ranks
     assert clean(r.stdout) == str(gf["stdout"]).replace("<TMP>/", "").splitlines()
     # --get_pop_like, sharded
     r = subprocess.run(base + ["--beagle", os.path.join(data, "amre.nonbreeding.ind34.ds_2x.sites-filter.top_50_each.beagle.gz"),
@@ -246,6 +245,10 @@ if rank == 0:                                                 # the same on ONE 
     with np.errstate(all="ignore"):
         loo_o, parts_o = oracle.loo(L, af.copy(), IDs, 4, 200, 1e-4, None, 2)
     ok &= ll.tobytes() == loo_o.tobytes() and parts.tobytes() == parts_o.tobytes()
+from wgsassign_amd import fisher
+ne = fisher.fisher_obs_ind(None, np.ascontiguousarray(af[lo:hi]), IDs, 1, beagle=b, comm=comm, m_total=m)   # --ne_obs, sharded
+if rank == 0:
+    ok &= ne.tobytes() == oracle.fisher_obs_ind(L, af.copy(), IDs, 4).tobytes()           # np.mean itself
 print("RANK", rank, "OK" if ok else "FAIL", flush=True)
 comm.barrier()
 sys.exit(0 if ok else 1)

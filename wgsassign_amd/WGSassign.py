@@ -164,8 +164,7 @@ def _run(args, comm):
             say("Saved reference population effective sample size estimates as " + str(args.out) +
                 ".ne_obs.txt (String - np.U25)\n")
             say("Estimating individual effective sample sizes.")
-            # float64 device sums all-reduced over the shards (the reference's float32 pairwise mean
-            # cannot be split across SNP shards; ~1e-7 relative)
+            # np.mean's running float32 total is handed from SNP shard to SNP shard (fisher.fisher_obs_ind)
             ne_ind_full = fisher.fisher_obs_ind(None, af, IDs, args.threads, beagle=beagle, comm=comm, m_total=m)
             if root:
                 np.savetxt(args.out + ".ne_ind.txt", ne_ind_full.reshape(-1, 1), fmt="%.7f")

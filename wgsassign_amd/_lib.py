@@ -75,6 +75,7 @@ SIGNATURES = {
     "wgs_fisher_obs_ind": (c_int, [c_vp, c_vp, c_f64p]),
     "wgs_fisher_ind_sites": (c_int, [c_vp, c_vp, c_i32, c_i32, c_f32p]),
     "wgs_fisher_ind_means": (c_int, [c_vp, c_vp, c_i32, c_i32, c_f32p]),
+    "wgs_fisher_ind_sums": (c_int, [c_vp, c_vp, c_i32, c_i32, c_f32p, c_f32p]),
     "wgs_reader_open": (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_vp)]),
     "wgs_reader_close": (None, [c_vp]),
     "wgs_reader_n_individuals": (c_int, [c_vp]),

@@ -1572,7 +1572,24 @@ void pairwise_plan(int64_t lo, int64_t n, PairwisePlan &p)
 /* fisher.py:52-59 for individuals [i0, i0 + count) of one population slab, entirely on the device:
  * means_out[i - i0] = np.mean of the individual's float32 per-site terms -- NumPy's pairwise float32 sum, divided by
  * the count in float64, stored as float32 -- without the count x m matrix ever crossing PCIe. */
+static int fisher_ind_reduce(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, const float *carry_in, int64_t divide_by, float *means_out);
+
 int wgs_fisher_ind_means(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *means_out)
+{
+    WGS_REQUIRE(b, "null argument");
+    return fisher_ind_reduce(b, a, i0, count, nullptr, b->m, means_out);
+}
+
+/* The same reduction over SNP shards: sums_out[i - i0] = NumPy's running float32 total after this shard, continued
+ * from carry_in (host, count floats, NULL = this is the first shard): total = total + pairwise(chunk) for every 8192-site
+ * chunk of the shard (shards start at multiples of 8192 sites: comm.shard_range).  The last shard's totals divided by
+ * the number of sites in float64 are np.mean's result. */
+int wgs_fisher_ind_sums(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, const float *carry_in, float *sums_out)
+{
+    return fisher_ind_reduce(b, a, i0, count, carry_in, 0, sums_out);
+}
+
+static int fisher_ind_reduce(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, const float *carry_in, int64_t divide_by, float *means_out)
 {
     WGS_REQUIRE(b && a && means_out && count > 0 && i0 >= 0 && (int64_t)i0 + count <= b->n, "bad argument");
     WGS_REQUIRE(a->m == b->m && a->K == b->n_groups, "allele frequencies do not match the population slabs");
@@ -1587,14 +1604,15 @@ int wgs_fisher_ind_means(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count,
     PairwisePlan plan;
     for (int64_t lo = 0; lo < b->m; lo += 8192) {            // total = total + pairwise(chunk); the first chunk starts it
         pairwise_plan(lo, std::min<int64_t>(8192, b->m - lo), plan);
-        if (lo > 0) plan.prog.push_back(-1);
+        if (lo > 0 || carry_in) plan.prog.push_back(-1);
     }
     const size_t nleaf = plan.leaf_lo.size(), nprog = plan.prog.size();
     WGS_REQUIRE(nleaf < (1u << 28), "too many SNPs for one pairwise plan");
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const size_t o_rows = 0, o_sums = o_rows + up((size_t)count * b->m * sizeof(float)), o_means = o_sums + up((size_t)count * nleaf * sizeof(float)),
                  o_lo = o_means + up(sizeof(float) * count), o_len = o_lo + up(sizeof(int64_t) * nleaf), o_prog = o_len + up(sizeof(int32_t) * nleaf),
-                 o_cols = o_prog + up(sizeof(int32_t) * nprog), total = o_cols + up(sizeof(int32_t) * count);
+                 o_cols = o_prog + up(sizeof(int32_t) * nprog), o_carry = o_cols + up(sizeof(int32_t) * count),
+                 total = o_carry + up(sizeof(float) * count);
     void *ws = nullptr;
     if (wgs_ctx_workspace(ctx, total, &ws)) return 1;
     char *w = reinterpret_cast<char *>(ws);
@@ -1605,10 +1623,14 @@ int wgs_fisher_ind_means(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count,
     HIP_TRY(hipMemcpyAsync(d_len, plan.leaf_len.data(), sizeof(int32_t) * nleaf, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_prog, plan.prog.data(), sizeof(int32_t) * nprog, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_cols, cols.data(), sizeof(int32_t) * count, hipMemcpyHostToDevice, ctx->stream));
+    float *d_carry = reinterpret_cast<float *>(w + o_carry);
+    if (carry_in) HIP_TRY(hipMemcpyAsync(d_carry, carry_in, sizeof(float) * count, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));              // the host vectors above go out of use here
     const Slab &s = b->slabs[g];
     if (launch_fisher_ind_sites(ctx, s.base, d_cols, a->buf + (size_t)g * a->m, d_rows, b->m, s.npairs, count)) return 1;
-    if (launch_pairwise_mean(ctx, d_rows, count, b->m, d_lo, d_len, (int)nleaf, d_prog, (int)nprog, d_sums, d_means)) return 1;
+    if (launch_pairwise_mean(ctx, d_rows, count, b->m, divide_by, d_lo, d_len, (int)nleaf, d_prog, (int)nprog, d_sums,
+                             carry_in ? d_carry : nullptr, d_means))
+        return 1;
     HIP_TRY(hipMemcpyAsync(means_out, d_means, sizeof(float) * count, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return 0;

@@ -117,8 +117,9 @@ struct FisherDesc {    // one population of the --ne_obs sweep
 int launch_fisher_pop(wgs_ctx *ctx, const FisherDesc *d_descs, int32_t n_desc, int64_t m);
 int launch_fisher_ind_sites(wgs_ctx *ctx, const float4 *slab, const int32_t *d_cols, const float *th, float *d_out, int64_t m,
                             int npairs, int count);
-int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m, const int64_t *d_leaf_lo, const int32_t *d_leaf_len,
-                         int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, float *d_means);
+int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m, int64_t divide_by, const int64_t *d_leaf_lo,
+                         const int32_t *d_leaf_len, int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, const float *d_carry,
+                         float *d_means);
 int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, const float *th, double *out, int64_t m,
                       int npairs, int ncols);
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);

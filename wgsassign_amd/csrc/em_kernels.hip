@@ -744,14 +744,18 @@ __global__ __launch_bounds__(256) void pairwise_leaf_kernel(const float *__restr
     if (r == 0) leaf_sums[(int64_t)j * nleaf + leaf] = res;
 }
 
+// carry (may be NULL): the running totals after the SNP shards before this one -- the program then adds every chunk to it.
+// m > 0: out = np.mean's float32(float64(total) / m); m == 0: out = the running total itself (a later shard continues).
 __global__ __launch_bounds__(64) void pairwise_combine_kernel(const float *__restrict__ leaf_sums, int nleaf, const int32_t *__restrict__ prog,
-                                                             int nprog, int count, int64_t m, float *__restrict__ means)
+                                                             int nprog, int count, int64_t m, const float *__restrict__ carry,
+                                                             float *__restrict__ means)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     const float *ls = leaf_sums + (int64_t)j * nleaf;
-    float stack[64];                                         // depth <= log2(m / 64) + 2
+    float stack[64];                                         // depth <= log2(8192 / 64) + 3
     int sp = 0;
+    if (carry) stack[sp++] = carry[j];
     for (int p = 0; p < nprog; ++p) {
         const int op = prog[p];
         if (op >= 0) {
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(64) void pairwise_combine_kernel(const float *__res
             stack[sp - 1] = stack[sp - 1] + stack[sp];
         }
     }
-    means[j] = (float)((double)stack[0] / (double)m);
+    means[j] = m > 0 ? (float)((double)stack[0] / (double)m) : stack[0];
 }
 
 // Per individual: sum over this shard's SNPs of its effective-sample-size term (fisher_cy.pyx:41-65,
@@ -926,14 +930,15 @@ int launch_fisher_ind_sites(wgs_ctx *ctx, const float4 *slab, const int32_t *d_c
     return 0;
 }
 
-int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m, const int64_t *d_leaf_lo, const int32_t *d_leaf_len,
-                         int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, float *d_means)
+int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m, int64_t divide_by, const int64_t *d_leaf_lo,
+                         const int32_t *d_leaf_len, int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, const float *d_carry,
+                         float *d_means)
 {
     if (count <= 0 || m <= 0) return 0;
     dim3 grid((unsigned)(((int64_t)nleaf * 8 + 255) / 256), (unsigned)count);
     hipLaunchKernelGGL(pairwise_leaf_kernel, grid, dim3(256), 0, ctx->stream, d_rows, m, d_leaf_lo, d_leaf_len, nleaf, d_leaf_sums);
     hipLaunchKernelGGL(pairwise_combine_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, d_leaf_sums, nleaf, d_prog, nprog,
-                       count, m, d_means);
+                       count, divide_by, d_carry, d_means);
     HIP_TRY(hipGetLastError());
     return 0;
 }

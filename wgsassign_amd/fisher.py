@@ -37,17 +37,34 @@ def fisher_obs_ind(L, af, IDs, t=1, beagle=None, comm=None, m_total=None, exact_
     individuals and np.mean of each row is formed there exactly as NumPy forms it (pairwise float32
     summation, float64 division; csrc/em_kernels.hip: pairwise_leaf_kernel) -- bit-identical to the
     reference without moving n x m floats over PCIe; host_mean=True downloads the rows and calls np.mean
-    itself (the cross-check).  SNP-sharded (comm given): float64 sums on the device, all-reduced
-    (the reference's float32 pairwise mean cannot be split across shards; ~1e-7 relative)."""
+    itself (the cross-check).  SNP-sharded (comm given): the same running float32 total continued from shard to
+    shard in SNP order (wgs_fisher_ind_sums) -- bit-identical as well."""
     own = beagle is None
     if own:
         beagle, _ = _slabs(L, np.asarray(IDs))
     afs = AFSet.from_host(np.ascontiguousarray(af, dtype=np.float32), ctx=beagle.ctx)
     lib = _lib.load()
     if comm is not None and comm.world > 1:
-        sums = np.zeros(beagle.n, dtype=np.float64)
-        _lib.check(lib.wgs_fisher_obs_ind(beagle.handle, afs.handle, _lib.f64p(sums)))
-        out = (comm.allreduce_sum(sums) / m_total).astype(np.float32)
+        # np.mean's running float32 total handed from shard to shard in SNP order (shards start at multiples of NumPy's
+        # 8192-element chunks: comm.shard_range); the batches must be the same on every rank
+        out = np.zeros(beagle.n, dtype=np.float32)
+        group_of = beagle.group_of
+        batch = int(max(1, min(256, exact_budget_bytes // max(1, 4 * (m_total // comm.world + 8192)))))
+        i = 0
+        while i < beagle.n:
+            j = i + 1
+            while j < beagle.n and j - i < batch and group_of[j] == group_of[i]:
+                j += 1
+            run = None
+            for r in range(comm.world):
+                mine = np.zeros(j - i, dtype=np.float32)
+                if r == comm.rank:
+                    _lib.check(lib.wgs_fisher_ind_sums(beagle.handle, afs.handle, i, j - i, _lib.f32p(run) if run is not None else None,
+                                                       _lib.f32p(mine)))
+                # only rank r contributes: a broadcast of float32 values (exact in float64)
+                run = np.ascontiguousarray(comm.allreduce_sum(mine.astype(np.float64)).astype(np.float32))
+            out[i:j] = (run.astype(np.float64) / m_total).astype(np.float32)      # np.mean: float64 division, float32 result
+            i = j
     else:
         out = np.zeros(beagle.n, dtype=np.float32)
         m, group_of = beagle.m, beagle.group_of
