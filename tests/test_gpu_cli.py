@@ -99,3 +99,17 @@ def test_cli_streams_in_many_chunks(tmp_path, golden, monkeypatch):
              "--out", out, "--threads", "2"])
     assert np.load(out + ".pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
     assert gzip.open(out + ".pop_like_LOO_partitions_3.tsv.gz", "rt").read() == str(g["parts_tsv"])
+
+
+@pytest.mark.parametrize("ranks, cases", [(1, 16), (3, 4)])
+def test_random_cases_through_the_command_line(ranks, cases):
+    """tools/fuzz_cli.py: random shapes (populations of one, one SNP, tile edges, 1-7 partitions, --ne_obs), plain gzip or
+    BGZF files, one process or `--gpus 3` on the one card: every output file equals, byte for byte or character for
+    character, what the oracle pipeline writes for the same matrix."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), str(cases), "2026", str(ranks)], capture_output=True,
+                       text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "%d cases, 0 mismatches" % cases in r.stdout

@@ -47,14 +47,31 @@ def fisher_obs_ind(L, af, IDs, t=1, beagle=None, comm=None, m_total=None, exact_
     if comm is not None and comm.world > 1:
         # np.mean's running float32 total handed from shard to shard in SNP order (shards start at multiples of NumPy's
         # 8192-element chunks: comm.shard_range); the batches must be the same on every rank
+        from .comm import SHARD_ALIGN, shard_range
         out = np.zeros(beagle.n, dtype=np.float32)
         group_of = beagle.group_of
+        aligned = m_total // comm.world >= SHARD_ALIGN          # else the shards cut through NumPy's summation tree
         batch = int(max(1, min(256, exact_budget_bytes // max(1, 4 * (m_total // comm.world + 8192)))))
+        if not aligned:
+            batch = int(max(1, min(batch, (64 << 20) // max(1, 8 * m_total))))
+        lo, hi = shard_range(m_total, comm.rank, comm.world)
         i = 0
         while i < beagle.n:
             j = i + 1
             while j < beagle.n and j - i < batch and group_of[j] == group_of[i]:
                 j += 1
+            if not aligned:
+                # few sites (< 8192 per rank): the rows themselves are small -- every rank contributes its columns of the
+                # (individuals x all sites) matrix and np.mean is applied to whole rows, as on one shard
+                rows = np.empty((j - i, beagle.m), dtype=np.float32)
+                _lib.check(lib.wgs_fisher_ind_sites(beagle.handle, afs.handle, i, j - i, _lib.f32p(rows)))
+                full = np.zeros((j - i, m_total), dtype=np.float64)
+                full[:, lo:hi] = rows
+                full = comm.allreduce_sum(full).astype(np.float32)             # float32 values: exact in float64
+                for r in range(j - i):
+                    out[i + r] = out[i + r] + np.mean(full[r])                  # fisher.py:59
+                i = j
+                continue
             run = None
             for r in range(comm.world):
                 mine = np.zeros(j - i, dtype=np.float32)
