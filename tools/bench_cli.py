@@ -33,7 +33,7 @@ def _bgzf_block(chunk):
             struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
 
 
-def text_rows(L, row0, row1):
+def text_rows(L, row0, row1, names=None):
     """Rows [row0, row1) of the Beagle text, as bytes: every value printed as %.6f (vectorised: the values are
     six-decimal numbers already, so their digits are those of round(v * 1e6))."""
     blk = L[row0:row1].astype(np.float64)
@@ -52,10 +52,12 @@ def text_rows(L, row0, row1):
     tok[:, :, 8] = ord("\t")
     tok[:, -1, 8] = ord("\n")
     flat = tok.reshape(m, -1)
+    if names is not None:
+        return b"".join(names[row0 + s].encode() + b"\t0\t1\t" + flat[s].tobytes() for s in range(m))
     return b"".join(b"chr1_%d\t0\t1\t" % (row0 + s + 1) + flat[s].tobytes() for s in range(m))
 
 
-def write_beagle(path, L, ids_path, IDs, fmt="gzip"):
+def write_beagle(path, L, ids_path, IDs, fmt="gzip", names=None):
     """fmt = gzip: one deflate stream (what `gzip` writes); bgzf: 60 kB members (what ANGSD / bgzip write)."""
     m, n = L.shape[0], L.shape[1] // 2
     head = ("marker\tallele1\tallele2\t" + "\t".join("Ind%d\tInd%d\tInd%d" % (i, i, i) for i in range(n)) + "\n").encode()
@@ -66,7 +68,7 @@ def write_beagle(path, L, ids_path, IDs, fmt="gzip"):
         with open(path, "wb") as fh, ThreadPoolExecutor(min(len(os.sched_getaffinity(0)), 16)) as pool:
             pending = head
             for r0 in range(0, m, step):
-                pending += text_rows(L, r0, min(m, r0 + step))
+                pending += text_rows(L, r0, min(m, r0 + step), names)
                 cut = len(pending) - len(pending) % 60000
                 chunks = [pending[i:i + 60000] for i in range(0, cut, 60000)]
                 for blk in pool.map(_bgzf_block, chunks):
@@ -82,7 +84,7 @@ def write_beagle(path, L, ids_path, IDs, fmt="gzip"):
             fh.write(head)
             text_bytes += len(head)
             for r0 in range(0, m, step):
-                t = text_rows(L, r0, min(m, r0 + step))
+                t = text_rows(L, r0, min(m, r0 + step), names)
                 fh.write(t)
                 text_bytes += len(t)
     with open(ids_path, "w") as fh:

@@ -100,19 +100,32 @@ def main():
         P = int(rng.choice([1, 2, 3, 7]))
         L, IDs = synth.make_beagle_for_labels(m, labels, K, seed=int(rng.integers(1 << 30)), depth=float(rng.choice([0.5, 2.0, 6.0])))
         ne = bool(rng.random() < 0.5)
+        ds = bool(rng.random() < 0.35) and m >= 63                 # --loo_downsampled_beagle: a subset of the sites, other GLs
         with tempfile.TemporaryDirectory() as d:
             os.environ["WGSASSIGN_INDEX_DIR"] = d
             path, fmt = write_case(rng, d, L, IDs)
             ids = os.path.join(d, "ids.txt")
             out = os.path.join(d, "run")
             argv = ["--beagle", path, "--pop_af_IDs", ids, "--get_reference_af", "--loo", "--out", out]
+            L_ds = None
+            if ds:
+                keep = rng.random(m) < 0.8
+                keep[int(rng.integers(m))] = True
+                L2, _ = synth.make_beagle_for_labels(m, labels, K, seed=int(rng.integers(1 << 30)), depth=0.7)
+                L_ds = np.ascontiguousarray(L2[keep])
+                names = ["chr1_%d" % (s + 1) for s in np.flatnonzero(keep)]
+                bench_cli.write_beagle(os.path.join(d, "ds.beagle.gz"), L_ds, os.path.join(d, "ids2.txt"), IDs,
+                                       "bgzf" if rng.random() < 0.5 else "gzip", names)
+                argv += ["--loo_downsampled_beagle", os.path.join(d, "ds.beagle.gz")]
+                L = np.ascontiguousarray(L[keep])                   # WGSassign.py:172-198: the reference keeps the common sites only
             if P > 1:
                 argv += ["--partition_sites", str(P)]
             if ne:
                 argv += ["--ne_obs"]
             with np.errstate(all="ignore"):
                 run(argv)
-                run(["--beagle", path, "--pop_af_file", out + ".pop_af.npy", "--get_pop_like", "--out", out])
+                if not ds:          # (the frequency file of a downsampled run covers the common sites only)
+                    run(["--beagle", path, "--pop_af_file", out + ".pop_af.npy", "--get_pop_like", "--out", out])
                 # the oracle pipeline on the same matrix
                 pops, af, _, _ = oracle.fit_reference_af(L, IDs, t=4)
                 samples = ["Ind%d" % i for i in range(n)]
@@ -123,14 +136,16 @@ def main():
                         wrong.append(name)
                 check("pop_af.npy", np.load(out + ".pop_af.npy").tobytes() == af.tobytes())
                 check("pop_names.txt", open(out + ".pop_names.txt").read() == "".join(p + "\n" for p in pops))
-                ll_o, parts_o = oracle.loo(L, af.copy(), IDs, 4, 200, 1e-4, None, P)
-                check("pop_like_LOO.tsv", open(out + ".pop_like_LOO.tsv").read() == expect_tsv(d, "e.tsv", ll_o, samples, pops, IDs, 1, False))
+                ll_o, parts_o = oracle.loo(L, af.copy(), IDs, 4, 200, 1e-4, L_ds, P)
+                sfx = "_downsampled" if ds else ""
+                check("pop_like_LOO.tsv", open(out + ".pop_like_LOO%s.tsv" % sfx).read() == expect_tsv(d, "e.tsv", ll_o, samples, pops, IDs, 1, False))
                 if P > 1:
-                    got = gzip.open(out + ".pop_like_LOO_partitions_%d.tsv.gz" % P, "rt").read()
+                    got = gzip.open(out + ".pop_like_LOO%s_partitions_%d.tsv.gz" % (sfx, P), "rt").read()
                     check("partitions.tsv.gz", got == expect_tsv(d, "e.tsv.gz", parts_o, samples, pops, IDs, P, True))
-                sio = io.StringIO()
-                np.savetxt(sio, oracle.assignLL(L, af.copy(), 4), fmt="%.7f")
-                check("pop_like.txt", open(out + ".pop_like.txt").read() == sio.getvalue())
+                if not ds:
+                    sio = io.StringIO()
+                    np.savetxt(sio, oracle.assignLL(L, af.copy(), 4), fmt="%.7f")
+                    check("pop_like.txt", open(out + ".pop_like.txt").read() == sio.getvalue())
                 if ne:
                     f_o, ne_o = oracle.fisher_obs(L, af.copy(), IDs, 4)
                     check("fisher_obs.npy", np.load(out + ".fisher_obs.npy").tobytes() == f_o.tobytes())
@@ -141,7 +156,7 @@ def main():
                     check("ne_ind.txt", open(out + ".ne_ind.txt").read() == sio.getvalue())
         ok = not wrong
         bad += not ok
-        print("case %3d  m=%6d n=%3d K=%d sizes=%s P=%d %s ne=%d  %s" % (c, m, n, K, list(map(int, sizes)), P, fmt, ne, "ok" if ok else "MISMATCH " + " ".join(wrong)), flush=True)
+        print("case %3d  m=%6d n=%3d K=%d sizes=%s P=%d %s ne=%d ds=%d  %s" % (c, m, n, K, list(map(int, sizes)), P, fmt, ne, ds, "ok" if ok else "MISMATCH " + " ".join(wrong)), flush=True)
     print("%d cases, %d mismatches" % (cases, bad))
     sys.exit(1 if bad else 0)
 
