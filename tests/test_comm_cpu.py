@@ -151,3 +151,18 @@ def test_launch_local_ranks_env_stdout_and_failure(tmp_path, capfd):
     t0 = time.time()
     assert comm.launch_local_ranks(3, [sys.executable, "-c", code]) == 7
     assert time.time() - t0 < 20
+
+
+def test_launch_local_ranks_retries_over_sockets_when_rccl_did_not_come_up(tmp_path, monkeypatch):
+    """A rank that leaves with status 75 (RcclComm's watchdog: the RCCL communicator did not initialise) makes
+    `WGSassign --gpus N` start all ranks again with WGSASSIGN_COMM=socket; any other failure is final."""
+    import sys
+    from wgsassign_amd import comm
+    monkeypatch.delenv("WGSASSIGN_COMM", raising=False)
+    monkeypatch.delenv("WGSASSIGN_BACKEND", raising=False)
+    code = ("import os, sys; open(os.path.join(%r, os.environ.get('WGSASSIGN_COMM', 'rccl') + os.environ['RANK']), 'w').close(); "
+            "sys.exit(0 if os.environ.get('WGSASSIGN_COMM') == 'socket' else 75)" % str(tmp_path))
+    assert comm.launch_local_ranks(2, [sys.executable, "-c", code]) == 0
+    assert sorted(os.listdir(tmp_path)) == ["rccl0", "rccl1", "socket0", "socket1"] or {"socket0", "socket1"} <= set(os.listdir(tmp_path))
+    monkeypatch.setenv("WGSASSIGN_COMM", "socket")           # an explicit choice is not overridden
+    assert comm.launch_local_ranks(2, [sys.executable, "-c", "import sys; sys.exit(75)"]) == 75

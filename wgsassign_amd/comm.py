@@ -249,7 +249,22 @@ class RcclComm(SocketComm):
         if blob[0]:
             ident = (ctypes.c_uint8 * 128).from_buffer_copy(blob[1:129])
             h = ctypes.c_void_p()
-            if lib.wgs_comm_init(ctx.handle, ident, self.rank, self.world, ctypes.byref(h)) == 0:
+            # ncclCommInitRank is collective: if a peer never arrives it does not return.  A rank stuck in it for
+            # `timeout` seconds leaves with COMM_INIT_FAILED -- the launchers (bench.py, `WGSassign --gpus N`) then start
+            # the ranks again over the socket all-reduce.
+            import threading
+            done = threading.Event()
+
+            def watchdog():
+                if not done.wait(timeout):
+                    import sys
+                    print("wgsassign_amd: rank %d: RCCL communicator did not initialise within %.0f s" % (self.rank, timeout),
+                          file=sys.stderr, flush=True)
+                    os._exit(COMM_INIT_FAILED)
+            threading.Thread(target=watchdog, daemon=True).start()
+            rc = lib.wgs_comm_init(ctx.handle, ident, self.rank, self.world, ctypes.byref(h))
+            done.set()
+            if rc == 0:
                 self._h = h
             else:
                 ok, self.native_error = 0, _lib.last_error()
@@ -423,6 +438,21 @@ def launch_local_ranks(n, argv, env=None, poll=0.05):
         port = sk.getsockname()[1]
     base = dict(os.environ if env is None else env)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    status = _run_ranks(n, argv, base, port, poll)
+    if status == COMM_INIT_FAILED and base.get("WGSASSIGN_COMM", "rccl") == "rccl" and base.get("WGSASSIGN_BACKEND") != "gloo":
+        import sys
+        print("wgsassign_amd: the RCCL communicator did not initialise; starting the ranks again over the socket all-reduce",
+              file=sys.stderr, flush=True)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        status = _run_ranks(n, argv, dict(base, WGSASSIGN_COMM="socket"), port, poll)
+    return status
+
+
+def _run_ranks(n, argv, base, port, poll):
+    import subprocess
+    import time
     procs = []
     for r in range(n):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
