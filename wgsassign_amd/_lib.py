@@ -139,7 +139,8 @@ def check(rc):
         msg = last_error()
         if rc == 2:
             raise ValueError(msg)
-        raise RuntimeError("wgsassign_amd HIP call failed: " + msg)
+        # HIP_TRY reports "<file>.hip:<line>: <call> failed: <hip error>"; other failures (the reader's) carry their own text
+        raise RuntimeError(("wgsassign_amd HIP call failed: " if ".hip:" in msg else "wgsassign_amd: ") + msg)
 
 
 def f32p(a):
