@@ -62,10 +62,23 @@ INIT_WATCHDOG_S = float(os.environ.get("WGS_BENCH_INIT_TIMEOUT", "120"))
 
 
 def free_port():
+    """MASTER_PORT for the ranks: a port p with p + 1 free as well (the communicators' TCP star listens on p + 1; + 7 is the
+    retry's)."""
     import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+    for _ in range(200):
+        with socket.socket() as a:
+            a.bind(("127.0.0.1", 0))
+            p = a.getsockname()[1]
+            if p >= 65520:
+                continue
+            try:
+                for q in (p + 1, p + 7, p + 8):
+                    with socket.socket() as b:
+                        b.bind(("127.0.0.1", q))
+            except OSError:
+                continue
+            return p
+    raise RuntimeError("no free port range")
 
 
 def launch_ranks(n_ranks, fixed_env):

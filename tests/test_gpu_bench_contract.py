@@ -70,10 +70,8 @@ def test_bench_under_torchrun(tmp_path):
     """The driver's documented multi-GPU launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (here N = 2 on the one GPU, all-reduce over the TCP
     star): every rank process supervises one worker, rank 0's JSON line is the only stdout line."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    from wgsassign_amd.comm import free_port_pair
+    port = free_port_pair()
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(WGSASSIGN_DEVICE="0", WGSASSIGN_COMM="socket")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

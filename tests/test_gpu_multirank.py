@@ -12,11 +12,9 @@ import pytest
 
 
 def free_port():
-    """A TCP port the OS reports free right now (fixed ports collide when suites overlap)."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
+    """A TCP port p the OS reports free right now, with p + 1 free too (the communicators' TCP star listens there)."""
+    from wgsassign_amd.comm import free_port_pair
+    return free_port_pair()
 
 
 from conftest import ROOT

@@ -73,7 +73,15 @@ class SideChannel:
         if self.rank == 0:
             srv = socket.socket()
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((addr, int(port)))
+            bind_until = time.monotonic() + min(10.0, timeout)
+            while True:                          # the port may be some connection's ephemeral local port for a moment
+                try:
+                    srv.bind((addr, int(port)))
+                    break
+                except OSError as e:
+                    if time.monotonic() > bind_until:
+                        raise RuntimeError("SideChannel: cannot listen on %s:%d (%s)" % (addr, port, e))
+                    time.sleep(0.2)
             srv.listen(self.world)
             try:
                 while len(self.peers) < self.world - 1:
@@ -430,12 +438,7 @@ def launch_local_ranks(n, argv, env=None, poll=0.05):
     torchrun.  Rank 0 writes to this process's stdout, the others only to stderr.  The caller must not have touched
     the GPU (children are separate processes; nothing is exec'ed).  When a rank fails the others are ended; returns
     the first non-zero exit status, else 0."""
-    import socket
-    import subprocess
-    import time
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
+    port = free_port_pair()
     base = dict(os.environ if env is None else env)
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     status = _run_ranks(n, argv, base, port, poll)
@@ -443,11 +446,26 @@ def launch_local_ranks(n, argv, env=None, poll=0.05):
         import sys
         print("wgsassign_amd: the RCCL communicator did not initialise; starting the ranks again over the socket all-reduce",
               file=sys.stderr, flush=True)
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        status = _run_ranks(n, argv, dict(base, WGSASSIGN_COMM="socket"), port, poll)
+        status = _run_ranks(n, argv, dict(base, WGSASSIGN_COMM="socket"), free_port_pair(), poll)
     return status
+
+
+def free_port_pair(addr="127.0.0.1"):
+    """A port p such that p and p + 1 can both be bound right now: MASTER_PORT for a launcher (the TCP star of the
+    communicators listens on MASTER_PORT + 1)."""
+    for _ in range(200):
+        with socket.socket() as a:
+            a.bind((addr, 0))
+            p = a.getsockname()[1]
+            if p >= 65535:
+                continue
+            with socket.socket() as b:
+                try:
+                    b.bind((addr, p + 1))
+                except OSError:
+                    continue
+            return p
+    raise RuntimeError("no two consecutive free ports on %s" % addr)
 
 
 def _run_ranks(n, argv, base, port, poll):
