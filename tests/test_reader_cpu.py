@@ -186,7 +186,7 @@ def test_indexed_open_starts_at_any_row(tmp_path, monkeypatch, layout):
     assert sites.value == m == reader_cy.count_sites(p)
     names = open(nam).read().split("\n")[:-1]
     assert names == ["ctg%d_%d" % (s % 7, s + 1) for s in range(m)]
-    assert os.path.getsize(idx) >= 2 * 32768 or layout == "members"         # access points with dictionaries were recorded
+    assert os.path.getsize(idx) > 3000 or layout == "members"     # access points with their (deflated) 32 KiB dictionaries
     for first in [0, 1, 2, 63, 64, 500, 1234, 2498, 2499]:
         with reader_cy.BeagleStream(p, threads=2, index=idx, first_row=first) as st:
             assert st.n == n and st.sample_names == ["I%d" % i for i in range(n)]

@@ -1012,7 +1012,7 @@ void put(FILE *f, const T &v) { fwrite(&v, sizeof v, 1, f); }
 template <typename T>
 bool get(FILE *f, T &v) { return fread(&v, sizeof v, 1, f) == 1; }
 
-const char kIndexMagic[8] = {'W', 'G', 'S', 'I', 'D', 'X', '1', 0};
+const char kIndexMagic[8] = {'W', 'G', 'S', 'I', 'D', 'X', '2', 0};     // 2: dictionaries stored deflated
 
 bool save_index(const char *path, const BeagleIndex &idx)
 {
@@ -1040,7 +1040,17 @@ bool save_index(const char *path, const BeagleIndex &idx)
         put(f, a.content);
         put(f, a.at_line_start);
         put(f, a.member_start);
-        if (!a.member_start) fwrite(a.window.data(), 1, GZ_WIN, f);
+        if (!a.member_start) {                                // the 32 KiB dictionary, deflated (text: ~4x smaller)
+            std::vector<unsigned char> z(compressBound(GZ_WIN));
+            uLongf zn = (uLongf)z.size();
+            if (compress2(z.data(), &zn, a.window.data(), GZ_WIN, 1) != Z_OK) {
+                fclose(f);
+                return false;
+            }
+            const uint32_t n32 = (uint32_t)zn;
+            put(f, n32);
+            fwrite(z.data(), 1, zn, f);
+        }
     }
     const bool ok = !ferror(f);
     fclose(f);
@@ -1069,8 +1079,13 @@ bool load_index(const char *path, BeagleIndex &idx)
         ok = get(f, a.in) && get(f, a.out) && get(f, a.lines_before) && get(f, a.bits) && get(f, a.content) &&
              get(f, a.at_line_start) && get(f, a.member_start);
         if (ok && !a.member_start) {
+            uint32_t zn = 0;
+            ok = get(f, zn) && zn > 0 && zn <= compressBound(GZ_WIN);
+            std::vector<unsigned char> z(ok ? zn : 0);
+            ok = ok && fread(z.data(), 1, zn, f) == zn;
             a.window.resize(GZ_WIN);
-            ok = fread(a.window.data(), 1, GZ_WIN, f) == GZ_WIN;
+            uLongf out = GZ_WIN;
+            ok = ok && uncompress(a.window.data(), &out, z.data(), zn) == Z_OK && out == GZ_WIN;
         }
         if (ok) idx.points.push_back(std::move(a));
     }
