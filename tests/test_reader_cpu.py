@@ -319,7 +319,7 @@ def test_bgzf_parallel_index_and_block_parallel_inflate(tmp_path, monkeypatch, v
     # without an index: from the start, block-parallel
     Lr, samples, sites_r = reader_cy.readBeagle(p)
     assert Lr.tobytes() == L.tobytes() and sites_r == names and samples == ["I%d" % i for i in range(n)]
-    # the names pass takes the serial route and agrees
+    # the names pass (blocks inflated in parallel, first tokens scanned serially) agrees
     s2, n2 = reader_cy.read_site_names(p)
     assert n2 == names and s2 == samples
     # blocks are inflated by libdeflate when its shared library is installed, by zlib otherwise (or on request): same matrix

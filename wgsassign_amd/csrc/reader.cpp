@@ -1111,8 +1111,36 @@ int wgs_reader_build_index(const char *path, const char *index_path, const char 
     BeagleIndex idx;
     std::string names;
     const int64_t span = index_path ? std::max<int64_t>(span_bytes, (int64_t)GZ_WIN) : 0;
-    // BGZF input (what ANGSD writes): blocks are independent -> all host threads; site names need the serial pass
-    int rc = names_path ? -1 : scan_file_bgzf(path, span, (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u), idx);
+    // BGZF input (what ANGSD writes): blocks are independent -> all host threads.  Site names then come from a second
+    // pass whose blocks are inflated in parallel as well (GzSource::read_bgzf) and only scanned serially for the first
+    // token of every line -- a memchr per line.  Anything else: one serial inflate pass that does everything.
+    const int threads = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    int rc = scan_file_bgzf(path, span, threads, idx);
+    if (rc == 0 && names_path) {
+        GzSource src;
+        if (!src.open(path, nullptr)) {
+            wgs_set_error("cannot open Beagle file %s", path);
+            return 2;
+        }
+        src.try_bgzf(threads);
+        LineScan ls;
+        ls.names = &names;
+        std::vector<char> buf(64u << 20);
+        for (;;) {
+            const long got = src.read(buf.data(), buf.size());
+            if (got < 0) {
+                wgs_set_error("read error in %s (corrupt gzip stream)", path);
+                return 1;
+            }
+            if (got == 0) break;
+            ls.feed(reinterpret_cast<const unsigned char *>(buf.data()), (size_t)got);
+        }
+        ls.finish();
+        if ((ls.lines > 0 ? ls.lines - 1 : 0) != idx.sites) {
+            wgs_set_error("Beagle file %s: the two passes disagree about the number of sites", path);
+            return 1;
+        }
+    }
     if (rc < 0) {
         idx = BeagleIndex();
         rc = scan_file(path, span, idx, names_path ? &names : nullptr);
