@@ -196,7 +196,7 @@ def main():
     elif use_dist:
         addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400"))
         try:
-            comm = wcomm.SocketComm(rank, world, addr, port) if kind == "socket" else wcomm.RcclComm(ctx, rank, world, addr, port)
+            comm = wcomm.SocketComm(rank, world, addr, port).attach(ctx) if kind == "socket" else wcomm.RcclComm(ctx, rank, world, addr, port)
         except Exception as e:
             print("bench.py rank %d: communicator failed: %s" % (rank, e), file=sys.stderr, flush=True)
             os._exit(COMM_INIT_FAILED)
@@ -343,7 +343,9 @@ def main():
                 "config": {"workload": "synthetic Beagle %d SNPs x %d ind, K=%d, --get_reference_af EM sweep (+ --get_pop_like sweep), SNP-sharded over %d GPU(s)"
                                        % (m_total, n, K, world), "mode": args.mode, "snps_per_gpu": m,
                            "gl_bytes_per_gpu": beagle.nbytes(), "comm": comm_note,
-                           "step": "wgs_em_fit iteration (enqueued ahead of the host)" if pipelined else "sweep + host all-reduce + readback"},
+                           "step": ("wgs_em_fit iteration (enqueued ahead of the host)" if not use_dist or getattr(comm, "native", False)
+                                    else "wgs_em_fit iteration, all-reduce staged through the host (TCP)") if pipelined
+                           else "sweep + host all-reduce + readback"},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
     em.close()

@@ -222,6 +222,10 @@ int wgs_debug_parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *cons
  * the host side distributes it (wgsassign_amd/comm.py: TCP on MASTER_ADDR), every rank inits. */
 int wgs_comm_unique_id(uint8_t *id128);
 int wgs_comm_init(wgs_ctx *ctx, const uint8_t *id128, int rank, int world, wgs_comm **out);
+/* A communicator over the caller's own transport: fn sums n host doubles in place over all ranks (0 = success).  The
+ * library's loops (wgs_em_fit, wgs_loo) stage their device buffers through pinned host memory for it. */
+typedef int (*wgs_allreduce_fn)(double *buf, int64_t n, void *user);
+int wgs_comm_create_host(wgs_ctx *ctx, int rank, int world, wgs_allreduce_fn fn, void *user, wgs_comm **out);
 void wgs_comm_destroy(wgs_comm *c);
 int wgs_comm_rank(wgs_comm *c, int *rank, int *world);
 /* In-place sum of n float64 in device memory, enqueued on the context's stream (pairs with wgs_em_step_dev). */

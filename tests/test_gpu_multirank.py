@@ -215,6 +215,18 @@ group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
 lo, hi = shard_range(m, rank, world)
 assert (lo % 8192 == 0 or rank == 0) and (hi % 8192 == 0 or rank == world - 1)
 ctx = device.Context(0)
+comm.attach(ctx)          # the library's own loops (wgs_em_fit, wgs_loo) run across the ranks, all-reducing through this transport
+assert comm.handle is not None
+from wgsassign_amd import emMAF
+import io, contextlib
+with contextlib.redirect_stdout(io.StringIO()):
+    bq = device.DeviceBeagle.from_host(np.ascontiguousarray(L[lo:hi]), group_of, K, site0=lo, ctx=ctx)
+    _, af_c, it_c = emMAF.emMAF_populations(None, IDs, 200, 1e-4, beagle=bq, comm=comm)          # wgs_em_fit over 3 ranks
+    os.environ["WGSASSIGN_EM_LOOP"] = "python"
+    _, af_p, it_p = emMAF.emMAF_populations(None, IDs, 200, 1e-4, beagle=bq, comm=comm)          # the step-by-step twin
+    del os.environ["WGSASSIGN_EM_LOOP"]
+    bq.close()
+assert af_c.tobytes() == af_p.tobytes() == np.ascontiguousarray(af[lo:hi]).tobytes() and list(it_c) == list(it_p)
 b = device.DeviceBeagle.from_host(np.ascontiguousarray(L[lo:hi]), group_of, K, site0=lo, ctx=ctx)
 afs = device.AFSet.from_host(np.ascontiguousarray(af[lo:hi]), ctx=ctx)
 out, _ = device.assign(b, afs, comm=comm)                      # --get_pop_like, SNP-sharded over 3 ranks

@@ -21,6 +21,7 @@ def worker(rank, world, port, m, n, K, P):
     comm = SocketComm(rank, world, "127.0.0.1", port)
     group_of = np.minimum(np.arange(n) // (n // K), K - 1).astype(np.int32)
     ctx = device.Context(0)
+    comm.attach(ctx)          # wgs_em_fit / wgs_loo run across the ranks (the host-backed communicator)
 
     def run(lo, hi, c):
         b = device.DeviceBeagle(hi - lo, n, group_of, K, site0=lo, ctx=ctx)

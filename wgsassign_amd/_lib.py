@@ -22,6 +22,9 @@ c_i32 = ctypes.c_int32
 c_int = ctypes.c_int
 
 # name -> (restype, argtypes); every symbol include/wgsassign_hip.h declares
+# int fn(double *buf, int64 n, void *user): in-place sum over ranks (wgs_comm_create_host)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.c_int64, ctypes.c_void_p)
+
 SIGNATURES = {
     "wgs_last_error": (ctypes.c_char_p, []),
     "wgs_version": (c_int, []),
@@ -66,6 +69,7 @@ SIGNATURES = {
     "wgs_assign_parts_exact": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_f32p, c_f32p]),
     "wgs_comm_unique_id": (c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "wgs_comm_init": (c_int, [c_vp, ctypes.POINTER(ctypes.c_uint8), c_int, c_int, ctypes.POINTER(c_vp)]),
+    "wgs_comm_create_host": (c_int, [c_vp, c_int, c_int, ALLREDUCE_FN, c_vp, ctypes.POINTER(c_vp)]),
     "wgs_comm_destroy": (None, [c_vp]),
     "wgs_comm_allreduce_f64_dev": (c_int, [c_vp, c_vp, c_i64]),
     "wgs_comm_allreduce_f64": (c_int, [c_vp, c_f64p, c_i64]),

@@ -200,6 +200,34 @@ class SocketComm:
     def __init__(self, rank, world, addr="127.0.0.1", port=29400, timeout=120.0):
         self.rank, self.world = int(rank), int(world)
         self.ch = SideChannel(rank, world, addr, int(port) + 1, timeout=timeout)
+        self._host_h = self._host_fn = None
+
+    def attach(self, ctx):
+        """Give the library's own loops (wgs_em_fit, wgs_loo) this transport: a wgs_comm whose all-reduce calls back into
+        allreduce_sum below (wgs_comm_create_host).  After this `handle` is set and EMBatch.run / glassy.loo_device take
+        their one-call C paths across the ranks, exactly as they do over RCCL."""
+        import ctypes
+        from . import _lib
+        if self._host_h is not None or self.world == 1:
+            return self
+
+        def fn(buf, n, _user):
+            try:
+                view = np.ctypeslib.as_array(buf, shape=(int(n),))
+                view[:] = SocketComm.allreduce_sum(self, view.copy())
+                return 0
+            except BaseException:
+                return 1
+        self._host_fn = _lib.ALLREDUCE_FN(fn)                  # kept alive with the communicator
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().wgs_comm_create_host(ctx.handle, self.rank, self.world, self._host_fn, None, ctypes.byref(h)))
+        self._host_h = h
+        return self
+
+    @property
+    def handle(self):
+        """wgs_comm* for the C entry points that run whole loops, or None (not attached: step-by-step Python drivers)."""
+        return self._host_h
 
     def allreduce_sum(self, arr):
         a = np.ascontiguousarray(arr, dtype=np.float64)
@@ -232,7 +260,14 @@ class SocketComm:
     def barrier(self):
         self.allreduce_sum(np.zeros(1))
 
+    def _detach(self):
+        if getattr(self, "_host_h", None) is not None:
+            from . import _lib
+            _lib.load().wgs_comm_destroy(self._host_h)
+            self._host_h = self._host_fn = None
+
     def close(self):
+        self._detach()
         self.ch.close()
 
 
@@ -278,9 +313,11 @@ class RcclComm(SocketComm):
                 ok, self.native_error = 0, _lib.last_error()
         flags = SocketComm.allreduce_sum(self, np.array([float(ok and blob[0])]))
         self.native = int(flags[0]) == self.world
-        if not self.native and self._h:
-            lib.wgs_comm_destroy(self._h)
-            self._h = None
+        if not self.native:
+            if self._h:
+                lib.wgs_comm_destroy(self._h)
+                self._h = None
+            self.attach(ctx)                     # the library's loops still run in one call, over the TCP all-reduce
 
     # ---- the collective
     def allreduce_sum(self, arr):
@@ -308,8 +345,8 @@ class RcclComm(SocketComm):
 
     @property
     def handle(self):
-        """wgs_comm* for the C entry points that run whole loops (wgs_em_fit), or None."""
-        return self._h if self.native else None
+        """wgs_comm* for the C entry points that run whole loops (wgs_em_fit, wgs_loo): RCCL, or the host-backed one."""
+        return self._h if self.native else self._host_h
 
     def close(self):
         if self._h:
@@ -414,7 +451,8 @@ def init_from_env(ctx=None):
     backend = os.environ.get("WGSASSIGN_BACKEND", "nccl")
     kind = os.environ.get("WGSASSIGN_COMM", "torch" if backend == "gloo" else "rccl")
     if kind == "socket":
-        return SocketComm(rank, world, addr, port)
+        from .device import get_context
+        return SocketComm(rank, world, addr, port).attach(ctx or get_context())
     if kind == "rccl":
         from .device import get_context
         return RcclComm(ctx or get_context(), rank, world, addr, port)

@@ -58,6 +58,11 @@ struct wgs_comm {
     int rank = 0, world = 1;
     double *buf = nullptr;     // device bounce buffer for host-side reductions
     size_t buf_elems = 0;
+    // host-backed variant (wgs_comm_create_host): the sums are formed by the caller's function (e.g. over TCP)
+    wgs_allreduce_fn host_fn = nullptr;
+    void *host_user = nullptr;
+    double *host_stage = nullptr;      // pinned
+    size_t host_elems = 0;
 };
 
 #define RCCL_TRY(expr)                                                                              \
@@ -101,6 +106,23 @@ int wgs_comm_init(wgs_ctx *ctx, const uint8_t *id128, int rank, int world, wgs_c
     return 0;
 }
 
+/* A communicator whose sum all-reduce is the caller's function (in place over n host doubles, 0 = success): the loops
+ * that run inside the library (wgs_em_fit, wgs_loo) then work over any transport -- the TCP all-reduce of
+ * wgsassign_amd/comm.py uses it, which is also how those loops are exercised with several ranks on one GPU.  Device
+ * buffers are staged through pinned host memory (a stream synchronisation per all-reduce: slower than RCCL, same sums). */
+int wgs_comm_create_host(wgs_ctx *ctx, int rank, int world, wgs_allreduce_fn fn, void *user, wgs_comm **out)
+{
+    WGS_REQUIRE(ctx && fn && out && world >= 1 && rank >= 0 && rank < world, "bad argument");
+    wgs_comm *c = new wgs_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world;
+    c->host_fn = fn;
+    c->host_user = user;
+    *out = c;
+    return 0;
+}
+
 int wgs_comm_rank(wgs_comm *c, int *rank, int *world)
 {
     WGS_REQUIRE(c, "null argument");
@@ -112,10 +134,11 @@ int wgs_comm_rank(wgs_comm *c, int *rank, int *world)
 void wgs_comm_destroy(wgs_comm *c)
 {
     if (!c) return;
-    Api *A = api();
+    Api *A = c->comm ? api() : nullptr;
     (void)hipSetDevice(c->ctx->device);
     if (A && c->comm) (void)A->CommDestroy(c->comm);
     if (c->buf) (void)hipFree(c->buf);
+    if (c->host_stage) (void)hipHostFree(c->host_stage);
     delete c;
 }
 
@@ -124,9 +147,28 @@ int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n)
 {
     WGS_REQUIRE(c && dev_buf && n >= 0, "bad argument");
     if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    if (c->host_fn) {
+        if ((size_t)n > c->host_elems) {
+            if (c->host_stage) (void)hipHostFree(c->host_stage);
+            c->host_stage = nullptr;
+            c->host_elems = 0;
+            const size_t want = (size_t)n < 1024 ? 1024 : (size_t)n;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->host_stage), sizeof(double) * want, hipHostMallocDefault));
+            c->host_elems = want;
+        }
+        HIP_TRY(hipMemcpyAsync(c->host_stage, dev_buf, sizeof(double) * n, hipMemcpyDeviceToHost, c->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        if (c->host_fn(c->host_stage, n, c->host_user) != 0) {
+            wgs_set_error("the communicator's all-reduce function failed");
+            return 1;
+        }
+        HIP_TRY(hipMemcpyAsync(dev_buf, c->host_stage, sizeof(double) * n, hipMemcpyHostToDevice, c->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));       // the staging buffer is reused by the next call
+        return 0;
+    }
     Api *A = api();
     WGS_REQUIRE(A, "librccl not loaded");
-    HIP_TRY(hipSetDevice(c->ctx->device));
     RCCL_TRY(A->AllReduce(dev_buf, dev_buf, (size_t)n, kFloat64, kSum, c->comm, c->ctx->stream));
     return 0;
 }
@@ -168,6 +210,13 @@ int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n)
 {
     WGS_REQUIRE(c && host_buf && n >= 0, "bad argument");
     if (n == 0) return 0;
+    if (c->host_fn) {
+        if (c->host_fn(host_buf, n, c->host_user) != 0) {
+            wgs_set_error("the communicator's all-reduce function failed");
+            return 1;
+        }
+        return 0;
+    }
     HIP_TRY(hipSetDevice(c->ctx->device));
     if (!wgs_comm_buffer(c, n)) return 1;
     HIP_TRY(hipMemcpyAsync(c->buf, host_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->ctx->stream));
