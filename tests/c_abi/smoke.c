@@ -17,6 +17,17 @@
         }                                                                    \
     } while (0)
 
+/* a one-rank "transport" for wgs_comm_create_host: the sum over one rank is the buffer itself */
+static int calls = 0;
+static int one_rank_sum(double *buf, int64_t n, void *user)
+{
+    (void)buf;
+    (void)n;
+    (void)user;
+    ++calls;
+    return 0;
+}
+
 int main(void)
 {
     enum { M = 1000, N = 6, K = 2 };
@@ -101,6 +112,20 @@ int main(void)
         fprintf(stderr, "wgs_em_fit stopped at rmse %g (float64 estimate %g)\n", rm, sqrt(d2 / M));
         return 1;
     }
+    /* the same fit through a communicator over the caller's own all-reduce function: same iteration counts */
+    wgs_comm *hc = NULL;
+    wgs_em *em3 = NULL;
+    int32_t iters3[K] = {0, 0};
+    CHECK(wgs_comm_create_host(ctx, 0, 1, one_rank_sum, NULL, &hc));
+    CHECK(wgs_em_create(b, K, fit_group, NULL, WGS_MODE_EXACT, &em3));
+    CHECK(wgs_em_fit(em3, 200, 1e-4, M, hc, 0.0, iters3));
+    if (iters3[0] != iters[0] || iters3[1] != iters[1] || calls < iters[0]) {
+        fprintf(stderr, "wgs_em_fit over a host communicator: iterations %d %d (expected %d %d), %d all-reduce calls\n", iters3[0], iters3[1],
+                iters[0], iters[1], calls);
+        return 1;
+    }
+    wgs_em_destroy(em3);
+    wgs_comm_destroy(hc);
     /* glassy.loo in one call: N re-fits, sticky columns, scores and exact partition sums */
     double loo[N * K];
     float parts[N * 2 * K];
