@@ -145,3 +145,33 @@ def test_sums_are_numpys_own_float64_sums(wg, oracle, m, n, K):
             vec = np.zeros(m, dtype=np.float32)
             oracle.loglike(L, af, vec, 4, i, k)
             assert out[i, k] == np.sum(vec, dtype=float), (m, i, k)
+
+
+def test_sum_order_matters_at_millions_of_sites_and_is_numpys(wg, oracle):
+    """With frequencies down to 3e-4 (per-site values from 2^-11 to 2^4) and 3M sites the running float64 total no longer
+    holds every partial sum exactly (24 + 15 + 22 bits; inside a 4096-site block 24 + 15 + 12 still fit), so the ORDER
+    of the additions across blocks shows in the last bits: plain block-after-block accumulation gives other float64 values
+    than np.sum(vec, dtype=float) -- the chunk order of block_prefix_kernel gives NumPy's, for every pair."""
+    m, n, K = 3_000_001, 6, 2
+    labels = np.arange(n) % K
+    L, IDs = synth.make_beagle_for_labels(m, labels, K, seed=99)
+    rng = np.random.default_rng(5)
+    af = rng.choice(np.array([3e-4, 2e-3, 0.05, 0.4, 0.9, 1 - 3e-4], dtype=np.float32), size=(m, K))
+    b = wg.device.DeviceBeagle.from_host(L)
+    afs = wg.device.AFSet.from_host(af)
+    out, _ = wg.device.assign(b, afs)
+    afs.close()
+    b.close()
+    plain_differs = 0
+    for i in range(n):
+        for k in range(K):
+            vec = np.zeros(m, dtype=np.float32)
+            oracle.loglike(L, af, vec, 8, i, k)
+            assert out[i, k] == np.sum(vec, dtype=float), (i, k)
+            v64 = vec.astype(np.float64)
+            blocks = np.add.reduceat(v64, np.arange(0, m, 4096))          # exact inside a block
+            plain = 0.0
+            for s in blocks:
+                plain = plain + s
+            plain_differs += plain != out[i, k]
+    assert plain_differs > 0          # i.e. this test would notice a different order

@@ -255,6 +255,32 @@ if rank == 0:                                                 # the same on ONE 
     with np.errstate(all="ignore"):
         loo_o, parts_o = oracle.loo(L, af.copy(), IDs, 4, 200, 1e-4, None, 2)
     ok &= ll.tobytes() == loo_o.tobytes() and parts.tobytes() == parts_o.tobytes()
+# a matrix on which the ORDER of the float64 additions shows (2M sites, per-site values from 2^-11 to 2^4): the running total
+# handed from shard to shard must follow NumPy's chunk order; adding the shard totals would not give the same bits
+m2, n2 = 2_000_003, 4
+L2, _ = synth.make_beagle_for_labels(m2, np.arange(n2) % 2, 2, seed=12)
+af2 = np.random.default_rng(3).choice(np.array([3e-4, 2e-3, 0.05, 0.4, 0.9, 1 - 3e-4], dtype=np.float32), size=(m2, 2))
+lo2, hi2 = shard_range(m2, rank, world)
+b2 = device.DeviceBeagle.from_host(np.ascontiguousarray(L2[lo2:hi2]), None, 1, site0=lo2, ctx=ctx)
+afs2 = device.AFSet.from_host(np.ascontiguousarray(af2[lo2:hi2]), ctx=ctx)
+out2, _ = device.assign(b2, afs2, comm=comm)
+if rank == 0:
+    cuts = [shard_range(m2, r, world)[0] for r in range(world)] + [m2]
+    shard_totals_differ = 0
+    for i in range(n2):
+        for k in range(2):
+            vec = np.zeros(m2, dtype=np.float32)
+            oracle.loglike(L2, af2, vec, 4, i, k)
+            ok &= out2[i, k] == np.sum(vec, dtype=float)
+            v64 = vec.astype(np.float64)
+            tot = 0.0
+            for r in range(world):          # what summing per-shard totals would give
+                part = 0.0
+                for c in np.add.reduceat(v64[cuts[r]:cuts[r + 1]], np.arange(0, cuts[r + 1] - cuts[r], 8192)):
+                    part = part + c
+                tot = tot + part
+            shard_totals_differ += tot != out2[i, k]
+    ok &= shard_totals_differ > 0          # i.e. this check notices a different order
 from wgsassign_amd import fisher
 ne = fisher.fisher_obs_ind(None, np.ascontiguousarray(af[lo:hi]), IDs, 1, beagle=b, comm=comm, m_total=m)   # --ne_obs, sharded
 if rank == 0:
