@@ -288,6 +288,32 @@ int wgs_reader_build_index(const char *path, const char *index_path, const char 
 int wgs_reader_index_sites(const char *path, const char *index_path, int64_t *sites);
 int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t first_row, int threads, wgs_reader **out);
 
+/* ------------------------------------------------------------------ device-side ingest
+ * reader_cy.pyx:52-66 (strtok + atof per value) on the MI355X: the reader only inflates, finds the newlines and keeps
+ * the site names; the TEXT goes to the device through page-locked buffers and a HIP kernel tokenises it straight into
+ * the population slabs of `b` (csrc/ingest.hip).  Values the kernel does not convert itself (inf/nan, hex, 16+ digits)
+ * flag their line, which the host then parses with strtod -- the results equal wgs_reader_next's bit for bit.
+ * `r` is a reader positioned at the first wanted row (wgs_reader_open / wgs_reader_open_indexed); after
+ * wgs_ingest_create it must only be used through the ingest, which is destroyed BEFORE the reader is closed.
+ * limit_rows < 0: to the end of the file.  chunk_bytes <= 0: 256 MiB of text per chunk. */
+typedef struct wgs_ingest wgs_ingest;
+int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t chunk_bytes, wgs_ingest **out);
+void wgs_ingest_destroy(wgs_ingest *g);
+/* Next chunk: its lines fill the slab rows row0, row0 + 1, ... (keep != NULL: keep[i] != 0 keeps the i-th line of this
+ * chunk, dropped lines take no row; keep_len = entries available).  *file_rows = lines consumed (0: end of the file or
+ * of the row limit), *rows_written = rows filled.  Synchronises the context's stream. */
+int wgs_ingest_next(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64_t keep_len, int64_t *file_rows, int64_t *rows_written);
+/* Site names of that chunk's lines (kept or not), '\n'-terminated each, *bytes long. */
+const char *wgs_ingest_chunk_sites(wgs_ingest *g, int64_t *bytes);
+/* stats[0..7]: seconds the caller waited for text; producer seconds in inflate / in the newline scan; device ms
+ * (H2D + tokeniser); lines parsed on the host; text bytes; lines; chunks. */
+int wgs_ingest_stats(wgs_ingest *g, double *stats);
+
+/* Test hook, needs no GPU: drains the reader through the text hand-over (producer thread, carried partial lines,
+ * parallel newline scan, row limit) with ordinary memory and the host parser in place of the device tokeniser. */
+int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit_rows, float *rows, int64_t max_rows, int64_t *nrows);
+int64_t wgs_debug_reader_text_chunks(wgs_reader *r);   /* chunks that hand-over produced */
+
 /* Test hooks for the convergence chain: wgs_rmse1d's value through the literal one-lane serial
  * kernel (serial != 0) or through the block-parallel exact emulation, reporting the number of
  * 4096-element blocks that fell back to the serial loop; the same count for the last

@@ -9,6 +9,8 @@ This is test infrastructure (NumPy); the at-scale generator used by bench.py run
 device (wgsassign_amd/csrc/synth.hip).
 """
 import hashlib
+import struct
+import zlib
 
 import numpy as np
 
@@ -83,3 +85,50 @@ def make_beagle_for_labels(m, labels, K, seed=SEED, depth=2.0):
 def digest(a):
     """sha256[:16] of the array bytes (same convention as BASELINE.md section 2)."""
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]
+
+
+# ---- BGZF files (what ANGSD writes) for the reader / ingest tests and tools/bench_reader.py
+def bgzf_block(chunk, level=6):
+    co = zlib.compressobj(level, zlib.DEFLATED, -15)
+    payload = co.compress(chunk) + co.flush()
+    return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(payload) + 8 - 1) +
+            payload + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+
+def write_bgzf(path, data, block=60000):
+    with open(path, "wb") as fh:
+        for i in range(0, len(data), block):
+            fh.write(bgzf_block(data[i:i + block]))
+        fh.write(bgzf_block(b""))
+
+
+def make_pool_file(path, n, m, pool=1024, seed=1):
+    """A BGZF Beagle file of m sites x n individuals without formatting m x 3n numbers in Python: a pool of
+    pre-compressed GL sections (one BGZF block each, the way low-depth ANGSD output looks: a third of the genotypes
+    missing = 0.333333 three times), each line = a small block with its own site name + one pool block.
+    Returns the pool's values (pool, 2n) float32 and the pool index of every line."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 1_000_001, size=(pool, n))
+    b = (rng.random((pool, n)) * (1_000_000 - a)).astype(np.int64)
+    c = 1_000_000 - a - b
+    missing = rng.random((pool, n)) < 0.35
+    a[missing], b[missing], c[missing] = 333333, 333333, 333333
+    v = np.stack([a, b, c], axis=2).reshape(pool, 3 * n)                      # micro-units
+    txt = np.empty((pool, 3 * n, 9), dtype=np.uint8)
+    txt[:, :, 0] = 9                                                          # '\t'
+    txt[:, :, 1] = 48 + v // 1_000_000
+    txt[:, :, 2] = 46
+    r = v % 1_000_000
+    for k in range(6):
+        txt[:, :, 3 + k] = 48 + (r // 10 ** (5 - k)) % 10
+    vals = (v.reshape(pool, n, 3)[:, :, :2].reshape(pool, 2 * n) / 1e6).astype(np.float32)
+    blocks = [bgzf_block(txt[i].tobytes() + b"\n", level=4) for i in range(pool)]
+    pick = rng.integers(0, pool, size=m)
+    head = "marker\tallele1\tallele2\t" + "\t".join("I%d\tI%d\tI%d" % (i, i, i) for i in range(n)) + "\n"
+    with open(path, "wb") as fh:
+        fh.write(bgzf_block(head.encode()))
+        for s in range(m):
+            fh.write(bgzf_block(b"chr7_%d\tA\tC" % (s + 1), level=1))
+            fh.write(blocks[pick[s]])
+        fh.write(bgzf_block(b""))
+    return vals, pick

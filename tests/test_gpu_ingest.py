@@ -1,0 +1,182 @@
+"""The device-side ingest (csrc/ingest.hip: Beagle text tokenised on the MI355X straight into the population slabs)
+against the host parser (csrc/reader.cpp, itself pinned to the reference's parse by tests/test_reader_cpu.py) and the
+golden parse of the bundled files (reader_cy.pyx:16-77)."""
+import gzip
+import os
+
+import numpy as np
+import pytest
+
+import synth
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+DATA = os.path.join(GOLDEN, "data")
+
+
+from synth import bgzf_block, make_pool_file, write_bgzf  # noqa: E402
+
+
+def device_rows(path, rank=0, world=1, keep=None, group_of=None, n_groups=1, env=None):
+    """The matrix as the device holds it after stream_to_device, back in host layout."""
+    from wgsassign_amd import reader_cy
+    old = os.environ.get("WGSASSIGN_INGEST")
+    if env:
+        os.environ["WGSASSIGN_INGEST"] = env
+    try:
+        b, samples, sites, m_total = reader_cy.stream_to_device(path, group_of, n_groups, rank=rank, world=world, keep=keep)
+    finally:
+        if env:
+            os.environ.pop("WGSASSIGN_INGEST")
+            if old is not None:
+                os.environ["WGSASSIGN_INGEST"] = old
+    rows = b.download_rows(0, b.m)
+    stats = b.ingest_stats
+    b.close()
+    return rows, samples, sites, stats
+
+
+def same_bits(a, b):
+    return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def test_bundled_files_through_the_device_tokeniser(golden, tmp_path, monkeypatch):
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    g = golden("amre_fit.npz")
+    rows, samples, sites, stats = device_rows(os.path.join(DATA, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),
+                                              group_of=np.arange(85, dtype=np.int32) % 5, n_groups=5)
+    assert same_bits(rows, g["L"]) and synth.digest(rows) == "432436039a568fb4"
+    assert samples == list(g["samples"]) and sites == list(g["sites"])
+    assert stats["host_lines"] == 0 and stats["lines"] == 449          # every value converted on the device
+    a = golden("amre_assign.npz")
+    rows, samples, sites, _ = device_rows(os.path.join(DATA, "amre.nonbreeding.ind34.ds_2x.sites-filter.top_50_each.beagle.gz"))
+    assert same_bits(rows, a["L"]) and samples == list(a["samples"]) and sites == list(a["sites"])
+
+
+def test_awkward_tokens_flag_lines_for_the_host(tmp_path, monkeypatch):
+    """Decimal tokens (with signs, exponents, odd widths, several delimiters, CRLF, blank lines, no final newline) are
+    converted on the device; inf/nan, hex floats, 16+ digits and junk flag their line for the strtod-backed host
+    parser.  Either way the bits are the host parser's."""
+    from wgsassign_amd import reader_cy
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    plain = ["1e-3", "+0.5", "-0.25", ".5", "5.", "1E2", "0.000001", "1.5e-003", "0.333333", "00.12345", "-0.12345", "9.999999",
+             "0.1234567", "0.12345", "1.000000", "123456789012345", "1e22", "2.5E-21", "0", "7", "0.00000000000001"]
+    hard = ["0.1234567890123456789", "nan", "inf", "123456789012345678", "0x1p-2", "1e", "0.5abc", "-.", "1e400", "1e-30", "2.5E-22",
+            "0.33333333333333333", "0.0000000000000001"]
+    rng = np.random.default_rng(2)
+    n = 24
+
+    def line(name, pool, sep="\t"):
+        t = [pool[int(k)] for k in rng.integers(0, len(pool), size=3 * n)]
+        return name + sep + "A" + sep + "C" + sep + sep.join(t)
+    head = "marker allele1 allele2 " + " ".join("S%d S%d S%d" % (i, i, i) for i in range(n))
+    lines = [head]
+    kinds = []
+    for s in range(400):
+        hard_line = s % 7 == 3
+        kinds.append(hard_line)
+        lines.append(line("s%d" % s, plain + hard if hard_line else plain, sep=["\t", " ", " \t", "  "][s % 4]))
+        if s % 50 == 9:
+            lines.append("")
+    text = "\r\n".join(lines)                                   # CRLF, no final newline
+    p = str(tmp_path / "awkward.beagle.gz")
+    with gzip.open(p, "wt", newline="") as fh:
+        fh.write(text)
+    want, samples_h, sites_h = reader_cy.readBeagle(p)
+    rows, samples, sites, stats = device_rows(p)
+    assert same_bits(rows, want) and samples == samples_h and sites == sites_h == ["s%d" % s for s in range(400)]
+    assert 0 < stats["host_lines"] <= sum(kinds)                # only lines that hold a hard token went to the host
+    # a short line is reported like the host reader reports it
+    with gzip.open(p, "wt") as fh:
+        fh.write(head + "\n" + line("s0", plain) + "\ns1\tA\tC\t0.1\t0.2\n")
+    with pytest.raises(ValueError, match="Beagle data line 3 has fewer than %d" % (3 * n)):
+        device_rows(p)
+
+
+@pytest.mark.parametrize("layout", ["plain", "bgzf", "bgzf_tiny_blocks", "no_final_newline_blank_lines"])
+def test_device_ingest_equals_host_parser(tmp_path, monkeypatch, layout):
+    """Random matrices in every container the reader knows, small text chunks (many carries), populations interleaved
+    over the slabs, ranks 0..2 of 3 (odd site0), a site mask: the slabs hold the host parser's floats, bit for bit."""
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    monkeypatch.setenv("WGSASSIGN_TEXT_CHUNK_BYTES", str(1 << 20))
+    m, n, K = 30_011, 53, 4
+    L, _ = synth.make_beagle(m, n, K, seed=17)
+    head = "marker\tallele1\tallele2\t" + "\t".join("I%d\tI%d\tI%d" % (i, i, i) for i in range(n))
+    body = []
+    for s in range(m):
+        vals = ["%.6f\t%.6f\t%.6f" % (L[s, 2 * i], L[s, 2 * i + 1], max(0.0, 1 - L[s, 2 * i] - L[s, 2 * i + 1])) for i in range(n)]
+        body.append("chr%d_%d\tA\tG\t" % (s % 5, s) + "\t".join(vals))
+        if "blank" in layout and s % 101 == 7:
+            body.append("")
+    text = (head + "\n" + "\n".join(body) + ("" if "no_final" in layout else "\n")).encode()
+    p = str(tmp_path / ("f_%s.beagle.gz" % layout))
+    if layout.startswith("bgzf"):
+        write_bgzf(p, text, block=900 if "tiny" in layout else 60000)
+    else:
+        with gzip.open(p, "wb", compresslevel=6) as fh:
+            fh.write(text)
+    names = ["chr%d_%d" % (s % 5, s) for s in range(m)]
+    group_of = (np.arange(n) * 7 % K).astype(np.int32)
+    rows, _, sites, stats = device_rows(p, group_of=group_of, n_groups=K)
+    assert same_bits(rows, L) and sites == names and stats["host_lines"] == 0
+    assert stats["chunks"] > 5
+    from wgsassign_amd.comm import shard_range
+    for rank in range(3):
+        lo, hi = shard_range(m, rank, 3)
+        rows, _, sites, _ = device_rows(p, rank=rank, world=3, group_of=group_of, n_groups=K)
+        assert same_bits(rows, L[lo:hi]) and sites == names[lo:hi], rank
+    keep = np.random.default_rng(4).random(m) < 0.8
+    for rank in range(2):
+        lo, hi = shard_range(int(keep.sum()), rank, 2)
+        rows, _, sites, _ = device_rows(p, rank=rank, world=2, keep=keep, group_of=group_of, n_groups=K)
+        assert same_bits(rows, L[keep][lo:hi]) and sites == [x for x, k in zip(names, keep) if k][lo:hi], rank
+        rows_h, _, sites_h, _ = device_rows(p, rank=rank, world=2, keep=keep, group_of=group_of, n_groups=K, env="host")
+        assert same_bits(rows, rows_h) and sites == sites_h
+
+
+def test_n2000_bgzf_two_ranks_on_one_card(tmp_path, monkeypatch):
+    """A shard of the streamed configuration (BASELINE configs[4]: n = 2000 individuals, K = 20 populations, BGZF as ANGSD
+    writes it): 200 k sites = 10.8 GB of text through the device tokeniser, as ranks 0 and 1 of 2 and as a reader started
+    at an odd row, against the host parser and against the values the file was written from."""
+    from wgsassign_amd import reader_cy
+    from wgsassign_amd.comm import shard_range
+    from wgsassign_amd.device import DeviceBeagle
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    n, m, K = 2000, 200_000, 20
+    p = str(tmp_path / "c5.beagle.gz")
+    vals, pick = make_pool_file(p, n, m)
+    group_of = (np.arange(n) % K).astype(np.int32)
+    idx, _, sites = reader_cy.ensure_index(p)
+    assert sites == m
+    report = {}
+    for rank in range(2):
+        lo, hi = shard_range(m, rank, 2)
+        import time
+        t0 = time.perf_counter()
+        b, samples, names, _ = reader_cy.stream_to_device(p, group_of, K, rank=rank, world=2, names="ends")
+        dt = time.perf_counter() - t0
+        st = b.ingest_stats
+        report[rank] = "%.0f sites/s (%.2f GB/s of text; waited %.1f s for inflate, device %.0f ms)" % (
+            (hi - lo) / dt, st["text_bytes"] / dt / 1e9, st["wait_s"], st["device_ms"])
+        assert b.m == hi - lo and b.site0 == lo and len(samples) == n and st["host_lines"] == 0
+        assert names[:2] == ["chr7_%d" % (lo + 1), "chr7_%d" % (lo + 2)] and names[-1] == "chr7_%d" % hi
+        # against the values the file was written from, 4096 rows at a time
+        for r0 in range(0, hi - lo, 4096):
+            k = min(4096, hi - lo - r0)
+            got = b.download_rows(r0, k)
+            assert got.tobytes() == vals[pick[lo + r0:lo + r0 + k]].tobytes(), (rank, r0)
+        if rank == 1:
+            # ... and against the host parser on a stretch of the same shard
+            with reader_cy.BeagleStream(p, index=idx, first_row=lo + 12_345) as stream:
+                rows, sn = next(stream.chunks(max_rows=3000))
+            assert rows.tobytes() == b.download_rows(12_345, 3000).tobytes() and sn[0] == "chr7_%d" % (lo + 12_346)
+        b.close()
+    print("device ingest, n=2000 BGZF:", report)
+    # a reader opened at an odd row, ingesting into rows 5.. of a matrix whose first global site is odd
+    first, cnt = 77_777, 10_001
+    b = DeviceBeagle(cnt + 5, n, group_of, K, site0=first - 5)
+    with reader_cy.BeagleStream(p, index=idx, first_row=first) as stream:
+        done = sum(k for k, _ in stream.ingest(b, row0=5, limit=cnt))
+    assert done == cnt and b.download_rows(5, cnt).tobytes() == vals[pick[first:first + cnt]].tobytes()
+    assert not b.download_rows(0, 5).any()
+    b.close()

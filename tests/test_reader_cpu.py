@@ -353,3 +353,123 @@ def test_reader_clean_under_address_and_thread_sanitizers():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "clean under ASan+UBSan and TSan" in r.stdout and r.stdout.count("\nok\n") == 8
     assert "ERROR: AddressSanitizer" not in r.stderr and "WARNING: ThreadSanitizer" not in r.stderr and "runtime error" not in r.stderr
+
+
+# ------------------------------------------------------------------ text hand-over to the device tokeniser (reader_text.h)
+def _text_rows(path, n, m_max, chunk_bytes, limit=-1, threads=3, index=None, first_row=0):
+    import ctypes
+    from wgsassign_amd import _lib, reader_cy
+    with reader_cy.BeagleStream(path, threads=threads, index=index, first_row=first_row) as st:
+        rows = np.full((m_max, 2 * n), -7.0, dtype=np.float32)
+        got = ctypes.c_int64()
+        lib = _lib.load()
+        _lib.check(lib.wgs_debug_reader_text_rows(st._h, chunk_bytes, limit, _lib.f32p(rows), m_max, ctypes.byref(got)))
+        nb = ctypes.c_int64()
+        ptr = lib.wgs_reader_chunk_sites(st._h, ctypes.byref(nb))
+        names = ctypes.string_at(ptr, nb.value).decode().split("\n")[:-1]
+    return rows[:got.value], names
+
+
+@pytest.mark.parametrize("layout", ["plain", "members", "plain_no_final_newline_blank_lines", "crlf"])
+def test_text_hand_over_lists_the_same_rows(tmp_path, monkeypatch, layout):
+    """The producer of the device ingest (inflate ahead, cut at the last newline, carry the partial line, list the
+    non-blank lines in parallel, stop at the row limit) hands over exactly the lines wgs_reader_next parses: same
+    rows, same names -- chunks far smaller than the file, from the start and from the middle through the index."""
+    from wgsassign_amd import reader_cy
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    m, n = 9000, 37
+    L, _ = synth.make_beagle(m, n, 2, seed=5)
+    text = _text_of(L, blank_lines="blank" in layout, final_newline="no_final" not in layout)
+    if layout == "crlf":
+        text = text.replace("\n", "\r\n")
+    p = str(tmp_path / ("t_%s.beagle.gz" % layout))
+    if layout == "members":
+        _bgzf_like(p, text)
+    else:
+        with gzip.open(p, "wt", newline="", compresslevel=6) as fh:
+            fh.write(text)
+    names = ["ctg%d_%d" % (s % 7, s + 1) for s in range(m)]
+    rows, got = _text_rows(p, n, m, 1 << 20)                  # ~9 chunks of the 9 MB of text
+    assert rows.shape[0] == m and rows.tobytes() == L.tobytes() and got == names
+    rows, got = _text_rows(p, n, m, 1 << 20, limit=4321)
+    assert rows.shape[0] == 4321 and rows.tobytes() == L[:4321].tobytes() and got == names[:4321]
+    rows, got = _text_rows(p, n, m, 1 << 20, limit=0)
+    assert rows.shape[0] == 0 and got == []
+    idx, _, sites = reader_cy.ensure_index(p)
+    assert sites == m
+    for first, limit, threads in [(3333, 2000, 4), (8990, -1, 2), (1, 8999, 8)]:
+        rows, got = _text_rows(p, n, m, 1 << 20, limit=limit, threads=threads, index=idx, first_row=first)
+        want = L[first:] if limit < 0 else L[first:first + limit]
+        assert rows.tobytes() == want.tobytes() and got == names[first:first + len(want)], (first, limit)
+
+
+def test_text_hand_over_long_lines_grow_the_buffer(tmp_path):
+    """A line longer than the chunk (n = 2000 individuals: 54 kB per line against 1 MiB chunks is fine, but a 3 MB
+    line is not) makes the buffer grow instead of splitting the line."""
+    n, m = 120_000, 3                                         # 3.2 MB per line
+    rng = np.random.default_rng(3)
+    L = (rng.integers(0, 1_000_001, size=(m, 2 * n)) / 1e6).astype(np.float32)
+    head = "m a b " + " ".join("S S S" for _ in range(n))
+    p = str(tmp_path / "long.beagle.gz")
+    with gzip.open(p, "wt", compresslevel=1) as fh:
+        fh.write(head + "\n")
+        for s in range(m):
+            fh.write("s%d A C " % s + " ".join("%.6f %.6f 0" % (L[s, 2 * i], L[s, 2 * i + 1]) for i in range(n)) + "\n")
+    rows, got = _text_rows(p, n, m, 1 << 20)
+    assert rows.tobytes() == L.tobytes() and got == ["s0", "s1", "s2"]
+
+
+def test_decimal_tokens_with_exponents_take_the_exact_path(tmp_path):
+    """[sign] digits [. digits] [e [sign] digits] with <= 15 significant digits and a net power of ten within +-22 is
+    converted by one correctly rounded operation (host: parse_double; device: ingest.hip parse_token) -- float()'s
+    value, which is strtod's; everything else goes to strtod itself."""
+    from wgsassign_amd import reader_cy
+    rng = np.random.default_rng(11)
+    toks = ["1e-3", "1.5E+3", "-2.5e-7", "123456789012345e-22", "0.000001e6", "9.99999e22", "1e23", "1e-23", "4.9e-324",
+            "1e", "1e+", "1.2.3", "-.", ".", "+.5e1", "0e999", "00012.5000e-01", "1e0005", "7E-0", "123456789012345678e-3"]
+    for _ in range(300):
+        digs = int(rng.integers(1, 16))
+        mant = "".join(str(int(d)) for d in rng.integers(0, 10, size=digs))
+        dot = int(rng.integers(0, digs + 1))
+        t = mant[:dot] + "." + mant[dot:] if rng.random() < 0.8 else mant
+        if rng.random() < 0.7:
+            t += "eE"[int(rng.integers(0, 2))] + ["", "+", "-"][int(rng.integers(0, 3))] + str(int(rng.integers(0, 40)))
+        toks.append(["", "-", "+"][int(rng.integers(0, 3))] + t)
+    if len(toks) % 2:
+        toks.append("0.5")
+    n = len(toks) // 2
+    p = str(tmp_path / "exp.beagle.gz")
+    with gzip.open(p, "wt") as fh:
+        fh.write("m a b " + " ".join("S S S" for _ in range(n)) + "\n")
+        fh.write("s1 A C " + " ".join("%s %s 0" % (toks[2 * i], toks[2 * i + 1]) for i in range(n)) + "\n")
+
+    def atof(t):                                              # C's atof: the longest valid prefix, 0.0 if there is none
+        import re
+        mm = re.match(r"[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?)", t)
+        return float(mm.group(0)) if mm else 0.0
+    with np.errstate(over="ignore"):
+        want = np.array([atof(t) for t in toks], dtype=np.float64).astype(np.float32)
+    L, _, _ = reader_cy.readBeagle(p)
+    assert L.shape == (1, 2 * n)
+    bad = [(t, float(a), float(b)) for t, a, b in zip(toks, L[0], want) if a.tobytes() != b.tobytes()]
+    assert not bad, bad[:5]
+
+
+def test_text_hand_over_really_chunks(tmp_path, monkeypatch):
+    """What the line-oriented calls had already inflated when the hand-over starts (up to 64 MiB) is cut into chunks
+    like everything after it: 1 MiB chunks over 9 MB of text are at least nine chunks (seen through the debug hook's
+    row order check and the wall clock of neither: counted here by the number of distinct first rows)."""
+    import ctypes
+    from wgsassign_amd import _lib, reader_cy
+    m, n = 9000, 37
+    L, _ = synth.make_beagle(m, n, 2, seed=5)
+    p = str(tmp_path / "c.beagle.gz")
+    with gzip.open(p, "wt", newline="", compresslevel=1) as fh:
+        fh.write(_text_of(L))
+    lib = _lib.load()
+    with reader_cy.BeagleStream(p, threads=2) as st:
+        rows = np.empty((m, 2 * n), dtype=np.float32)
+        got, chunks = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.wgs_debug_reader_text_rows(st._h, 1 << 20, -1, _lib.f32p(rows), m, ctypes.byref(got)))
+        assert got.value == m and rows.tobytes() == L.tobytes()
+        assert lib.wgs_debug_reader_text_chunks(st._h) >= 9

@@ -25,51 +25,32 @@ def main():
     ap.add_argument("--bgzf", action="store_true", help="write the file as BGZF (what ANGSD produces) instead of plain gzip")
     a = ap.parse_args()
     n, m = a.inds, a.sites
-    rng = np.random.default_rng(1)
     d = tempfile.mkdtemp()
     os.environ["WGSASSIGN_INDEX_DIR"] = d
     path = os.path.join(d, "bench.beagle.gz")
-    head = "marker\tallele1\tallele2\t" + "\t".join("I%d\tI%d\tI%d" % (i, i, i) for i in range(n))
-    text_bytes = 0
-    import struct
-    import zlib
-
-    class Bgzf:
-        """minimal BGZF writer: 60 kB blocks, 'BC' size subfield, end marker"""
-        def __init__(self, path):
-            self.fh, self.buf = open(path, "wb"), b""
-
-        def block(self, chunk):
-            co = zlib.compressobj(6, zlib.DEFLATED, -15)
-            payload = co.compress(chunk) + co.flush()
-            self.fh.write(b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" +
-                          struct.pack("<HH", 2, 12 + 6 + len(payload) + 8 - 1) + payload +
-                          struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
-
-        def write(self, text):
-            self.buf += text.encode()
-            while len(self.buf) >= 60000:
-                self.block(self.buf[:60000])
-                self.buf = self.buf[60000:]
-
-        def __enter__(self):
-            return self
-
-        def __exit__(self, *exc):
-            if self.buf:
-                self.block(self.buf)
-            self.block(b"")
-            self.fh.close()
-
-    with (Bgzf(path) if a.bgzf else gzip.open(path, "wt", compresslevel=6)) as fh:
-        fh.write(head + "\n")
-        for s in range(m):
-            g = rng.dirichlet((0.6, 0.6, 0.6), size=n)
-            line = "chr1_%d\t0\t1\t" % (s + 1) + "\t".join("%.6f\t%.6f\t%.6f" % tuple(x) for x in g) + "\n"
-            text_bytes += len(line)
-            fh.write(line)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import synth
+    # lines come from a pool of pre-made GL sections (a third of the genotypes missing, like low-depth ANGSD output):
+    # formatting m x 3n numbers in Python would take longer than everything measured here
+    if a.bgzf:
+        synth.make_pool_file(path, n, m, pool=min(1024, m))
+        text_bytes = m * (27 * n + 1 + len("chr7_1\tA\tC")) + sum(len(str(s + 1)) - 1 for s in range(m))
+    else:
+        tmp = os.path.join(d, "pool.bgzf")
+        synth.make_pool_file(tmp, n, m, pool=min(1024, m))
+        text_bytes = 0
+        with gzip.open(tmp, "rb") as src, gzip.open(path, "wb", compresslevel=4) as dst:
+            src.readline()
+            dst.write(("marker\tallele1\tallele2\t" + "\t".join("I%d\tI%d\tI%d" % (i, i, i) for i in range(n)) + "\n").encode())
+            while True:
+                buf = src.read(64 << 20)
+                if not buf:
+                    break
+                text_bytes += len(buf)
+                dst.write(buf)
+        os.remove(tmp)
     res = {"individuals": n, "sites": m, "text_MB": round(text_bytes / 1e6, 1), "gz_MB": round(os.path.getsize(path) / 1e6, 1),
-           "threads": min(len(os.sched_getaffinity(0)), 16), "format": "bgzf" if a.bgzf else "gzip"}
+           "threads": reader_cy.host_threads(), "format": "bgzf" if a.bgzf else "gzip"}
     t0 = time.perf_counter()
     idx, _, sites = reader_cy.ensure_index(path)
     t = time.perf_counter() - t0
@@ -84,12 +65,24 @@ def main():
     if a.device:
         from wgsassign_amd import device
         ctx = device.get_context()
-        t0 = time.perf_counter()
-        b, _, _, _ = reader_cy.stream_to_device(path, np.arange(n, dtype=np.int32) % 20, 20, ctx=ctx)
-        ctx.sync()
-        t = time.perf_counter() - t0
-        res["stream_to_device"] = {"seconds": round(t, 3), "sites_per_s": round(m / t)}
-        b.close()
+        for label, mode in (("into_slabs_device_tokeniser", "device"), ("into_slabs_host_parser", "host")):
+            os.environ["WGSASSIGN_INGEST"] = mode
+            best = None
+            for _ in range(2):                      # the second run has the pinned buffers' pages and the file cache warm
+                t0 = time.perf_counter()
+                b, _, _, _ = reader_cy.stream_to_device(path, np.arange(n, dtype=np.int32) % 20, 20, ctx=ctx, names="ends")
+                ctx.sync()
+                t = time.perf_counter() - t0
+                st = b.ingest_stats
+                b.close()
+                if best is None or t < best[0]:
+                    best = (t, st)
+            t, st = best
+            res[label] = {"seconds": round(t, 3), "sites_per_s": round(m / t), "text_GB_per_s": round(text_bytes / 1e9 / t, 2)}
+            if st:
+                res[label].update({"waited_for_inflate_s": round(st["wait_s"], 3), "producer_inflate_s": round(st["inflate_s"], 3),
+                                   "producer_newline_scan_s": round(st["scan_s"], 3), "device_ms_h2d_plus_tokeniser": round(st["device_ms"], 1),
+                                   "lines_parsed_on_host": int(st["host_lines"]), "chunks": int(st["chunks"])})
     print(json.dumps(res))
 
 

@@ -16,7 +16,8 @@ parser = argparse.ArgumentParser(prog="WGSassign")
 parser.add_argument("-b", "--beagle", metavar="FILE",
                     help="Filepath to genotype likelihoods in gzipped Beagle format from ANGSD")
 parser.add_argument("-t", "--threads", metavar="INT", type=int, default=1,
-                    help="Number of threads (kept for compatibility; the GPU path ignores it)")
+                    help="Number of threads (1: chosen automatically). The arithmetic runs on the GPU; the host threads of "
+                         "this node's job inflate the Beagle file -- with several ranks the budget is divided between them")
 parser.add_argument("-o", "--out", metavar="OUTPUT", default="wgsassign", help="Prefix for output files")
 parser.add_argument("--maf_iter", metavar="INT", type=int, default=200,
                     help="Maximum iterations for minor allele frequencies estimation - EM (200)")
@@ -66,6 +67,7 @@ def _run(args, comm):
             print(*a)
 
     ctx = get_context()
+    reader_cy.set_threads(args.threads)
     say("Parsing Beagle file.")
     assert os.path.isfile(args.beagle), "Beagle file doesn't exist!"
     IDs = pops = None

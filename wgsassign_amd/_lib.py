@@ -92,6 +92,13 @@ SIGNATURES = {
     "wgs_reader_build_index": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_i64, c_i32, ctypes.POINTER(c_i64)]),
     "wgs_reader_index_sites": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "wgs_reader_open_indexed": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_i64, c_int, ctypes.POINTER(c_vp)]),
+    "wgs_ingest_create": (c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.POINTER(c_vp)]),
+    "wgs_ingest_destroy": (None, [c_vp]),
+    "wgs_ingest_next": (c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "wgs_ingest_chunk_sites": (c_vp, [c_vp, ctypes.POINTER(c_i64)]),
+    "wgs_ingest_stats": (c_int, [c_vp, c_f64p]),
+    "wgs_debug_reader_text_rows": (c_int, [c_vp, c_i64, c_i64, c_f32p, c_i64, ctypes.POINTER(c_i64)]),
+    "wgs_debug_reader_text_chunks": (c_i64, [c_vp]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),
     "wgs_em_last_chain_serial_blocks": (c_int, [c_vp]),
     "wgs_debug_rcp_error": (c_int, [c_vp, c_int, c_f64p]),

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwgsassign_hip.so")
-SOURCES = ["api.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "rccl_comm.hip", "reader.cpp"]
+SOURCES = ["api.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "ingest.hip", "rccl_comm.hip", "reader.cpp"]
 # -ffp-contract=off: the exact-mode kernels restate the reference's rounding sequence operation by
 # operation; hipcc's default (fast) contraction would fuse a*b+c and change results.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -30,7 +30,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     cc = hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "log_table.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "log_table.h"), os.path.join(CSRC, "reader_text.h"),
                os.path.join(HERE, "..", "include", "wgsassign_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:

@@ -23,11 +23,16 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "../../include/wgsassign_hip.h"
+#include "reader_text.h"
 
 void wgs_set_error(const char *fmt, ...);
 
@@ -38,32 +43,50 @@ inline bool is_delim(char c) { return c == '\t' || c == ' ' || c == '\n' || c ==
 const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
                            1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
 
-// atof of the token [p, e) (no delimiters inside).
+// atof of the token [p, e) (no delimiters inside).  Decimal tokens -- [sign] digits [. digits] [e [sign] digits] -- whose
+// mantissa fits 53 bits and whose net power of ten is at most 22 in magnitude take the exact path: one correctly
+// rounded multiplication or division of two exactly representable numbers, which is the correctly rounded value of
+// the token, i.e. strtod's result.  Everything else (longer mantissas, inf/nan, hex, trailing junk) is strtod's.
+// ingest.hip holds the device twin of this function (tokenise_kernel): the two must accept the same tokens.
 inline double parse_double(const char *p, const char *e)
 {
     const char *q = p;
     bool neg = false;
     if (q < e && (*q == '-' || *q == '+')) neg = *q++ == '-';
     uint64_t mant = 0;
-    int digits = 0, frac = 0;
-    bool dot = false, ok = q < e;
+    int digits = 0, frac = 0, seen = 0;
+    bool dot = false, ok = true;
     for (; q < e; ++q) {
         const char c = *q;
         if (c >= '0' && c <= '9') {
-            if (mant == 0 && c == '0' && !dot) continue;     // leading integer zeros
-            if (mant != 0 || c != '0') ++digits;             // significant digits
+            ++seen;
+            if (mant == 0 && c == '0') {                     // zeros before the first significant digit
+                if (dot) ++frac;
+                continue;
+            }
+            if (++digits > 15) break;
             mant = mant * 10 + (uint64_t)(c - '0');
             if (dot) ++frac;
         } else if (c == '.' && !dot) {
             dot = true;
         } else {
-            ok = false;
             break;
         }
     }
-    // exact when the mantissa fits 53 bits and the power of ten is exactly representable
-    if (ok && digits <= 15 && frac <= 22 && mant < (1ull << 53)) {
-        const double v = (double)mant / kPow10[frac];
+    int ex = 0;
+    if (q < e && (*q == 'e' || *q == 'E') && seen > 0 && digits <= 15) {
+        const char *x = q + 1;
+        bool xneg = false;
+        if (x < e && (*x == '-' || *x == '+')) xneg = *x++ == '-';
+        int xd = 0;
+        for (; x < e && *x >= '0' && *x <= '9' && xd < 4; ++x, ++xd) ex = ex * 10 + (*x - '0');
+        if (xd == 0 || xd > 3) ok = false;                   // "1e", "1e+": atof stops before the 'e'
+        if (xneg) ex = -ex;
+        q = x;
+    }
+    const int net = ex - frac;
+    if (ok && q == e && seen > 0 && digits <= 15 && net >= -22 && net <= 22) {
+        const double v = net < 0 ? (double)mant / kPow10[-net] : (double)mant * kPow10[net];
         return neg ? -v : v;
     }
     char tmp[64];
@@ -73,8 +96,8 @@ inline double parse_double(const char *p, const char *e)
         tmp[len] = 0;
         return strtod(tmp, nullptr);
     }
-    std::string s(p, e);
-    return strtod(s.c_str(), nullptr);
+    std::string str(p, e);
+    return strtod(str.c_str(), nullptr);
 }
 
 // The token almost every Beagle file consists of: "d.dddddd" (ANGSD prints %f) followed by a delimiter or the end of
@@ -283,7 +306,7 @@ struct GzSource {
         if (bgzf_member_size(head, got, &hdr) > 0) {
             bgzf = true;
             threads = nthreads > 0 ? nthreads : 1;
-            cbuf.resize(32u << 20);
+            cbuf.resize(64u << 20);
             clen = cpos = 0;
         }
     }
@@ -349,7 +372,36 @@ struct GzSource {
                 clen -= cpos;
                 cpos = 0;
             }
-            const size_t got = fread(cbuf.data() + clen, 1, cbuf.size() - clen, fp);
+            // the next stretch of the file, its slices copied out of the page cache by all threads (one fread of 32 MiB
+            // was a quarter of the whole pass on a 32-thread host)
+            const size_t want = cbuf.size() - clen;
+            const off_t at = ftello(fp);
+            const int fd = fileno(fp);
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, want >> 20));
+            std::vector<size_t> part(T, 0);
+            auto rd = [&](int t) {
+                const size_t a = want * (size_t)t / (size_t)T, b = want * (size_t)(t + 1) / (size_t)T;
+                size_t done = 0;
+                while (a + done < b) {
+                    const ssize_t k = pread(fd, cbuf.data() + clen + a + done, b - a - done, at + (off_t)(a + done));
+                    if (k <= 0) break;
+                    done += (size_t)k;
+                }
+                part[t] = done;
+            };
+            if (T <= 1) {
+                rd(0);
+            } else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < T; ++t) th.emplace_back(rd, t);
+                for (auto &x : th) x.join();
+            }
+            size_t got = 0;                          // contiguous bytes from the start: a short slice is the end of the file
+            for (int t = 0; t < T; ++t) {
+                got += part[t];
+                if (part[t] < want * (size_t)(t + 1) / (size_t)T - want * (size_t)t / (size_t)T) break;
+            }
+            fseeko(fp, at + (off_t)got, SEEK_SET);
             clen += got;
             if (got == 0) {
                 eof = true;
@@ -510,6 +562,8 @@ struct wgs_reader {
     std::string chunk_sites;   // '\n'-joined site names of the last chunk
     int threads = 1;
     int64_t lines_read = 0;
+    int64_t text_chunks = 0;           // chunks the last text hand-over produced
+    struct TextPipe *pipe = nullptr;   // the text hand-over to the device tokeniser (reader_text.h), when started
 };
 
 static bool fill(wgs_reader *r)
@@ -639,7 +693,12 @@ int wgs_reader_open(const char *path, int threads, wgs_reader **out)
     return 0;
 }
 
-void wgs_reader_close(wgs_reader *r) { delete r; }
+void wgs_reader_close(wgs_reader *r)
+{
+    if (!r) return;
+    reader_text_stop(r);
+    delete r;
+}
 
 }  // extern "C"
 
@@ -1426,6 +1485,344 @@ const char *wgs_reader_chunk_sites(wgs_reader *r, int64_t *bytes)
     if (!r) return nullptr;
     if (bytes) *bytes = (int64_t)r->chunk_sites.size();
     return r->chunk_sites.c_str();
+}
+
+}  // extern "C"
+
+// ---- text hand-over to the device tokeniser (reader_text.h) ----------------------------------------------------
+// A producer thread inflates ahead into caller-allocated (pinned) buffers, cuts each at its last newline, carries
+// the partial line into the next buffer, and lists the non-blank lines -- newline scan and first tokens (site names)
+// on all of the reader's threads.  Everything per VALUE happens on the GPU.
+struct TextPipe {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<TextChunk *> free_q, ready_q;
+    std::vector<TextChunk *> all;
+    TextAllocator alloc;
+    size_t chunk_bytes = 0;
+    int64_t limit = -1, rows = 0;
+    bool finished = false, stop = false;
+    int rc = 0;
+    std::string err;
+    int64_t chunks = 0;
+    std::vector<char> carry;    // text not handed out yet: [carry_pos, size)
+    size_t carry_pos = 0;
+};
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// room for `want` bytes of text plus the pad; keeps data[0 .. len)
+bool chunk_reserve(TextPipe *p, TextChunk *c, size_t want)
+{
+    if (c->data && want + TEXT_PAD <= c->cap) return true;
+    const size_t cap = want + TEXT_PAD;
+    char *q = (char *)p->alloc.alloc(cap, p->alloc.user);
+    if (!q) return false;
+    if (c->len) memcpy(q, c->data, c->len);
+    if (c->data) p->alloc.release(c->data, p->alloc.user);
+    c->data = q;
+    c->cap = cap;
+    return true;
+}
+
+template <typename F>
+void run_threads(int T, F work)
+{
+    if (T <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+}
+
+// The non-blank lines of data[0 .. len) -- every line ends with a newline, or (at the end of the file) with the buffer.
+void list_lines(const char *data, size_t len, int threads, std::vector<uint32_t> &begin, std::vector<uint32_t> &end, std::string &names)
+{
+    begin.clear();
+    end.clear();
+    names.clear();
+    if (len == 0) return;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, len >> 20));
+    std::vector<std::vector<uint32_t>> nl(T), lb(T), le(T);
+    std::vector<std::string> nm(T);
+    run_threads(T, [&](int t) {
+        const size_t a = len * (size_t)t / (size_t)T, b = len * (size_t)(t + 1) / (size_t)T;
+        for (const char *q = data + a, *e = data + b; q < e;) {
+            q = (const char *)memchr(q, '\n', (size_t)(e - q));
+            if (!q) break;
+            nl[t].push_back((uint32_t)(q - data));
+            ++q;
+        }
+    });
+    // thread t lists the lines that END in its range; the first of them starts after the last newline before the range
+    std::vector<size_t> start(T, 0);
+    {
+        size_t prev = 0;
+        for (int t = 0; t < T; ++t) {
+            start[t] = prev;
+            if (!nl[t].empty()) prev = (size_t)nl[t].back() + 1;
+        }
+        if (prev < len) nl[T - 1].push_back((uint32_t)len);      // last line without a newline
+    }
+    run_threads(T, [&](int t) {
+        size_t b = start[t];
+        for (uint32_t stop : nl[t]) {
+            const char *q = data + b, *e = data + stop;
+            while (q < e && is_delim(*q)) ++q;
+            if (q < e) {                                         // blank lines are not rows
+                lb[t].push_back((uint32_t)b);
+                le[t].push_back(stop);
+                const char *x = q;
+                while (x < e && !is_delim(*x)) ++x;
+                nm[t].append(q, x);
+                nm[t].push_back('\n');
+            }
+            b = (size_t)stop + 1;
+        }
+    });
+    for (int t = 0; t < T; ++t) {
+        begin.insert(begin.end(), lb[t].begin(), lb[t].end());
+        end.insert(end.end(), le[t].begin(), le[t].end());
+        names += nm[t];
+    }
+}
+
+void text_producer(wgs_reader *r)
+{
+    TextPipe *p = r->pipe;
+    auto fail = [&](int rc, const char *msg) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->rc = rc;
+        p->err = msg;
+        p->finished = true;
+        p->cv.notify_all();
+    };
+    for (;;) {
+        TextChunk *c = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [&] { return p->stop || !p->free_q.empty(); });
+            if (p->stop) return;
+            c = p->free_q.front();
+            p->free_q.pop_front();
+        }
+        const double t0 = now_s();
+        c->len = 0;
+        const size_t pending0 = p->carry.size() - p->carry_pos;
+        if (!chunk_reserve(p, c, std::max(p->chunk_bytes, std::min(pending0, p->chunk_bytes) + r->src.want_room()))) return fail(1, "out of (pinned) memory for the text buffers");
+        size_t complete = 0;
+        bool from_carry_only = false;
+        for (;;) {
+            // first what is pending from before (the partial line of the last chunk; at the start, everything the
+            // line-oriented calls had already inflated), then the inflater
+            if (p->carry_pos < p->carry.size()) {
+                const size_t take = std::min(p->carry.size() - p->carry_pos, c->cap - TEXT_PAD - c->len);
+                memcpy(c->data + c->len, p->carry.data() + p->carry_pos, take);
+                c->len += take;
+                p->carry_pos += take;
+                if (p->carry_pos == p->carry.size()) {
+                    p->carry.clear();
+                    p->carry_pos = 0;
+                }
+            }
+            from_carry_only = p->carry_pos > 0;              // pending text left: nothing was inflated into this chunk
+            while (!from_carry_only && !r->eof) {
+                const size_t room = c->cap - TEXT_PAD - c->len;
+                if (room < r->src.min_room()) break;
+                const bool batch = r->src.segmented;
+                const long got = r->src.read(c->data + c->len, room);
+                if (got == -2) break;
+                if (got < 0) return fail(1, "read error while inflating the Beagle file");
+                if (got == 0) {
+                    r->eof = true;
+                    break;
+                }
+                c->len += (size_t)got;
+                if (batch) break;
+            }
+            const char *last = c->len ? (const char *)memrchr(c->data, '\n', c->len) : nullptr;
+            if (r->eof && !from_carry_only) {
+                complete = c->len;
+                break;
+            }
+            if (last && (from_carry_only || c->cap - TEXT_PAD - c->len < r->src.min_room() || r->src.segmented || c->len >= p->chunk_bytes / 2)) {
+                complete = (size_t)(last - c->data) + 1;
+                break;
+            }
+            // one line longer than the buffer, or the next unit does not fit behind what is there: grow
+            if (c->len + std::max(p->chunk_bytes, r->src.want_room()) >= (1ull << 32) - TEXT_PAD)
+                return fail(1, "a Beagle line longer than 4 GiB");
+            if (!chunk_reserve(p, c, c->len + std::max(p->chunk_bytes, r->src.want_room()))) return fail(1, "out of (pinned) memory for the text buffers");
+        }
+        if (from_carry_only) p->carry_pos -= c->len - complete;      // the cut-off tail is still there, right before carry_pos
+        else p->carry.assign(c->data + complete, c->data + c->len);
+        c->len = complete;
+        memset(c->data + c->len, '\n', TEXT_PAD);
+        const double t1 = now_s();
+        list_lines(c->data, c->len, r->threads, c->begin, c->end, c->names);
+        c->inflate_s = t1 - t0;
+        c->scan_s = now_s() - t1;
+        bool last_chunk = r->eof && p->carry.empty();
+        c->first_row = p->rows;
+        if (p->limit >= 0 && p->rows + (int64_t)c->begin.size() >= p->limit) {
+            const size_t keep = (size_t)(p->limit - p->rows);
+            if (keep < c->begin.size()) {
+                c->begin.resize(keep);
+                c->end.resize(keep);
+                size_t at = 0;
+                for (size_t i = 0; i < keep; ++i) at = c->names.find('\n', at) + 1;
+                c->names.resize(at);
+            }
+            last_chunk = true;
+        }
+        p->rows += (int64_t)c->begin.size();
+        p->chunks += c->begin.empty() ? 0 : 1;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (c->begin.empty()) p->free_q.push_back(c);
+            else p->ready_q.push_back(c);
+            if (last_chunk) p->finished = true;
+            p->cv.notify_all();
+        }
+        if (last_chunk) return;
+    }
+}
+
+}  // namespace
+
+int reader_text_start(wgs_reader *r, size_t chunk_bytes, int nbuf, TextAllocator a, int64_t limit_rows)
+{
+    if (!r || r->pipe || !a.alloc || !a.release || nbuf < 1) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    TextPipe *p = new TextPipe();
+    p->alloc = a;
+    p->chunk_bytes = std::min<size_t>(std::max<size_t>(chunk_bytes, 1u << 20), (size_t)2 << 30);
+    p->limit = limit_rows;
+    // what the line-oriented calls left in the reader's buffer comes first
+    p->carry.assign(r->buf.data() + r->pos, r->buf.data() + r->len);
+    r->pos = r->len = 0;
+    for (int i = 0; i < nbuf; ++i) {
+        TextChunk *c = new TextChunk();
+        p->all.push_back(c);
+        p->free_q.push_back(c);
+    }
+    r->pipe = p;
+    if (limit_rows == 0) p->finished = true;
+    else p->th = std::thread(text_producer, r);
+    return 0;
+}
+
+int reader_text_next(wgs_reader *r, TextChunk **out, double *waited_s)
+{
+    TextPipe *p = r ? r->pipe : nullptr;
+    if (!p || !out) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    const double t0 = now_s();
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv.wait(lk, [&] { return !p->ready_q.empty() || p->finished; });
+    if (waited_s) *waited_s = now_s() - t0;
+    *out = nullptr;
+    if (!p->ready_q.empty()) {
+        *out = p->ready_q.front();
+        p->ready_q.pop_front();
+        return 0;
+    }
+    if (p->rc) wgs_set_error("%s", p->err.c_str());
+    return p->rc;
+}
+
+void reader_text_release(wgs_reader *r, TextChunk *c)
+{
+    TextPipe *p = r ? r->pipe : nullptr;
+    if (!p || !c) return;
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->free_q.push_back(c);
+    p->cv.notify_all();
+}
+
+void reader_text_stop(wgs_reader *r)
+{
+    TextPipe *p = r ? r->pipe : nullptr;
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+        p->cv.notify_all();
+    }
+    if (p->th.joinable()) p->th.join();
+    r->lines_read += p->rows;
+    r->text_chunks = p->chunks;
+    for (TextChunk *c : p->all) {
+        if (c->data) p->alloc.release(c->data, p->alloc.user);
+        delete c;
+    }
+    delete p;
+    r->pipe = nullptr;
+}
+
+int reader_text_parse_line(const wgs_reader *r, const char *b, const char *e, float *out)
+{
+    std::string site;
+    return parse_line(r, Line{b, e}, out, &site) ? 0 : 1;
+}
+
+int reader_text_n_inds(const wgs_reader *r) { return r->n_inds; }
+int reader_text_gl_cols(const wgs_reader *r) { return r->gl_cols; }
+int64_t reader_text_lines_read(const wgs_reader *r) { return r->lines_read; }
+
+extern "C" {
+
+/* Test hook (needs no GPU): the rows of wgs_reader_next, but through the text hand-over -- the producer thread, the
+ * carried partial lines, the parallel newline scan, the row limit -- with ordinary memory for the buffers and the host
+ * parser in place of the device tokeniser.  One call drains the reader: rows[max_rows][2n], site names through
+ * wgs_reader_chunk_sites. */
+int64_t wgs_debug_reader_text_chunks(wgs_reader *r) { return r ? r->text_chunks : 0; }
+
+int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit_rows, float *rows, int64_t max_rows, int64_t *nrows)
+{
+    if (!r || !rows || !nrows) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    TextAllocator a;
+    a.alloc = [](size_t n, void *) { return malloc(n); };
+    a.release = [](void *p, void *) { free(p); };
+    if (int rc = reader_text_start(r, (size_t)chunk_bytes, 2, a, limit_rows)) return rc;
+    r->chunk_sites.clear();
+    const size_t row_floats = (size_t)2 * r->n_inds;
+    int64_t done = 0;
+    int rc = 0;
+    for (;;) {
+        TextChunk *c = nullptr;
+        if ((rc = reader_text_next(r, &c, nullptr)) != 0 || !c) break;
+        if (c->first_row != done) rc = 1, wgs_set_error("text chunks out of order");
+        for (size_t i = 0; i < c->begin.size() && !rc; ++i) {
+            if (done >= max_rows) {
+                rc = 2;
+                wgs_set_error("more rows than the caller has room for");
+            } else if (reader_text_parse_line(r, c->data + c->begin[i], c->data + c->end[i], rows + (size_t)done * row_floats)) {
+                rc = 2;
+                wgs_set_error("Beagle data line %lld has fewer than %d genotype-likelihood columns", (long long)(r->lines_read + done + 2), r->gl_cols);
+            } else {
+                ++done;
+            }
+        }
+        r->chunk_sites += c->names;
+        reader_text_release(r, c);
+        if (rc) break;
+    }
+    reader_text_stop(r);
+    *nrows = done;
+    return rc;
 }
 
 }  // extern "C"

@@ -20,6 +20,30 @@ from . import _lib
 INDEX_SPAN_BYTES = 16 << 20       # text between two access points of the index (= one unit of parallel inflate)
 INDEX_MAX_POINTS = 4096
 
+_requested_threads = None         # -t / --threads of the command line (set_threads), when it asks for more than one
+
+
+def set_threads(t):
+    """-t/--threads of the command line (WGSassign.py:28-29, default 1): a value above 1 is the host-thread budget of
+    this NODE's job -- inflate and newline scan of the reader; 1 (the reference's default) leaves the choice to
+    host_threads()."""
+    global _requested_threads
+    _requested_threads = int(t) if t and int(t) > 1 else None
+
+
+def host_threads():
+    """Host threads ONE rank gives its reader: the node's budget -- WGSASSIGN_THREADS, else -t, else the CPUs this
+    process may run on (at most 32 per rank) -- divided by the ranks sharing the node (LOCAL_WORLD_SIZE, exported by
+    torchrun and by comm.launch_local_ranks): eight ranks on a 128-thread node take 16 each instead of 8 x 16 on the
+    one-GPU share."""
+    local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    env = os.environ.get("WGSASSIGN_THREADS")
+    if env:
+        return max(1, int(env) // local)
+    if _requested_threads:
+        return max(1, _requested_threads // local)
+    return max(1, min(len(os.sched_getaffinity(0)) // local, 32))
+
 
 class BeagleStream:
     """Chunked reader: iterate (rows float32 (k, 2n), site_names list) until the file ends."""
@@ -29,7 +53,9 @@ class BeagleStream:
         without inflating the file up to there."""
         lib = _lib.load()
         if threads is None:
-            threads = min(len(os.sched_getaffinity(0)), 16)
+            threads = host_threads()
+        self.threads = int(threads)
+        self._ingest = None
         h = ctypes.c_void_p()
         if index is None:
             _lib.check(lib.wgs_reader_open(os.fsencode(path), int(threads), ctypes.byref(h)))
@@ -76,8 +102,50 @@ class BeagleStream:
             names = ctypes.string_at(ptr, nbytes.value).decode().split("\n")[:-1]
             yield rows[:got.value], names
 
+    def ingest(self, beagle, row0=0, limit=None, keep=None, chunk_bytes=None):
+        """Device-side ingest (csrc/ingest.hip): the rest of the file -- at most `limit` sites -- goes as TEXT to the
+        GPU, which tokenises it straight into the slabs of `beagle` from row `row0` on.  keep: bool array over those
+        sites (False = the site takes no row).  Yields (rows_written, site_names of the chunk's kept sites)."""
+        lib = _lib.load()
+        if chunk_bytes is None:
+            chunk_bytes = int(os.environ.get("WGSASSIGN_TEXT_CHUNK_BYTES", 0))
+        g = ctypes.c_void_p()
+        _lib.check(lib.wgs_ingest_create(beagle.handle, self._h, -1 if limit is None else int(limit), int(chunk_bytes),
+                                         ctypes.byref(g)))
+        self._ingest = g
+        if keep is not None:
+            keep = np.ascontiguousarray(keep, dtype=np.uint8)
+        consumed = 0
+        try:
+            while True:
+                nfile, nrows = ctypes.c_int64(), ctypes.c_int64()
+                kp = ctypes.c_void_p(keep.ctypes.data + consumed) if keep is not None else None
+                _lib.check(lib.wgs_ingest_next(g, int(row0), kp, (len(keep) - consumed) if keep is not None else 0,
+                                               ctypes.byref(nfile), ctypes.byref(nrows)))
+                if nfile.value == 0:
+                    break
+                nbytes = ctypes.c_int64()
+                ptr = lib.wgs_ingest_chunk_sites(g, ctypes.byref(nbytes))
+                names = ctypes.string_at(ptr, nbytes.value).decode().split("\n")[:-1]
+                if keep is not None:
+                    names = [x for x, k in zip(names, keep[consumed:consumed + nfile.value]) if k]
+                consumed += nfile.value
+                row0 += nrows.value
+                yield nrows.value, names
+            st = (ctypes.c_double * 8)()
+            _lib.check(lib.wgs_ingest_stats(g, st))
+            self.ingest_stats = dict(zip(("wait_s", "inflate_s", "scan_s", "device_ms", "host_lines", "text_bytes", "lines",
+                                          "chunks"), st))
+        finally:
+            if self._ingest is not None:     # close() may have destroyed it already
+                self._ingest = None
+                lib.wgs_ingest_destroy(g)
+
     def close(self):
         if self._h:
+            if self._ingest:
+                _lib.load().wgs_ingest_destroy(self._ingest)
+                self._ingest = None
             _lib.load().wgs_reader_close(self._h)
             self._h = None
 
@@ -231,21 +299,31 @@ def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, ra
             group_of, n_groups = group_of(list(st.sample_names))
         beagle = DeviceBeagle(hi - lo, st.n, group_of, n_groups, site0=lo, ctx=ctx)
         row0, frow, site_names, tail, names_mode = 0, r0, [], [], names
-        for rows, names in prefetched(st.chunks(limit=r1 - r0)):
-            if keep is not None:
-                sel = keep[frow:frow + rows.shape[0]]
-                frow += rows.shape[0]
-                rows = rows[sel]
-                names = [x for x, k in zip(names, sel) if k]
-            if rows.shape[0]:
-                beagle.upload_rows(np.ascontiguousarray(rows), row0)
-            row0 += rows.shape[0]
+        if os.environ.get("WGSASSIGN_INGEST", "device") == "host":
+            # the round-2 path, kept as the comparator: every value parsed on the host (wgs_reader_next), rows uploaded
+            def chunks():
+                nonlocal frow
+                for rows, names in prefetched(st.chunks(limit=r1 - r0)):
+                    if keep is not None:
+                        sel = keep[frow:frow + rows.shape[0]]
+                        frow += rows.shape[0]
+                        rows = rows[sel]
+                        names = [x for x, k in zip(names, sel) if k]
+                    if rows.shape[0]:
+                        beagle.upload_rows(np.ascontiguousarray(rows), row0)
+                    yield rows.shape[0], names
+        else:
+            def chunks():
+                return st.ingest(beagle, 0, r1 - r0, None if keep is None else keep[r0:r1])
+        for nrows, names in chunks():
+            row0 += nrows
             if names_mode == "all":
                 site_names.extend(names)
             else:
                 if len(site_names) < 4:
                     site_names = (site_names + names)[:4]
                 tail = (tail + names)[-4:]
+        beagle.ingest_stats = getattr(st, "ingest_stats", None)
         if names_mode != "all" and row0 > 4:
             site_names = site_names + tail         # [:4] are the first four names of the range, [-4:] the last four
         if row0 != hi - lo:
