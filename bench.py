@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--arith", dest="mode", default=os.environ.get("WGSASSIGN_MODE", "exact"), choices=["exact", "fast"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-assign", action="store_true", help="skip the assignment sweep leg")
+    ap.add_argument("--no-paths", action="store_true", help="skip extra.paths (whole-path timings of the other configurations)")
     ap.add_argument("--cpu-snps", type=int, default=200_000, help="SNP sample for the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum CPU-baseline EM timing window")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)     # one rank, started by the launcher below
@@ -221,6 +222,7 @@ def main():
     beagle.synth(SEED, 2.0)
     ctx.sync()
     t_gen = time.time() - t0
+    gl_bytes = beagle.nbytes()
     em = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
 
     def barrier():
@@ -274,6 +276,8 @@ def main():
 
     pmc = committed_pmc(m, n, K, args.mode)
     roofline["traffic"], roofline["traffic_source"] = pmc.get("em_traffic"), pmc.get("source")
+    if pmc.get("reason"):
+        roofline["traffic_note"] = pmc["reason"]
     if pmc.get("em_valu_busy_frac") is not None:
         # the exact-mode sweep sits on the FP64 issue roof as well: share of cycles the vector units were busy
         roofline["valu_busy_frac"] = round(pmc["em_valu_busy_frac"], 4)
@@ -332,8 +336,18 @@ def main():
         afs.close()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(beagle, group_of, K, min(args.cpu_snps, m), args.cpu_seconds)
+    if rank == 0 and not args.no_cpu:
+        # rank 0's host cores; at N > 1 a shorter window (the other ranks wait at the closing barrier)
+        cpu = cpu_baseline(beagle, group_of, K, min(args.cpu_snps, m), args.cpu_seconds if world == 1 else min(args.cpu_seconds, 6.0))
+    paths = None
+    if rank == 0 and world == 1 and not args.no_paths:
+        # the other BASELINE.json configurations and the reference README's LOO shape, whole paths, after the 80 GB
+        # of the headline workload have been released
+        em.close()
+        beagle.close()
+        em = beagle = None
+        paths = whole_paths(ctx, device, args.mode)
+        extra["paths"] = paths
 
     if rank == 0:
         line = {"metric": "EM SNP-updates/s (per-population update, n_call=%g)" % n_call, "value": value,
@@ -342,19 +356,127 @@ def main():
                 "dtype": "f64" if args.mode == "exact" else "f32", "data": "synthetic",
                 "config": {"workload": "synthetic Beagle %d SNPs x %d ind, K=%d, --get_reference_af EM sweep (+ --get_pop_like sweep), SNP-sharded over %d GPU(s)"
                                        % (m_total, n, K, world), "mode": args.mode, "snps_per_gpu": m,
-                           "gl_bytes_per_gpu": beagle.nbytes(), "comm": comm_note,
+                           "gl_bytes_per_gpu": gl_bytes, "comm": comm_note,
                            "step": ("wgs_em_fit iteration (enqueued ahead of the host)" if not use_dist or getattr(comm, "native", False)
                                     else "wgs_em_fit iteration, all-reduce staged through the host (TCP)") if pipelined
                            else "sweep + host all-reduce + readback"},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line), flush=True)
-    em.close()
-    beagle.close()
+    if em is not None:
+        em.close()
+        beagle.close()
     if use_dist:
         comm.barrier()
         comm.close()
         if dist is not None:
             dist.destroy_process_group()
+
+
+FP64_ISSUE_CLOCK_GHZ = 2.4      # MI355X peak engine clock: issue fractions below are lower bounds of the busy share
+WAVE_ISSUE_PER_S = 1024 * FP64_ISSUE_CLOCK_GHZ * 1e9 / 4.0       # 1024 SIMDs, 4 cycles per wave-wide FP64-rate instruction
+# VALU wave-instructions per (SNP, individual[, population]) term of the FP64-issue-bound kernels, from the committed PMC
+# passes (profiles/r02_e_loo_final: em_sweep_group_kernel 2.49e10 per sweep of 6.15e10 terms; r02_g_final: score sweep)
+INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "score_sweep_kernel<exact>": 41.6}
+
+
+def whole_paths(ctx, device, mode_name):
+    """extra.paths: every other BASELINE.json configuration and the reference README's --loo shape (README.md:129-131:
+    "30 min" at ~5M SNPs x 180 individuals) as WHOLE paths on device-generated data -- all kernel launches, readbacks,
+    exact chains and collectives-of-one included, file parsing excluded -- each with the roof that bounds its
+    dominant kernel: `hbm` (fraction of 8 TB/s the sweeps' algorithmic bytes / kernel time reach) or `valu_fp64_issue`
+    (wave-instructions of the committed PMC pass x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time): a lower bound
+    of the busy share, the chip clocks lower under FP64 load)."""
+    from wgsassign_amd import glassy
+    out = {"mode": mode_name, "note": "seconds = wall clock of the whole call(s) on one MI355X, matrix resident in HBM"}
+
+    def matrix(m, n, K):
+        group_of = np.minimum(np.arange(n) // (n // K), K - 1).astype(np.int32)
+        b = device.DeviceBeagle(m, n, group_of, K, ctx=ctx)
+        b.synth(SEED, 2.0)
+        ctx.sync()
+        return b, group_of, np.bincount(group_of, minlength=K)
+
+    def fit(b, K, counts):
+        t0 = time.perf_counter()
+        em = device.EMBatch(b, np.arange(K, dtype=np.int32))
+        iters = em.run(200, 1e-4)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        st = em.fit_stats()                 # iterations enqueued, chain batches, seconds in wgs_em_fit, sweep kernels ms
+        alg = float(np.sum([(8.0 * counts[k] + 8.0) * b.m * iters[k] for k in range(K)]))
+        res = {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
+               "sweep_kernels_ms": round(st[3], 3), "bound": "hbm",
+               "hbm_frac_of_sweeps": round(alg / (st[3] * 1e-3) / HBM_PEAK, 4) if st[3] > 0 else None,
+               "snp_updates_per_s": float(b.m) * float(np.sum(iters)) / dt}
+        return em, res
+
+    def pop_like(b, em, K, counts):
+        afs = device.AFSet(b.m, K, ctx=ctx)
+        for k in range(K):
+            em.clamp(k, int(counts[k]))
+            afs.set_column_from_em(k, em, k)
+        ctx.sync()
+        t0 = time.perf_counter()
+        o, _ = device.assign(b, afs)
+        dt = time.perf_counter() - t0
+        ms = device.assign.last_ms
+        terms = float(b.m) * b.n * K
+        res = {"seconds": round(dt, 4), "kernel_ms": round(ms, 3), "snps_per_s": b.m / dt, "bound": "valu_fp64_issue",
+               "fp64_issue_frac": round(terms * INSTS_PER_TERM["score_sweep_kernel<exact>"] / 64.0 / WAVE_ISSUE_PER_S / (ms * 1e-3), 4),
+               "hbm_frac": round((8.0 * b.n + 4.0 * K) * b.m / (ms * 1e-3) / HBM_PEAK, 4), "checksum": float(np.sum(o))}
+        af = afs.to_host()
+        afs.close()
+        return af, res
+
+    def loo(b, group_of, counts, af, P):
+        tm = {}
+        t0 = time.perf_counter()
+        ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, P, verbose=False, timings=tm, need_parts=P > 1)
+        dt = time.perf_counter() - t0
+        it = tm["iters"]
+        terms = float(np.sum([float(it[i]) * (counts[group_of[i]] - 1) for i in range(b.n)])) * b.m
+        kms = tm.get("em_sweep_kernel_ms", 0.0)
+        return {"seconds": round(dt, 4), "re_fits": int(b.n), "partitions": P, "one_call_wgs_loo": bool(tm.get("one_call")),
+                "em_seconds": round(tm.get("em_seconds", 0.0), 4), "scoring_seconds": round(tm.get("score_seconds", 0.0), 4),
+                "partition_chain_seconds": round(tm.get("chain_seconds", 0.0), 4), "em_sweep_kernels_ms": round(kms, 2),
+                "em_batches": tm.get("em_batches"), "iterations_min_max": [int(it.min()), int(it.max())], "bound": "valu_fp64_issue",
+                "fp64_issue_frac_of_em_sweeps": round(terms * INSTS_PER_TERM["em_sweep_group_kernel<exact>"] / 64.0 / WAVE_ISSUE_PER_S / (kms * 1e-3), 4) if kms > 0 else None,
+                "self_assignment_accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of)),
+                "checksum": float(np.sum(ll.astype(np.float64))), "partitions_checksum": float(np.sum(parts.astype(np.float64))) if P > 1 else None}
+
+    t_all = time.perf_counter()
+    # BASELINE configs[1]: 1M x 200, K=5, --get_reference_af
+    b, g, c = matrix(1_000_000, 200, 5)
+    em, r = fit(b, 5, c)
+    em.close()
+    em2, r2 = fit(b, 5, c)                       # second run: allocations and code objects warm
+    em2.close()
+    r["seconds_second_run"] = r2["seconds"]
+    out["config2_1Mx200_K5_get_reference_af"] = r
+    b.close()
+    # BASELINE configs[3]: 2M x 500, K=8, --get_reference_af --loo --partition_sites 3 (+ --get_pop_like)
+    b, g, c = matrix(2_000_000, 500, 8)
+    em, r = fit(b, 8, c)
+    af, rp = pop_like(b, em, 8, c)
+    em.close()
+    out["config4_2Mx500_K8"] = {"get_reference_af": r, "get_pop_like": rp, "loo_partition_sites_3": loo(b, g, c, af, 3)}
+    b.close()
+    # the reference README's timing claim (README.md:129-131): --loo at ~5M SNPs x 180 individuals, "30 min"
+    b, g, c = matrix(5_000_000, 180, 5)
+    em, r = fit(b, 5, c)
+    af, rp = pop_like(b, em, 5, c)
+    em.close()
+    out["readme_5Mx180_K5"] = {"get_reference_af": r, "loo": loo(b, g, c, af, 1), "reference_readme_claim": "30 min (hardware and threads not stated)"}
+    b.close()
+    # BASELINE configs[4]: one GPU's shard of 50M x 2000, K=20 on 8 GPUs = 6.25M SNPs (100 GB of genotype likelihoods)
+    b, g, c = matrix(6_250_000, 2000, 20)
+    em, r = fit(b, 20, c)
+    af, rp = pop_like(b, em, 20, c)
+    em.close()
+    out["config5_shard_6.25Mx2000_K20"] = {"get_reference_af": r, "get_pop_like": rp, "gl_bytes": b.nbytes()}
+    b.close()
+    out["seconds_total"] = round(time.perf_counter() - t_all, 2)
+    return out
 
 
 def committed_pmc(m, n, K, mode):
@@ -364,7 +486,9 @@ def committed_pmc(m, n, K, mode):
     / 8)); the newest matching profile wins, {} when none matches the workload being run."""
     import glob
     import re
-    best = {}
+    from wgsassign_amd import _lib
+    loaded = _lib.load().wgs_kernels_id().decode()
+    best = {"reason": "no committed profile of this workload (profiles/*/pmc_summary.json)"}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
         try:
             d = json.load(open(f))
@@ -372,7 +496,13 @@ def committed_pmc(m, n, K, mode):
             continue
         if d.get("bench_config") != {"snps_per_gpu": m, "n": n, "K": K, "mode": mode}:
             continue
-        cur = {"source": os.path.relpath(f, ROOT)}
+        if d.get("kernels_id") != loaded:
+            # counters of other code say nothing about the kernels being timed now
+            if "em_traffic" not in best:
+                best = {"reason": "the committed profile of this workload (%s) was taken from kernels %s, the loaded library has %s: "
+                                  "re-profile (tools/gpu_prof.sh + tools/summarize_profile.py)" % (os.path.relpath(f, ROOT), d.get("kernels_id"), loaded)}
+            continue
+        cur = {"source": os.path.relpath(f, ROOT), "kernels_id": loaded}
         for k, e in d.get("kernels", {}).items():
             if "em_sweep_kernel<%d" % (0 if mode == "exact" else 1) in k:
                 cur["em_traffic"] = e.get("traffic_bytes_per_launch")
@@ -405,7 +535,8 @@ def cpu_baseline(beagle, group_of, K, ms, seconds=12.0):
     bit-exact C/OpenMP restatement -- on the first `ms` SNPs of the same synthetic matrix."""
     from oracle import oracle as orc
     orc.build()
-    threads = int(os.environ.get("WGS_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # the box's CPU share
+    affinity = len(os.sched_getaffinity(0))
+    threads = int(os.environ.get("WGS_CPU_THREADS", affinity))      # every CPU this process may run on (SURVEY 8d: OMP_NUM_THREADS = nproc)
     rows = beagle.download_rows(0, ms)
     slabs = [orc.gather(rows, np.flatnonzero(group_of == k), threads) for k in range(K)]
     fs = [np.full(ms, 0.25, dtype=np.float32) for _ in range(K)]
@@ -435,8 +566,10 @@ def cpu_baseline(beagle, group_of, K, ms, seconds=12.0):
         pairs += 1
     t_pair = (time.perf_counter() - t_a0) / pairs
     assign_snps_per_s = ms / (t_pair * beagle.n * K)
-    return {"value": K * ms * sweeps / el, "unit": "SNP-updates/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+    return {"value": K * ms * sweeps / el, "unit": "SNP-updates/s", "cores": threads, "nproc": os.cpu_count(), "affinity": affinity,
+            "cpu_model": cpu_model(), "kind": "port",
             "assign_value": assign_snps_per_s, "assign_unit": "SNPs/s (all n x K terms of a SNP = 1)",
+            "assign_extrapolated": True, "assign_pairs_timed": pairs, "assign_pairs_of_full_output": int(beagle.n * K),
             "sample": "first %d SNPs x %d ind of the same synthetic matrix, K=%d populations, %d sweeps in %.1f s "
                       "(OpenMP threads=%d; per-population gather %.2f s not included); assignment leg: %d (individual, population) "
                       "scans over the sample timed, %.2f ms each, of the %d a full matrix needs" %

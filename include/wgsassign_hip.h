@@ -42,6 +42,11 @@ typedef struct wgs_em wgs_em;         /* a batch of EM fits over one wgs_beagle 
 /* ------------------------------------------------------------------ context */
 const char *wgs_last_error(void);
 int wgs_version(void);
+/* sha256[:16] over every source of the library / over the sources of the EM and scoring kernels (em_kernels.hip,
+ * assign_kernels.hip, common.h, log_table.h), fixed at build time: profiles record them, bench.py quotes hardware
+ * counters only from a profile whose kernels id equals the loaded library's. */
+const char *wgs_build_id(void);
+const char *wgs_kernels_id(void);
 int wgs_device_count(int *count);
 int wgs_ctx_create(int device, wgs_ctx **out);
 void wgs_ctx_destroy(wgs_ctx *ctx);
@@ -209,6 +214,10 @@ int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out
 int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, double tole, int64_t m_total,
             wgs_comm *comm, int32_t P, int32_t batch, int em_mode, int score_mode, double *ll_out, float *parts_out,
             int32_t *iters_out);
+/* Phases of the last wgs_loo of this process: stats[0..5] = seconds in the EM re-fits (wgs_em_fit incl. its exact
+ * chains), in the scoring sweeps (+ cross-rank totals), in the exact partition chains; EM sweep kernel ms; EM batches;
+ * batched chain resolutions of the re-fits. */
+int wgs_loo_stats(double *stats);
 
 /* Test hooks: (chain, block) pairs of the last walk that took the literal serial loop / walked in all;
  * the literal one-lane-per-chain kernel behind wgs_assign_parts_exact, whatever P. */

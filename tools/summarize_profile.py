@@ -44,6 +44,14 @@ def main():
                 if any(t in k for t in KERNELS):
                     counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     summary = {"config": config, "kernels": {}}
+    # what was profiled: the ids the library on the GPU box reported (tools/gpu_prof.sh), and this tree's commit
+    ids = os.path.join(ROOT, "gpurun_out", prefix + "_ids.json")
+    if os.path.exists(ids):
+        summary.update(json.load(open(ids)))
+    import subprocess
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "wgsassign_amd/csrc", "include"], capture_output=True, text=True).stdout.strip()
+    summary["git_head"] = head + ("+uncommitted changes under csrc/" if dirty else "")
     if len(sys.argv) > 4:   # m_per_gpu n K mode, so bench.py can match its workload to this measurement
         summary["bench_config"] = {"snps_per_gpu": int(sys.argv[4]), "n": int(sys.argv[5]), "K": int(sys.argv[6]), "mode": sys.argv[7]}
     for k, cs in counters.items():

@@ -28,6 +28,8 @@ ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_double), c
 SIGNATURES = {
     "wgs_last_error": (ctypes.c_char_p, []),
     "wgs_version": (c_int, []),
+    "wgs_build_id": (ctypes.c_char_p, []),
+    "wgs_kernels_id": (ctypes.c_char_p, []),
     "wgs_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "wgs_ctx_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
     "wgs_ctx_destroy": (None, [c_vp]),
@@ -113,6 +115,7 @@ SIGNATURES = {
     "wgs_score_chains_prepare": (c_int, [c_vp, c_i32, c_f64p]),
     "wgs_score_chains_walk": (c_int, [c_vp, c_f32p, c_f32p]),
     "wgs_loo": (c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_double, c_i64, c_vp, c_i32, c_i32, c_int, c_int, c_f64p, c_f32p, c_i32p]),
+    "wgs_loo_stats": (c_int, [c_f64p]),
     "wgs_score_last_serial_blocks": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_debug_parts_exact_literal": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_f32p, c_f32p]),
     "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),

@@ -28,16 +28,41 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+KERNEL_SOURCES = ["em_kernels.hip", "assign_kernels.hip", "common.h", "log_table.h"]   # what the profiled kernels are made of
+
+
+def source_ids():
+    """(build id, kernels id): sha256[:16] over every source of the library / over the sources of the EM and scoring
+    kernels.  Compiled into the library (wgs_build_id, wgs_kernels_id) and written into every profile summary
+    (tools/summarize_profile.py), so that bench.py quotes counters only from a profile of the kernels it is timing."""
+    import hashlib
+
+    def digest(paths):
+        h = hashlib.sha256()
+        for p in paths:
+            h.update(os.path.basename(p).encode() + b"\0")
+            h.update(open(p, "rb").read())
+        return h.hexdigest()[:16]
+    every = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) and f != "build_id.h")
+    every.append(os.path.join(HERE, "..", "include", "wgsassign_hip.h"))
+    return digest(every), digest([os.path.join(CSRC, f) for f in KERNEL_SOURCES])
+
+
 def build(force=False, verbose=False):
     cc = hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "log_table.h"), os.path.join(CSRC, "reader_text.h"),
                os.path.join(HERE, "..", "include", "wgsassign_hip.h")]
+    id_header = os.path.join(CSRC, "build_id.h")
+    text = '#define WGS_BUILD_ID "%s"\n#define WGS_KERNELS_ID "%s"\n' % source_ids()
+    if not os.path.exists(id_header) or open(id_header).read() != text:
+        with open(id_header, "w") as fh:
+            fh.write(text)
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        if force or _stale(o, [s] + headers + ([id_header] if src == "api.hip" else [])):
             if src.endswith(".cpp"):      # host-only C++ (the streamed reader)
                 jobs.append([cc, "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", s, "-o", o])
             else:

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <string>
 
+#include "build_id.h"
 #include "common.h"
 
 static thread_local std::string g_err;
@@ -27,6 +28,8 @@ extern "C" {
 
 const char *wgs_last_error(void) { return g_err.c_str(); }
 int wgs_version(void) { return 1; }
+const char *wgs_build_id(void) { return WGS_BUILD_ID; }
+const char *wgs_kernels_id(void) { return WGS_KERNELS_ID; }
 
 int wgs_device_count(int *count)
 {
@@ -1237,9 +1240,24 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
  *   a       in: the full-population estimates; out: each population's LAST re-fit (glassy.py:89);
  *   batch   re-fits per EM batch, 0 = what fits the free device memory (agreed across ranks);
  *   ll_out  host float64 [n*K] (overwritten); parts_out host float32 [n*P*K] or NULL; iters_out [n]. */
+static double g_loo_stats[6];      // of the last wgs_loo of this process: see wgs_loo_stats
+
+static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+/* Phases of the last wgs_loo: stats[0..5] = seconds in the EM re-fits (wgs_em_fit incl. its exact chains), in the
+ * scoring sweeps (+ their cross-rank totals), in the exact partition chains; EM sweep kernel ms; EM batches; chain
+ * resolutions of the re-fits. */
+int wgs_loo_stats(double *stats)
+{
+    WGS_REQUIRE(stats, "null argument");
+    for (int i = 0; i < 6; ++i) stats[i] = g_loo_stats[i];
+    return 0;
+}
+
 int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm,
             int32_t P, int32_t batch, int em_mode, int score_mode, double *ll_out, float *parts_out, int32_t *iters_out)
 {
+    for (double &x : g_loo_stats) x = 0.0;
     WGS_REQUIRE(b && a && ll_out && iters_out, "null argument");
     if (!scored) scored = b;
     WGS_REQUIRE(scored->n == b->n && scored->m == b->m && scored->n_groups == b->n_groups && scored->group_of == b->group_of,
@@ -1283,9 +1301,20 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
         wgs_em *em = nullptr;
         wgs_score *sc = nullptr;
         auto guard = on_failure([&] { wgs_score_destroy(sc); wgs_em_destroy(em); });
+        double t_phase = wall_s();
         int rc = wgs_em_create(b, nb, grp.data(), skip.data(), em_mode, &em);
         if (rc) return rc;
         if ((rc = wgs_em_fit(em, max_iter, tole, m_total, comm, 0.0, iters_out + i0))) return rc;
+        {
+            int32_t it = 0, cb = 0;
+            double sec = 0.0, sweep_ms = 0.0;
+            wgs_em_fit_stats(em, &it, &cb, &sec, &sweep_ms);
+            g_loo_stats[0] += wall_s() - t_phase;
+            g_loo_stats[3] += sweep_ms;
+            g_loo_stats[4] += 1.0;
+            g_loo_stats[5] += cb;
+        }
+        t_phase = wall_s();
         for (int x = 0; x < nb; ++x) {
             const int npop = counts[grp[x]] - 1;
             const double lo = 1.0 / (2.0 * (npop + 1));
@@ -1321,6 +1350,8 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
             }
         }
         for (size_t c = (size_t)i0 * K; c < (size_t)i1 * K; ++c) ll_out[c] = sums[c];
+        g_loo_stats[1] += wall_s() - t_phase;
+        t_phase = wall_s();
         if (parts_out) {
             if ((rc = wgs_score_chains_prepare(sc, P, world > 1 && rank > 0 ? start.data() : nullptr))) return rc;
             parts.assign(cells * P, 0.0f);
@@ -1338,6 +1369,7 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
             }
             const std::vector<float> &fin = world > 1 ? carry : parts;
             for (size_t c = (size_t)i0 * P * K; c < (size_t)i1 * P * K; ++c) parts_out[c] = fin[c];
+            g_loo_stats[2] += wall_s() - t_phase;
         }
         // the last re-fit of each population in this batch becomes the current column
         std::vector<int32_t> last(K, -1);
