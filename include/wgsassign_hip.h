@@ -166,11 +166,9 @@ const float *wgs_afset_col_dev(wgs_afset *a, int32_t col);
  * (glassy_cy.pyx:18-21), accumulated in float64 (the reference sums with np.sum(dtype=float),
  * glassy.py:38) in a fixed order (run-to-run reproducible).  colptr (may be NULL) overrides the frequency vector per (individual, k):
  * colptr[i*K + k] is a device pointer to m floats -- this is how the leave-one-out scoring of
- * glassy.py:87-105 (per-individual columns, sticky overwrite) is expressed.  With P > 1 also
- * fills parts[(i*P + p)*K + k], the sum over SNPs whose GLOBAL index is p modulo P
- * (utils.py:129-151).  out/parts are host float64 buffers, summed into (caller zeroes). */
-int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
-               double *out, double *parts);
+ * glassy.py:87-105 (per-individual columns, sticky overwrite) is expressed.  out is a host float64
+ * buffer [n*K], summed into (caller zeroes).  Partition sums (utils.py:129-151): wgs_assign_parts_exact. */
+int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int mode, double *out);
 
 /* utils.partition_loglikes(per_site_ll, P) -- utils.py:129-151 -- for every (individual, population)
  * pair, BIT-EXACT: the reference accumulates each partition serially in float32 in site order
@@ -253,11 +251,8 @@ int wgs_comm_allreduce_buffer(wgs_comm *c, int64_t n, double *host_out);
  * individuals of the observed-information term, and n_tilde = 0.5 * f * a * (1 - a).  The slabs of
  * `b` must be the populations of `a`'s columns.  Outputs are host (m, K) float32 matrices. */
 int wgs_fisher_obs(wgs_beagle *b, wgs_afset *a, float *f_obs_mK, float *ne_obs_mK);
-/* fisher.fisher_obs_ind -- fisher.py:46-60 over fisher_cy.pyx:41-65: ne_sum[i] += the sum over this
- * shard's SNPs of individual i's n_tilde (float64); the caller divides by the SNP count
- * (the reference takes np.mean of the float32 per-site vector). */
-int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum);
-/* The per-site float32 values themselves for individuals [i0, i0+count) of ONE population
+/* fisher.fisher_obs_ind -- fisher.py:46-60 over fisher_cy.pyx:41-65 -- is wgs_fisher_ind_means / _sums below.
+ * The per-site float32 values themselves for individuals [i0, i0+count) of ONE population
  * (rows_out[(i - i0) * m + s]), so the host can apply np.mean to each row exactly as fisher.py:59. */
 int wgs_fisher_ind_sites(wgs_beagle *b, wgs_afset *a, int32_t i0, int32_t count, float *rows_out);
 /* ... and np.mean of each of those rows formed on the device exactly as NumPy forms it (pairwise float32 sum, float64
@@ -344,6 +339,12 @@ int wgs_debug_rcp_error(wgs_ctx *ctx, int exponent, double *max_rel);
  * float32-rounded log differs from the device math library's, and the values themselves. */
 int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first);
 int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, int use_libm);
+
+/* Cross-check only: FLOAT64 partition sums parts[(i*P + p)*K + k] (labels = global site index % P) and totals from the
+ * round-1 kernel (lanes <-> pairs of individuals, tile ranges combined with float64 atomics): ~1e-5 from the
+ * reference's serial float32 partition sums, not reproducible run to run.  Not on the product path. */
+int wgs_debug_assign_parts_f64(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
+                               double *out, double *parts);
 
 /* Kernel time (HIP events on the context's stream) of the context's last wgs_assign / wgs_score_* call. */
 int wgs_assign_last_ms(wgs_ctx *ctx, float *ms);

@@ -87,7 +87,7 @@ int main(void)
     CHECK(wgs_ctx_sync(ctx));
     CHECK(wgs_afset_download(af, &A[0][0]));
     double out[N * K] = {0};
-    CHECK(wgs_assign(b, af, NULL, 1, WGS_MODE_EXACT, out, NULL));
+    CHECK(wgs_assign(b, af, NULL, WGS_MODE_EXACT, out));
     for (int i = 0; i < N * K; ++i)
         if (!(out[i] < 0.0) || !isfinite(out[i])) {
             fprintf(stderr, "log-likelihood %d not negative/finite: %g\n", i, out[i]);

@@ -78,7 +78,6 @@ SIGNATURES = {
     "wgs_comm_buffer": (c_vp, [c_vp, c_i64]),
     "wgs_comm_allreduce_buffer": (c_int, [c_vp, c_i64, c_f64p]),
     "wgs_fisher_obs": (c_int, [c_vp, c_vp, c_f32p, c_f32p]),
-    "wgs_fisher_obs_ind": (c_int, [c_vp, c_vp, c_f64p]),
     "wgs_fisher_ind_sites": (c_int, [c_vp, c_vp, c_i32, c_i32, c_f32p]),
     "wgs_fisher_ind_means": (c_int, [c_vp, c_vp, c_i32, c_i32, c_f32p]),
     "wgs_fisher_ind_sums": (c_int, [c_vp, c_vp, c_i32, c_i32, c_f32p, c_f32p]),
@@ -118,7 +117,8 @@ SIGNATURES = {
     "wgs_loo_stats": (c_int, [c_f64p]),
     "wgs_score_last_serial_blocks": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_debug_parts_exact_literal": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_f32p, c_f32p]),
-    "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),
+    "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_int, c_f64p]),
+    "wgs_debug_assign_parts_f64": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),
 }
 
 _lib = None

@@ -970,7 +970,7 @@ int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, in
         HIP_TRY(hipMalloc(&sc->d_colptr, sizeof(float *) * sc->cells));
         HIP_TRY(hipMemcpy(sc->d_colptr, colptr, sizeof(float *) * sc->cells, hipMemcpyHostToDevice));
     }
-    const int np_sweep = score_pairs_per_wave(a->K), np_chain = chain_pairs_per_wave(a->K, sc->per_ind);
+    const int np_sweep = score_pairs_per_wave(a->K, sc->per_ind), np_chain = chain_pairs_per_wave(a->K, sc->per_ind);
     if (build_slab_table(sc, np_sweep, 0)) return 1;
     if (np_chain == np_sweep) {
         sc->d_slabs[1] = sc->d_slabs[0];
@@ -1157,12 +1157,34 @@ int wgs_score_last_serial_blocks(wgs_score *sc, int64_t *total_blocks)
     return sc->last_serial_blocks;
 }
 
-int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode, double *out, double *parts)
+int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int mode, double *out)
 {
     WGS_REQUIRE(b && a && out, "null argument");
     WGS_REQUIRE(a->m == b->m, "allele frequencies cover %lld SNPs, the Beagle shard %lld", (long long)a->m, (long long)b->m);
+    wgs_ctx *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t cells = (size_t)b->n * a->K;
+    ctx->last_assign_ms = 0.0f;
+    std::vector<double> h(cells);
+    // one launch over all population slabs, reproducible sums (wgs_score_sums)
+    wgs_score *sc = nullptr;
+    int rc = wgs_score_create(b, a, colptr, 0, (int32_t)b->n, &sc);
+    if (!rc) rc = wgs_score_sums(sc, mode, h.data());
+    wgs_score_destroy(sc);
+    if (rc) return rc;
+    for (size_t c = 0; c < cells; ++c) out[c] += h[c];
+    return 0;
+}
+
+/* Cross-check only (tests, tools/check_fast_mode.py): FLOAT64 partition sums (labels = global site index % P) from the
+ * round-1 kernel that maps lanes to pairs of individuals and combines tile ranges with float64 atomics -- within
+ * ~1e-5 of the reference's serial float32 partition sums and not reproducible run to run.  The product path is
+ * wgs_assign_parts_exact / wgs_score_chains_*.  out [n*K] and parts [n*P*K] are accumulated into. */
+int wgs_debug_assign_parts_f64(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode, double *out, double *parts)
+{
+    WGS_REQUIRE(b && a && out && parts, "null argument");
+    WGS_REQUIRE(a->m == b->m, "allele frequencies cover %lld SNPs, the Beagle shard %lld", (long long)a->m, (long long)b->m);
     WGS_REQUIRE(P >= 1, "partition count must be >= 1");
-    WGS_REQUIRE(P == 1 || parts, "parts buffer required when P > 1");
     wgs_ctx *ctx = b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const int K = a->K;
@@ -1170,17 +1192,6 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t 
     const size_t cells = (size_t)n * P * K;
     ctx->last_assign_ms = 0.0f;
     std::vector<double> h(cells);
-    if (P == 1) {
-        // one launch over all population slabs, reproducible sums (wgs_score_sums)
-        wgs_score *sc = nullptr;
-        int rc = wgs_score_create(b, a, colptr, 0, (int32_t)n, &sc);
-        if (!rc) rc = wgs_score_sums(sc, mode, h.data());
-        wgs_score_destroy(sc);
-        if (rc) return rc;
-        for (size_t c = 0; c < cells; ++c) out[c] += h[c];
-        return 0;
-    }
-    // P > 1: float64 partition sums (the WGSASSIGN_PARTS=fast path), lane <-> individual pair, one slab per launch
     // one grow-only workspace: [cells doubles | K shared pointers | n*K per-individual pointers]
     const size_t off_acol = (sizeof(double) * cells + 255) & ~(size_t)255;
     const size_t off_colptr = (off_acol + sizeof(float *) * K + 255) & ~(size_t)255;
@@ -1522,28 +1533,6 @@ int wgs_fisher_obs(wgs_beagle *b, wgs_afset *a, float *f_obs_mK, float *ne_obs_m
     if (launch_transpose_Km_to_mK(ctx, d_ne, d_t, b->m, K)) return 1;
     HIP_TRY(hipMemcpyAsync(ne_obs_mK, d_t, mk * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
-}
-
-int wgs_fisher_obs_ind(wgs_beagle *b, wgs_afset *a, double *ne_sum)
-{
-    WGS_REQUIRE(b && a && ne_sum, "null argument");
-    WGS_REQUIRE(a->m == b->m && a->K == b->n_groups, "allele frequencies do not match the population slabs");
-    wgs_ctx *ctx = b->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
-    void *ws = nullptr;
-    if (wgs_ctx_workspace(ctx, sizeof(double) * b->n, &ws)) return 1;
-    double *d_out = reinterpret_cast<double *>(ws);
-    HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(double) * b->n, ctx->stream));
-    for (int g = 0; g < b->n_groups; ++g) {
-        const Slab &s = b->slabs[g];
-        if (s.ncols == 0) continue;
-        if (launch_fisher_ind(ctx, s.base, s.d_members, a->buf + (size_t)g * a->m, d_out, b->m, s.npairs, s.ncols)) return 1;
-    }
-    std::vector<double> h(b->n);
-    HIP_TRY(hipMemcpyAsync(h.data(), d_out, sizeof(double) * b->n, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int64_t i = 0; i < b->n; ++i) ne_sum[i] += h[i];
     return 0;
 }
 

@@ -246,13 +246,24 @@ __device__ __forceinline__ bool decode_wave(const ScoreArgs &A, WaveWork<NP> &w)
     return true;
 }
 
-// Register budget: 3 waves per SIMD (<= 168 VGPRs) with shared columns, 2 (<= 256) with the per-individual
-// pointer and frequency tables of leave-one-out; beyond 256 the compiler would shuttle values through AGPRs.
-#ifndef WGS_SWEEP_MIN_BLOCKS
-#define WGS_SWEEP_MIN_BLOCKS 3
-#endif
+// Register budget: 3 waves per SIMD (<= 168 VGPRs) where the instantiation fits it WITHOUT spilling -- shared
+// columns with 8 (exact) or 10 (float32) accumulator pairs per lane, except KB = 8 whose ten hoisted frequencies in
+// double push it over --, 2 (<= 256) otherwise and with the per-individual pointer and frequency tables of
+// leave-one-out.  tools/kernel_resources.py prints what the compiler made of every instantiation
+// (profiles/r03_kernel_resources.txt): none spills.
+constexpr int sweep_waves_per_simd(int KB, int NP, int MODE, bool PER_IND)
+{
+    if (PER_IND) return 2;
+    if (MODE == WGS_MODE_EXACT) return (KB * NP <= 8 && KB != 8) ? 3 : 2;
+    return (KB * NP > 10 || KB > 8) ? 2 : 3;
+}
+// Pairs of slab columns per wave: two halve the per-tile frequency loads and conversions per term (measured
+// 174 -> 150 ms at K = 10 as two passes of 5) while the accumulators leave room for it.
+constexpr int sweep_pairs(int KB, bool PER_IND) { return KB <= (PER_IND ? 4 : 6) ? 2 : 1; }
+constexpr int chain_pairs(int KB, bool PER_IND) { return !PER_IND && KB <= 4 ? 2 : 1; }
+
 template <int KB, int NP, int MODE, bool PER_IND>
-__global__ __launch_bounds__(256, (PER_IND || KB * NP > 10 || KB > 8) ? 2 : WGS_SWEEP_MIN_BLOCKS) void score_sweep_kernel(ScoreArgs A)
+__global__ __launch_bounds__(256, sweep_waves_per_simd(KB, NP, MODE, PER_IND)) void score_sweep_kernel(ScoreArgs A)
 {
     __shared__ double2 tab_lds[WGS_LOG_N * WGS_LOG_REP];
     const double2 *tab = load_log_table(tab_lds);
@@ -859,14 +870,12 @@ static int pick_kb(int K, int kb_max = 10)
     return best;
 }
 
-// NP = 2 pairs per wave halves the per-tile frequency loads/conversions per term (measured 174 -> 150 ms at
-// K = 10, KB = 5); for KB >= 7 the accumulators leave no room for it.
-int score_pairs_per_wave(int K) { return pick_kb(K) <= 6 ? 2 : 1; }
+int score_pairs_per_wave(int K, bool per_ind) { return sweep_pairs(pick_kb(K), per_ind); }
 // The chain kernel keeps three float32 per (cell, lane) instead of one float64; with per-individual columns
 // its pointer and frequency tables leave room for one pair only.
 // It stays with batches of at most 8 populations (9 and 10 would spill).
 static int pick_kb_chain(int K) { return pick_kb(K, 8); }
-int chain_pairs_per_wave(int K, bool per_ind) { return per_ind ? 1 : (pick_kb_chain(K) <= 6 ? 2 : 1); }
+int chain_pairs_per_wave(int K, bool per_ind) { return chain_pairs(pick_kb_chain(K), per_ind); }
 
 // The float64 partition sums of WGSASSIGN_PARTS=fast (P > 1): lane <-> individual pair, one slab per launch.
 int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
@@ -894,15 +903,15 @@ int launch_assign(wgs_ctx *ctx, const AssignArgs &a_in, int mode)
     }
 }
 
-#define WGS_FOR_KB_NP(X, K)                \
-    switch (pick_kb(K)) {                  \
-        case 4: X(4, 2); break;            \
-        case 5: X(5, 2); break;            \
-        case 6: X(6, 2); break;            \
-        case 7: X(7, 1); break;            \
-        case 8: X(8, 1); break;            \
-        case 9: X(9, 1); break;            \
-        default: X(10, 1); break;          \
+#define WGS_FOR_KB(X, K)                \
+    switch (pick_kb(K)) {               \
+        case 4: X(4); break;            \
+        case 5: X(5); break;            \
+        case 6: X(6); break;            \
+        case 7: X(7); break;            \
+        case 8: X(8); break;            \
+        case 9: X(9); break;            \
+        default: X(10); break;          \
     }
 
 int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode)
@@ -913,17 +922,17 @@ int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode)
     WGS_REQUIRE(waves < (1ll << 32), "scoring sweep: too many work units for one launch");
     dim3 grid((unsigned)((waves + 3) / 4));
     const bool per_ind = a.colptr != nullptr;
-#define WGS_SWEEP(KB, NP)                                                                                                      \
-    do {                                                                                                                       \
-        if (mode == WGS_MODE_EXACT) {                                                                                          \
-            if (per_ind) hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_EXACT, true>), grid, dim3(256), 0, ctx->stream, a);  \
-            else hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_EXACT, false>), grid, dim3(256), 0, ctx->stream, a);         \
-        } else {                                                                                                               \
-            if (per_ind) hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_FAST, true>), grid, dim3(256), 0, ctx->stream, a);   \
-            else hipLaunchKernelGGL((score_sweep_kernel<KB, NP, WGS_MODE_FAST, false>), grid, dim3(256), 0, ctx->stream, a);          \
-        }                                                                                                                      \
+#define WGS_SWEEP(KB)                                                                                                                          \
+    do {                                                                                                                                       \
+        if (mode == WGS_MODE_EXACT) {                                                                                                          \
+            if (per_ind) hipLaunchKernelGGL((score_sweep_kernel<KB, sweep_pairs(KB, true), WGS_MODE_EXACT, true>), grid, dim3(256), 0, ctx->stream, a);   \
+            else hipLaunchKernelGGL((score_sweep_kernel<KB, sweep_pairs(KB, false), WGS_MODE_EXACT, false>), grid, dim3(256), 0, ctx->stream, a);         \
+        } else {                                                                                                                               \
+            if (per_ind) hipLaunchKernelGGL((score_sweep_kernel<KB, sweep_pairs(KB, true), WGS_MODE_FAST, true>), grid, dim3(256), 0, ctx->stream, a);    \
+            else hipLaunchKernelGGL((score_sweep_kernel<KB, sweep_pairs(KB, false), WGS_MODE_FAST, false>), grid, dim3(256), 0, ctx->stream, a);          \
+        }                                                                                                                                      \
     } while (0)
-    WGS_FOR_KB_NP(WGS_SWEEP, a.K)
+    WGS_FOR_KB(WGS_SWEEP, a.K)
 #undef WGS_SWEEP
     HIP_TRY(hipGetLastError());
     return 0;
@@ -962,17 +971,17 @@ int launch_chain_cand(wgs_ctx *ctx, const ScoreArgs &a)
     const bool per_ind = a.colptr != nullptr;
     const size_t lds = chain_cand_lds_bytes(a.K, a.P, per_ind);
     WGS_REQUIRE(lds <= 96 * 1024, "partition chains: too many partitions for the block-parallel kernel");
-#define WGS_CAND(KB, NP)                                                                                              \
-    do {                                                                                                              \
-        if (per_ind) hipLaunchKernelGGL((chain_cand_kernel<KB, 1, true>), grid, dim3(256), lds, ctx->stream, a);      \
-        else hipLaunchKernelGGL((chain_cand_kernel<KB, NP, false>), grid, dim3(256), lds, ctx->stream, a);            \
+#define WGS_CAND(KB)                                                                                                                  \
+    do {                                                                                                                              \
+        if (per_ind) hipLaunchKernelGGL((chain_cand_kernel<KB, chain_pairs(KB, true), true>), grid, dim3(256), lds, ctx->stream, a);  \
+        else hipLaunchKernelGGL((chain_cand_kernel<KB, chain_pairs(KB, false), false>), grid, dim3(256), lds, ctx->stream, a);        \
     } while (0)
     switch (pick_kb_chain(a.K)) {
-        case 4: WGS_CAND(4, 2); break;
-        case 5: WGS_CAND(5, 2); break;
-        case 6: WGS_CAND(6, 2); break;
-        case 7: WGS_CAND(7, 1); break;
-        default: WGS_CAND(8, 1); break;
+        case 4: WGS_CAND(4); break;
+        case 5: WGS_CAND(5); break;
+        case 6: WGS_CAND(6); break;
+        case 7: WGS_CAND(7); break;
+        default: WGS_CAND(8); break;
     }
 #undef WGS_CAND
     HIP_TRY(hipGetLastError());

@@ -120,8 +120,6 @@ int launch_fisher_ind_sites(wgs_ctx *ctx, const float4 *slab, const int32_t *d_c
 int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m, int64_t divide_by, const int64_t *d_leaf_lo,
                          const int32_t *d_leaf_len, int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, const float *d_carry,
                          float *d_means);
-int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, const float *th, double *out, int64_t m,
-                      int npairs, int ncols);
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
@@ -200,7 +198,7 @@ struct WalkArgs {
     int32_t n, K, P, nblocks, row_lo, row_hi;
     int32_t *n_serial;             // device counter: blocks that took the literal serial loop (or nullptr)
 };
-int score_pairs_per_wave(int K);               // NP of the sweep for K populations (depends on the register batch KB)
+int score_pairs_per_wave(int K, bool per_ind); // NP of the sweep for K populations (depends on the register batch KB)
 int chain_pairs_per_wave(int K, bool per_ind); // NP of the chain kernel (the slab table must be built for it)
 int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode);
 int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix, double *chunks);

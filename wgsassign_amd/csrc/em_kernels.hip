@@ -768,44 +768,6 @@ __global__ __launch_bounds__(64) void pairwise_combine_kernel(const float *__res
     means[j] = m > 0 ? (float)((double)stack[0] / (double)m) : stack[0];
 }
 
-// Per individual: sum over this shard's SNPs of its effective-sample-size term (fisher_cy.pyx:41-65,
-// fisher.py:52-59 takes the mean).  lane <-> SNP, wave <-> (pair of individuals, range of tiles).
-__global__ __launch_bounds__(256) void fisher_ind_kernel(const float4 *__restrict__ slab, const int32_t *__restrict__ members,
-                                                        const float *__restrict__ th_vec, double *__restrict__ out, int64_t m,
-                                                        int npairs, int ncols, int tiles_per_wave)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
-    const int pair = (int)(wid % npairs);
-    const int64_t ntiles = (m + 63) >> 6;
-    const int64_t t0 = (wid / npairs) * tiles_per_wave;
-    int64_t t1 = t0 + tiles_per_wave;
-    if (t1 > ntiles) t1 = ntiles;
-    if (t0 >= t1) return;
-    double acc_a = 0.0, acc_b = 0.0;
-    for (int64_t t = t0; t < t1; ++t) {
-        const int64_t s = (t << 6) + lane;
-        const bool live = s < m;
-        const float th = th_vec[live ? s : m - 1];
-        const double thd = (double)th, omt = 1.0 - thd;
-        const float4 g = slab[((t * npairs + pair) << 6) + lane];
-        const float fa = fisher_term(g.x, g.y, th, thd, omt), fb = fisher_term(g.z, g.w, th, thd, omt);
-        const float na = (float)(((0.5 * (double)fa) * thd) * omt), nb = (float)(((0.5 * (double)fb) * thd) * omt);
-        acc_a += live ? (double)na : 0.0;
-        acc_b += live ? (double)nb : 0.0;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        acc_a += __shfl_down(acc_a, off, 64);
-        acc_b += __shfl_down(acc_b, off, 64);
-    }
-    if (lane == 0) {
-        atomicAdd(&out[members[2 * pair]], acc_a);
-        if (2 * pair + 1 < ncols) atomicAdd(&out[members[2 * pair + 1]], acc_b);
-    }
-}
-
-
 // Test hook: div_exact against the compiler's IEEE divide on operands shaped like the EM term's
 // (den = a float32 sum widened to double, num = p1 + 2*p2 with float32 p1, p2 >= 0, num <~ 2 den,
 // plus den = 0 and tiny/huge magnitudes).  Counts bitwise mismatches.
@@ -939,24 +901,6 @@ int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m
     hipLaunchKernelGGL(pairwise_leaf_kernel, grid, dim3(256), 0, ctx->stream, d_rows, m, d_leaf_lo, d_leaf_len, nleaf, d_leaf_sums);
     hipLaunchKernelGGL(pairwise_combine_kernel, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, ctx->stream, d_leaf_sums, nleaf, d_prog, nprog,
                        count, divide_by, d_carry, d_means);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-int launch_fisher_ind(wgs_ctx *ctx, const float4 *slab, const int32_t *members, const float *th, double *out, int64_t m,
-                      int npairs, int ncols)
-{
-    if (m <= 0 || npairs <= 0) return 0;
-    const int64_t ntiles = wgs_ntiles(m);
-    int64_t ranges = ((int64_t)ctx->cus * 32 + npairs - 1) / npairs;
-    if (ranges < 1) ranges = 1;
-    int64_t tpw = (ntiles + ranges - 1) / ranges;
-    if (tpw < 8) tpw = 8;
-    if (tpw > ntiles) tpw = ntiles;
-    ranges = (ntiles + tpw - 1) / tpw;
-    const int64_t waves = ranges * npairs;
-    hipLaunchKernelGGL(fisher_ind_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, slab, members, th, out, m,
-                       npairs, ncols, (int)tpw);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -447,8 +447,9 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
 
     Returns (out (n, K) float64, parts (n*P, K) float64 or None), already summed over ranks.
     colptr: optional (n, K) array of device addresses (per-individual frequency vectors).
-    P > 1 also returns float64 partition sums (the WGSASSIGN_PARTS=fast path; the reference's serial
-    float32 partition sums come from partition_sums_exact / Score).
+    P > 1 also returns FLOAT64 partition sums through the library's cross-check entry (wgs_debug_assign_parts_f64:
+    float64 atomics, ~1e-5 from the reference's serial float32 partition sums -- what WGSASSIGN_PARTS=fast selects and the
+    tests compare against); the reference's own partition sums come from partition_sums_exact / Score.
     """
     mode = default_mode() if mode is None else mode
     n, K = beagle.n, afset.K
@@ -463,8 +464,10 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
     out = np.zeros((n, K), dtype=np.float64)
     parts = np.zeros((n * P, K), dtype=np.float64) if P > 1 else None
     _keep, cp = _colptr_arg(colptr, n, K)
-    check(_lib.load().wgs_assign(beagle.handle, afset.handle, cp, int(P), mode, f64p(out),
-                                 f64p(parts) if parts is not None else None))
+    if P == 1:
+        check(_lib.load().wgs_assign(beagle.handle, afset.handle, cp, mode, f64p(out)))
+    else:
+        check(_lib.load().wgs_debug_assign_parts_f64(beagle.handle, afset.handle, cp, int(P), mode, f64p(out), f64p(parts)))
     assign.last_ms = last_assign_ms(beagle.ctx)
     if comm is not None and comm.world > 1:
         out = comm.allreduce_sum(out)
