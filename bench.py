@@ -73,7 +73,7 @@ def free_port():
             if p >= 65520:
                 continue
             try:
-                for q in (p + 1, p + 7, p + 8):
+                for q in (p + 1, p + 7, p + 8, p + 14, p + 15):
                     with socket.socket() as b:
                         b.bind(("127.0.0.1", q))
             except OSError:
@@ -87,14 +87,23 @@ def launch_ranks(n_ranks, fixed_env):
     status.  Only rank 0's stdout (the JSON line) is forwarded.  Children are separate processes started
     with subprocess -- this process never initialises the GPU and never execs."""
     argv = [sys.executable, os.path.abspath(__file__)] + [a for a in sys.argv[1:] if a != "--worker"] + ["--worker"]
-    for attempt, kind in enumerate(("", "socket")):
+    # Attempts, each with fresh child processes (wgsassign_amd.comm.comm_attempts; restated here because the launcher
+    # must not import the package): RCCL with dmabuf IPC between the ranks (HSA_ENABLE_IPC_MODE_LEGACY=0, what this
+    # host driver supports), RCCL with that setting flipped, the socket all-reduce.
+    first = os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if os.environ.get("WGSASSIGN_COMM", "rccl") == "rccl" and os.environ.get("WGSASSIGN_BACKEND") != "gloo":
+        attempts = [("rccl, HSA_ENABLE_IPC_MODE_LEGACY=" + first, {"HSA_ENABLE_IPC_MODE_LEGACY": first}),
+                    ("rccl, HSA_ENABLE_IPC_MODE_LEGACY=" + ("1" if first == "0" else "0"), {"HSA_ENABLE_IPC_MODE_LEGACY": "1" if first == "0" else "0"}),
+                    ("socket all-reduce", {"HSA_ENABLE_IPC_MODE_LEGACY": first, "WGSASSIGN_COMM": "socket"})]
+    else:
+        attempts = [("as configured", {"HSA_ENABLE_IPC_MODE_LEGACY": first})]
+    for attempt, (label, over) in enumerate(attempts):
         procs = []
         for env_r in fixed_env:
             env = dict(os.environ, **env_r)
-            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: what RCCL needs between processes on this host driver
-            if kind:
-                env["WGSASSIGN_COMM"] = kind
-                env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 7 * attempt)      # a fresh side-channel port
+            env.update(over)
+            env["WGS_BENCH_COMM_ATTEMPT"] = label
+            env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 7 * attempt)      # a fresh side-channel port per attempt
             # rank 0's stdout is filtered: only the JSON line goes to this process's stdout (librccl prints a version
             # banner on stdout when its communicator initialises); everything else is passed on to stderr
             out = subprocess.PIPE if env["RANK"] == "0" else subprocess.DEVNULL
@@ -126,8 +135,8 @@ def launch_ranks(n_ranks, fixed_env):
             th.join(10)
         if all(c == 0 for c in codes):
             return 0
-        if any(c == COMM_INIT_FAILED for c in codes) and not kind and os.environ.get("WGSASSIGN_COMM", "rccl") == "rccl":
-            print("bench.py: RCCL communicator did not initialise (exit 75); restarting the ranks over the socket all-reduce",
+        if any(c == COMM_INIT_FAILED for c in codes) and attempt + 1 < len(attempts):
+            print("bench.py: the communicator did not initialise (exit 75; %s); starting the ranks again: %s" % (label, attempts[attempt + 1][0]),
                   file=sys.stderr, flush=True)
             continue
         return next((c for c in codes if c > 0), 1)       # a rank's own status rather than the -SIGTERM of the ones ended here
@@ -205,6 +214,8 @@ def main():
             comm_note = "socket all-reduce (RCCL init failed: %s)" % comm.native_error
         else:
             comm_note = "rccl (library communicator, no torch)" if kind == "rccl" else "socket all-reduce"
+        if os.environ.get("WGS_BENCH_COMM_ATTEMPT"):
+            comm_note += " [launcher attempt: %s]" % os.environ["WGS_BENCH_COMM_ATTEMPT"]
     else:
         comm = wcomm.LocalComm()
     comm.force_device = True

@@ -166,3 +166,29 @@ def test_launch_local_ranks_retries_over_sockets_when_rccl_did_not_come_up(tmp_p
     assert sorted(os.listdir(tmp_path)) == ["rccl0", "rccl1", "socket0", "socket1"] or {"socket0", "socket1"} <= set(os.listdir(tmp_path))
     monkeypatch.setenv("WGSASSIGN_COMM", "socket")           # an explicit choice is not overridden
     assert comm.launch_local_ranks(2, [sys.executable, "-c", "import sys; sys.exit(75)"]) == 75
+
+
+def test_launch_local_ranks_tries_rccl_twice_and_sees_every_exit_status(tmp_path, monkeypatch):
+    """The attempts of comm.comm_attempts, each in fresh processes: RCCL with HSA_ENABLE_IPC_MODE_LEGACY=0, RCCL with
+    the setting flipped, sockets.  A status 75 counts whichever rank reports it and even when a lower rank has just
+    left with another status (a peer whose TCP star lost the rank that timed out)."""
+    import sys
+    from wgsassign_amd import comm
+    monkeypatch.delenv("WGSASSIGN_COMM", raising=False)
+    monkeypatch.delenv("WGSASSIGN_BACKEND", raising=False)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    assert [a[1] for a in comm.comm_attempts({})] == [{"HSA_ENABLE_IPC_MODE_LEGACY": "0"}, {"HSA_ENABLE_IPC_MODE_LEGACY": "1"},
+                                                      {"HSA_ENABLE_IPC_MODE_LEGACY": "0", "WGSASSIGN_COMM": "socket"}]
+    # comes up only with legacy IPC: the second attempt, still RCCL
+    code = ("import os, sys; e = os.environ; tag = e.get('WGSASSIGN_COMM', 'rccl') + e['HSA_ENABLE_IPC_MODE_LEGACY'] + '_' + e['RANK']; "
+            "open(os.path.join(%r, tag), 'w').close(); sys.exit(0 if e['HSA_ENABLE_IPC_MODE_LEGACY'] == '1' else 75)" % str(tmp_path))
+    assert comm.launch_local_ranks(2, [sys.executable, "-c", code]) == 0
+    assert sorted(os.listdir(tmp_path)) == ["rccl0_0", "rccl0_1", "rccl1_0", "rccl1_1"]
+    # rank 0 dies with status 1 at once, rank 1 reports 75 half a second later: still a communicator failure -> next attempt
+    for f in os.listdir(tmp_path):
+        os.remove(tmp_path / f)
+    code = ("import os, sys, time; e = os.environ; first = e.get('WGSASSIGN_COMM', 'rccl') == 'rccl' and e['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'; "
+            "open(os.path.join(%r, ('a' if first else 'b') + e['RANK']), 'w').close(); "
+            "(sys.exit(1) if e['RANK'] == '0' else (time.sleep(0.5), sys.exit(75))) if first else sys.exit(0)" % str(tmp_path))
+    assert comm.launch_local_ranks(2, [sys.executable, "-c", code]) == 0
+    assert sorted(os.listdir(tmp_path)) == ["a0", "a1", "b0", "b1"]

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 import synth
-from test_gpu_parity import close, nearly_all_identical, quiet, same, same_nan, RTOL_PARTS
+from test_gpu_parity import close, quiet, same, same_nan, RTOL_PARTS
 
 pytestmark = pytest.mark.gpu
 
@@ -61,13 +61,13 @@ def test_assign_shared_columns_against_oracle(wg, oracle, K):
     # (a) --get_pop_like shape: all individuals in one slab
     ll, text = quiet(wg.glassy.assignLL, L, af.copy(), 1)
     assert text.strip() == "%d individuals to assign to %d populations" % (n, K)
-    assert ll.dtype == np.float32 and nearly_all_identical(ll, ll_o), (K, "one slab")
+    assert ll.dtype == np.float32 and same_nan(ll, ll_o), (K, "one slab")
     # (b) the same sums from K population slabs of odd sizes (the layout --get_reference_af leaves on the device)
     group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
     b = wg.device.DeviceBeagle.from_host(L, group_of, K)
     afs = wg.device.AFSet.from_host(af)
     out, _ = wg.device.assign(b, afs)
-    assert nearly_all_identical(out.astype(np.float32), ll_o), (K, "population slabs")
+    assert same_nan(out.astype(np.float32), ll_o), (K, "population slabs")
     # run-to-run reproducible, bit for bit, in float64
     out2, _ = wg.device.assign(b, afs)
     assert same(out, out2)
@@ -87,7 +87,7 @@ def test_loo_per_individual_columns_against_oracle(wg, oracle, K, P):
     with np.errstate(all="ignore"):
         loo_o, parts_o = oracle.loo(L, af1, IDs, 4, 200, 1e-4, None, P)
         (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 200, 1e-4, None, P)
-    assert nearly_all_identical(loo, loo_o), (K, P)
+    assert same_nan(loo, loo_o), (K, P)
     assert same_nan(parts, parts_o), (K, P)          # serial float32 partition sums: bit-identical
     assert same_nan(af2, af1), (K, P)                # the sticky column overwrite
 
@@ -104,7 +104,7 @@ def test_loo_with_more_partitions_than_the_block_parallel_chains_take(wg, oracle
         loo_o, parts_o = oracle.loo(L, af1, IDs, 4, 200, 1e-4, None, P)
         (loo, parts), _ = quiet(wg.glassy.loo, L, af2, IDs, 1, 200, 1e-4, None, P)
     assert parts.shape == (len(IDs) * P, K)
-    assert nearly_all_identical(loo, loo_o) and same_nan(parts, parts_o) and same_nan(af2, af1)
+    assert same_nan(loo, loo_o) and same_nan(parts, parts_o) and same_nan(af2, af1)
 
 
 @pytest.mark.parametrize("K", [8, 10, 13])

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import synth
-from test_gpu_parity import nearly_all_identical, quiet, same, same_nan
+from test_gpu_parity import quiet, same, same_nan
 
 pytestmark = pytest.mark.gpu
 
@@ -52,11 +52,11 @@ def test_snp_counts_around_tile_and_block_edges(wg, oracle, m):
     assert list(iters) == list(iters_o) and same_nan(af, af_o), m
     with np.errstate(all="ignore"):
         ll, _ = quiet(wg.glassy.assignLL, L, af.copy(), 1)
-        assert nearly_all_identical(ll, oracle.assignLL(L, af_o.copy(), 4)), m
+        assert same_nan(ll, oracle.assignLL(L, af_o.copy(), 4)), m
         a1, a2 = af_o.copy(), af_o.copy()
         loo_o, parts_o = oracle.loo(L, a1, IDs, 4, 200, 1e-4, None, 2)
         (loo, parts), _ = quiet(wg.glassy.loo, L, a2, IDs, 1, 200, 1e-4, None, 2)
-    assert nearly_all_identical(loo, loo_o) and same_nan(parts, parts_o) and same_nan(a1, a2), m
+    assert same_nan(loo, loo_o) and same_nan(parts, parts_o) and same_nan(a1, a2), m
 
 
 def test_one_individual_one_population(wg, oracle):
@@ -68,7 +68,7 @@ def test_one_individual_one_population(wg, oracle):
     assert same_nan(f, f_o)
     af = np.clip(np.nan_to_num(f_o, nan=0.5), 0.25, 0.75).reshape(m, 1).astype(np.float32)
     ll, _ = quiet(wg.glassy.assignLL, L, af.copy(), 1)
-    assert ll.shape == (1, 1) and nearly_all_identical(ll, oracle.assignLL(L, af.copy(), 4))
+    assert ll.shape == (1, 1) and same_nan(ll, oracle.assignLL(L, af.copy(), 4))
     # leave-one-out of the only member: an empty re-fit -> NaN column, NaN likelihoods (glassy.py:69-89)
     with np.errstate(all="ignore"):
         a1, a2 = af.copy(), af.copy()

@@ -35,9 +35,10 @@ def same_nan(a, b):
 
 
 def nearly_all_identical(a, b, frac=0.99):
-    """float64-accumulated sums stored as float32: within 1e-6 everywhere and the very same float32
-    in (at least) 99 % of the entries (in practice all: the per-site values are bit-identical and only
-    the float64 summation order differs from NumPy's)."""
+    """For matrices that do NOT start at a multiple of 8192 sites (windows cut out of a larger matrix): the per-site
+    values are bit-identical but NumPy's float64 summation (chunks of 8192 sites from the window's first site) groups
+    them differently from the device (blocks of 4096 sites on the global grid) -- within 1e-6 everywhere and the very
+    same float32 in at least `frac` of the entries.  Everything that starts at site 0 is held to same_nan()."""
     a, b = np.asarray(a), np.asarray(b)
     return close(a, b) and np.mean(a.view(np.uint32) == b.view(np.uint32)) >= frac
 
@@ -147,7 +148,7 @@ def test_amre_assign(wg, golden):
     g = golden("amre_assign.npz")
     af = golden("amre_fit.npz")["pop_af"]
     logl, text = quiet(wg.glassy.assignLL, g["L"], af.copy(), 1)
-    assert logl.dtype == np.float32 and nearly_all_identical(logl, g["logl"])
+    assert logl.dtype == np.float32 and same_nan(logl, g["logl"])
     assert text.strip() == "34 individuals to assign to 5 populations"
 
 
@@ -156,7 +157,7 @@ def test_amre_loo(wg, golden, P):
     g, fit = golden("amre_loo.npz"), golden("amre_fit.npz")
     af = fit["pop_af"].copy()
     (ll, parts), _ = quiet(wg.glassy.loo, fit["L"], af, fit["IDs"], 1, 200, 1e-4, None, P)
-    assert nearly_all_identical(ll, g["loo_P%d" % P])
+    assert same_nan(ll, g["loo_P%d" % P])
     assert same(parts, g["parts_P%d" % P])          # serial float32 partition sums: bit-identical
     assert same(af, g["af_after_P%d" % P])          # the in-place, never-restored column overwrite
 
@@ -233,13 +234,13 @@ def test_synth_mid(wg, golden):
     (pops, af, iters), _ = quiet(wg.emMAF.emMAF_populations, L, IDs, 200, 1e-4)
     assert same(af, g["pop_af"]) and list(iters) == list(g["iters"])
     logl, _ = quiet(wg.glassy.assignLL, np.ascontiguousarray(L[:5000]), np.ascontiguousarray(af[:5000]), 1)
-    assert nearly_all_identical(logl, g["logl_5000"])
+    assert same_nan(logl, g["logl_5000"])
     ms = int(g["loo_ms"])
     Ls = np.ascontiguousarray(L[:ms])
     (pops, af2, it2), _ = quiet(wg.emMAF.emMAF_populations, Ls, IDs, 200, 1e-4)
     assert same(af2, g["loo_pop_af"]) and list(it2) == list(g["loo_iters"])
     (ll, parts), _ = quiet(wg.glassy.loo, Ls, af2, IDs, 1, 200, 1e-4, None, 4)
-    assert nearly_all_identical(ll, g["loo"]) and same(parts, g["loo_parts"]) and same(af2, g["loo_af_after"])
+    assert same_nan(ll, g["loo"]) and same(parts, g["loo_parts"]) and same(af2, g["loo_af_after"])
 
 
 def test_fast_partition_sums_within_tolerance(wg, golden, monkeypatch):
@@ -432,10 +433,10 @@ def test_loo_in_batches(wg, golden, monkeypatch, batch):
     g, fit = golden("amre_loo.npz"), golden("amre_fit.npz")
     af = fit["pop_af"].copy()
     (ll, parts), text = quiet(wg.glassy.loo, fit["L"], af, fit["IDs"], 1, 200, 1e-4, None, 3)
-    assert nearly_all_identical(ll, g["loo_P3"]) and same(parts, g["parts_P3"]) and same(af, g["af_after_P3"])
+    assert same_nan(ll, g["loo_P3"]) and same(parts, g["parts_P3"]) and same(af, g["af_after_P3"])
     assert len([l for l in text.splitlines() if l.startswith("EM (MAF) converged")]) == 85
     gi = golden("synth_interleaved.npz")
     L, IDs = synth.make_beagle(6000, 37, 4, seed=88, interleave=True)
     af = gi["pop_af"].copy()
     (ll, _), _ = quiet(wg.glassy.loo, L, af, IDs, 1, 200, 1e-4, None, 1)
-    assert nearly_all_identical(ll, gi["loo"]) and same(af, gi["af_after"])
+    assert same_nan(ll, gi["loo"]) and same(af, gi["af_after"])

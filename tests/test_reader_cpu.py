@@ -207,7 +207,7 @@ def test_indexed_open_starts_at_any_row(tmp_path, monkeypatch, layout):
         raw = open(p, "rb").read()
         open(cut, "wb").write(raw[:len(raw) // 2] + bytes(len(raw) - len(raw) // 2))
         st_p = os.stat(p)
-        os.utime(cut, (st_p.st_atime, st_p.st_mtime))
+        os.utime(cut, ns=(st_p.st_atime_ns, st_p.st_mtime_ns))
         with pytest.raises(RuntimeError):
             with reader_cy.BeagleStream(cut, threads=4, index=idx, first_row=0) as st:
                 list(st.chunks(max_rows=333))
@@ -473,3 +473,50 @@ def test_text_hand_over_really_chunks(tmp_path, monkeypatch):
         _lib.check(lib.wgs_debug_reader_text_rows(st._h, 1 << 20, -1, _lib.f32p(rows), m, ctypes.byref(got)))
         assert got.value == m and rows.tobytes() == L.tobytes()
         assert lib.wgs_debug_reader_text_chunks(st._h) >= 9
+
+
+def test_index_cache_is_private_and_checked(tmp_path, monkeypatch):
+    """The cache of indices and site names: a per-user 0700 directory by default, files created exclusively (a planted
+    symlink is not followed), read only if they are regular files of this user; a names file with the wrong number of
+    lines (a run killed mid-write in an earlier version) is rebuilt, a same-size rewrite of the Beagle file is noticed
+    (modification time in nanoseconds)."""
+    from wgsassign_amd import reader_cy
+    monkeypatch.delenv("WGSASSIGN_INDEX_DIR", raising=False)
+    monkeypatch.setenv("XDG_CACHE_HOME", str(tmp_path / "cache"))
+    d = reader_cy.cache_dir()
+    assert d == str(tmp_path / "cache" / "wgsassign") and (os.stat(d).st_mode & 0o777) == 0o700
+    L, _ = synth.make_beagle(300, 5, 1, seed=2)
+    p = str(tmp_path / "a.beagle.gz")
+    write_beagle(p, L)
+    idx, nam = reader_cy.index_paths(p)
+    # a symlink planted where the temporary file would go must not be written through
+    victim = tmp_path / "victim"
+    victim.write_text("precious")
+    os.symlink(str(victim), idx + ".tmp.%d.0" % os.getpid())
+    samples, names = reader_cy.read_site_names(p)
+    assert victim.read_text() == "precious" and names == ["chr1_%d" % (s + 1) for s in range(300)]
+    assert (os.stat(idx).st_mode & 0o777) == 0o600 and (os.stat(nam).st_mode & 0o777) == 0o600
+    # truncated names file: rebuilt, not trusted
+    open(nam, "wb").write(open(nam, "rb").read()[:100])
+    assert reader_cy.read_site_names(p)[1] == names
+    # an index that is a symlink (to a perfectly good index) is not read
+    real = idx + ".real"
+    os.rename(idx, real)
+    os.symlink(real, idx)
+    assert not reader_cy._private_file(idx)
+    os.remove(idx)
+    os.rename(real, idx)
+    # same size, same second, different content: the key changes with the nanoseconds
+    st = os.stat(p)
+    L2 = L.copy()
+    L2[0, 0] = np.float32(0.5) if L[0, 0] != np.float32(0.5) else np.float32(0.25)
+    write_beagle(p, L2)
+    os.utime(p, ns=(st.st_atime_ns, st.st_mtime_ns + 1000))
+    assert reader_cy.index_paths(p)[0] != idx
+    # a cache directory others can write to is refused
+    bad = tmp_path / "shared"
+    bad.mkdir(mode=0o777)
+    os.chmod(str(bad), 0o777)
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(bad))
+    with pytest.raises(RuntimeError, match="not a private directory"):
+        reader_cy.cache_dir()

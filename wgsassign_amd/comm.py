@@ -470,22 +470,65 @@ def init_from_env(ctx=None):
     return TorchComm(device=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
 
+def usable_cpus():
+    """CPUs this process can really keep busy: its affinity set, cut down to the CPU-time quota of its control group
+    (cgroup v2 cpu.max / v1 cpu.cfs_quota_us) when there is one -- a container with 256 visible CPUs and a quota of 16
+    runs 256 OpenMP threads 50x slower than 16."""
+    n = len(os.sched_getaffinity(0))
+
+    def read(p):
+        try:
+            return open(p).read().split()
+        except OSError:
+            return None
+    v2 = read("/sys/fs/cgroup/cpu.max")
+    quota = None
+    if v2 and len(v2) == 2 and v2[0] != "max":
+        quota = float(v2[0]) / float(v2[1])
+    else:
+        q, per = read("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"), read("/sys/fs/cgroup/cpu/cpu.cfs_period_us")
+        if q and per and float(q[0]) > 0:
+            quota = float(q[0]) / float(per[0])
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n
+
+
+def comm_attempts(base):
+    """What a launcher tries, in order, each with fresh child processes: RCCL with dmabuf IPC between the ranks
+    (HSA_ENABLE_IPC_MODE_LEGACY=0 -- what this host driver supports, and the default here unless the caller's
+    environment says otherwise); RCCL with that setting flipped (other drivers only do legacy IPC); the socket
+    all-reduce, which needs nothing from the GPU runtime.  A rank leaves with COMM_INIT_FAILED (75) when its
+    communicator cannot be built or does not come up within the watchdog's time; any other failure ends the job.
+    Returns [(label, environment overrides)]."""
+    first = base.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if base.get("WGSASSIGN_COMM", "rccl") != "rccl" or base.get("WGSASSIGN_BACKEND") == "gloo":
+        return [("as configured", {"HSA_ENABLE_IPC_MODE_LEGACY": first})]
+    return [("rccl, HSA_ENABLE_IPC_MODE_LEGACY=%s" % first, {"HSA_ENABLE_IPC_MODE_LEGACY": first}),
+            ("rccl, HSA_ENABLE_IPC_MODE_LEGACY=%s" % ("1" if first == "0" else "0"), {"HSA_ENABLE_IPC_MODE_LEGACY": "1" if first == "0" else "0"}),
+            ("socket all-reduce", {"HSA_ENABLE_IPC_MODE_LEGACY": first, "WGSASSIGN_COMM": "socket"})]
+
+
 def launch_local_ranks(n, argv, env=None, poll=0.05):
-    """Start `argv` n times as ranks 0 .. n-1 of this node -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
-    MASTER_PORT set, a free port chosen -- and wait for them: what `WGSassign --gpus N` does instead of asking for
-    torchrun.  Rank 0 writes to this process's stdout, the others only to stderr.  The caller must not have touched
-    the GPU (children are separate processes; nothing is exec'ed).  When a rank fails the others are ended; returns
-    the first non-zero exit status, else 0."""
-    port = free_port_pair()
+    """Start `argv` n times as ranks 0 .. n-1 of this node -- RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, a free port chosen -- and wait for them: what `WGSassign --gpus N` does instead of
+    asking for torchrun.  Rank 0 writes to this process's stdout, the others only to stderr.  The caller must not have
+    touched the GPU (children are separate processes; nothing is exec'ed).  When ANY rank reports that its
+    communicator did not initialise (status 75) the ranks are started again with the next of comm_attempts().
+    Returns 0, or a failed rank's own status."""
+    import sys
     base = dict(os.environ if env is None else env)
-    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    status = _run_ranks(n, argv, base, port, poll)
-    if status == COMM_INIT_FAILED and base.get("WGSASSIGN_COMM", "rccl") == "rccl" and base.get("WGSASSIGN_BACKEND") != "gloo":
-        import sys
-        print("wgsassign_amd: the RCCL communicator did not initialise; starting the ranks again over the socket all-reduce",
+    attempts = comm_attempts(base)
+    codes = [1]
+    for i, (label, over) in enumerate(attempts):
+        codes = _run_ranks(n, argv, dict(base, **over), free_port_pair(), poll)
+        if all(c == 0 for c in codes):
+            return 0
+        if not any(c == COMM_INIT_FAILED for c in codes) or i + 1 == len(attempts):
+            break
+        print("wgsassign_amd: the communicator did not initialise (%s); starting the ranks again: %s" % (label, attempts[i + 1][0]),
               file=sys.stderr, flush=True)
-        status = _run_ranks(n, argv, dict(base, WGSASSIGN_COMM="socket"), free_port_pair(), poll)
-    return status
+    return next((c for c in codes if c > 0), 1)      # a rank's own status rather than the -SIGTERM of the ones ended here
 
 
 def free_port_pair(addr="127.0.0.1"):
@@ -506,7 +549,9 @@ def free_port_pair(addr="127.0.0.1"):
     raise RuntimeError("no two consecutive free ports on %s" % addr)
 
 
-def _run_ranks(n, argv, base, port, poll):
+def _run_ranks(n, argv, base, port, poll, grace=3.0):
+    """One attempt: every rank's exit status.  After the first failure the others get `grace` seconds to leave by
+    themselves (a rank whose peer failed fast may still be on its way to its own status 75), then they are ended."""
     import subprocess
     import time
     procs = []
@@ -514,18 +559,12 @@ def _run_ranks(n, argv, base, port, poll):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                  MASTER_PORT=str(port))
         procs.append(subprocess.Popen(argv, env=e, stdout=None if r == 0 else subprocess.DEVNULL))
-    status = 0
     try:
-        left = set(range(n))
-        while left:
-            for r in sorted(left):
-                rc = procs[r].poll()
-                if rc is None:
-                    continue
-                left.discard(r)
-                if rc != 0 and status == 0:
-                    status = rc if rc > 0 else 1
-            if status != 0:
+        failed_at = None
+        while any(p.poll() is None for p in procs):
+            if failed_at is None and any(p.poll() not in (None, 0) for p in procs):
+                failed_at = time.time()
+            if failed_at is not None and time.time() - failed_at > grace:
                 break
             time.sleep(poll)
     finally:
@@ -537,7 +576,8 @@ def _run_ranks(n, argv, base, port, poll):
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
-    return status
+                p.wait()
+    return [p.returncode for p in procs]
 
 
 SHARD_ALIGN = 8192      # NumPy's reductions work through 8192-element chunks (device.Score.sums)

@@ -14,6 +14,8 @@
 // of ten, one correctly rounded division -- identical to strtod for such inputs); anything else
 // (exponents, inf/nan, hex) goes through strtod itself.
 #include <dlfcn.h>
+#include <errno.h>
+#include <fcntl.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -778,13 +780,45 @@ struct BeagleIndex {
     std::vector<AccessPoint> points;
 };
 
+// size and modification time in NANOSECONDS: a same-size rewrite within one second must not reuse a stale index
 bool file_identity(const char *path, uint64_t &size, uint64_t &mtime)
 {
     struct stat st;
     if (stat(path, &st) != 0) return false;
     size = (uint64_t)st.st_size;
-    mtime = (uint64_t)st.st_mtime;
+    mtime = (uint64_t)st.st_mtim.tv_sec * 1000000000ull + (uint64_t)st.st_mtim.tv_nsec;
     return true;
+}
+
+// Cache files (index, site names) are written under a fresh name that must not exist (no symlink is followed, nothing
+// of another user is overwritten) and renamed into place; they are read only if they are regular files of this user.
+FILE *create_private(const std::string &final_path, std::string &tmp)
+{
+    for (int attempt = 0; attempt < 16; ++attempt) {
+        tmp = final_path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(attempt);
+        const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+        if (fd >= 0) {
+            FILE *f = fdopen(fd, "wb");
+            if (!f) close(fd);
+            return f;
+        }
+        if (errno != EEXIST) return nullptr;
+    }
+    return nullptr;
+}
+
+FILE *open_private(const char *path)
+{
+    const int fd = open(path, O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_uid != geteuid()) {
+        close(fd);
+        return nullptr;
+    }
+    FILE *f = fdopen(fd, "rb");
+    if (!f) close(fd);
+    return f;
 }
 
 // One inflate pass: count the sites, read the header, record access points every `span` output bytes.
@@ -1071,12 +1105,12 @@ void put(FILE *f, const T &v) { fwrite(&v, sizeof v, 1, f); }
 template <typename T>
 bool get(FILE *f, T &v) { return fread(&v, sizeof v, 1, f) == 1; }
 
-const char kIndexMagic[8] = {'W', 'G', 'S', 'I', 'D', 'X', '2', 0};     // 2: dictionaries stored deflated
+const char kIndexMagic[8] = {'W', 'G', 'S', 'I', 'D', 'X', '3', 0};     // 3: modification time in nanoseconds
 
 bool save_index(const char *path, const BeagleIndex &idx)
 {
-    const std::string tmp = std::string(path) + ".tmp";
-    FILE *f = fopen(tmp.c_str(), "wb");
+    std::string tmp;
+    FILE *f = create_private(path, tmp);
     if (!f) return false;
     fwrite(kIndexMagic, 1, 8, f);
     put(f, idx.file_size);
@@ -1111,14 +1145,16 @@ bool save_index(const char *path, const BeagleIndex &idx)
             fwrite(z.data(), 1, zn, f);
         }
     }
-    const bool ok = !ferror(f);
+    const bool ok = !ferror(f) && fflush(f) == 0;
     fclose(f);
-    return ok && rename(tmp.c_str(), path) == 0;     // atomic: readers never see a partial index
+    if (ok && rename(tmp.c_str(), path) == 0) return true;     // atomic: readers never see a partial index
+    unlink(tmp.c_str());
+    return false;
 }
 
 bool load_index(const char *path, BeagleIndex &idx)
 {
-    FILE *f = fopen(path, "rb");
+    FILE *f = open_private(path);
     if (!f) return false;
     char magic[8];
     bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kIndexMagic, 8) == 0;
@@ -1206,6 +1242,19 @@ int wgs_reader_build_index(const char *path, const char *index_path, const char 
     }
     if (rc) return rc;
     *sites = idx.sites;
+    // the site names first, then the index: an index in place implies that the names written with it are complete
+    // (both appear by rename; a run that is killed in between leaves a names file without an index -- rebuilt)
+    if (names_path) {
+        std::string tmp;
+        FILE *f = create_private(names_path, tmp);
+        const bool ok = f && fwrite(names.data(), 1, names.size(), f) == names.size() && fflush(f) == 0;
+        if (f) fclose(f);
+        if (!ok || rename(tmp.c_str(), names_path) != 0) {
+            if (f) unlink(tmp.c_str());
+            wgs_set_error("cannot write the site names to %s", names_path);
+            return 1;
+        }
+    }
     if (index_path) {
         if (max_points > 0 && (int64_t)idx.points.size() > max_points) {       // thin out evenly
             std::vector<AccessPoint> keep;
@@ -1217,15 +1266,6 @@ int wgs_reader_build_index(const char *path, const char *index_path, const char 
             wgs_set_error("cannot write the Beagle index %s", index_path);
             return 1;
         }
-    }
-    if (names_path) {
-        FILE *f = fopen(names_path, "wb");
-        if (!f || fwrite(names.data(), 1, names.size(), f) != names.size()) {
-            if (f) fclose(f);
-            wgs_set_error("cannot write the site names to %s", names_path);
-            return 1;
-        }
-        fclose(f);
     }
     return 0;
 }

@@ -162,30 +162,70 @@ def count_sites(path):
     return n.value
 
 
+def cache_dir():
+    """Where indices and site-name lists are cached: WGSASSIGN_INDEX_DIR, else a per-user directory
+    ($XDG_CACHE_HOME/wgsassign or ~/.cache/wgsassign; the per-user temporary directory when there is no home), created
+    with mode 0700.  A directory that belongs to somebody else, or that others may write to, is refused -- the access
+    points and line numbers of an index are trusted by every later run."""
+    d = os.environ.get("WGSASSIGN_INDEX_DIR")
+    if not d:
+        base = os.environ.get("XDG_CACHE_HOME") or (os.path.join(os.path.expanduser("~"), ".cache") if os.path.expanduser("~") != "~" else None)
+        d = os.path.join(base, "wgsassign") if base else os.path.join(tempfile.gettempdir(), "wgsassign-%d" % os.geteuid())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.geteuid() or (st.st_mode & 0o022 and not st.st_mode & 0o1000):
+        raise RuntimeError("index cache directory %s is not a private directory of this user (set WGSASSIGN_INDEX_DIR)" % d)
+    return d
+
+
 def index_paths(path):
-    """Where the index (and the site-name list) of a Beagle file are cached: the temporary directory
-    (WGSASSIGN_INDEX_DIR overrides it), keyed by the file's absolute path, size and modification time."""
+    """Index and site-name cache files of a Beagle file, keyed by its absolute path, size and modification time (ns)."""
     st = os.stat(path)
-    key = hashlib.sha1(("%s|%d|%d" % (os.path.abspath(path), st.st_size, int(st.st_mtime))).encode()).hexdigest()[:20]
-    base = os.path.join(os.environ.get("WGSASSIGN_INDEX_DIR", tempfile.gettempdir()), "wgsassign_" + key)
+    key = hashlib.sha1(("%s|%d|%d" % (os.path.abspath(path), st.st_size, st.st_mtime_ns)).encode()).hexdigest()[:20]
+    base = os.path.join(cache_dir(), "wgsassign_" + key)
     return base + ".idx", base + ".names"
 
 
+def _private_file(path):
+    """A regular file (not a symlink) of this user."""
+    try:
+        st = os.lstat(path)
+    except OSError:
+        return False
+    import stat as _stat
+    return _stat.S_ISREG(st.st_mode) and st.st_uid == os.geteuid()
+
+
+def _count_lines(path):
+    n = 0
+    with open(path, "rb") as fh:
+        while True:
+            buf = fh.read(16 << 20)
+            if not buf:
+                return n
+            n += buf.count(b"\n")
+
+
 def ensure_index(path, comm=None, names=False):
-    """ONE inflate pass per file and node: the first rank counts the sites, records the access points (and the
-    site names when asked) next to each other in the index cache; the other ranks wait and read the result.
+    """ONE inflate pass per file and node: the first rank OF EVERY NODE (LOCAL_RANK 0; the cache directory is node-local)
+    counts the sites, records the access points (and the site names when asked) in the index cache; the other ranks
+    wait and read the result.  A cached index is used only if it still describes the file (size, mtime in ns), belongs to
+    this user, and -- when names are wanted -- comes with a names file holding exactly one name per site.
     Returns (index_path, names_path or None, sites)."""
     lib = _lib.load()
     idx, nam = index_paths(path)
     rank = comm.rank if comm is not None else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", rank)) if comm is not None and comm.world > 1 else 0
 
     def valid():
         n = ctypes.c_int64()
-        ok = os.path.exists(idx) and lib.wgs_reader_index_sites(os.fsencode(path), os.fsencode(idx), ctypes.byref(n)) == 0
-        return (ok and (not names or os.path.exists(nam))), n.value
+        ok = _private_file(idx) and lib.wgs_reader_index_sites(os.fsencode(path), os.fsencode(idx), ctypes.byref(n)) == 0
+        if ok and names:
+            ok = _private_file(nam) and _count_lines(nam) == n.value
+        return ok, n.value
 
     ok, sites = valid()
-    if rank == 0 and not ok:
+    if local_rank == 0 and not ok:
         n = ctypes.c_int64()
         _lib.check(lib.wgs_reader_build_index(os.fsencode(path), os.fsencode(idx), os.fsencode(nam) if names else None,
                                               INDEX_SPAN_BYTES, INDEX_MAX_POINTS, ctypes.byref(n)))
