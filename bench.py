@@ -546,8 +546,11 @@ def cpu_baseline(beagle, group_of, K, ms, seconds=12.0):
     bit-exact C/OpenMP restatement -- on the first `ms` SNPs of the same synthetic matrix."""
     from oracle import oracle as orc
     orc.build()
+    from wgsassign_amd.comm import usable_cpus
     affinity = len(os.sched_getaffinity(0))
-    threads = int(os.environ.get("WGS_CPU_THREADS", affinity))      # every CPU this process may run on (SURVEY 8d: OMP_NUM_THREADS = nproc)
+    # every CPU this process can keep busy (SURVEY 8d: OMP_NUM_THREADS = nproc): the affinity set cut down to the control
+    # group's CPU quota -- the one-GPU box shows 256 CPUs with a quota of 16, where 256 OpenMP threads run 50x slower than 16
+    threads = int(os.environ.get("WGS_CPU_THREADS", usable_cpus()))
     rows = beagle.download_rows(0, ms)
     slabs = [orc.gather(rows, np.flatnonzero(group_of == k), threads) for k in range(K)]
     fs = [np.full(ms, 0.25, dtype=np.float32) for _ in range(K)]
@@ -577,7 +580,7 @@ def cpu_baseline(beagle, group_of, K, ms, seconds=12.0):
         pairs += 1
     t_pair = (time.perf_counter() - t_a0) / pairs
     assign_snps_per_s = ms / (t_pair * beagle.n * K)
-    return {"value": K * ms * sweeps / el, "unit": "SNP-updates/s", "cores": threads, "nproc": os.cpu_count(), "affinity": affinity,
+    return {"value": K * ms * sweeps / el, "unit": "SNP-updates/s", "cores": threads, "nproc": os.cpu_count(), "affinity": affinity, "cgroup_cpu_quota": usable_cpus(),
             "cpu_model": cpu_model(), "kind": "port",
             "assign_value": assign_snps_per_s, "assign_unit": "SNPs/s (all n x K terms of a SNP = 1)",
             "assign_extrapolated": True, "assign_pairs_timed": pairs, "assign_pairs_of_full_output": int(beagle.n * K),

@@ -198,8 +198,15 @@ void wgs_score_destroy(wgs_score *sc);
 int wgs_score_sums(wgs_score *sc, int mode, double *out);
 /* ... continued from the SNP shards before this one (NumPy's running total handed from shard to shard): see api.hip. */
 int wgs_score_total_from(wgs_score *sc, const double *carry_in, double *out);
+/* The same for ALL shards in one call: the running total goes from shard to shard in SNP order ON THE STREAM -- `world`
+ * broadcasts of n*K float64, one readback.  totals_out: the totals (every rank); before_out (may be NULL): the total of
+ * the shards before this one (wgs_score_chains_prepare's `start`).  comm NULL = one shard.  Needs wgs_score_sums first. */
+int wgs_score_totals_all(wgs_score *sc, wgs_comm *comm, double *totals_out, double *before_out);
 int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start);
 int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out);
+/* The walks of ALL shards in one call (every rank has prepared its block functions): `world` broadcasts of n*P*K
+ * float32 on the stream, one readback; parts_out receives the values after the last shard on every rank. */
+int wgs_score_chains_walk_all(wgs_score *sc, wgs_comm *comm, float *parts_out);
 /* glassy.loo(L, af, IDs, t, maf_iter, maf_tole, downsampled_L, num_partitions) -- glassy.py:47-112 -- in one
  * call on device-resident data: per individual (file order) the re-fit of its population without it
  * (wgs_em_fit, a batch of individuals at once), the clamp with n_pop - 1, the never-restored overwrite of
@@ -212,9 +219,9 @@ int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out
 int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, double tole, int64_t m_total,
             wgs_comm *comm, int32_t P, int32_t batch, int em_mode, int score_mode, double *ll_out, float *parts_out,
             int32_t *iters_out);
-/* Phases of the last wgs_loo of this process: stats[0..5] = seconds in the EM re-fits (wgs_em_fit incl. its exact
+/* Phases of the last wgs_loo of this process: stats[0..6] = seconds in the EM re-fits (wgs_em_fit incl. its exact
  * chains), in the scoring sweeps (+ cross-rank totals), in the exact partition chains; EM sweep kernel ms; EM batches;
- * batched chain resolutions of the re-fits. */
+ * batched chain resolutions of the re-fits; EM iterations enqueued. */
 int wgs_loo_stats(double *stats);
 
 /* Test hooks: (chain, block) pairs of the last walk that took the literal serial loop / walked in all;
@@ -237,6 +244,13 @@ void wgs_comm_destroy(wgs_comm *c);
 int wgs_comm_rank(wgs_comm *c, int *rank, int *world);
 /* In-place sum of n float64 in device memory, enqueued on the context's stream (pairs with wgs_em_step_dev). */
 int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n);
+/* Broadcast of `bytes` bytes (a multiple of 4) of DEVICE memory from rank `root`, enqueued on the context's stream: how
+ * a running value -- np.sum's float64 total, a float32 chain carry -- passes from SNP shard to SNP shard without a host
+ * round trip (ncclBroadcast; over a host-backed communicator: 32-bit words widened to float64 through its sum all-reduce). */
+int wgs_comm_bcast_dev(wgs_comm *c, void *dev_buf, int64_t bytes, int root);
+/* stats[0..3]: all-reduces, broadcasts, payload bytes, host round trips (stream synchronisations) of this
+ * communicator's collectives so far. */
+int wgs_comm_stats(wgs_comm *c, int64_t *stats);
 /* Same for a host buffer (staged through the device); returns when the result is back. */
 int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n);
 /* The communicator's device bounce buffer (>= n float64), e.g. as the target of wgs_em_step_dev;

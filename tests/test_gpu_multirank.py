@@ -229,11 +229,26 @@ with contextlib.redirect_stdout(io.StringIO()):
 assert af_c.tobytes() == af_p.tobytes() == np.ascontiguousarray(af[lo:hi]).tobytes() and list(it_c) == list(it_p)
 b = device.DeviceBeagle.from_host(np.ascontiguousarray(L[lo:hi]), group_of, K, site0=lo, ctx=ctx)
 afs = device.AFSet.from_host(np.ascontiguousarray(af[lo:hi]), ctx=ctx)
+import ctypes
+from wgsassign_amd import _lib
+def collectives():
+    st = (ctypes.c_int64 * 4)()
+    _lib.check(_lib.load().wgs_comm_stats(comm.handle, st))
+    return np.array(st[:2])                                   # all-reduces, broadcasts through the library's communicator
+c0 = collectives()
 out, _ = device.assign(b, afs, comm=comm)                      # --get_pop_like, SNP-sharded over 3 ranks
+# what crosses the ranks for the n x K totals in NumPy's order: `world` broadcasts (the running float64 total handed
+# from shard to shard on the stream), no all-reduce
+assert list(collectives() - c0) == [0, world], collectives() - c0
 import io, contextlib
 a1 = np.ascontiguousarray(af[lo:hi]).copy()
+c0, tm = collectives(), {{}}
 with contextlib.redirect_stdout(io.StringIO()):
-    ll, parts = glassy.loo_device(b, b, a1, group_of, 200, 1e-4, 2, comm=comm, verbose=False)      # one C call (wgs_loo)
+    ll, parts = glassy.loo_device(b, b, a1, group_of, 200, 1e-4, 2, comm=comm, verbose=False, timings=tm)      # one C call (wgs_loo)
+# --loo, one batch: the batch-size agreement + one all-reduce of the convergence sums per EM iteration enqueued;
+# `world` broadcasts per batched resolution of undecided fits, for the totals, and for the partition chains
+assert tm["one_call"] and tm["em_batches"] == 1
+assert list(collectives() - c0) == [1 + tm["em_iterations_enqueued"], world * (2 + tm["em_chain_resolutions"])], (collectives() - c0, tm)
 os.environ["WGSASSIGN_LOO"] = "python"
 a2 = np.ascontiguousarray(af[lo:hi]).copy()
 with contextlib.redirect_stdout(io.StringIO()):

@@ -75,6 +75,8 @@ SIGNATURES = {
     "wgs_comm_destroy": (None, [c_vp]),
     "wgs_comm_allreduce_f64_dev": (c_int, [c_vp, c_vp, c_i64]),
     "wgs_comm_allreduce_f64": (c_int, [c_vp, c_f64p, c_i64]),
+    "wgs_comm_bcast_dev": (c_int, [c_vp, c_vp, c_i64, c_int]),
+    "wgs_comm_stats": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_comm_buffer": (c_vp, [c_vp, c_i64]),
     "wgs_comm_allreduce_buffer": (c_int, [c_vp, c_i64, c_f64p]),
     "wgs_fisher_obs": (c_int, [c_vp, c_vp, c_f32p, c_f32p]),
@@ -111,6 +113,8 @@ SIGNATURES = {
     "wgs_score_destroy": (None, [c_vp]),
     "wgs_score_sums": (c_int, [c_vp, c_int, c_f64p]),
     "wgs_score_total_from": (c_int, [c_vp, c_f64p, c_f64p]),
+    "wgs_score_totals_all": (c_int, [c_vp, c_vp, c_f64p, c_f64p]),
+    "wgs_score_chains_walk_all": (c_int, [c_vp, c_vp, c_f32p]),
     "wgs_score_chains_prepare": (c_int, [c_vp, c_i32, c_f64p]),
     "wgs_score_chains_walk": (c_int, [c_vp, c_f32p, c_f32p]),
     "wgs_loo": (c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_double, c_i64, c_vp, c_i32, c_i32, c_int, c_int, c_f64p, c_f32p, c_i32p]),

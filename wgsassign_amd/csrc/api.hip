@@ -550,6 +550,10 @@ static int em_fit_alloc(wgs_em *em)
     HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * n));
     HIP_TRY(hipMalloc(&em->d_jobs, sizeof(ChainJob) * n));
     HIP_TRY(hipMalloc(&em->d_chain_out, sizeof(float) * 2 * n));
+    // workspace of the exact chains for all fits at once (60 bytes per fit and block of 4096 SNPs): no allocation
+    // inside the convergence loop
+    HIP_TRY(hipMalloc(&em->d_chain_batch, rmse_chain_workspace_bytes(em->b->m) * n));
+    em->chain_batch_jobs = n;
     HIP_TRY(hipHostMalloc(&em->h_jobs, sizeof(ChainJob) * n, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&em->h_chain_out, sizeof(float) * 2 * n, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&em->h_setstate, sizeof(int32_t) * n, hipHostMallocDefault));
@@ -574,38 +578,27 @@ static int em_resolve_chains(wgs_em *em, const std::vector<int32_t> &fits, doubl
     const int nj = (int)fits.size();
     converged.assign(nj, 0);
     if (nj == 0) return 0;
-    const size_t per = rmse_chain_workspace_bytes(em->b->m);
-    if ((size_t)nj > em->chain_batch_jobs) {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (em->d_chain_batch) (void)hipFree(em->d_chain_batch);
-        em->d_chain_batch = nullptr;
-        em->chain_batch_jobs = 0;
-        const size_t want = std::min<size_t>((size_t)em->n_fits, std::max<size_t>((size_t)nj, 16));
-        HIP_TRY(hipMalloc(&em->d_chain_batch, per * want));
-        em->chain_batch_jobs = want;
-    }
     int world = 1, rank = 0;
     if (comm) wgs_comm_rank(comm, &rank, &world);
-    std::vector<float> carry(nj, 0.0f);
-    std::vector<double> hop(nj);
+    // The serial float32 chain crosses the SNP shards in rank order ON THE STREAM: rank r walks its blocks from the
+    // running values it received and broadcasts the result (`world` broadcasts of nj float32, one readback at the end).
+    for (int i = 0; i < nj; ++i) {
+        const int j = fits[i];
+        em->h_jobs[i] = ChainJob{em_f(em, j, em->cur[j]), em_f(em, j, em->cur[j] ^ 1), 0.0f};
+    }
+    HIP_TRY(hipMemcpyAsync(em->d_jobs, em->h_jobs, sizeof(ChainJob) * nj, hipMemcpyHostToDevice, ctx->stream));
     for (int r = 0; r < world; ++r) {
-        std::fill(hop.begin(), hop.end(), 0.0);
         if (r == rank) {
-            for (int i = 0; i < nj; ++i) {
-                const int j = fits[i];
-                em->h_jobs[i] = ChainJob{em_f(em, j, em->cur[j]), em_f(em, j, em->cur[j] ^ 1), carry[i]};
-            }
-            HIP_TRY(hipMemcpyAsync(em->d_jobs, em->h_jobs, sizeof(ChainJob) * nj, hipMemcpyHostToDevice, ctx->stream));
+            if (r > 0 && launch_chain_set_carry(ctx, em->d_jobs, em->d_chain_out, nj)) return 1;
             if (launch_rmse_chain_batch(ctx, em->d_jobs, nj, em->b->m, em->d_chain_out, em->d_chain_batch,
                                         reinterpret_cast<int *>(em->d_chain_out + em->n_fits)))
                 return 1;
-            HIP_TRY(hipMemcpyAsync(em->h_chain_out, em->d_chain_out, sizeof(float) * nj, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            for (int i = 0; i < nj; ++i) hop[i] = (double)em->h_chain_out[i];
         }
-        if (world > 1 && wgs_comm_allreduce_f64(comm, hop.data(), nj)) return 1;   // only rank r contributes: a broadcast
-        for (int i = 0; i < nj; ++i) carry[i] = (float)hop[i];
+        if (world > 1 && wgs_comm_bcast_dev(comm, em->d_chain_out, (int64_t)sizeof(float) * nj, r)) return 1;
     }
+    HIP_TRY(hipMemcpyAsync(em->h_chain_out, em->d_chain_out, sizeof(float) * nj, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));       // also: h_jobs has been consumed
+    const float *carry = em->h_chain_out;
     ++em->fit_chain_batches;
     for (int i = 0; i < nj; ++i) {
         const float res = carry[i] / (float)m_total;         // emMAF_cy.pyx:32
@@ -891,7 +884,7 @@ struct wgs_score {
     const float **d_acol = nullptr, **d_colptr = nullptr;
     ScoreSlab *d_slabs[2] = {nullptr, nullptr};      // [0] table of the sweep, [1] table of the chain kernel
     int n_slabs[2] = {0, 0}, total_pg[2] = {0, 0};
-    double *d_S = nullptr, *d_out = nullptr, *d_start = nullptr, *d_chunks = nullptr;     // d_chunks: [ceil(nblocks/2)][cells]
+    double *d_S = nullptr, *d_out = nullptr, *d_start = nullptr, *d_run = nullptr, *d_chunks = nullptr;     // d_chunks: [ceil(nblocks/2)][cells]
     uint32_t *d_cand = nullptr;
     float *d_carry = nullptr, *d_parts = nullptr;
     int32_t *d_nserial = nullptr;
@@ -904,7 +897,7 @@ void wgs_score_destroy(wgs_score *sc)
     (void)hipSetDevice(sc->b->ctx->device);
     (void)hipStreamSynchronize(sc->b->ctx->stream);
     void *bufs[] = {sc->d_acol, sc->d_colptr, sc->d_slabs[0], sc->d_slabs[1] == sc->d_slabs[0] ? nullptr : sc->d_slabs[1], sc->d_S,
-                    sc->d_out, sc->d_start, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial, sc->d_chunks};
+                    sc->d_out, sc->d_start, sc->d_run, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial, sc->d_chunks};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete sc;
@@ -1054,6 +1047,37 @@ int wgs_score_total_from(wgs_score *sc, const double *carry_in, double *out)
     return 0;
 }
 
+/* The n x K totals over ALL SNP shards in NumPy's order, one call: np.sum's running float64 total is handed from shard to
+ * shard in SNP order ON THE STREAM -- rank r continues it over its chunk sums (chunk_total_kernel) and broadcasts the
+ * result, rank r + 1 picks it up as its carry -- `world` broadcasts of n*K float64 enqueued back to back, ONE readback.
+ * totals_out (host, n*K) receives the totals on every rank; before_out (host, n*K, may be NULL) the total over the shards
+ * BEFORE this one (what wgs_score_chains_prepare wants as `start`).  comm == NULL or one rank: the local sums.
+ * Needs wgs_score_sums first. */
+int wgs_score_totals_all(wgs_score *sc, wgs_comm *comm, double *totals_out, double *before_out)
+{
+    WGS_REQUIRE(sc && totals_out, "null argument");
+    WGS_REQUIRE(sc->d_chunks, "wgs_score_totals_all needs wgs_score_sums first");
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int world = 1, rank = 0;
+    if (comm) wgs_comm_rank(comm, &rank, &world);
+    const size_t bytes = sizeof(double) * sc->cells;
+    if (!sc->d_start) HIP_TRY(hipMalloc(&sc->d_start, bytes));
+    if (!sc->d_run) HIP_TRY(hipMalloc(&sc->d_run, bytes));
+    HIP_TRY(hipMemsetAsync(sc->d_start, 0, bytes, ctx->stream));
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) {
+            if (r > 0) HIP_TRY(hipMemcpyAsync(sc->d_start, sc->d_run, bytes, hipMemcpyDeviceToDevice, ctx->stream));   // what precedes this shard
+            if (launch_chunk_total(ctx, sc->d_chunks, (sc->nblocks + 1) / 2, sc->cells, r > 0 ? sc->d_start : nullptr, sc->d_run)) return 1;
+        }
+        if (world > 1 && wgs_comm_bcast_dev(comm, sc->d_run, (int64_t)bytes, r)) return 1;
+    }
+    HIP_TRY(hipMemcpyAsync(totals_out, sc->d_run, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (before_out) HIP_TRY(hipMemcpyAsync(before_out, sc->d_start, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 /* Block functions of the exact partition chains (utils.py:147-149) for P partitions; needs the block
  * sums of wgs_score_sums(WGS_MODE_EXACT).  start (host, n*K doubles, may be NULL) = the float64 sums over
  * the SNP shards that precede this one (its partitions are predicted to hold equal shares).  rc 2 when P is
@@ -1109,19 +1133,15 @@ int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start)
 /* Walk the chains of this shard: carry_in (host float32 [n*P*K], NULL = zeros) is the running value after
  * the preceding shards, parts_out (host float32 [n*P*K], index (i*P + p)*K + k) the value after this one;
  * rows of individuals outside the scored range are 0. */
-int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out)
+static int chains_walk_enqueue(wgs_score *sc, bool with_carry)
 {
-    WGS_REQUIRE(sc && parts_out, "null argument");
-    WGS_REQUIRE(sc->P >= 1 && sc->d_cand, "wgs_score_chains_walk needs wgs_score_chains_prepare first");
     wgs_ctx *ctx = sc->b->ctx;
-    HIP_TRY(hipSetDevice(ctx->device));
     const size_t chains = (size_t)sc->cells * sc->P;
-    if (carry_in) HIP_TRY(hipMemcpyAsync(sc->d_carry, carry_in, sizeof(float) * chains, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(sc->d_parts, 0, sizeof(float) * chains, ctx->stream));
     HIP_TRY(hipMemsetAsync(sc->d_nserial, 0, sizeof(int32_t), ctx->stream));
     WalkArgs W;
     W.cand = sc->d_cand;
-    W.carry = carry_in ? sc->d_carry : nullptr;
+    W.carry = with_carry ? sc->d_carry : nullptr;
     W.parts = sc->d_parts;
     W.group_of = sc->b->d_group_of;
     W.col_of = sc->b->d_col_of;
@@ -1141,8 +1161,46 @@ int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     if (launch_chain_walk(ctx, W)) return 1;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    return 0;
+}
+
+int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out)
+{
+    WGS_REQUIRE(sc && parts_out, "null argument");
+    WGS_REQUIRE(sc->P >= 1 && sc->d_cand, "wgs_score_chains_walk needs wgs_score_chains_prepare first");
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t chains = (size_t)sc->cells * sc->P;
+    if (carry_in) HIP_TRY(hipMemcpyAsync(sc->d_carry, carry_in, sizeof(float) * chains, hipMemcpyHostToDevice, ctx->stream));
+    if (chains_walk_enqueue(sc, carry_in != nullptr)) return 1;
     HIP_TRY(hipMemcpyAsync(parts_out, sc->d_parts, sizeof(float) * chains, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&sc->last_serial_blocks, sc->d_nserial, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    return 0;
+}
+
+/* The chains of ALL SNP shards, one call: rank 0 walks its blocks from zero, broadcasts its float32 values, rank 1 walks on
+ * from them, ... -- `world` broadcasts of n*P*K float32 on the stream, ONE readback; parts_out (host) receives the
+ * values after the last shard on every rank.  Every rank has prepared its block functions before (in parallel). */
+int wgs_score_chains_walk_all(wgs_score *sc, wgs_comm *comm, float *parts_out)
+{
+    WGS_REQUIRE(sc && parts_out, "null argument");
+    WGS_REQUIRE(sc->P >= 1 && sc->d_cand, "wgs_score_chains_walk_all needs wgs_score_chains_prepare first");
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int world = 1, rank = 0;
+    if (comm) wgs_comm_rank(comm, &rank, &world);
+    const size_t bytes = sizeof(float) * (size_t)sc->cells * sc->P;
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) {
+            if (r > 0) HIP_TRY(hipMemcpyAsync(sc->d_carry, sc->d_parts, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+            if (chains_walk_enqueue(sc, r > 0)) return 1;
+            HIP_TRY(hipMemcpyAsync(&sc->last_serial_blocks, sc->d_nserial, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (world > 1 && wgs_comm_bcast_dev(comm, sc->d_parts, (int64_t)bytes, r)) return 1;
+    }
+    HIP_TRY(hipMemcpyAsync(parts_out, sc->d_parts, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
     return 0;
@@ -1251,17 +1309,17 @@ int wgs_debug_assign_parts_f64(wgs_beagle *b, wgs_afset *a, const float *const *
  *   a       in: the full-population estimates; out: each population's LAST re-fit (glassy.py:89);
  *   batch   re-fits per EM batch, 0 = what fits the free device memory (agreed across ranks);
  *   ll_out  host float64 [n*K] (overwritten); parts_out host float32 [n*P*K] or NULL; iters_out [n]. */
-static double g_loo_stats[6];      // of the last wgs_loo of this process: see wgs_loo_stats
+static double g_loo_stats[7];      // of the last wgs_loo of this process: see wgs_loo_stats
 
 static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 /* Phases of the last wgs_loo: stats[0..5] = seconds in the EM re-fits (wgs_em_fit incl. its exact chains), in the
  * scoring sweeps (+ their cross-rank totals), in the exact partition chains; EM sweep kernel ms; EM batches; chain
- * resolutions of the re-fits. */
+ * resolutions of the re-fits; EM iterations enqueued (= all-reduces of the convergence sums across SNP shards). */
 int wgs_loo_stats(double *stats)
 {
     WGS_REQUIRE(stats, "null argument");
-    for (int i = 0; i < 6; ++i) stats[i] = g_loo_stats[i];
+    for (int i = 0; i < 7; ++i) stats[i] = g_loo_stats[i];
     return 0;
 }
 
@@ -1301,9 +1359,8 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
     std::fill(ll_out, ll_out + cells, 0.0);
     if (parts_out) std::fill(parts_out, parts_out + cells * P, 0.0f);
     std::vector<const float *> colptr(cells), cur(K);
-    std::vector<double> sums(cells), by_rank, start(cells);
-    std::vector<float> parts, carry;
-    std::vector<double> hop;
+    std::vector<double> sums(cells), start(cells);
+    std::vector<float> parts;
     for (int64_t i0 = 0; i0 < n; i0 += batch) {
         const int64_t i1 = std::min<int64_t>(n, i0 + batch);
         const int nb = (int)(i1 - i0);
@@ -1324,6 +1381,7 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
             g_loo_stats[3] += sweep_ms;
             g_loo_stats[4] += 1.0;
             g_loo_stats[5] += cb;
+            g_loo_stats[6] += it;
         }
         t_phase = wall_s();
         for (int x = 0; x < nb; ++x) {
@@ -1341,24 +1399,10 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
         }
         if ((rc = wgs_score_create(scored, a, colptr.data(), (int32_t)i0, (int32_t)i1, &sc))) return rc;
         if ((rc = wgs_score_sums(sc, parts_out ? WGS_MODE_EXACT : score_mode, sums.data()))) return rc;
-        if (world > 1) {   // every rank's sums: the total, and what precedes each shard (for the chain prediction)
-            by_rank.assign(cells * world, 0.0);
-            std::copy(sums.begin(), sums.end(), by_rank.begin() + cells * rank);
-            if (wgs_comm_allreduce_f64(comm, by_rank.data(), (int64_t)by_rank.size())) return 1;
-            std::fill(start.begin(), start.end(), 0.0);
-            for (int r = 0; r < rank; ++r)
-                for (size_t c = 0; c < cells; ++c) start[c] += by_rank[cells * r + c];
-            // the totals themselves: np.sum's running float64 total handed from shard to shard in SNP order
-            std::vector<double> run(cells, 0.0);
-            for (int r = 0; r < world; ++r) {
-                if (r == rank) {
-                    if ((rc = wgs_score_total_from(sc, r > 0 ? run.data() : nullptr, sums.data()))) return rc;
-                } else {
-                    std::fill(sums.begin(), sums.end(), 0.0);
-                }
-                if (wgs_comm_allreduce_f64(comm, sums.data(), (int64_t)cells)) return 1;   // only rank r contributes
-                run = sums;
-            }
+        if (world > 1) {
+            // np.sum's running float64 total handed from shard to shard in SNP order on the stream (`world` broadcasts,
+            // one readback); `start` = what precedes this shard, for the chain prediction
+            if ((rc = wgs_score_totals_all(sc, comm, sums.data(), start.data()))) return rc;
         }
         for (size_t c = (size_t)i0 * K; c < (size_t)i1 * K; ++c) ll_out[c] = sums[c];
         g_loo_stats[1] += wall_s() - t_phase;
@@ -1366,20 +1410,9 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
         if (parts_out) {
             if ((rc = wgs_score_chains_prepare(sc, P, world > 1 && rank > 0 ? start.data() : nullptr))) return rc;
             parts.assign(cells * P, 0.0f);
-            carry.clear();
-            for (int r = 0; r < world; ++r) {
-                if (r == rank && (rc = wgs_score_chains_walk(sc, carry.empty() ? nullptr : carry.data(), parts.data()))) return rc;
-                if (world > 1) {                             // rank r's float32 values to everyone (exact in float64)
-                    hop.assign(cells * P, 0.0);
-                    if (r == rank)
-                        for (size_t c = 0; c < cells * P; ++c) hop[c] = (double)parts[c];
-                    if (wgs_comm_allreduce_f64(comm, hop.data(), (int64_t)hop.size())) return 1;
-                    carry.resize(cells * P);
-                    for (size_t c = 0; c < cells * P; ++c) carry[c] = (float)hop[c];
-                }
-            }
-            const std::vector<float> &fin = world > 1 ? carry : parts;
-            for (size_t c = (size_t)i0 * P * K; c < (size_t)i1 * P * K; ++c) parts_out[c] = fin[c];
+            // every rank has its block functions; the walks follow each other with the float32 carries (`world` broadcasts)
+            if ((rc = wgs_score_chains_walk_all(sc, comm, parts.data()))) return rc;
+            for (size_t c = (size_t)i0 * P * K; c < (size_t)i1 * P * K; ++c) parts_out[c] = parts[c];
             g_loo_stats[2] += wall_s() - t_phase;
         }
         // the last re-fit of each population in this batch becomes the current column

@@ -136,6 +136,7 @@ size_t rmse_chain_workspace_bytes(int64_t m);
 int launch_rmse_chain(wgs_ctx *ctx, const float *a, const float *b, int64_t m, float carry_in, float *d_out, void *work,
                       int *d_serial);
 // n_jobs chains at once (device array of jobs): d_out[j] / d_serial[j]; work: n_jobs * rmse_chain_workspace_bytes(m)
+int launch_chain_set_carry(wgs_ctx *ctx, ChainJob *d_jobs, const float *d_carry, int n_jobs);
 int launch_rmse_chain_batch(wgs_ctx *ctx, const ChainJob *d_jobs, int n_jobs, int64_t m, float *d_out, void *work, int *d_serial);
 
 struct AssignArgs {

@@ -955,6 +955,21 @@ size_t rmse_chain_workspace_bytes(int64_t m)
     return ((nb * (sizeof(double) + sizeof(int) + 6 * sizeof(long long)) + 7) & ~(size_t)7) + 64;   // + one ChainJob
 }
 
+// The running values after the preceding SNP shard (broadcast into `carry`) become the jobs' starting values.
+__global__ void chain_set_carry_kernel(ChainJob *__restrict__ jobs, const float *__restrict__ carry, int n)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) jobs[j].carry_in = carry[j];
+}
+
+int launch_chain_set_carry(wgs_ctx *ctx, ChainJob *d_jobs, const float *d_carry, int n_jobs)
+{
+    if (n_jobs <= 0) return 0;
+    hipLaunchKernelGGL(chain_set_carry_kernel, dim3((unsigned)((n_jobs + 255) / 256)), dim3(256), 0, ctx->stream, d_jobs, d_carry, n_jobs);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // work: n_jobs * rmse_chain_workspace_bytes(m) bytes of device memory (the first sizeof(ChainJob) * n_jobs bytes
 // of each call's job table live at its end); d_serial (may be null) receives per job the number of blocks that
 // took the literal serial loop.

@@ -16,13 +16,14 @@ namespace {
 typedef struct { char internal[128]; } rcclUniqueId;
 typedef void *rcclComm_t;
 // values from rccl.h (ncclDataType_t / ncclRedOp_t)
-constexpr int kFloat64 = 8, kSum = 0;
+constexpr int kFloat64 = 8, kUint8 = 1, kSum = 0;
 
 struct Api {
     void *handle = nullptr;
     int (*GetUniqueId)(rcclUniqueId *) = nullptr;
     int (*CommInitRank)(rcclComm_t *, int, rcclUniqueId, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(rcclComm_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -42,11 +43,12 @@ Api *api()
             a.GetUniqueId = (int (*)(rcclUniqueId *))dlsym(a.handle, "ncclGetUniqueId");
             a.CommInitRank = (int (*)(rcclComm_t *, int, rcclUniqueId, int))dlsym(a.handle, "ncclCommInitRank");
             a.AllReduce = (int (*)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t))dlsym(a.handle, "ncclAllReduce");
+            a.Broadcast = (int (*)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t))dlsym(a.handle, "ncclBroadcast");
             a.CommDestroy = (int (*)(rcclComm_t))dlsym(a.handle, "ncclCommDestroy");
             a.GetErrorString = (const char *(*)(int))dlsym(a.handle, "ncclGetErrorString");
         }
     }
-    if (!a.handle || !a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.CommDestroy) return nullptr;
+    if (!a.handle || !a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.Broadcast || !a.CommDestroy) return nullptr;
     return &a;
 }
 
@@ -63,6 +65,8 @@ struct wgs_comm {
     void *host_user = nullptr;
     double *host_stage = nullptr;      // pinned
     size_t host_elems = 0;
+    // what crossed ranks so far (wgs_comm_stats): collectives, their payload, host round trips they cost
+    int64_t n_allreduce = 0, n_bcast = 0, bytes_moved = 0, n_syncs = 0;
 };
 
 #define RCCL_TRY(expr)                                                                              \
@@ -148,7 +152,10 @@ int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n)
     WGS_REQUIRE(c && dev_buf && n >= 0, "bad argument");
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->ctx->device));
+    c->n_allreduce += 1;
+    c->bytes_moved += n * (int64_t)sizeof(double);
     if (c->host_fn) {
+        c->n_syncs += 2;
         if ((size_t)n > c->host_elems) {
             if (c->host_stage) (void)hipHostFree(c->host_stage);
             c->host_stage = nullptr;
@@ -170,6 +177,75 @@ int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n)
     Api *A = api();
     WGS_REQUIRE(A, "librccl not loaded");
     RCCL_TRY(A->AllReduce(dev_buf, dev_buf, (size_t)n, kFloat64, kSum, c->comm, c->ctx->stream));
+    return 0;
+}
+
+/* Broadcast of `bytes` bytes of DEVICE memory from rank `root`, enqueued on the context's stream: how a running value
+ * (np.sum's float64 total, a float32 chain carry) is handed from SNP shard to SNP shard without a host round trip.
+ * Over a host-backed communicator the payload goes as 32-bit words widened to float64 through the caller's sum
+ * all-reduce with zeros from everybody else -- exact for every bit pattern, NaN payloads included. */
+int wgs_comm_bcast_dev(wgs_comm *c, void *dev_buf, int64_t bytes, int root)
+{
+    WGS_REQUIRE(c && dev_buf && bytes >= 0 && root >= 0 && root < c->world, "bad argument");
+    if (bytes == 0 || c->world == 1) return 0;
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    c->n_bcast += 1;
+    c->bytes_moved += bytes;
+    if (c->host_fn) {
+        WGS_REQUIRE(bytes % 4 == 0, "broadcast payload must be a multiple of 4 bytes");
+        const size_t words = (size_t)bytes / 4;
+        c->n_syncs += 2;
+        if (words > c->host_elems) {
+            if (c->host_stage) (void)hipHostFree(c->host_stage);
+            c->host_stage = nullptr;
+            c->host_elems = 0;
+            const size_t want = words < 1024 ? 1024 : words;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->host_stage), sizeof(double) * want, hipHostMallocDefault));
+            c->host_elems = want;
+        }
+        char *raw = reinterpret_cast<char *>(c->host_stage);               // the words first, widened in place from the back
+        if (c->rank == root) {
+            HIP_TRY(hipMemcpyAsync(raw, dev_buf, (size_t)bytes, hipMemcpyDeviceToHost, c->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+            for (size_t i = words; i-- > 0;) {
+                uint32_t w;
+                memcpy(&w, raw + 4 * i, 4);
+                const double d = (double)w;
+                memcpy(raw + 8 * i, &d, 8);
+            }
+        } else {
+            HIP_TRY(hipStreamSynchronize(c->ctx->stream));                   // the staging buffer may still be in flight
+            for (size_t i = 0; i < words; ++i) c->host_stage[i] = 0.0;
+        }
+        if (c->host_fn(c->host_stage, (int64_t)words, c->host_user) != 0) {
+            wgs_set_error("the communicator's all-reduce function failed");
+            return 1;
+        }
+        for (size_t i = 0; i < words; ++i) {
+            double d;
+            memcpy(&d, raw + 8 * i, 8);
+            const uint32_t w = (uint32_t)d;
+            memcpy(raw + 4 * i, &w, 4);
+        }
+        HIP_TRY(hipMemcpyAsync(dev_buf, raw, (size_t)bytes, hipMemcpyHostToDevice, c->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(c->ctx->stream));
+        return 0;
+    }
+    Api *A = api();
+    WGS_REQUIRE(A, "librccl not loaded");
+    RCCL_TRY(A->Broadcast(dev_buf, dev_buf, (size_t)bytes, kUint8, root, c->comm, c->ctx->stream));
+    return 0;
+}
+
+/* stats[0..3]: all-reduces, broadcasts, payload bytes, host round trips (stream synchronisations) the collectives of
+ * this communicator have cost so far. */
+int wgs_comm_stats(wgs_comm *c, int64_t *stats)
+{
+    WGS_REQUIRE(c && stats, "null argument");
+    stats[0] = c->n_allreduce;
+    stats[1] = c->n_bcast;
+    stats[2] = c->bytes_moved;
+    stats[3] = c->n_syncs;
     return 0;
 }
 
@@ -211,6 +287,8 @@ int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n)
     WGS_REQUIRE(c && host_buf && n >= 0, "bad argument");
     if (n == 0) return 0;
     if (c->host_fn) {
+        c->n_allreduce += 1;
+        c->bytes_moved += n * (int64_t)sizeof(double);
         if (c->host_fn(host_buf, n, c->host_user) != 0) {
             wgs_set_error("the communicator's all-reduce function failed");
             return 1;
@@ -218,6 +296,7 @@ int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n)
         return 0;
     }
     HIP_TRY(hipSetDevice(c->ctx->device));
+    c->n_syncs += 1;
     if (!wgs_comm_buffer(c, n)) return 1;
     HIP_TRY(hipMemcpyAsync(c->buf, host_buf, sizeof(double) * n, hipMemcpyHostToDevice, c->ctx->stream));
     if (wgs_comm_allreduce_f64_dev(c, c->buf, n)) return 1;

@@ -511,12 +511,20 @@ class Score:
         self.ms["sweep"] = last_assign_ms(self.b.ctx)
         self.local, self.mode = out, mode
         if comm is not None and comm.world > 1:
-            # every rank's totals: rank r needs the sum over the shards before it to predict its chains
+            handle = getattr(comm, "handle", None)
+            if handle is not None:
+                # np.sum's running float64 total (glassy.py:38) handed from shard to shard in SNP order ON THE STREAM
+                # (wgs_score_totals_all: `world` broadcasts, one readback); `before` = the total of the shards before this
+                # one, from which this rank predicts its chains
+                run, before = np.zeros_like(out), np.zeros_like(out)
+                check(_lib.load().wgs_score_totals_all(self._h, handle, f64p(run), f64p(before)))
+                self.before = before if comm.rank > 0 else None
+                return run
+            # communicators without a library handle (torch.distributed): the same hand-over through host all-reduces
             slots = np.zeros((comm.world,) + out.shape)
             slots[comm.rank] = out
-            self.by_rank = comm.allreduce_sum(slots)
-            # the totals: np.sum's running float64 total (glassy.py:38) handed from shard to shard in SNP order, each
-            # shard continuing it over its own 8192-site chunk sums (shard_range aligns the shards to such chunks)
+            by_rank = comm.allreduce_sum(slots)
+            self.before = np.ascontiguousarray(by_rank[:comm.rank].sum(axis=0)) if comm.rank > 0 else None
             run = None
             for r in range(comm.world):
                 mine = np.zeros_like(out)
@@ -524,7 +532,7 @@ class Score:
                     check(_lib.load().wgs_score_total_from(self._h, f64p(run) if run is not None else None, f64p(mine)))
                 run = np.ascontiguousarray(comm.allreduce_sum(mine))      # only rank r contributes: a broadcast
             return run
-        self.by_rank = out[None]
+        self.before = None
         return out
 
     def parts_exact(self, P, comm=None):
@@ -536,10 +544,16 @@ class Score:
         lib = _lib.load()
         world = comm.world if comm is not None else 1
         rank = comm.rank if comm is not None else 0
-        start = np.ascontiguousarray(self.by_rank[:rank].sum(axis=0)) if rank > 0 else None
+        start = self.before
         check(lib.wgs_score_chains_prepare(self._h, int(P), f64p(start) if start is not None else None))
         self.ms["chains"] = last_assign_ms(self.b.ctx)
         parts = np.zeros((self.n * P, self.K), dtype=np.float32)
+        handle = getattr(comm, "handle", None) if world > 1 else None
+        if world == 1 or handle is not None:
+            # all walks in one call: the float32 carries pass from shard to shard on the stream (`world` broadcasts)
+            check(lib.wgs_score_chains_walk_all(self._h, handle, f32p(parts)))
+            self.ms["walk"] = last_assign_ms(self.b.ctx)
+            return parts
         carry = None
         for r in range(world):
             mine = np.zeros((self.n * P, self.K), dtype=np.float64)
@@ -547,10 +561,9 @@ class Score:
                 check(lib.wgs_score_chains_walk(self._h, f32p(carry) if carry is not None else None, f32p(parts)))
                 self.ms["walk"] = last_assign_ms(self.b.ctx)
                 mine = parts.astype(np.float64)
-            if world > 1:
-                mine = comm.allreduce_sum(mine)      # only rank r contributes: a broadcast of its float32 values
-                carry = np.ascontiguousarray(mine.astype(np.float32))
-        return carry if world > 1 else parts
+            mine = comm.allreduce_sum(mine)      # only rank r contributes: a broadcast of its float32 values
+            carry = np.ascontiguousarray(mine.astype(np.float32))
+        return carry
 
     def serial_blocks(self):
         """(blocks redone with the literal serial loop, (chain, block) pairs walked) of the last walk."""

@@ -151,10 +151,11 @@ def loo_device(beagle, scored, af, group_of, maf_iter, maf_tole, P=1, comm=None,
         af[:, :] = afset.to_host()
         afset.close()
         if timings is not None:
-            st = (ctypes.c_double * 6)()
+            st = (ctypes.c_double * 7)()
             _lib.check(_lib.load().wgs_loo_stats(st))
             timings.update(seconds=time.perf_counter() - t0, iters=iters, one_call=True, em_seconds=st[0], score_seconds=st[1],
-                           chain_seconds=st[2], em_sweep_kernel_ms=st[3], em_batches=int(st[4]), em_chain_resolutions=int(st[5]))
+                           chain_seconds=st[2], em_sweep_kernel_ms=st[3], em_batches=int(st[4]), em_chain_resolutions=int(st[5]),
+                           em_iterations_enqueued=int(st[6]))
         with np.errstate(over="ignore"):
             logl = out.astype(np.float32)
         return logl, (parts if parts is not None else logl.copy())

@@ -33,16 +33,17 @@ def set_threads(t):
 
 def host_threads():
     """Host threads ONE rank gives its reader: the node's budget -- WGSASSIGN_THREADS, else -t, else the CPUs this
-    process may run on (at most 32 per rank) -- divided by the ranks sharing the node (LOCAL_WORLD_SIZE, exported by
-    torchrun and by comm.launch_local_ranks): eight ranks on a 128-thread node take 16 each instead of 8 x 16 on the
-    one-GPU share."""
+    process can keep busy (comm.usable_cpus: affinity cut down to the control group's CPU quota; at most 32 per rank)
+    -- divided by the ranks sharing the node (LOCAL_WORLD_SIZE, exported by torchrun and by comm.launch_local_ranks):
+    eight ranks on a 128-thread node take 16 each instead of 8 x 16 on the one-GPU share."""
     local = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
     env = os.environ.get("WGSASSIGN_THREADS")
     if env:
         return max(1, int(env) // local)
     if _requested_threads:
         return max(1, _requested_threads // local)
-    return max(1, min(len(os.sched_getaffinity(0)) // local, 32))
+    from .comm import usable_cpus
+    return max(1, min(usable_cpus() // local, 32))
 
 
 class BeagleStream:
