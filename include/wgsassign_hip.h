@@ -94,6 +94,13 @@ int wgs_beagle_download_rows(wgs_beagle *b, float *L_rows, int64_t row0, int64_t
  * per-group frequencies, Poisson(depth) reads, error 0.01, GLs rounded to 6 decimals). */
 int wgs_beagle_synth(wgs_beagle *b, uint64_t seed, double depth);
 int64_t wgs_beagle_bytes(const wgs_beagle *b);
+/* Class codes of the matrix: low-depth genotype likelihoods take few distinct (g0, g1) values per SNP (29 on average in
+ * the bundled 85-individual data, 27 among 1000 individuals of the 2x synthetic matrices), so the kernels evaluate the
+ * EM term's quotient / the per-site log-likelihood once per CLASS and SNP and look it up per individual -- same
+ * values, same order of accumulation, same bits.  Built on first use (one byte per (SNP, individual) + a dictionary;
+ * WGSASSIGN_CODES=0 disables them); a matrix with more than 64 classes in some SNP is not coded and takes the direct
+ * kernels.  info[0..4] = available, classes of the richest SNP, bytes held, build milliseconds, mean classes per SNP. */
+int wgs_beagle_codes_info(wgs_beagle *b, double *info);
 
 /* A batch of EM fits (emMAF.py:15-27) over slabs of `b`.  Fit j estimates the frequency of
  * every SNP from the individuals of group fit_group[j], leaving out individual fit_skip[j]

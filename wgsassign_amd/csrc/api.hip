@@ -127,9 +127,114 @@ int wgs_ctx_info(wgs_ctx *ctx, char *name, int name_len, int *cus, int64_t *mem_
 
 /* ------------------------------------------------------------------ beagle */
 
+}   // extern "C"
+
+void wgs_beagle_drop_codes(wgs_beagle *b)
+{
+    if (!b) return;
+    if (wgs_codes *c = b->codes) {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+        for (auto &s : c->slabs) {
+            if (s.codes) (void)hipFree(s.codes);
+            if (s.present) (void)hipFree(s.present);
+        }
+        if (c->dict) (void)hipFree(c->dict);
+        if (c->ncls) (void)hipFree(c->ncls);
+        if (c->d_slabs) (void)hipFree(c->d_slabs);
+        delete c;
+    }
+    b->codes = nullptr;
+    b->codes_state = 0;
+}
+
+// Builds the class codes on first use (two walks over the matrix: ~3 x its streaming time, once).  Not codable -- a SNP
+// with more than 64 distinct (g0, g1) pairs, or no memory for the codes (an eighth of the matrix + the dictionary) --
+// returns nullptr and the direct kernels run; WGSASSIGN_CODES=0 turns the codes off altogether.
+wgs_codes *wgs_beagle_codes(wgs_beagle *b)
+{
+    if (!b || b->codes_state < 0) return nullptr;
+    if (b->codes_state > 0) {
+        const char *env = getenv("WGSASSIGN_CODES");
+        return env && env[0] == '0' ? nullptr : b->codes;
+    }
+    {
+        const char *env = getenv("WGSASSIGN_CODES");          // read at every use, so one process can compare both paths
+        if (env && env[0] == '0') return nullptr;
+    }
+    b->codes_state = -1;
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return nullptr;
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    const size_t rows = (size_t)wgs_ntiles(b->m) * 64;
+    wgs_codes *c = new wgs_codes();
+    b->codes = c;
+    auto fail = [&]() -> wgs_codes * {
+        (void)hipGetLastError();
+        wgs_beagle_drop_codes(b);
+        b->codes_state = -1;
+        return nullptr;
+    };
+    if (hipMalloc(&c->ncls, rows) != hipSuccess) return fail();
+    c->bytes += (int64_t)rows;
+    if (launch_class_count(b, c->ncls)) return fail();
+    std::vector<uint8_t> h(rows);
+    if (hipMemcpy(h.data(), c->ncls, rows, hipMemcpyDeviceToHost) != hipSuccess) return fail();
+    int cmax = 1;
+    for (size_t i = 0; i < rows; ++i) cmax = std::max<int>(cmax, h[i]);
+    if (cmax > 64) return fail();                              // 255 marks a SNP with more than 64 classes
+    c->cmax = cmax;
+    if (hipMalloc(&c->dict, rows * (size_t)cmax * sizeof(float2)) != hipSuccess) return fail();
+    c->bytes += (int64_t)(rows * (size_t)cmax * sizeof(float2));
+    c->slabs.resize(b->n_groups);
+    int quad0 = 0;
+    for (int g = 0; g < b->n_groups; ++g) {
+        SlabCodes &s = c->slabs[g];
+        s.nquads = (b->slabs[g].ncols + 3) / 4;
+        s.quad0 = quad0;
+        quad0 += s.nquads;
+        if (s.nquads == 0) continue;
+        const size_t words = (size_t)wgs_ntiles(b->m) * s.nquads * 64;
+        if (hipMalloc(&s.codes, words * sizeof(uint32_t)) != hipSuccess || hipMalloc(&s.present, rows * sizeof(uint64_t)) != hipSuccess) return fail();
+        c->bytes += (int64_t)(words * sizeof(uint32_t) + rows * sizeof(uint64_t));
+    }
+    c->total_quads = quad0;
+    if (hipMalloc(&c->d_slabs, sizeof(SlabCodes) * b->n_groups) != hipSuccess ||
+        hipMemcpy(c->d_slabs, c->slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) != hipSuccess)
+        return fail();
+    if (launch_class_encode(b, c)) return fail();
+    c->build_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3;
+    b->codes_state = 1;
+    return c;
+}
+
+extern "C" {
+
+/* Class codes of the matrix (csrc/common.h: wgs_codes), built on first use by the kernels that look values up per
+ * class: info[0..4] = available (0/1), classes of the richest SNP, bytes held, milliseconds the build took, mean classes
+ * per SNP (computed on request).  Builds them if they have not been tried yet. */
+int wgs_beagle_codes_info(wgs_beagle *b, double *info)
+{
+    WGS_REQUIRE(b && info, "null argument");
+    wgs_codes *c = wgs_beagle_codes(b);
+    for (int i = 0; i < 5; ++i) info[i] = 0.0;
+    if (!c) return 0;
+    info[0] = 1.0;
+    info[1] = c->cmax;
+    info[2] = (double)c->bytes;
+    info[3] = c->build_ms;
+    const size_t rows = (size_t)b->m;
+    std::vector<uint8_t> h(rows);
+    HIP_TRY(hipMemcpy(h.data(), c->ncls, rows, hipMemcpyDeviceToHost));
+    double tot = 0.0;
+    for (size_t i = 0; i < rows; ++i) tot += h[i];
+    info[4] = rows ? tot / (double)rows : 0.0;
+    return 0;
+}
+
 void wgs_beagle_destroy(wgs_beagle *b)
 {
     if (!b) return;
+    wgs_beagle_drop_codes(b);
     (void)hipSetDevice(b->ctx->device);
     for (auto &s : b->slabs) {
         if (s.base) (void)hipFree(s.base);
@@ -224,6 +329,7 @@ int wgs_beagle_upload_rows(wgs_beagle *b, const float *L_rows, int64_t row0, int
                 (long long)(row0 + nrows), (long long)b->m);
     if (nrows == 0) return 0;
     HIP_TRY(hipSetDevice(b->ctx->device));
+    wgs_beagle_drop_codes(b);                        // the matrix changes: its class codes are rebuilt on next use
     const int64_t chunk = staging_rows(b, nrows);
     const size_t row_bytes = (size_t)b->n * 2 * sizeof(float);
     void *ws = nullptr;
@@ -275,6 +381,7 @@ int wgs_beagle_synth(wgs_beagle *b, uint64_t seed, double depth)
 {
     WGS_REQUIRE(b, "null argument");
     HIP_TRY(hipSetDevice(b->ctx->device));
+    wgs_beagle_drop_codes(b);
     return launch_synth(b, seed, depth);
 }
 
@@ -889,6 +996,10 @@ struct wgs_score {
     float *d_carry = nullptr, *d_parts = nullptr;
     int32_t *d_nserial = nullptr;
     int32_t last_serial_blocks = 0;
+    CodedSlabHost *d_coded = nullptr;     // slab table of the sweep through the class codes (shared columns)
+    int n_coded = 0, coded_quads = 0;
+    const wgs_codes *coded_for = nullptr; // the codes d_coded was built from
+    int last_path = 0;                    // 1: the last wgs_score_sums went through the class codes
 };
 
 void wgs_score_destroy(wgs_score *sc)
@@ -897,7 +1008,7 @@ void wgs_score_destroy(wgs_score *sc)
     (void)hipSetDevice(sc->b->ctx->device);
     (void)hipStreamSynchronize(sc->b->ctx->stream);
     void *bufs[] = {sc->d_acol, sc->d_colptr, sc->d_slabs[0], sc->d_slabs[1] == sc->d_slabs[0] ? nullptr : sc->d_slabs[1], sc->d_S,
-                    sc->d_out, sc->d_start, sc->d_run, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial, sc->d_chunks};
+                    sc->d_out, sc->d_start, sc->d_run, sc->d_coded, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial, sc->d_chunks};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
     delete sc;
@@ -1013,9 +1124,49 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     WGS_REQUIRE(mode == WGS_MODE_EXACT || mode == WGS_MODE_FAST, "unknown mode %d", mode);
     wgs_ctx *ctx = sc->b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
+    // shared columns + a codable matrix: the sweep through the class codes (same S, bit for bit)
+    wgs_codes *codes = sc->per_ind ? nullptr : wgs_beagle_codes(sc->b);
+    if (codes && score_coded_lds_bytes(codes->cmax, 10) > 64 * 1024) codes = nullptr;
+    if (codes && sc->coded_for != codes) {
+        std::vector<CodedSlabHost> tab;
+        int quad0 = 0;
+        for (int g = 0; g < sc->b->n_groups; ++g) {
+            const Slab &s = sc->b->slabs[g];
+            if (s.ncols == 0) continue;
+            const int lo = (int)(std::lower_bound(s.members.begin(), s.members.end(), sc->row_lo) - s.members.begin());
+            const int hi = (int)(std::lower_bound(s.members.begin(), s.members.end(), sc->row_hi) - s.members.begin());
+            if (hi <= lo) continue;
+            CodedSlabHost e;
+            e.codes = codes->slabs[g].codes;
+            e.members = s.d_members;
+            e.nquads = codes->slabs[g].nquads;
+            e.ncols = s.ncols;
+            e.quad0 = quad0;
+            e.col_lo = lo;
+            e.col_hi = hi;
+            quad0 += e.nquads;
+            tab.push_back(e);
+        }
+        if (sc->d_coded) HIP_TRY(hipFree(sc->d_coded));
+        sc->d_coded = nullptr;
+        sc->n_coded = (int)tab.size();
+        sc->coded_quads = quad0;
+        if (!tab.empty()) {
+            HIP_TRY(hipMalloc(&sc->d_coded, sizeof(CodedSlabHost) * tab.size()));
+            HIP_TRY(hipMemcpy(sc->d_coded, tab.data(), sizeof(CodedSlabHost) * tab.size(), hipMemcpyHostToDevice));
+        }
+        sc->coded_for = codes;
+    }
     HIP_TRY(hipMemsetAsync(sc->d_S, 0, sizeof(double) * (size_t)sc->nblocks * sc->cells, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    if (launch_score_sweep(ctx, score_args(sc, 0), mode)) return 1;
+    sc->last_path = codes ? 1 : 0;
+    if (codes) {
+        if (launch_score_coded(ctx, codes, sc->d_coded, sc->n_coded, sc->coded_quads, sc->d_acol, sc->b->m, sc->cells, sc->K, sc->nblocks,
+                               sc->d_S, mode))
+            return 1;
+    } else if (launch_score_sweep(ctx, score_args(sc, 0), mode)) {
+        return 1;
+    }
     if (!sc->d_chunks && hipMalloc(&sc->d_chunks, sizeof(double) * (size_t)((sc->nblocks + 1) / 2) * sc->cells) != hipSuccess) {
         wgs_set_error("hipMalloc of the chunk sums failed");
         return 1;

@@ -41,6 +41,7 @@ __device__ __forceinline__ double log_c8()
     return c;
 }
 
+template <int REP = WGS_LOG_REP>
 __device__ __forceinline__ double log_f32arg(double x, const double2 *tab, double c8 = -0.125)
 {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(x);
@@ -49,7 +50,7 @@ __device__ __forceinline__ double log_f32arg(double x, const double2 *tab, doubl
     const int k = (int)tmp >> 20;                          // x = z * 2^k, z in [0.6875, 1.375)
     const unsigned int i = (tmp >> 13) & (WGS_LOG_N - 1);
     const double z = __hiloint2double((int)(hi - (tmp & 0xFFF00000u)), (int)lo);
-    const double2 t = tab[i * WGS_LOG_REP];                // {invc, logc}; tab already points at this lane's copy
+    const double2 t = tab[i * REP];                        // {invc, logc}; tab already points at this lane's copy
     const double r = __builtin_fma(z, t.x, -1.0);          // exact
     const double kd = (double)k;
     const double w = __builtin_fma(kd, WGS_LN2HI, t.y);    // kd*Ln2hi is exact
@@ -390,6 +391,153 @@ __global__ __launch_bounds__(256, sweep_waves_per_simd(KB, NP, MODE, PER_IND)) v
                         if (lane == 0 && w.ok[q][h]) A.S[w.blk * A.cells + (int64_t)w.ind[q][h] * A.K + kb + j] = tot;
                     }
                 }
+    }
+}
+
+// ---- scoring through the class codes (common.h: wgs_codes) ---------------------------------------------------
+// The per-site value (float)log(like0 + like1 + like2) depends on the individual only through its (g0, g1), and a SNP has
+// few distinct (g0, g1): 27 on average among 1000 individuals at 2x.  So the values are computed ONCE per (SNP, class,
+// population) into an LDS table and the individuals only look them up:
+//   workgroup <-> one block of 4096 SNPs x up to 1024 individuals; lane <-> QUAD of individuals (4 x KB float64 sums in
+//   registers, no cross-lane reduction at all); SNPs are taken 16 at a time -- the 16 code words of a quad are one
+//   64-byte line:
+//     phase 1  all threads fill vtab[snp in batch][class][population] (the reference's rounding sequence and the
+//              table log of the direct sweep, special values through the hardware log as in logf_of_f32);
+//     phase 2  every lane adds vtab[snp][code][.] of its four individuals to its sums.
+// The per-site float32 values are the direct sweep's bit for bit and a block's float64 partial sums are exact in any
+// order, so S[block][cell] -- and everything built on it: NumPy-order totals, chain predictions -- is unchanged.
+// Cost per (SNP, individual, population): a quarter of an LDS read, one conversion, one add (41.6 instructions in the
+// direct sweep) plus classes/individuals of the table work.
+struct CodedSlab {
+    const uint32_t *codes;
+    const int32_t *members;
+    int32_t nquads, ncols, quad0, col_lo, col_hi;
+};
+struct CodedScoreArgs {
+    const float2 *dict;
+    const uint8_t *ncls;
+    const CodedSlab *slabs;
+    int32_t n_slabs, cmax, total_quads;
+    uint32_t inv_rows;             // ceil(2^32 / (cmax * KB)): batch-local SNP index of a table element by multiplication
+    const float *const *acol;
+    int64_t m, cells;
+    int32_t K, nblocks;
+    double *S;
+    const double2 *logtab;         // the log table in device memory (wgs_log_table_dev)
+};
+constexpr int CODED_BATCH = 16;    // SNPs per table: the code words of 16 SNPs of one quad are one 64-byte line
+constexpr int CODED_LOG_REP = 4;   // LDS copies of the log table here (phase 1 is a third of the kernel; 8 KiB instead of 32)
+
+template <int KB, int MODE>
+__global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
+{
+    constexpr int KBP = (KB + 3) & ~3;                         // table rows padded to float4
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    double2 *tab_lds = reinterpret_cast<double2 *>(lds_raw);
+    float *vtab = reinterpret_cast<float *>(lds_raw + sizeof(double2) * WGS_LOG_N * CODED_LOG_REP);
+    if (MODE == WGS_MODE_EXACT) {
+        for (int e = threadIdx.x; e < WGS_LOG_N * CODED_LOG_REP; e += blockDim.x) tab_lds[e] = A.logtab[e / CODED_LOG_REP];
+    }
+    const double2 *tab = tab_lds + (threadIdx.x & (CODED_LOG_REP - 1));
+    const int tid = threadIdx.x;
+    const int64_t blk = blockIdx.x;
+    const int64_t ntiles = (A.m + 63) >> 6;
+    const int64_t t0 = blk * WGS_BLOCK_TILES, t1 = t0 + WGS_BLOCK_TILES < ntiles ? t0 + WGS_BLOCK_TILES : ntiles;
+    // this lane's quad
+    const int Q = (int)blockIdx.y * 256 + tid;
+    const bool have = Q < A.total_quads;
+    int g = 0;
+    if (have)
+        while (g + 1 < A.n_slabs && Q >= A.slabs[g + 1].quad0) ++g;
+    const CodedSlab sl = A.slabs[g];
+    const int q = have ? Q - sl.quad0 : 0;
+    int ind[4];
+    bool ok[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int col = 4 * q + h;
+        ok[h] = have && col >= sl.col_lo && col < sl.col_hi;
+        ind[h] = sl.members[ok[h] ? col : sl.col_lo];
+    }
+    const uint4 *cptr = reinterpret_cast<const uint4 *>(sl.codes + (int64_t)q * 64);     // + tile * nquads * 64 + 16-SNP group
+    const int rows = A.cmax * KB;                              // table elements per SNP (before padding)
+    __syncthreads();
+
+    for (int kb = 0; kb < A.K; kb += KB) {
+        double acc[4][KB];
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int k = 0; k < KB; ++k) acc[h][k] = 0.0;
+        for (int64_t t = t0; t < t1; ++t) {
+            for (int sub = 0; sub < 4; ++sub) {
+                const int l0 = sub * CODED_BATCH;
+                const int64_t s0 = (t << 6) + l0;
+                if (s0 >= A.m) break;
+                const int nj = A.m - s0 < CODED_BATCH ? (int)(A.m - s0) : CODED_BATCH;
+                // this quad's code words for the 16 SNPs (one 64-byte line), in flight during phase 1
+                uint4 cw[4];
+                if (have) {
+                    const uint4 *line = cptr + (t * sl.nquads * 64 + l0) / 4;
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) cw[x] = line[x];
+                } else {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
+                }
+                // phase 1: vtab[j][c][k]
+                const int total = nj * rows;
+                for (int e = tid; e < total; e += 256) {
+                    const int j = (int)__umulhi((unsigned)e, A.inv_rows);
+                    const int r = e - j * rows;
+                    const int c = r / KB, k = r - c * KB;
+                    const int64_t s = s0 + j;
+                    if (c < (int)A.ncls[s]) {
+                        const float2 gl = A.dict[(t * A.cmax + c) * 64 + l0 + j];
+                        const int kk = kb + k < A.K ? kb + k : A.K - 1;
+                        const float a = A.acol[kk][s];
+                        float v;
+                        if (MODE == WGS_MODE_EXACT) {
+                            const double g0d = (double)gl.x, g1d = (double)gl.y, ad = (double)a;
+                            const float ssum = like_sum_exact(g0d, g1d * 2.0, (1.0 - g0d) - g1d, ad, 1.0 - ad);
+                            const float plain = (float)log_f32arg<CODED_LOG_REP>((double)ssum, tab);
+                            v = __builtin_isfpclass(ssum, FP_POS_FINITE) ? plain : __builtin_amdgcn_logf(ssum);
+                        } else {
+                            v = site_ll_fast(gl.x, gl.y, (1.0f - gl.x) - gl.y, a);
+                        }
+                        vtab[(j * A.cmax + c) * KBP + k] = v;
+                    }
+                }
+                __syncthreads();
+                // phase 2: look up and add
+                const unsigned *cwv = reinterpret_cast<const unsigned *>(cw);
+#pragma unroll
+                for (int j = 0; j < CODED_BATCH; ++j) {
+                    if (j < nj) {
+                        const unsigned w = cwv[j];
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const int code = (w >> (8 * h)) & 255;
+                            const float4 *row = reinterpret_cast<const float4 *>(vtab + (j * A.cmax + code) * KBP);
+                            float vals[KBP];
+#pragma unroll
+                            for (int x = 0; x < KBP / 4; ++x) {
+                                const float4 f = row[x];
+                                vals[4 * x] = f.x, vals[4 * x + 1] = f.y, vals[4 * x + 2] = f.z, vals[4 * x + 3] = f.w;
+                            }
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) acc[h][k] += (double)vals[k];
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (ok[h] && kb + k < A.K) A.S[blk * A.cells + (int64_t)ind[h] * A.K + kb + k] = acc[h][k];
     }
 }
 
@@ -934,6 +1082,46 @@ int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode)
     } while (0)
     WGS_FOR_KB(WGS_SWEEP, a.K)
 #undef WGS_SWEEP
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t score_coded_lds_bytes(int cmax, int kb) { return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + sizeof(float) * CODED_BATCH * cmax * ((kb + 3) & ~3); }
+
+// The scoring sweep through the class codes (shared columns only).  d_slabs: n_slabs CodedSlab records in device memory.
+int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, int n_slabs, int total_quads, const float *const *d_acol,
+                       int64_t m, int64_t cells, int K, int nblocks, double *S, int mode)
+{
+    if (m <= 0 || total_quads <= 0 || K <= 0 || nblocks <= 0) return 0;
+    if (ensure_log_table(ctx)) return 1;
+    CodedScoreArgs A;
+    A.dict = c->dict;
+    A.ncls = c->ncls;
+    A.slabs = reinterpret_cast<const CodedSlab *>(d_slabs);
+    A.n_slabs = n_slabs;
+    A.cmax = c->cmax;
+    A.total_quads = total_quads;
+    A.acol = d_acol;
+    A.m = m;
+    A.cells = cells;
+    A.K = K;
+    A.nblocks = nblocks;
+    A.S = S;
+    void *sym = nullptr;
+    HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(wgs_log_table_dev)));
+    A.logtab = reinterpret_cast<const double2 *>(sym);
+    const int kb = pick_kb(K);
+    A.inv_rows = (uint32_t)(((1ull << 32) + (uint64_t)(c->cmax * kb) - 1) / (uint64_t)(c->cmax * kb));
+    const size_t lds = score_coded_lds_bytes(c->cmax, kb);
+    WGS_REQUIRE(lds <= 64 * 1024, "class table too large for LDS");
+    dim3 grid((unsigned)nblocks, (unsigned)((total_quads + 255) / 256));
+#define WGS_CODED(KB)                                                                                                     \
+    do {                                                                                                                  \
+        if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT>), grid, dim3(256), lds, ctx->stream, A); \
+        else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST>), grid, dim3(256), lds, ctx->stream, A);           \
+    } while (0)
+    WGS_FOR_KB(WGS_CODED, K)
+#undef WGS_CODED
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -149,6 +149,105 @@ __global__ void synth_kernel(float4 *__restrict__ slab, int64_t m, int npairs, i
     }
 }
 
+// ---- class codes (common.h: wgs_codes) ---------------------------------------------------------------------
+// lane <-> SNP, one wavefront per tile: every lane walks the individuals of ITS SNP through all slabs (the slabs'
+// native coalesced loads) and keeps the distinct (g0, g1) bit patterns in a private open-addressing table of 64 slots
+// in LDS (slot-major, so a wave-wide access with per-lane slots is conflict-free); occupancy is a 64-bit mask in
+// registers.  A class's id is the number of occupied slots below its slot -- known once the walk is complete, hence
+// two walks: classes first, codes second.  More than 64 classes in one SNP: not codable (ncls = 255).
+struct ClassTable {
+    uint64_t *keys;                // LDS: [slot * 64 + lane]
+    uint64_t mask = 0;
+    bool overflow = false;
+    __device__ __forceinline__ static int home(uint64_t key) { return (int)((key * 0x9E3779B97F4A7C15ull) >> 58); }
+    __device__ __forceinline__ int find_or_insert(uint64_t key, int lane, bool insert)
+    {
+        int h = home(key);
+        for (int probes = 0; probes < 64; ++probes) {
+            if (!((mask >> h) & 1)) {
+                if (!insert) return -1;
+                keys[h * 64 + lane] = key;
+                mask |= 1ull << h;
+                return h;
+            }
+            if (keys[h * 64 + lane] == key) return h;
+            h = (h + 1) & 63;
+        }
+        overflow = true;
+        return -1;
+    }
+    __device__ __forceinline__ int id_of(int slot) const { return slot < 0 ? 0 : __popcll(mask & ((1ull << slot) - 1)); }
+};
+
+__device__ __forceinline__ uint64_t gl_key(float g0, float g1) { return ((uint64_t)__float_as_uint(g0) << 32) | __float_as_uint(g1); }
+
+struct EncodeArgs {
+    float4 *const *base;           // device: slab bases
+    const int32_t *npairs, *ncols; // device: per slab
+    int32_t n_slabs;
+    int64_t m;
+    // outputs (encode pass): nullptr in the counting pass
+    float2 *dict;
+    int32_t cmax;
+    const SlabCodes *slabs;
+    uint8_t *ncls;
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
+{
+    __shared__ uint64_t keys[64 * 64];
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t snp = tile * 64 + lane;
+    ClassTable T;
+    T.keys = keys;
+    for (int g = 0; g < A.n_slabs; ++g) {
+        const int np = A.npairs[g], nc = A.ncols[g];
+        const float4 *src = A.base[g] + tile * np * 64 + lane;
+        for (int p = 0; p < np; ++p) {
+            const float4 v = src[(int64_t)p * 64];
+            T.find_or_insert(gl_key(v.x, v.y), lane, true);
+            if (2 * p + 1 < nc) T.find_or_insert(gl_key(v.z, v.w), lane, true);
+        }
+    }
+    const int n = T.overflow ? 255 : __popcll(T.mask);
+    A.ncls[snp] = (uint8_t)n;          // the arrays cover whole tiles
+    if (!EMIT) return;
+    // the dictionary, class id = rank of the slot among the occupied ones
+    for (uint64_t left = T.mask; left;) {
+        const int slot = __builtin_ctzll(left);
+        left &= left - 1;
+        const uint64_t key = keys[slot * 64 + lane];
+        A.dict[(tile * A.cmax + T.id_of(slot)) * 64 + lane] = make_float2(__uint_as_float((uint32_t)(key >> 32)), __uint_as_float((uint32_t)key));
+    }
+    for (int g = 0; g < A.n_slabs; ++g) {
+        const int np = A.npairs[g], nc = A.ncols[g];
+        const SlabCodes sc = A.slabs[g];
+        const float4 *src = A.base[g] + tile * np * 64 + lane;
+        uint64_t present = 0;
+        for (int q = 0; q < sc.nquads; ++q) {
+            uint32_t word = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int p = 2 * q + h;
+                if (p >= np) break;
+                const float4 v = src[(int64_t)p * 64];
+                const int c0 = T.id_of(T.find_or_insert(gl_key(v.x, v.y), lane, false));
+                word |= (uint32_t)c0 << (16 * h);
+                present |= 1ull << c0;
+                if (2 * p + 1 < nc) {
+                    const int c1 = T.id_of(T.find_or_insert(gl_key(v.z, v.w), lane, false));
+                    word |= (uint32_t)c1 << (16 * h + 8);
+                    present |= 1ull << c1;
+                }
+            }
+            sc.codes[(tile * sc.nquads + q) * 64 + lane] = word;
+        }
+        sc.present[snp] = present;
+    }
+}
+
 inline unsigned grid_for(int64_t total)
 {
     int64_t blocks = (total + 255) / 256;
@@ -188,6 +287,55 @@ int launch_synth(wgs_beagle *b, uint64_t seed, double depth)
                            sl.base, b->m, sl.npairs, sl.ncols, sl.d_members, g, b->site0, seed, (float)depth);
         HIP_TRY(hipGetLastError());
     }
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+static EncodeArgs encode_args(wgs_beagle *b, int32_t *d_ncols)
+{
+    EncodeArgs A;
+    A.base = b->d_base;
+    A.npairs = b->d_npairs;
+    A.ncols = d_ncols;
+    A.n_slabs = b->n_groups;
+    A.m = b->m;
+    A.dict = nullptr;
+    A.cmax = 0;
+    A.slabs = nullptr;
+    A.ncls = nullptr;
+    return A;
+}
+
+// ncls[SNP] = distinct (g0, g1) pairs of the SNP over all individuals (255: more than 64).
+int launch_class_count(wgs_beagle *b, uint8_t *d_ncls)
+{
+    std::vector<int32_t> ncols(b->n_groups);
+    for (int g = 0; g < b->n_groups; ++g) ncols[g] = b->slabs[g].ncols;
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(b->ctx, sizeof(int32_t) * b->n_groups, &ws)) return 1;
+    HIP_TRY(hipMemcpyAsync(ws, ncols.data(), sizeof(int32_t) * b->n_groups, hipMemcpyHostToDevice, b->ctx->stream));
+    EncodeArgs A = encode_args(b, reinterpret_cast<int32_t *>(ws));
+    A.ncls = d_ncls;
+    hipLaunchKernelGGL(class_encode_kernel<false>, dim3((unsigned)wgs_ntiles(b->m)), dim3(64), 0, b->ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));      // ncols (a local vector) has been consumed
+    return 0;
+}
+
+int launch_class_encode(wgs_beagle *b, wgs_codes *c)
+{
+    std::vector<int32_t> ncols(b->n_groups);
+    for (int g = 0; g < b->n_groups; ++g) ncols[g] = b->slabs[g].ncols;
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(b->ctx, sizeof(int32_t) * b->n_groups, &ws)) return 1;
+    HIP_TRY(hipMemcpyAsync(ws, ncols.data(), sizeof(int32_t) * b->n_groups, hipMemcpyHostToDevice, b->ctx->stream));
+    EncodeArgs A = encode_args(b, reinterpret_cast<int32_t *>(ws));
+    A.dict = c->dict;
+    A.cmax = c->cmax;
+    A.slabs = c->d_slabs;
+    A.ncls = c->ncls;
+    hipLaunchKernelGGL(class_encode_kernel<true>, dim3((unsigned)wgs_ntiles(b->m)), dim3(64), 0, b->ctx->stream, A);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     return 0;
 }

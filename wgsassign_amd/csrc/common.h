@@ -69,6 +69,35 @@ struct Slab {
 };
 static inline int64_t wgs_ntiles(int64_t m) { return (m + 63) / 64; }
 
+// Class codes of a matrix (wgs_beagle_codes): low-depth genotype likelihoods take few distinct (g0, g1) values per SNP
+// -- the bundled 85-individual data 29 on average, the 2x synthetic matrices 27 among 1000 individuals -- and both hot
+// kernels evaluate an expensive function of (g0, g1, per-SNP parameter) per individual: the EM term's quotient, the
+// per-site log-likelihood.  With the classes known, that function is evaluated once per CLASS and SNP and looked up per
+// individual; the serial float32 accumulation / the float64 sums run over the individuals exactly as before, on the
+// very same values, so every result keeps its bits.
+//   dict   [(tile * cmax + class) * 64 + lane]  the (g0, g1) of class `class` of SNP 64 * tile + lane (tile-interleaved)
+//   ncls   [SNP]                                classes of the SNP (<= cmax <= 64)
+//   codes  per slab: [(tile * nquads + quad) * 64 + lane]  the classes of individuals 4 quad .. 4 quad + 3 (one byte
+//          each, low byte first) of the slab for SNP 64 * tile + lane: coalesced for lane <-> SNP kernels, and 16
+//          consecutive SNPs of one quad are one 64-byte line for lane <-> quad kernels
+//   present per slab: [SNP] bit c = class c occurs among the slab's individuals
+struct SlabCodes {
+    uint32_t *codes = nullptr;
+    uint64_t *present = nullptr;
+    int32_t nquads = 0;
+    int32_t quad0 = 0;             // first matrix-wide quad index of this slab
+};
+struct wgs_codes {
+    int32_t cmax = 0;
+    int32_t total_quads = 0;
+    float2 *dict = nullptr;
+    uint8_t *ncls = nullptr;
+    std::vector<SlabCodes> slabs;
+    SlabCodes *d_slabs = nullptr;  // device copy (+ per-slab member tables come from wgs_beagle)
+    int64_t bytes = 0;
+    double build_ms = 0.0;
+};
+
 struct wgs_beagle {
     wgs_ctx *ctx = nullptr;
     int64_t m = 0, n = 0, site0 = 0;
@@ -79,7 +108,16 @@ struct wgs_beagle {
     int32_t *d_group_of = nullptr, *d_col_of = nullptr, *d_npairs = nullptr;
     float4 **d_base = nullptr;
     int64_t bytes = 0;
+    // class codes, built on first use (wgs_beagle_codes) and dropped when rows change; codes_state: 0 = not tried,
+    // 1 = available, -1 = not codable (a SNP with more than 64 classes, or no memory): the direct kernels run
+    wgs_codes *codes = nullptr;
+    int codes_state = 0;
 };
+// The matrix's class codes, or nullptr when it is not codable (then the direct kernels are used).
+wgs_codes *wgs_beagle_codes(wgs_beagle *b);
+void wgs_beagle_drop_codes(wgs_beagle *b);
+int launch_class_count(wgs_beagle *b, uint8_t *d_ncls);
+int launch_class_encode(wgs_beagle *b, wgs_codes *c);
 
 struct wgs_afset {
     wgs_ctx *ctx = nullptr;
@@ -202,6 +240,14 @@ struct WalkArgs {
 int score_pairs_per_wave(int K, bool per_ind); // NP of the sweep for K populations (depends on the register batch KB)
 int chain_pairs_per_wave(int K, bool per_ind); // NP of the chain kernel (the slab table must be built for it)
 int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode);
+struct CodedSlabHost {             // = CodedSlab of assign_kernels.hip
+    const uint32_t *codes;
+    const int32_t *members;
+    int32_t nquads, ncols, quad0, col_lo, col_hi;
+};
+size_t score_coded_lds_bytes(int cmax, int kb);
+int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, int n_slabs, int total_quads, const float *const *d_acol,
+                       int64_t m, int64_t cells, int K, int nblocks, double *S, int mode);
 int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix, double *chunks);
 int launch_chunk_total(wgs_ctx *ctx, const double *chunks, int nchunks, int64_t cells, const double *carry, double *out);
 size_t chain_cand_lds_bytes(int K, int P, bool per_ind);

@@ -281,6 +281,7 @@ int wgs_ingest_next(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64_t ke
     hipStream_t st = b->ctx->stream;
     *file_rows = *rows_written = 0;
     g->names.clear();
+    wgs_beagle_drop_codes(b);                                  // the matrix changes: its class codes are rebuilt on next use
     TextChunk *c = nullptr;
     double waited = 0.0;
     if (int rc = reader_text_next(g->r, &c, &waited)) return rc;
