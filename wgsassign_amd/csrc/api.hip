@@ -538,10 +538,16 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
         seen[em->group[j]] = 1;
     }
     if (shared) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return em->group[x] < em->group[y]; });
+    // exact mode on a codable matrix: the sweep through the class codes (same frequencies, bit for bit)
+    wgs_codes *codes = em->mode == WGS_MODE_EXACT ? wgs_beagle_codes(em->b) : nullptr;
+    if (codes && !em_coded_fits(codes->cmax)) codes = nullptr;
     for (size_t i = 0; i < order.size(); ++i) {
         const int j = order[i];
         const Slab &s = em->b->slabs[em->group[j]];
         FitDesc &d = H[i];
+        d.codes = codes ? codes->slabs[em->group[j]].codes : nullptr;
+        d.present = codes ? codes->slabs[em->group[j]].present : nullptr;
+        d.nquads = codes ? codes->slabs[em->group[j]].nquads : 0;
         d.slab = s.base;
         d.f_old = em_f(em, j, em->cur[j]);
         d.f_new = em_f(em, j, em->cur[j] ^ 1);
@@ -556,7 +562,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     // H (pinned) stays untouched until the caller has waited for this sweep
     HIP_TRY(hipMemcpyAsync(D, H, sizeof(FitDesc) * order.size(), hipMemcpyHostToDevice, ctx->stream));
     int32_t n_groups = 0;
-    if (shared) {
+    if (shared && !codes) {
         const int fg = em_fits_per_group();
         for (size_t i = 0; i < order.size();) {
             size_t k = i + 1;
@@ -571,7 +577,14 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     if (ev0) HIP_TRY(hipEventRecord(ev0, ctx->stream));
     const int64_t per_unit = ((ntiles + 3) / 4 + 7) / 8 * 8 + 8;       // workgroups per fit / per group: slices stay below 2^31
     const size_t max_units = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_unit);
-    if (shared) {
+    if (codes) {
+        const int64_t per_fit = ((ntiles + 1) / 2 + 7) / 8 * 8 + 8;
+        const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
+        for (size_t off = 0; off < order.size(); off += max_fits) {
+            const int cnt = (int)std::min<size_t>(max_fits, order.size() - off);
+            if (launch_em_coded(ctx, D + off, cnt, em->b->m, codes->dict, codes->cmax)) return 1;
+        }
+    } else if (shared) {
         for (size_t off = 0; off < (size_t)n_groups; off += max_units) {
             const int cnt = (int)std::min<size_t>(max_units, (size_t)n_groups - off);
             if (launch_em_sweep_groups(ctx, D, Dg + 2 * off, cnt, em->b->m, em->mode)) return 1;

@@ -138,6 +138,10 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     int32_t skip;      // local column left out (LOO) or -1
     int32_t n_eff;     // ncols - (skip >= 0)
     const int32_t *state;  // device: fit state (EM_ACTIVE / EM_CONVERGED / EM_UNDECIDED) or nullptr = always sweep
+    // the slab's class codes (common.h: wgs_codes), or nullptr: then only the direct kernels can take this fit
+    const uint32_t *codes;
+    const uint64_t *present;
+    int32_t nquads;
 };
 enum { EM_ACTIVE = 0, EM_CONVERGED = 1, EM_UNDECIDED = 2 };
 // One exact convergence chain (emMAF_cy.pyx:30-31 over this shard): float32 running sum of (a-b)^2 from carry_in.
@@ -159,6 +163,9 @@ int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m
                          const int32_t *d_leaf_len, int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, const float *d_carry,
                          float *d_means);
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
+// the same sweep through the class codes (exact mode; every fit's descriptor carries its slab's codes)
+bool em_coded_fits(int cmax);
+int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, const float2 *dict, int cmax);
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
 int ssq_reduce_chunks(void);

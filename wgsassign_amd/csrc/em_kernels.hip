@@ -336,6 +336,120 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDes
     }
 }
 
+// ---- the sweep through the class codes (common.h: wgs_codes) --------------------------------------------------
+// The quotient q = (p1 + 2 p2) / ((p0 + p1) + p2) of a term depends on the individual only through its (g0, g1); a SNP has
+// few distinct (g0, g1) and a population slab fewer still (`present`).  Per (fit, tile), lane <-> SNP as before:
+//   phase 0  the tile's dictionary goes into LDS, [class][lane] (coalesced rows);
+//   phase 1  every lane replaces, for each class PRESENT in its slab, the (g0, g1) in its slot by the quotient q --
+//            the rounding sequence of term_exact_shared up to the divide, evaluated once per class instead of once per
+//            individual (lanes walk their own set bits; slot [class][lane] is touched by its lane only: no barrier);
+//   phase 2  the individuals are walked in order: tmp = (float)fma(0.5, q[code], (double)tmp) -- the serial float32
+//            accumulation of emMAF_cy.pyx:22 on the very same addends, with the leave-one-out skip and the column bound
+//            wave-uniform as in the direct kernels.
+// Leave-one-out fits of one population read the same dictionary and code words: workgroups are dealt to the XCDs so
+// that all fits of a tile meet in one L2 (as em_sweep_group_kernel does).
+constexpr int WAVES_C = 2;         // waves per workgroup: the per-wave table is cmax * 512 bytes of LDS
+
+template <int U>
+__global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m,
+                                                                 const float2 *__restrict__ dict, int cmax)
+{
+    extern __shared__ __align__(16) double qtab_all[];
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const int fit = (int)(j % (unsigned)n_fits);
+    const int64_t tgroup = (int64_t)(j / (unsigned)n_fits) * 8 + xcd;
+    const FitDesc fd = fits[fit];
+    if (fd.state && *fd.state != EM_ACTIVE) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t tile = tgroup * WAVES_C + wave;
+    const int64_t row0 = tile * 64;
+    if (row0 >= m) return;                       // wave-uniform; no barriers below
+    double *q = qtab_all + (size_t)wave * cmax * 64 + lane;      // slot of class c: q[c * 64]
+
+    const int64_t my_row = row0 + lane;
+    const int64_t my_row_c = my_row < m ? my_row : m - 1;
+    const float f_old = ((gf32_ptr)fd.f_old)[my_row_c];
+    SnpState st;
+    st.fd = (double)f_old;
+    st.omf = 1.0 - st.fd;
+    st.fd2 = 2.0 * st.fd;
+
+    // phase 0: dictionary rows -> LDS (as raw 8-byte words)
+    {
+        const double *drow = reinterpret_cast<const double *>(dict) + tile * cmax * 64 + lane;
+        for (int c = 0; c < cmax; ++c) q[c * 64] = drow[(int64_t)c * 64];
+    }
+    // phase 1: (g0, g1) -> quotient, for the classes present in this slab
+    uint64_t left = fd.present[row0 + lane];
+    while (__any(left != 0)) {
+        const bool on = left != 0;
+        const int c = on ? __builtin_ctzll(left) : 0;
+        left &= left - 1;
+        const double raw = q[c * 64];
+        const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
+                    g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
+        const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
+        const float p0 = (float)((g0d * st.omf) * st.omf);
+        const float p1 = (float)((g1d * st.fd2) * st.omf);
+        const float p2 = (float)((g2d * st.fd) * st.fd);
+        const float ssum = (p0 + p1) + p2;
+        const double num = __builtin_fma(2.0, (double)p2, (double)p1);
+        const double qv = div_exact<true>(num, (double)ssum);
+        if (on) q[c * 64] = qv;
+    }
+    // phase 2: the serial accumulation over the slab's individuals
+    const int nquads = fd.nquads;
+    const uint32_t *src = fd.codes + tile * nquads * 64 + lane;
+    const int last = nquads - 1;
+    uint32_t cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
+    float tmp = 0.0f;
+    for (int q0 = 0; q0 < nquads; q0 += U) {
+        if (q0 + U < nquads) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int qq = q0 + U + u;
+                nxt[u] = src[(qq < last ? qq : last) * 64];
+            }
+        }
+        const bool plain = 4 * (q0 + U) <= fd.ncols && (fd.skip < 4 * q0 || fd.skip >= 4 * (q0 + U));
+        if (plain) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t w = cur[u];
+                double qv[4];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) qv[h] = q[((w >> (8 * h)) & 255u) * 64];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) tmp = (float)__builtin_fma(0.5, qv[h], (double)tmp);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t w = cur[u];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int col = 4 * (q0 + u) + h;
+                    if (col < fd.ncols && col != fd.skip) tmp = (float)__builtin_fma(0.5, q[((w >> (8 * h)) & 255u) * 64], (double)tmp);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+    const float f_new = tmp / (float)fd.n_eff;           // emMAF_cy.pyx:23 (float32 divide)
+    double sq = 0.0;
+    if (my_row < m) {
+        ((gf32_wptr)fd.f_new)[my_row] = f_new;
+        const float d = f_new - f_old;                    // emMAF_cy.pyx:31, float32
+        sq = (double)(d * d);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+    if (lane == 0) fd.ssq_part[tile] = sq;
+}
+
 // ssq[fit] = sum over tiles of the per-tile partials, in a fixed summation order (reproducible):
 // stage 1, RED_CHUNKS workgroups per fit each reduce a contiguous slice of the partials into
 // part2[fit][chunk]; stage 2, one wavefront per fit adds the RED_CHUNKS slice sums.
@@ -838,6 +952,21 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
         hipLaunchKernelGGL((em_sweep_kernel<WGS_MODE_EXACT, 4>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
     else
         hipLaunchKernelGGL((em_sweep_kernel<WGS_MODE_FAST, 4>), grid, dim3(WAVES * 64), 0, ctx->stream, d_descs, n_fits, m);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+bool em_coded_fits(int cmax) { return cmax >= 1 && (size_t)WAVES_C * cmax * 512 <= 64 * 1024; }
+
+int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, const float2 *dict, int cmax)
+{
+    if (n_fits <= 0 || m <= 0) return 0;
+    const int64_t tiles = (m + 63) / 64;
+    const int64_t tgroups = ((tiles + WAVES_C - 1) / WAVES_C + 7) / 8 * 8;      // the XCD-aware order covers whole groups of 8
+    const int64_t blocks = tgroups * n_fits;
+    WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
+    const size_t lds = (size_t)WAVES_C * cmax * 512;
+    hipLaunchKernelGGL((em_coded_kernel<4>), dim3((unsigned)blocks), dim3(WAVES_C * 64), lds, ctx->stream, d_descs, n_fits, m, dict, cmax);
     HIP_TRY(hipGetLastError());
     return 0;
 }
