@@ -99,7 +99,8 @@ int64_t wgs_beagle_bytes(const wgs_beagle *b);
  * EM term's quotient / the per-site log-likelihood once per CLASS and SNP and look it up per individual -- same
  * values, same order of accumulation, same bits.  Built on first use (one byte per (SNP, individual) + a dictionary;
  * WGSASSIGN_CODES=0 disables them); a matrix with more than 64 classes in some SNP is not coded and takes the direct
- * kernels.  info[0..4] = available, classes of the richest SNP, bytes held, build milliseconds, mean classes per SNP. */
+ * kernels.  info[0..5] = available, classes of the richest SNP, bytes held, build milliseconds (allocations included),
+ * mean classes per SNP, milliseconds of the encode kernel alone. */
 int wgs_beagle_codes_info(wgs_beagle *b, double *info);
 
 /* A batch of EM fits (emMAF.py:15-27) over slabs of `b`.  Fit j estimates the frequency of

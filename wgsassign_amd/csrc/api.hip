@@ -176,15 +176,8 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b)
     };
     if (hipMalloc(&c->ncls, rows) != hipSuccess) return fail();
     c->bytes += (int64_t)rows;
-    if (launch_class_count(b, c->ncls)) return fail();
-    std::vector<uint8_t> h(rows);
-    if (hipMemcpy(h.data(), c->ncls, rows, hipMemcpyDeviceToHost) != hipSuccess) return fail();
-    int cmax = 1;
-    for (size_t i = 0; i < rows; ++i) cmax = std::max<int>(cmax, h[i]);
-    if (cmax > 64) return fail();                              // 255 marks a SNP with more than 64 classes
-    c->cmax = cmax;
-    if (hipMalloc(&c->dict, rows * (size_t)cmax * sizeof(float2)) != hipSuccess) return fail();
-    c->bytes += (int64_t)(rows * (size_t)cmax * sizeof(float2));
+    if (hipMalloc(&c->dict, rows * (size_t)WGS_CODE_ROWS * sizeof(float2)) != hipSuccess) return fail();
+    c->bytes += (int64_t)(rows * (size_t)WGS_CODE_ROWS * sizeof(float2));
     c->slabs.resize(b->n_groups);
     int quad0 = 0;
     for (int g = 0; g < b->n_groups; ++g) {
@@ -201,7 +194,16 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b)
     if (hipMalloc(&c->d_slabs, sizeof(SlabCodes) * b->n_groups) != hipSuccess ||
         hipMemcpy(c->d_slabs, c->slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) != hipSuccess)
         return fail();
+    c->cmax = WGS_CODE_ROWS;                                   // row stride of the dictionary while encoding
+    const double tk = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     if (launch_class_encode(b, c)) return fail();
+    c->kernel_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tk) * 1e3;
+    std::vector<uint8_t> h(rows);
+    if (hipMemcpy(h.data(), c->ncls, rows, hipMemcpyDeviceToHost) != hipSuccess) return fail();
+    int cmax = 1;
+    for (size_t i = 0; i < rows; ++i) cmax = std::max<int>(cmax, h[i]);
+    if (cmax > 64) return fail();                              // 255 marks a SNP with more than 64 classes
+    c->cmax = cmax;
     c->build_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3;
     b->codes_state = 1;
     return c;
@@ -216,12 +218,13 @@ int wgs_beagle_codes_info(wgs_beagle *b, double *info)
 {
     WGS_REQUIRE(b && info, "null argument");
     wgs_codes *c = wgs_beagle_codes(b);
-    for (int i = 0; i < 5; ++i) info[i] = 0.0;
+    for (int i = 0; i < 6; ++i) info[i] = 0.0;
     if (!c) return 0;
     info[0] = 1.0;
     info[1] = c->cmax;
     info[2] = (double)c->bytes;
     info[3] = c->build_ms;
+    info[5] = c->kernel_ms;
     const size_t rows = (size_t)b->m;
     std::vector<uint8_t> h(rows);
     HIP_TRY(hipMemcpy(h.data(), c->ncls, rows, hipMemcpyDeviceToHost));
@@ -539,7 +542,15 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     }
     if (shared) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return em->group[x] < em->group[y]; });
     // exact mode on a codable matrix: the sweep through the class codes (same frequencies, bit for bit)
-    wgs_codes *codes = em->mode == WGS_MODE_EXACT ? wgs_beagle_codes(em->b) : nullptr;
+    // -- for fits of different slabs; leave-one-out batches (several fits per slab) stay with em_sweep_group_kernel,
+    // whose shared loads and conversions serve them better than a quotient table per fit
+    // -- and small populations stay with em_sweep_kernel too: below ~40 individuals the table costs more than it saves
+    // (measured: 20 individuals 0.68x, 62 1.14x, 100 1.39x)
+    bool worth = em->mode == WGS_MODE_EXACT && !shared;
+    const char *min_env = getenv("WGSASSIGN_EM_CODES_MIN");    // tests lower it to run small populations through the codes
+    const int min_cols = min_env ? atoi(min_env) : 40;
+    for (int j : order) worth = worth && em->b->slabs[em->group[j]].ncols >= min_cols;
+    wgs_codes *codes = worth ? wgs_beagle_codes(em->b) : nullptr;
     if (codes && !em_coded_fits(codes->cmax)) codes = nullptr;
     for (size_t i = 0; i < order.size(); ++i) {
         const int j = order[i];

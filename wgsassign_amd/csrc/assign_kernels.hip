@@ -422,6 +422,9 @@ struct CodedScoreArgs {
     const float *const *acol;
     int64_t m, cells;
     int32_t K, nblocks;
+    int32_t parts;                 // a block's 64 tiles are shared by `parts` workgroups (short matrices: enough workgroups
+                                   // to fill the chip); their partial sums go to Sp[part][block][cell] and are added in a
+                                   // fixed order by combine_parts_kernel
     double *S;
     const double2 *logtab;         // the log table in device memory (wgs_log_table_dev)
 };
@@ -442,7 +445,10 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
     const int tid = threadIdx.x;
     const int64_t blk = blockIdx.x;
     const int64_t ntiles = (A.m + 63) >> 6;
-    const int64_t t0 = blk * WGS_BLOCK_TILES, t1 = t0 + WGS_BLOCK_TILES < ntiles ? t0 + WGS_BLOCK_TILES : ntiles;
+    const int tiles_per_part = WGS_BLOCK_TILES / A.parts;
+    const int64_t t0 = blk * WGS_BLOCK_TILES + (int64_t)blockIdx.z * tiles_per_part;
+    const int64_t t1 = t0 + tiles_per_part < ntiles ? t0 + tiles_per_part : ntiles;
+    double *const Sout = A.S + ((int64_t)blockIdx.z * A.nblocks + blk) * A.cells;      // parts == 1: S[block]
     // this lane's quad
     const int Q = (int)blockIdx.y * 256 + tid;
     const bool have = Q < A.total_quads;
@@ -493,7 +499,7 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
                     const int c = r / KB, k = r - c * KB;
                     const int64_t s = s0 + j;
                     if (c < (int)A.ncls[s]) {
-                        const float2 gl = A.dict[(t * A.cmax + c) * 64 + l0 + j];
+                        const float2 gl = A.dict[(t * WGS_CODE_ROWS + c) * 64 + l0 + j];
                         const int kk = kb + k < A.K ? kb + k : A.K - 1;
                         const float a = A.acol[kk][s];
                         float v;
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
         for (int h = 0; h < 4; ++h)
 #pragma unroll
             for (int k = 0; k < KB; ++k)
-                if (ok[h] && kb + k < A.K) A.S[blk * A.cells + (int64_t)ind[h] * A.K + kb + k] = acc[h][k];
+                if (ok[h] && kb + k < A.K) Sout[(int64_t)ind[h] * A.K + kb + k] = acc[h][k];
     }
 }
 
@@ -1086,6 +1092,17 @@ int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode)
     return 0;
 }
 
+// S[block][cell] = ((Sp[0] + Sp[1]) + Sp[2]) + ... over the parts of a block: a fixed order (and exact anyway while the
+// block's partial sums are).
+__global__ __launch_bounds__(256) void combine_parts_kernel(const double *__restrict__ Sp, double *__restrict__ S, int64_t total, int parts)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    double acc = Sp[e];
+    for (int p = 1; p < parts; ++p) acc += Sp[(int64_t)p * total + e];
+    S[e] = acc;
+}
+
 size_t score_coded_lds_bytes(int cmax, int kb) { return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + sizeof(float) * CODED_BATCH * cmax * ((kb + 3) & ~3); }
 
 // The scoring sweep through the class codes (shared columns only).  d_slabs: n_slabs CodedSlab records in device memory.
@@ -1114,7 +1131,18 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     A.inv_rows = (uint32_t)(((1ull << 32) + (uint64_t)(c->cmax * kb) - 1) / (uint64_t)(c->cmax * kb));
     const size_t lds = score_coded_lds_bytes(c->cmax, kb);
     WGS_REQUIRE(lds <= 64 * 1024, "class table too large for LDS");
-    dim3 grid((unsigned)nblocks, (unsigned)((total_quads + 255) / 256));
+    const unsigned ygroups = (unsigned)((total_quads + 255) / 256);
+    int parts = 1;
+    while (parts < 16 && (int64_t)nblocks * ygroups * parts < 1536) parts *= 2;   // >= 6 workgroups per CU, or 4 tiles per part
+    A.parts = parts;
+    const int64_t total = (int64_t)nblocks * cells;
+    if (parts > 1) {
+        void *ws = nullptr;
+        if (wgs_ctx_workspace(ctx, sizeof(double) * (size_t)total * parts, &ws)) return 1;
+        HIP_TRY(hipMemsetAsync(ws, 0, sizeof(double) * (size_t)total * parts, ctx->stream));   // rows outside the scored range stay 0
+        A.S = reinterpret_cast<double *>(ws);
+    }
+    dim3 grid((unsigned)nblocks, ygroups, (unsigned)parts);
 #define WGS_CODED(KB)                                                                                                     \
     do {                                                                                                                  \
         if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT>), grid, dim3(256), lds, ctx->stream, A); \
@@ -1123,6 +1151,10 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     WGS_FOR_KB(WGS_CODED, K)
 #undef WGS_CODED
     HIP_TRY(hipGetLastError());
+    if (parts > 1) {
+        hipLaunchKernelGGL(combine_parts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A.S, S, total, parts);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 

@@ -193,7 +193,6 @@ struct EncodeArgs {
     uint8_t *ncls;
 };
 
-template <bool EMIT>
 __global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
 {
     __shared__ uint64_t keys[64 * 64];
@@ -213,13 +212,13 @@ __global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
     }
     const int n = T.overflow ? 255 : __popcll(T.mask);
     A.ncls[snp] = (uint8_t)n;          // the arrays cover whole tiles
-    if (!EMIT) return;
+    if (__any(T.overflow)) return;     // not codable: the host sees ncls = 255 and drops the codes
     // the dictionary, class id = rank of the slot among the occupied ones
     for (uint64_t left = T.mask; left;) {
         const int slot = __builtin_ctzll(left);
         left &= left - 1;
         const uint64_t key = keys[slot * 64 + lane];
-        A.dict[(tile * A.cmax + T.id_of(slot)) * 64 + lane] = make_float2(__uint_as_float((uint32_t)(key >> 32)), __uint_as_float((uint32_t)key));
+        A.dict[(tile * WGS_CODE_ROWS + T.id_of(slot)) * 64 + lane] = make_float2(__uint_as_float((uint32_t)(key >> 32)), __uint_as_float((uint32_t)key));
     }
     for (int g = 0; g < A.n_slabs; ++g) {
         const int np = A.npairs[g], nc = A.ncols[g];
@@ -306,22 +305,6 @@ static EncodeArgs encode_args(wgs_beagle *b, int32_t *d_ncols)
     return A;
 }
 
-// ncls[SNP] = distinct (g0, g1) pairs of the SNP over all individuals (255: more than 64).
-int launch_class_count(wgs_beagle *b, uint8_t *d_ncls)
-{
-    std::vector<int32_t> ncols(b->n_groups);
-    for (int g = 0; g < b->n_groups; ++g) ncols[g] = b->slabs[g].ncols;
-    void *ws = nullptr;
-    if (wgs_ctx_workspace(b->ctx, sizeof(int32_t) * b->n_groups, &ws)) return 1;
-    HIP_TRY(hipMemcpyAsync(ws, ncols.data(), sizeof(int32_t) * b->n_groups, hipMemcpyHostToDevice, b->ctx->stream));
-    EncodeArgs A = encode_args(b, reinterpret_cast<int32_t *>(ws));
-    A.ncls = d_ncls;
-    hipLaunchKernelGGL(class_encode_kernel<false>, dim3((unsigned)wgs_ntiles(b->m)), dim3(64), 0, b->ctx->stream, A);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));      // ncols (a local vector) has been consumed
-    return 0;
-}
-
 int launch_class_encode(wgs_beagle *b, wgs_codes *c)
 {
     std::vector<int32_t> ncols(b->n_groups);
@@ -334,7 +317,7 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
     A.cmax = c->cmax;
     A.slabs = c->d_slabs;
     A.ncls = c->ncls;
-    hipLaunchKernelGGL(class_encode_kernel<true>, dim3((unsigned)wgs_ntiles(b->m)), dim3(64), 0, b->ctx->stream, A);
+    hipLaunchKernelGGL(class_encode_kernel, dim3((unsigned)wgs_ntiles(b->m)), dim3(64), 0, b->ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     return 0;

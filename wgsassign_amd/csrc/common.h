@@ -75,12 +75,14 @@ static inline int64_t wgs_ntiles(int64_t m) { return (m + 63) / 64; }
 // per-site log-likelihood.  With the classes known, that function is evaluated once per CLASS and SNP and looked up per
 // individual; the serial float32 accumulation / the float64 sums run over the individuals exactly as before, on the
 // very same values, so every result keeps its bits.
-//   dict   [(tile * cmax + class) * 64 + lane]  the (g0, g1) of class `class` of SNP 64 * tile + lane (tile-interleaved)
+//   dict   [(tile * 64 + class) * 64 + lane]    the (g0, g1) of class `class` of SNP 64 * tile + lane (tile-interleaved;
+//                                               WGS_CODE_ROWS = 64 rows per tile, so one launch encodes without knowing cmax)
 //   ncls   [SNP]                                classes of the SNP (<= cmax <= 64)
 //   codes  per slab: [(tile * nquads + quad) * 64 + lane]  the classes of individuals 4 quad .. 4 quad + 3 (one byte
 //          each, low byte first) of the slab for SNP 64 * tile + lane: coalesced for lane <-> SNP kernels, and 16
 //          consecutive SNPs of one quad are one 64-byte line for lane <-> quad kernels
 //   present per slab: [SNP] bit c = class c occurs among the slab's individuals
+constexpr int WGS_CODE_ROWS = 64;  // dictionary rows per tile = the most classes a SNP may have
 struct SlabCodes {
     uint32_t *codes = nullptr;
     uint64_t *present = nullptr;
@@ -95,7 +97,7 @@ struct wgs_codes {
     std::vector<SlabCodes> slabs;
     SlabCodes *d_slabs = nullptr;  // device copy (+ per-slab member tables come from wgs_beagle)
     int64_t bytes = 0;
-    double build_ms = 0.0;
+    double build_ms = 0.0, kernel_ms = 0.0;
 };
 
 struct wgs_beagle {
@@ -116,7 +118,6 @@ struct wgs_beagle {
 // The matrix's class codes, or nullptr when it is not codable (then the direct kernels are used).
 wgs_codes *wgs_beagle_codes(wgs_beagle *b);
 void wgs_beagle_drop_codes(wgs_beagle *b);
-int launch_class_count(wgs_beagle *b, uint8_t *d_ncls);
 int launch_class_encode(wgs_beagle *b, wgs_codes *c);
 
 struct wgs_afset {

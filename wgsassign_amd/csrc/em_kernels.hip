@@ -364,7 +364,7 @@ __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *_
     const int64_t tile = tgroup * WAVES_C + wave;
     const int64_t row0 = tile * 64;
     if (row0 >= m) return;                       // wave-uniform; no barriers below
-    double *q = qtab_all + (size_t)wave * cmax * 64 + lane;      // slot of class c: q[c * 64]
+    double *q = qtab_all + (size_t)wave * ((cmax + 7) & ~7) * 64 + lane;      // slot of class c: q[c * 64]
 
     const int64_t my_row = row0 + lane;
     const int64_t my_row_c = my_row < m ? my_row : m - 1;
@@ -374,13 +374,43 @@ __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *_
     st.omf = 1.0 - st.fd;
     st.fd2 = 2.0 * st.fd;
 
-    // phase 0: dictionary rows -> LDS (as raw 8-byte words)
+    // the first code words and the slab's class set: in flight while the dictionary is staged
+    const int nquads = fd.nquads;
+    const uint32_t *src = fd.codes + tile * nquads * 64 + lane;
+    const int last = nquads - 1;
+    uint32_t cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
+    uint64_t left = fd.present[row0 + lane];
+    // phase 0: dictionary rows -> LDS (as raw 8-byte words), eight loads in flight at a time; rows of classes that occur
+    // in none of the tile's 64 SNPs within this slab are skipped
+    uint64_t uni = left;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) uni |= __shfl_xor(uni, off, 64);
     {
-        const double *drow = reinterpret_cast<const double *>(dict) + tile * cmax * 64 + lane;
-        for (int c = 0; c < cmax; ++c) q[c * 64] = drow[(int64_t)c * 64];
+        const double *drow = reinterpret_cast<const double *>(dict) + tile * WGS_CODE_ROWS * 64 + lane;
+        for (int c0 = 0; c0 < cmax; c0 += 8) {
+            if (!((uni >> c0) & 0xFFull)) continue;          // wave-uniform
+            double r0, r1, r2, r3, r4, r5, r6, r7;
+            r0 = drow[(int64_t)(c0 + 0) * 64];                  // the dictionary has WGS_CODE_ROWS = 64 rows per tile
+            r1 = drow[(int64_t)(c0 + 1) * 64];
+            r2 = drow[(int64_t)(c0 + 2) * 64];
+            r3 = drow[(int64_t)(c0 + 3) * 64];
+            r4 = drow[(int64_t)(c0 + 4) * 64];
+            r5 = drow[(int64_t)(c0 + 5) * 64];
+            r6 = drow[(int64_t)(c0 + 6) * 64];
+            r7 = drow[(int64_t)(c0 + 7) * 64];
+            q[(c0 + 0) * 64] = r0;                           // the table has room for whole groups of eight (launch_em_coded)
+            q[(c0 + 1) * 64] = r1;
+            q[(c0 + 2) * 64] = r2;
+            q[(c0 + 3) * 64] = r3;
+            q[(c0 + 4) * 64] = r4;
+            q[(c0 + 5) * 64] = r5;
+            q[(c0 + 6) * 64] = r6;
+            q[(c0 + 7) * 64] = r7;
+        }
     }
     // phase 1: (g0, g1) -> quotient, for the classes present in this slab
-    uint64_t left = fd.present[row0 + lane];
     while (__any(left != 0)) {
         const bool on = left != 0;
         const int c = on ? __builtin_ctzll(left) : 0;
@@ -397,13 +427,8 @@ __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *_
         const double qv = div_exact<true>(num, (double)ssum);
         if (on) q[c * 64] = qv;
     }
-    // phase 2: the serial accumulation over the slab's individuals
-    const int nquads = fd.nquads;
-    const uint32_t *src = fd.codes + tile * nquads * 64 + lane;
-    const int last = nquads - 1;
-    uint32_t cur[U], nxt[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
+    // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
+    // table before the chain of that buffer starts
     float tmp = 0.0f;
     for (int q0 = 0; q0 < nquads; q0 += U) {
         if (q0 + U < nquads) {
@@ -413,27 +438,25 @@ __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *_
                 nxt[u] = src[(qq < last ? qq : last) * 64];
             }
         }
+        double qv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) qv[u][h] = q[((cur[u] >> (8 * h)) & 255u) * 64];
         const bool plain = 4 * (q0 + U) <= fd.ncols && (fd.skip < 4 * q0 || fd.skip >= 4 * (q0 + U));
         if (plain) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t w = cur[u];
-                double qv[4];
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int h = 0; h < 4; ++h) qv[h] = q[((w >> (8 * h)) & 255u) * 64];
-#pragma unroll
-                for (int h = 0; h < 4; ++h) tmp = (float)__builtin_fma(0.5, qv[h], (double)tmp);
-            }
+                for (int h = 0; h < 4; ++h) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
         } else {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const uint32_t w = cur[u];
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     const int col = 4 * (q0 + u) + h;
-                    if (col < fd.ncols && col != fd.skip) tmp = (float)__builtin_fma(0.5, q[((w >> (8 * h)) & 255u) * 64], (double)tmp);
+                    if (col < fd.ncols && col != fd.skip) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
                 }
-            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
@@ -956,7 +979,8 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     return 0;
 }
 
-bool em_coded_fits(int cmax) { return cmax >= 1 && (size_t)WAVES_C * cmax * 512 <= 64 * 1024; }
+static int coded_rows(int cmax) { return (cmax + 7) & ~7; }      // table rows: whole groups of eight classes
+bool em_coded_fits(int cmax) { return cmax >= 1 && (size_t)WAVES_C * coded_rows(cmax) * 512 <= 64 * 1024; }
 
 int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, const float2 *dict, int cmax)
 {
@@ -965,7 +989,7 @@ int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     const int64_t tgroups = ((tiles + WAVES_C - 1) / WAVES_C + 7) / 8 * 8;      // the XCD-aware order covers whole groups of 8
     const int64_t blocks = tgroups * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
-    const size_t lds = (size_t)WAVES_C * cmax * 512;
+    const size_t lds = (size_t)WAVES_C * coded_rows(cmax) * 512;
     hipLaunchKernelGGL((em_coded_kernel<4>), dim3((unsigned)blocks), dim3(WAVES_C * 64), lds, ctx->stream, d_descs, n_fits, m, dict, cmax);
     HIP_TRY(hipGetLastError());
     return 0;

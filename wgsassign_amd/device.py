@@ -170,10 +170,10 @@ class DeviceBeagle:
     def codes_info(self):
         """Class codes of the matrix (built on first use; csrc/common.h: wgs_codes): dict with `available`, `max_classes`
         (of the richest SNP), `bytes`, `build_ms`, `mean_classes`."""
-        info = (ctypes.c_double * 5)()
+        info = (ctypes.c_double * 6)()
         check(_lib.load().wgs_beagle_codes_info(self._h, info))
         return {"available": bool(info[0]), "max_classes": int(info[1]), "bytes": int(info[2]), "build_ms": info[3],
-                "mean_classes": info[4]}
+                "encode_kernel_ms": info[5], "mean_classes": info[4]}
 
     def close(self):
         if self._h:
