@@ -234,6 +234,9 @@ def main():
     ctx.sync()
     t_gen = time.time() - t0
     gl_bytes = beagle.nbytes()
+    # the class codes of the matrix (csrc/common.h: wgs_codes; built once per matrix like the slab layout itself, on first
+    # use -- here explicitly, so that the build is never inside the timed region)
+    codes = beagle.codes_info() if args.mode == "exact" else {"available": False}
     em = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
 
     def barrier():
@@ -280,12 +283,18 @@ def main():
     alg_bytes = (8.0 * n + 8.0 * K) * m
     k_avg = float(np.mean(kernel_ms)) * 1e-3
     achieved = alg_bytes / k_avg
+    coded_em = bool(codes.get("available")) and per >= 40 and os.environ.get("WGSASSIGN_CODES", "1") != "0"
     roofline = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
-                "kernel": "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
+                "kernel": "em_coded_kernel" if coded_em else "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
                 "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_snp": 8 * n + 8 * K}
+    if coded_em:
+        roofline["note"] = ("achieved = ALGORITHMIC bytes (8 per (SNP, individual) of the float32 matrix, SURVEY 8d) / kernel time; the "
+                            "production sweep reads the matrix through its class codes -- 1 byte per (SNP, individual) + a per-SNP "
+                            "dictionary -- so it is not bound by those bytes and `frac` may exceed 1; `traffic` is what it really moves. "
+                            "Same frequencies bit for bit as the sweep over the float32 slabs (extra.direct_sweep).")
 
-    pmc = committed_pmc(m, n, K, args.mode)
+    pmc = committed_pmc(m, n, K, args.mode, coded_em, bool(codes.get("available")))
     roofline["traffic"], roofline["traffic_source"] = pmc.get("em_traffic"), pmc.get("source")
     if pmc.get("reason"):
         roofline["traffic_note"] = pmc["reason"]
@@ -296,6 +305,22 @@ def main():
 
     extra = {"gl_pair_terms_per_s": value * n_call, "synth_seconds": round(t_gen, 2),
              "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
+    if codes.get("available"):
+        extra["class_codes"] = {"bytes": codes["bytes"], "build_ms_once_per_matrix": round(codes["build_ms"], 1), "mean_classes_per_snp":
+                                round(codes["mean_classes"], 2), "max_classes_per_snp": codes["max_classes"]}
+    if coded_em:
+        # the same iterations over the float32 slabs (WGSASSIGN_CODES=0): the kernel the HBM roofline of SURVEY 8d describes
+        os.environ["WGSASSIGN_CODES"] = "0"
+        em_d = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
+        em_d.fit(2, 0.0, comm if use_dist else None, m_total)
+        em_d.fit(6, 0.0, comm if use_dist else None, m_total)
+        dk = em_d.fit_stats()[3] / 6 * 1e-3
+        ssq_d = em_d.step_reduced(comm if use_dist else None)
+        em_d.close()
+        os.environ["WGSASSIGN_CODES"] = "1"
+        extra["direct_sweep"] = {"kernel": "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(dk * 1e3, 4),
+                                 "hbm_frac": round(alg_bytes / dk / HBM_PEAK, 4), "value_if_used": K * m_total / (dk * world) if dk > 0 else None,
+                                 "note": "float32 slabs, traffic = algorithmic bytes; identical frequencies (tests/test_gpu_codes.py)"}
 
     # the same sweep in WGS_MODE_FAST (float32 term evaluation, ~1e-6 of the reference), for comparison
     if args.mode == "exact":
@@ -325,13 +350,21 @@ def main():
         barrier()
         t_as = max_over_ranks(time.perf_counter() - t0)
         as_ms = device.assign.last_ms
+        coded_score = bool(codes.get("available"))
         extra["assign"] = {"metric": "assignment log-lik SNPs/s (all n x K terms of a SNP = 1)",
                            "value": m_total / t_as, "unit": "SNPs/s", "seconds": round(t_as, 4),
                            "terms_per_s": m_total * float(n) * K / t_as,
                            "kernel_ms": round(as_ms, 3),
                            "hbm_frac": round((8.0 * n + 4.0 * K) * m / (as_ms * 1e-3) / HBM_PEAK, 4) if as_ms > 0 else None,
-                           "kernel": "score_sweep_kernel<%s> + block_prefix_kernel (one launch over all population slabs)" % args.mode,
+                           "kernel": ("score_coded_kernel<%s> (per-class value table in LDS)" if coded_score else "score_sweep_kernel<%s>") % args.mode
+                                     + " + block_prefix_kernel (one launch over all population slabs)",
                            "checksum": float(np.sum(out))}
+        if coded_score:
+            os.environ["WGSASSIGN_CODES"] = "0"
+            out_d, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
+            os.environ["WGSASSIGN_CODES"] = "1"
+            extra["assign"]["direct_sweep"] = {"kernel": "score_sweep_kernel<%s>" % args.mode, "kernel_ms": round(device.assign.last_ms, 3),
+                                               "identical_sums": bool(out_d.tobytes() == out.tobytes())}
         if args.mode == "exact":
             # the float32 scoring sweep (WGSASSIGN_MODE=fast), validated against exact on this very matrix
             out_f, _ = device.assign(beagle, afs, mode=MODE_FAST, comm=comm if use_dist else None)
@@ -341,7 +374,7 @@ def main():
         if pmc.get("assign_valu_busy_frac") is not None and pmc.get("assign_insts_valu"):
             # bound: FP64 vector issue (one double log per term), not HBM.  valu_frac = SQ_ACTIVE_INST_VALU * 4 /
             # (1024 SIMDs * GRBM_GUI_ACTIVE / 8) from the committed rocprofv3 PMC pass of this workload
-            extra["assign"].update({"bound": "valu_fp64_issue", "valu_frac": round(pmc["assign_valu_busy_frac"], 4),
+            extra["assign"].update({"bound": "valu_issue (+ LDS table reads)" if coded_score else "valu_fp64_issue", "valu_frac": round(pmc["assign_valu_busy_frac"], 4),
                                     "valu_insts_per_term": round(pmc["assign_insts_valu"] * 64.0 / (float(m) * n * K), 2),
                                     "traffic": pmc.get("assign_traffic"), "pmc_source": pmc.get("source")})
         afs.close()
@@ -387,7 +420,7 @@ FP64_ISSUE_CLOCK_GHZ = 2.4      # MI355X peak engine clock: issue fractions belo
 WAVE_ISSUE_PER_S = 1024 * FP64_ISSUE_CLOCK_GHZ * 1e9 / 4.0       # 1024 SIMDs, 4 cycles per wave-wide FP64-rate instruction
 # VALU wave-instructions per (SNP, individual[, population]) term of the FP64-issue-bound kernels, from the committed PMC
 # passes (profiles/r02_e_loo_final: em_sweep_group_kernel 2.49e10 per sweep of 6.15e10 terms; r02_g_final: score sweep)
-INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "score_sweep_kernel<exact>": 41.6}
+INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "score_sweep_kernel<exact>": 41.6, "score_coded_kernel<exact>": 4.9}
 
 
 def whole_paths(ctx, device, mode_name):
@@ -432,8 +465,9 @@ def whole_paths(ctx, device, mode_name):
         dt = time.perf_counter() - t0
         ms = device.assign.last_ms
         terms = float(b.m) * b.n * K
-        res = {"seconds": round(dt, 4), "kernel_ms": round(ms, 3), "snps_per_s": b.m / dt, "bound": "valu_fp64_issue",
-               "fp64_issue_frac": round(terms * INSTS_PER_TERM["score_sweep_kernel<exact>"] / 64.0 / WAVE_ISSUE_PER_S / (ms * 1e-3), 4),
+        kern = "score_coded_kernel<exact>" if b.codes_info()["available"] else "score_sweep_kernel<exact>"
+        res = {"seconds": round(dt, 4), "kernel": kern, "kernel_ms": round(ms, 3), "snps_per_s": b.m / dt, "bound": "valu_fp64_issue",
+               "fp64_issue_frac": round(terms * INSTS_PER_TERM[kern] / 64.0 / WAVE_ISSUE_PER_S / (ms * 1e-3), 4),
                "hbm_frac": round((8.0 * b.n + 4.0 * K) * b.m / (ms * 1e-3) / HBM_PEAK, 4), "checksum": float(np.sum(o))}
         af = afs.to_host()
         afs.close()
@@ -490,7 +524,7 @@ def whole_paths(ctx, device, mode_name):
     return out
 
 
-def committed_pmc(m, n, K, mode):
+def committed_pmc(m, n, K, mode, coded_em=False, coded_score=False):
     """Counters of the EM sweep and the scoring sweep from the committed rocprofv3 PMC passes of THIS workload
     (profiles/*/pmc_summary.json, written by tools/summarize_profile.py: traffic = (2*FETCH_SIZE + WRITE_SIZE)
     * 1024 with the gfx950 correction, valu_busy_frac = SQ_ACTIVE_INST_VALU * 4 / (1024 SIMDs * GRBM_GUI_ACTIVE
@@ -515,12 +549,17 @@ def committed_pmc(m, n, K, mode):
             continue
         cur = {"source": os.path.relpath(f, ROOT), "kernels_id": loaded}
         for k, e in d.get("kernels", {}).items():
-            if "em_sweep_kernel<%d" % (0 if mode == "exact" else 1) in k:
+            if ("em_coded_kernel" if coded_em else "em_sweep_kernel<%d" % (0 if mode == "exact" else 1)) in k:
                 cur["em_traffic"] = e.get("traffic_bytes_per_launch")
                 cur["em_valu_busy_frac"] = e.get("valu_busy_frac")
                 cur["em_clock_ghz"] = e.get("effective_clock_ghz")
+            ck = re.search(r"score_coded_kernel<(\d+), (\d+)>", k)
+            if coded_score and ck and int(ck.group(2)) == (0 if mode == "exact" else 1):
+                cur["assign_traffic"] = e.get("traffic_bytes_per_launch")
+                cur["assign_valu_busy_frac"] = e.get("valu_busy_frac")
+                cur["assign_insts_valu"] = e.get("SQ_INSTS_VALU", {}).get("mean")
             sk = re.search(r"score_sweep_kernel<(\d+), (\d+), (\d+), (true|false)>", k)
-            if sk and int(sk.group(3)) == (0 if mode == "exact" else 1) and sk.group(4) == "false":
+            if not coded_score and sk and int(sk.group(3)) == (0 if mode == "exact" else 1) and sk.group(4) == "false":
                 # ONE launch scores the whole matrix (template arguments: KB, NP, MODE, PER_IND)
                 cur["assign_traffic"] = e.get("traffic_bytes_per_launch")
                 cur["assign_valu_busy_frac"] = e.get("valu_busy_frac")

@@ -589,7 +589,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     const int64_t per_unit = ((ntiles + 3) / 4 + 7) / 8 * 8 + 8;       // workgroups per fit / per group: slices stay below 2^31
     const size_t max_units = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_unit);
     if (codes) {
-        const int64_t per_fit = ((ntiles + 1) / 2 + 7) / 8 * 8 + 8;
+        const int64_t per_fit = (ntiles + 7) / 8 * 8 + 8;            // at least one tile per workgroup
         const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
         for (size_t off = 0; off < order.size(); off += max_fits) {
             const int cnt = (int)std::min<size_t>(max_fits, order.size() - off);

@@ -348,9 +348,8 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDes
 //            wave-uniform as in the direct kernels.
 // Leave-one-out fits of one population read the same dictionary and code words: workgroups are dealt to the XCDs so
 // that all fits of a tile meet in one L2 (as em_sweep_group_kernel does).
-constexpr int WAVES_C = 2;         // waves per workgroup: the per-wave table is cmax * 512 bytes of LDS
 
-template <int U>
+template <int U, int WAVES_C, int ILP, int ROWS>
 __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m,
                                                                  const float2 *__restrict__ dict, int cmax)
 {
@@ -388,34 +387,28 @@ __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *_
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) uni |= __shfl_xor(uni, off, 64);
     {
+        // ALL rows are requested before the first is waited for (one memory latency per tile, not one per group of
+        // eight: with two or three waves per SIMD nothing else would hide the others); ROWS = the table's rows
         const double *drow = reinterpret_cast<const double *>(dict) + tile * WGS_CODE_ROWS * 64 + lane;
-        for (int c0 = 0; c0 < cmax; c0 += 8) {
-            if (!((uni >> c0) & 0xFFull)) continue;          // wave-uniform
-            double r0, r1, r2, r3, r4, r5, r6, r7;
-            r0 = drow[(int64_t)(c0 + 0) * 64];                  // the dictionary has WGS_CODE_ROWS = 64 rows per tile
-            r1 = drow[(int64_t)(c0 + 1) * 64];
-            r2 = drow[(int64_t)(c0 + 2) * 64];
-            r3 = drow[(int64_t)(c0 + 3) * 64];
-            r4 = drow[(int64_t)(c0 + 4) * 64];
-            r5 = drow[(int64_t)(c0 + 5) * 64];
-            r6 = drow[(int64_t)(c0 + 6) * 64];
-            r7 = drow[(int64_t)(c0 + 7) * 64];
-            q[(c0 + 0) * 64] = r0;                           // the table has room for whole groups of eight (launch_em_coded)
-            q[(c0 + 1) * 64] = r1;
-            q[(c0 + 2) * 64] = r2;
-            q[(c0 + 3) * 64] = r3;
-            q[(c0 + 4) * 64] = r4;
-            q[(c0 + 5) * 64] = r5;
-            q[(c0 + 6) * 64] = r6;
-            q[(c0 + 7) * 64] = r7;
+        double r[ROWS];
+#pragma unroll
+        for (int g8 = 0; g8 < ROWS / 8; ++g8) {
+            if ((uni >> (8 * g8)) & 0xFFull) {               // wave-uniform
+#pragma unroll
+                for (int u = 0; u < 8; ++u) r[8 * g8 + u] = drow[(int64_t)(8 * g8 + u) * 64];
+            }
+        }
+#pragma unroll
+        for (int g8 = 0; g8 < ROWS / 8; ++g8) {
+            if ((uni >> (8 * g8)) & 0xFFull) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[(8 * g8 + u) * 64] = r[8 * g8 + u];
+            }
         }
     }
-    // phase 1: (g0, g1) -> quotient, for the classes present in this slab
-    while (__any(left != 0)) {
-        const bool on = left != 0;
-        const int c = on ? __builtin_ctzll(left) : 0;
-        left &= left - 1;
-        const double raw = q[c * 64];
+    // phase 1: (g0, g1) -> quotient, for the classes present in this slab (ILP classes per step: the divide is a chain of
+    // dependent FP64 operations, a second class gives the pipeline independent work)
+    auto quotient = [&](double raw) {
         const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
                     g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
         const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
@@ -424,8 +417,24 @@ __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *_
         const float p2 = (float)((g2d * st.fd) * st.fd);
         const float ssum = (p0 + p1) + p2;
         const double num = __builtin_fma(2.0, (double)p2, (double)p1);
-        const double qv = div_exact<true>(num, (double)ssum);
-        if (on) q[c * 64] = qv;
+        return div_exact<true>(num, (double)ssum);
+    };
+    while (__any(left != 0)) {
+        bool on[ILP];
+        int c[ILP];
+        double raw[ILP], qv[ILP];
+#pragma unroll
+        for (int x = 0; x < ILP; ++x) {
+            on[x] = left != 0;
+            c[x] = on[x] ? __builtin_ctzll(left) : 0;
+            left &= left - 1;
+            raw[x] = q[c[x] * 64];
+        }
+#pragma unroll
+        for (int x = 0; x < ILP; ++x) qv[x] = quotient(raw[x]);
+#pragma unroll
+        for (int x = 0; x < ILP; ++x)
+            if (on[x]) q[c[x] * 64] = qv[x];
     }
     // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
     // table before the chain of that buffer starts
@@ -980,17 +989,41 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 }
 
 static int coded_rows(int cmax) { return (cmax + 7) & ~7; }      // table rows: whole groups of eight classes
-bool em_coded_fits(int cmax) { return cmax >= 1 && (size_t)WAVES_C * coded_rows(cmax) * 512 <= 64 * 1024; }
+static int coded_variant()
+{
+    const char *e = getenv("WGS_EM_CODED_VARIANT");              // experiments: waves per workgroup * 10 + classes per step
+    return e ? atoi(e) : 12;
+}
+bool em_coded_fits(int cmax) { return cmax >= 1 && (size_t)(coded_variant() / 10) * coded_rows(cmax) * 512 <= 64 * 1024; }
 
 int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, const float2 *dict, int cmax)
 {
     if (n_fits <= 0 || m <= 0) return 0;
+    const int variant = coded_variant(), W = variant / 10;
     const int64_t tiles = (m + 63) / 64;
-    const int64_t tgroups = ((tiles + WAVES_C - 1) / WAVES_C + 7) / 8 * 8;      // the XCD-aware order covers whole groups of 8
+    const int64_t tgroups = ((tiles + W - 1) / W + 7) / 8 * 8;      // the XCD-aware order covers whole groups of 8
     const int64_t blocks = tgroups * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
-    const size_t lds = (size_t)WAVES_C * coded_rows(cmax) * 512;
-    hipLaunchKernelGGL((em_coded_kernel<4>), dim3((unsigned)blocks), dim3(WAVES_C * 64), lds, ctx->stream, d_descs, n_fits, m, dict, cmax);
+    const size_t lds = (size_t)W * coded_rows(cmax) * 512;
+#define WGS_EMC2(WV, IL, RW) hipLaunchKernelGGL((em_coded_kernel<4, WV, IL, RW>), dim3((unsigned)blocks), dim3(WV * 64), lds, ctx->stream, d_descs, n_fits, m, dict, cmax)
+#define WGS_EMC(WV, IL)                            \
+    switch (coded_rows(cmax)) {                    \
+        case 8: WGS_EMC2(WV, IL, 8); break;        \
+        case 16: WGS_EMC2(WV, IL, 16); break;      \
+        case 24: WGS_EMC2(WV, IL, 24); break;      \
+        case 32: WGS_EMC2(WV, IL, 32); break;      \
+        case 40: WGS_EMC2(WV, IL, 40); break;      \
+        case 48: WGS_EMC2(WV, IL, 48); break;      \
+        case 56: WGS_EMC2(WV, IL, 56); break;      \
+        default: WGS_EMC2(WV, IL, 64); break;      \
+    }
+    switch (variant) {
+        case 11: WGS_EMC(1, 1); break;
+        case 12: WGS_EMC(1, 2); break;
+        default: WGS_EMC(2, 1); break;
+    }
+#undef WGS_EMC
+#undef WGS_EMC2
     HIP_TRY(hipGetLastError());
     return 0;
 }
