@@ -431,13 +431,19 @@ def whole_paths(ctx, device, mode_name):
     (wave-instructions of the committed PMC pass x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time): a lower bound
     of the busy share, the chip clocks lower under FP64 load)."""
     from wgsassign_amd import glassy
-    out = {"mode": mode_name, "note": "seconds = wall clock of the whole call(s) on one MI355X, matrix resident in HBM"}
+    out = {"mode": mode_name, "note": "seconds = wall clock of the whole call(s) on one MI355X, matrix (and its class codes) resident in HBM"}
+    codes_note = [None]
 
     def matrix(m, n, K):
         group_of = np.minimum(np.arange(n) // (n // K), K - 1).astype(np.int32)
         b = device.DeviceBeagle(m, n, group_of, K, ctx=ctx)
         b.synth(SEED, 2.0)
         ctx.sync()
+        # the class codes belong to the resident matrix like its slab layout (built once, on first use; a run from a
+        # file builds them while the host is still inflating): outside the timed calls, reported per configuration
+        info = b.codes_info()
+        codes_note[0] = {"available": info["available"], "build_ms": round(info["build_ms"], 1), "bytes": info["bytes"],
+                         "mean_classes_per_snp": round(info["mean_classes"], 2)}
         return b, group_of, np.bincount(group_of, minlength=K)
 
     def fit(b, K, counts):
@@ -448,7 +454,10 @@ def whole_paths(ctx, device, mode_name):
         dt = time.perf_counter() - t0
         st = em.fit_stats()                 # iterations enqueued, chain batches, seconds in wgs_em_fit, sweep kernels ms
         alg = float(np.sum([(8.0 * counts[k] + 8.0) * b.m * iters[k] for k in range(K)]))
+        coded = b.codes_info()["available"] and int(min(counts)) >= 40
         res = {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
+               "sweep_kernel": "em_coded_kernel (class codes; hbm_frac counts the float32 matrix's algorithmic bytes and may exceed 1)" if coded
+               else "em_sweep_kernel<exact>",
                "sweep_kernels_ms": round(st[3], 3), "bound": "hbm",
                "hbm_frac_of_sweeps": round(alg / (st[3] * 1e-3) / HBM_PEAK, 4) if st[3] > 0 else None,
                "snp_updates_per_s": float(b.m) * float(np.sum(iters)) / dt}
@@ -497,6 +506,7 @@ def whole_paths(ctx, device, mode_name):
     em2, r2 = fit(b, 5, c)                       # second run: allocations and code objects warm
     em2.close()
     r["seconds_second_run"] = r2["seconds"]
+    r["class_codes"] = codes_note[0]
     out["config2_1Mx200_K5_get_reference_af"] = r
     b.close()
     # BASELINE configs[3]: 2M x 500, K=8, --get_reference_af --loo --partition_sites 3 (+ --get_pop_like)
@@ -504,21 +514,22 @@ def whole_paths(ctx, device, mode_name):
     em, r = fit(b, 8, c)
     af, rp = pop_like(b, em, 8, c)
     em.close()
-    out["config4_2Mx500_K8"] = {"get_reference_af": r, "get_pop_like": rp, "loo_partition_sites_3": loo(b, g, c, af, 3)}
+    out["config4_2Mx500_K8"] = {"get_reference_af": r, "get_pop_like": rp, "loo_partition_sites_3": loo(b, g, c, af, 3), "class_codes": codes_note[0]}
     b.close()
     # the reference README's timing claim (README.md:129-131): --loo at ~5M SNPs x 180 individuals, "30 min"
     b, g, c = matrix(5_000_000, 180, 5)
     em, r = fit(b, 5, c)
     af, rp = pop_like(b, em, 5, c)
     em.close()
-    out["readme_5Mx180_K5"] = {"get_reference_af": r, "loo": loo(b, g, c, af, 1), "reference_readme_claim": "30 min (hardware and threads not stated)"}
+    out["readme_5Mx180_K5"] = {"get_reference_af": r, "loo": loo(b, g, c, af, 1), "reference_readme_claim": "30 min (hardware and threads not stated)",
+                               "class_codes": codes_note[0]}
     b.close()
     # BASELINE configs[4]: one GPU's shard of 50M x 2000, K=20 on 8 GPUs = 6.25M SNPs (100 GB of genotype likelihoods)
     b, g, c = matrix(6_250_000, 2000, 20)
     em, r = fit(b, 20, c)
     af, rp = pop_like(b, em, 20, c)
     em.close()
-    out["config5_shard_6.25Mx2000_K20"] = {"get_reference_af": r, "get_pop_like": rp, "gl_bytes": b.nbytes()}
+    out["config5_shard_6.25Mx2000_K20"] = {"get_reference_af": r, "get_pop_like": rp, "gl_bytes": b.nbytes(), "class_codes": codes_note[0]}
     b.close()
     out["seconds_total"] = round(time.perf_counter() - t_all, 2)
     return out

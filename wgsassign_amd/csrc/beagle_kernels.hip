@@ -201,13 +201,22 @@ __global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
     const int64_t snp = tile * 64 + lane;
     ClassTable T;
     T.keys = keys;
+    constexpr int PF = 8;              // pair loads in flight (one wave per workgroup: nothing else hides their latency)
     for (int g = 0; g < A.n_slabs; ++g) {
         const int np = A.npairs[g], nc = A.ncols[g];
         const float4 *src = A.base[g] + tile * np * 64 + lane;
-        for (int p = 0; p < np; ++p) {
-            const float4 v = src[(int64_t)p * 64];
-            T.find_or_insert(gl_key(v.x, v.y), lane, true);
-            if (2 * p + 1 < nc) T.find_or_insert(gl_key(v.z, v.w), lane, true);
+        for (int p0 = 0; p0 < np; p0 += PF) {
+            float4 v[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) v[u] = src[(int64_t)(p0 + u < np ? p0 + u : np - 1) * 64];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int p = p0 + u;
+                if (p < np) {
+                    T.find_or_insert(gl_key(v[u].x, v[u].y), lane, true);
+                    if (2 * p + 1 < nc) T.find_or_insert(gl_key(v[u].z, v[u].w), lane, true);
+                }
+            }
         }
     }
     const int n = T.overflow ? 255 : __popcll(T.mask);
@@ -225,23 +234,31 @@ __global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
         const SlabCodes sc = A.slabs[g];
         const float4 *src = A.base[g] + tile * np * 64 + lane;
         uint64_t present = 0;
-        for (int q = 0; q < sc.nquads; ++q) {
-            uint32_t word = 0;
+        for (int q0 = 0; q0 < sc.nquads; q0 += PF / 2) {
+            float4 v[PF];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int p = 2 * q + h;
-                if (p >= np) break;
-                const float4 v = src[(int64_t)p * 64];
-                const int c0 = T.id_of(T.find_or_insert(gl_key(v.x, v.y), lane, false));
-                word |= (uint32_t)c0 << (16 * h);
-                present |= 1ull << c0;
-                if (2 * p + 1 < nc) {
-                    const int c1 = T.id_of(T.find_or_insert(gl_key(v.z, v.w), lane, false));
-                    word |= (uint32_t)c1 << (16 * h + 8);
-                    present |= 1ull << c1;
+            for (int u = 0; u < PF; ++u) v[u] = src[(int64_t)(2 * q0 + u < np ? 2 * q0 + u : np - 1) * 64];
+#pragma unroll
+            for (int x = 0; x < PF / 2; ++x) {
+                const int q = q0 + x;
+                if (q >= sc.nquads) break;
+                uint32_t word = 0;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int p = 2 * q + h;
+                    if (p >= np) break;
+                    const float4 vv = v[2 * x + h];
+                    const int c0 = T.id_of(T.find_or_insert(gl_key(vv.x, vv.y), lane, false));
+                    word |= (uint32_t)c0 << (16 * h);
+                    present |= 1ull << c0;
+                    if (2 * p + 1 < nc) {
+                        const int c1 = T.id_of(T.find_or_insert(gl_key(vv.z, vv.w), lane, false));
+                        word |= (uint32_t)c1 << (16 * h + 8);
+                        present |= 1ull << c1;
+                    }
                 }
+                sc.codes[(tile * sc.nquads + q) * 64 + lane] = word;
             }
-            sc.codes[(tile * sc.nquads + q) * 64 + lane] = word;
         }
         sc.present[snp] = present;
     }
