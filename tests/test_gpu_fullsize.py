@@ -293,7 +293,10 @@ def test_fast_mode_at_full_size_config3(wg):
     comparator): the float32 SCORING sweep keeps every n x K sum within 1e-6 of exact (measured 5e-8 in float64,
     1.2e-7 after the float32 store) -- it is what WGSASSIGN_MODE=fast selects; the float32 EM update reproduces the
     iteration counts but its frequencies drift beyond 1e-6 (measured 7.2e-6, 0.12 % of the entries), which is why it
-    is a separate opt-in (WGSASSIGN_EM_MODE) and never a default."""
+    is a separate opt-in (WGSASSIGN_EM_MODE) and never a default.  No float32 evaluation of the term can do better
+    (tools/sim_em_modes.py: the reference's serial float32 accumulation turns a 2^-24 perturbation of a
+    repeated addend into an ulp per repetition); the faster mode that IS bit-exact is the sweep through the class codes,
+    which this test's exact fits run through (tests/test_gpu_codes.py holds it to the direct kernel)."""
     from wgsassign_amd._lib import MODE_EXACT, MODE_FAST
     dev = wg.device
     m, n, K = 10_000_000, 1000, 10

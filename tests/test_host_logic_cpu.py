@@ -264,3 +264,48 @@ def test_console_script_declared_like_the_reference():
     assert set(meta["tool"]["setuptools"]["packages"]) == {"wgsassign_amd", "WGSassign"}
     import WGSassign.WGSassign as ref_path
     assert ref_path.main is getattr(importlib.import_module(mod), func)
+
+
+def test_installed_numpy_sums_float32_in_8192_element_chunks():
+    """The device forms `np.sum(vec, dtype=float)` (glassy.py:38) and `np.mean(vec)` of float32 vectors (fisher.py:59) in
+    NumPy's own order -- which the build measured on NumPy 2.2: the reduction hands its inner loop 8192 elements at a time,
+    each chunk summed pairwise (leaves of at most 128 elements, eight interleaved accumulators) and added to a running
+    total.  A NumPy that sums differently (older releases may sum a contiguous vector in one pairwise pass) would silently
+    break the bit-for-bit claims: this test fails loudly instead.  (The reference pins numpy<=1.22.3 for its z-score code
+    only; the bit-exact claim is stated for the NumPy this test passes on.)"""
+    rng = np.random.default_rng(0)
+
+    def pairwise(a):                  # NumPy's pairwise_sum for one chunk, in the accumulator type of `a`
+        n = len(a)
+        if n < 8:
+            r = a.dtype.type(0)
+            for x in a:
+                r = a.dtype.type(r + x)
+            return r
+        if n <= 128:
+            acc = [a[i] for i in range(8)]
+            for i in range(8, n - n % 8, 8):
+                for j in range(8):
+                    acc[j] = a.dtype.type(acc[j] + a[i + j])
+            t = a.dtype.type
+            r = t(t(t(acc[0] + acc[1]) + t(acc[2] + acc[3])) + t(t(acc[4] + acc[5]) + t(acc[6] + acc[7])))
+            for i in range(n - n % 8, n):
+                r = t(r + a[i])
+            return r
+        half = n // 2
+        half -= half % 8
+        return a.dtype.type(pairwise(a[:half]) + pairwise(a[half:]))
+
+    for m in (8192 * 3 + 77, 20_000, 8191, 8193):
+        v = (rng.random(m) * np.exp(rng.normal(0, 6, size=m))).astype(np.float32)
+        # float32 accumulation (np.mean / np.sum without dtype): chunks of 8192 added to a running float32 total
+        tot = np.float32(0)
+        for c in range(0, m, 8192):
+            tot = np.float32(tot + pairwise(v[c:c + 8192]))
+        assert np.sum(v).tobytes() == tot.tobytes(), ("float32 sum", m, np.__version__)
+        # float64 accumulation of float32 data (np.sum(dtype=float)): the same chunking on the cast values
+        v64 = v.astype(np.float64)
+        tot = np.float64(0)
+        for c in range(0, m, 8192):
+            tot = np.float64(tot + pairwise(v64[c:c + 8192]))
+        assert np.sum(v, dtype=float).tobytes() == tot.tobytes(), ("float64 sum of float32", m, np.__version__)
