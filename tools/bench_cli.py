@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--inds", type=int, default=100)
     ap.add_argument("--pops", type=int, default=5)
     ap.add_argument("--module", default="wgsassign_amd.WGSassign")
-    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--threads", type=int, default=1, help="-t of the command line (1 = automatic)")
     ap.add_argument("--format", default="gzip", choices=["gzip", "bgzf"])
     ap.add_argument("--no-loo", action="store_true", help="skip the --loo run (hours on the reference at 1M x 200)")
     a = ap.parse_args()

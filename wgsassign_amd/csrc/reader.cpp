@@ -1829,7 +1829,7 @@ int64_t wgs_debug_reader_text_chunks(wgs_reader *r) { return r ? r->text_chunks 
 
 int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit_rows, float *rows, int64_t max_rows, int64_t *nrows)
 {
-    if (!r || !rows || !nrows) {
+    if (!r || !nrows) {                                    // rows == NULL: only drain the hand-over (inflate + line lists), for timing
         wgs_set_error("bad argument");
         return 2;
     }
@@ -1845,7 +1845,8 @@ int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit
         TextChunk *c = nullptr;
         if ((rc = reader_text_next(r, &c, nullptr)) != 0 || !c) break;
         if (c->first_row != done) rc = 1, wgs_set_error("text chunks out of order");
-        for (size_t i = 0; i < c->begin.size() && !rc; ++i) {
+        if (!rows) done += (int64_t)c->begin.size();
+        for (size_t i = 0; rows && i < c->begin.size() && !rc; ++i) {
             if (done >= max_rows) {
                 rc = 2;
                 wgs_set_error("more rows than the caller has room for");
