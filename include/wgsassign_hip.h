@@ -312,6 +312,14 @@ int wgs_reader_count_sites(const char *path, int64_t *sites);
 int wgs_reader_build_index(const char *path, const char *index_path, const char *names_path, int64_t span_bytes,
                            int32_t max_points, int64_t *sites);
 int wgs_reader_index_sites(const char *path, const char *index_path, int64_t *sites);
+/* The same pass over a BGZF file SPLIT over the ranks of a node (and the threads of each): rank `part` of `nparts` finds the
+ * first block of its byte range by its 16-byte signature, inflates and summarises its blocks into part_path
+ * (= parts_prefix + "." + part); after a barrier one rank chains the parts -- accepted only if every part starts exactly
+ * where the one before ended -- into the index.  rc 3: the file cannot be done in parts (not BGZF, a range off the block
+ * chain); one rank then calls wgs_reader_build_index. */
+int wgs_reader_index_part(const char *path, const char *part_path, int part, int nparts, int threads);
+int wgs_reader_index_merge(const char *path, const char *index_path, const char *parts_prefix, int nparts, int64_t span_bytes,
+                           int32_t max_points, int64_t *sites);
 int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t first_row, int threads, wgs_reader **out);
 
 /* ------------------------------------------------------------------ device-side ingest

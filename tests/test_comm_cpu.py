@@ -192,3 +192,65 @@ def test_launch_local_ranks_tries_rccl_twice_and_sees_every_exit_status(tmp_path
             "(sys.exit(1) if e['RANK'] == '0' else (time.sleep(0.5), sys.exit(75))) if first else sys.exit(0)" % str(tmp_path))
     assert comm.launch_local_ranks(2, [sys.executable, "-c", code]) == 0
     assert sorted(os.listdir(tmp_path)) == ["a0", "a1", "b0", "b1"]
+
+
+_INDEX_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r})
+rank = int(sys.argv[1])
+os.environ.update(LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE="3", WGSASSIGN_INDEX_DIR={cache!r}, WGSASSIGN_THREADS="6")
+from wgsassign_amd import reader_cy
+from wgsassign_amd.comm import SocketComm
+comm = SocketComm(rank, 3, "127.0.0.1", {port})
+idx, _, sites = reader_cy.ensure_index({path!r}, comm)
+assert sites == {sites}, sites
+with reader_cy.BeagleStream({path!r}, threads=1, index=idx, first_row=1000 * rank + 7) as st:
+    rows, names = next(st.chunks(max_rows=5))
+assert names[0] == "ctg%d_%d" % ((1000 * rank + 7) % 7, 1000 * rank + 8), names
+comm.barrier()
+comm.close()
+print("RANK %d OK" % rank)
+'''
+
+
+def test_three_ranks_split_the_bgzf_index_pass(tmp_path):
+    """`ensure_index` with several ranks on a node: every rank inflates and summarises the blocks of its third of a BGZF
+    file, the first rank chains the parts -- the index is byte for byte the one a single process builds; a plain-gzip file
+    takes the single-rank pass."""
+    import ctypes
+    import subprocess
+    import sys
+    import numpy as np
+    import synth
+    from conftest import ROOT
+    from test_reader_cpu import _bgzf_write, _text_of
+    from wgsassign_amd import _lib, reader_cy
+    from wgsassign_amd.comm import free_port_pair
+    m, n = 4000, 15
+    L, _ = synth.make_beagle(m, n, 2, seed=21)
+    text = _text_of(L)
+    for kind in ("bgzf", "gzip"):
+        p = str(tmp_path / ("x_%s.beagle.gz" % kind))
+        if kind == "bgzf":
+            _bgzf_write(p, text, block=5000)
+        else:
+            import gzip
+            with gzip.open(p, "wt", newline="") as fh:
+                fh.write(text)
+        cache = str(tmp_path / ("cache_" + kind))
+        os.makedirs(cache, mode=0o700)
+        port = free_port_pair()
+        script = tmp_path / ("w_%s.py" % kind)
+        script.write_text(_INDEX_WORKER.format(root=ROOT, cache=cache, port=port, path=p, sites=m))
+        procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                 for r in range(3)]
+        outs = [q.communicate(timeout=300)[0] for q in procs]
+        for r, (q, o) in enumerate(zip(procs, outs)):
+            assert q.returncode == 0 and "RANK %d OK" % r in o, "rank %d failed:\n%s" % (r, o[-3000:])
+        files = sorted(os.listdir(cache))
+        assert len(files) == 1 and files[0].endswith(".idx"), files            # no part files left behind
+        alone = str(tmp_path / ("alone_%s.idx" % kind))
+        sites = ctypes.c_int64()
+        _lib.check(_lib.load().wgs_reader_build_index(p.encode(), alone.encode(), None, reader_cy.INDEX_SPAN_BYTES,
+                                                      reader_cy.INDEX_MAX_POINTS, ctypes.byref(sites)))
+        assert open(os.path.join(cache, files[0]), "rb").read() == open(alone, "rb").read()

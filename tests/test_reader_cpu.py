@@ -520,3 +520,111 @@ def test_index_cache_is_private_and_checked(tmp_path, monkeypatch):
     monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(bad))
     with pytest.raises(RuntimeError, match="not a private directory"):
         reader_cy.cache_dir()
+
+
+# ------------------------------------------------------------------ the BGZF index pass in parts
+def _index_fields(idx_path, path):
+    """(sites, first rows readable through the index at a few positions) -- what an index is for"""
+    import ctypes
+    from wgsassign_amd import _lib, reader_cy
+    n = ctypes.c_int64()
+    _lib.check(_lib.load().wgs_reader_index_sites(os.fsencode(path), os.fsencode(idx_path), ctypes.byref(n)))
+    return n.value
+
+
+@pytest.mark.parametrize("block", [60000, 700])
+def test_bgzf_index_in_parts_equals_the_single_pass(tmp_path, monkeypatch, block):
+    """The index pass split into byte ranges (ranks of a node, threads of a rank): every part finds its first block by the
+    BGZF signature, the merge chains them -- same site count, same access points as the single pass; readers opened through
+    the merged index return the same rows.  Tiny blocks (700 bytes of text each) make thousands of hops and resyncs."""
+    import ctypes
+    from wgsassign_amd import _lib, reader_cy
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    m, n = 6000, 19
+    L, _ = synth.make_beagle(m, n, 2, seed=13)
+    p = str(tmp_path / "p.beagle.gz")
+    _bgzf_write(p, _text_of(L, blank_lines=True), block=block)
+    lib = _lib.load()
+    one = str(tmp_path / "one.idx")
+    sites = ctypes.c_int64()
+    _lib.check(lib.wgs_reader_build_index(p.encode(), one.encode(), None, 40_000, 100_000, ctypes.byref(sites)))
+    assert sites.value == m
+    for nparts, threads in [(1, 1), (2, 3), (3, 1), (5, 2), (8, 4)]:
+        prefix = str(tmp_path / ("parts_%d_%d" % (nparts, threads)))
+        for k in range(nparts):
+            _lib.check(lib.wgs_reader_index_part(p.encode(), ("%s.%d" % (prefix, k)).encode(), k, nparts, threads))
+        merged = str(tmp_path / ("m_%d_%d.idx" % (nparts, threads)))
+        got = ctypes.c_int64()
+        _lib.check(lib.wgs_reader_index_merge(p.encode(), merged.encode(), prefix.encode(), nparts, 40_000, 100_000, ctypes.byref(got)))
+        assert got.value == m
+        assert open(merged, "rb").read() == open(one, "rb").read(), (nparts, threads)     # the very same index file
+        assert not os.path.exists(prefix + ".0")                                          # parts are removed after the merge
+    for first in (0, 1234, 5999):
+        with reader_cy.BeagleStream(p, threads=2, index=merged, first_row=first) as st:
+            rows, _ = next(st.chunks(max_rows=50))
+        assert rows.tobytes() == L[first:first + 50].tobytes()
+
+
+def test_bgzf_parts_reject_a_planted_signature_and_a_plain_gzip_file(tmp_path):
+    """A block whose (stored) payload contains a chain of look-alike BGZF headers: a part that resynchronises onto it
+    starts off the true chain; the merge notices (the parts do not chain) and reports rc 3, so the caller falls back to the
+    serial pass.  Plain gzip cannot be done in parts at all."""
+    import ctypes
+    import struct
+    import zlib
+    from wgsassign_amd import _lib, reader_cy
+
+    def member(chunk, level):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = co.compress(chunk) + co.flush()
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(payload) + 8 - 1) +
+                payload + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    head = "marker a b " + " ".join("S S S" for _ in range(3)) + "\n"
+    line = lambda s: "s%d A C " % s + " ".join("0.250000 0.500000 0.250000" for _ in range(3)) + "\n"
+    # four fake members back to back, each announcing a size that leads exactly to the next: inside ONE stored block
+    fake = b"".join(member(b"x" * 40, 0) for _ in range(6))
+    text_before = (head + "".join(line(s) for s in range(300))).encode()
+    evil_line = b"evil" + b"x" * 600 + b" A C " + fake.replace(b"\n", b"_").replace(b" ", b"_").replace(b"\t", b"_") + b" 0.1 0.2 0.7 0.1 0.2 0.7 0.1 0.2 0.7\n"
+    text_after = "".join(line(s) for s in range(300, 900)).encode()
+    p = str(tmp_path / "evil.beagle.gz")
+    with open(p, "wb") as fh:
+        for i in range(0, len(text_before), 3000):
+            fh.write(member(text_before[i:i + 3000], 6))
+        fh.write(member(evil_line, 0))                     # level 0 = stored: the look-alike headers appear verbatim in the file
+        for i in range(0, len(text_after), 3000):
+            fh.write(member(text_after[i:i + 3000], 6))
+        fh.write(member(b"", 6))
+    assert fake.replace(b"\n", b"_").replace(b" ", b"_").replace(b"\t", b"_") == fake     # the fakes survived the token rules
+    lib = _lib.load()
+    L, _, sites = reader_cy.readBeagle(p)
+    assert len(sites) == 901 and sites[300] == "evil" + "x" * 600
+    size = os.path.getsize(p)
+    raw = open(p, "rb").read()
+    evil_at = raw.index(fake)
+    # choose a split whose second part starts just before the planted chain
+    found_bad = False
+    for nparts in range(2, 40):
+        lo = [size * k // nparts for k in range(nparts)]
+        if not any(evil_at - 580 < x <= evil_at for x in lo):         # inside the evil member, before the planted chain
+            continue
+        prefix = str(tmp_path / ("e%d" % nparts))
+        rcs = [lib.wgs_reader_index_part(p.encode(), ("%s.%d" % (prefix, k)).encode(), k, nparts, 1) for k in range(nparts)]
+        # the part that landed on the planted chain either runs into garbage behind it (rc 3 at once) or delivers blocks
+        # that do not chain with its neighbours (rc 3 from the merge): never a wrong index
+        assert all(r in (0, 3) for r in rcs)
+        if all(r == 0 for r in rcs):
+            got = ctypes.c_int64()
+            rc = lib.wgs_reader_index_merge(p.encode(), str(tmp_path / "e.idx").encode(), prefix.encode(), nparts, 40_000, 1000, ctypes.byref(got))
+            assert rc == 3 and b"do not chain" in lib.wgs_last_error()
+        found_bad = True
+        break
+    assert found_bad
+    # the single-process pass (threads resynchronise too) still gets it right: its fall-back is the serial hop
+    n = ctypes.c_int64()
+    _lib.check(lib.wgs_reader_build_index(p.encode(), str(tmp_path / "ok.idx").encode(), None, 40_000, 1000, ctypes.byref(n)))
+    assert n.value == 901
+    # plain gzip: rc 3
+    g = str(tmp_path / "plain.beagle.gz")
+    with gzip.open(g, "wb") as fh:
+        fh.write(text_before)
+    assert lib.wgs_reader_index_part(g.encode(), str(tmp_path / "g.0").encode(), 0, 2, 1) == 3

@@ -95,6 +95,8 @@ SIGNATURES = {
     "wgs_reader_count_sites": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "wgs_reader_build_index": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_i64, c_i32, ctypes.POINTER(c_i64)]),
     "wgs_reader_index_sites": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(c_i64)]),
+    "wgs_reader_index_part": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, c_int]),
+    "wgs_reader_index_merge": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_int, c_i64, c_i32, ctypes.POINTER(c_i64)]),
     "wgs_reader_open_indexed": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_i64, c_int, ctypes.POINTER(c_vp)]),
     "wgs_ingest_create": (c_int, [c_vp, c_vp, c_i64, c_i64, ctypes.POINTER(c_vp)]),
     "wgs_ingest_destroy": (None, [c_vp]),

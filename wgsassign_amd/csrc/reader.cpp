@@ -40,6 +40,18 @@ void wgs_set_error(const char *fmt, ...);
 
 namespace {
 
+template <typename F>
+void run_threads(int T, F work)
+{
+    if (T <= 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+}
+
 inline bool is_delim(char c) { return c == '\t' || c == ' ' || c == '\n' || c == '\r'; }
 
 const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
@@ -985,119 +997,241 @@ void summarise_block(const unsigned char *p, size_t n, BlockLines &bl)
     bl.last_is_nl = n > 0 && p[n - 1] == '\n';
 }
 
-// Returns 0 on success, -1 when the file is not (entirely) BGZF -- the caller then takes the serial pass.
-int scan_file_bgzf(const char *path, int64_t span, int threads, BeagleIndex &idx)
-{
+// ---- the BGZF pass in parts: threads of one process, and processes of one node -------------------------------------
+// Finding the blocks by hopping from header to header is serial (41 M hops for 2.7 TB of text), and so was the pass of
+// round 2 across ranks (the first rank inflated the whole file).  A part -- any byte range of the file -- can find its own
+// first block instead: BGZF members start with a 16-byte signature (gzip magic, FEXTRA, XLEN = 6, 'B' 'C' 2 0); the first
+// position at or after the range's start where a header parses AND three further hops land on headers (or the end of the
+// file) is taken as a block boundary.  That is a heuristic only for SPEED: every part reports where it started and where
+// the block after its last one starts, and the merge accepts the parts only if they chain exactly (part 0 starts at byte
+// 0, so by induction every part hopped the true chain); otherwise the classic serial hop takes over.
+struct PartData {
+    uint64_t first = 0, next = 0;          // file offset of the part's first block / of the first block after its last
     std::vector<BgzfBlock> blocks;
-    if (!bgzf_block_table(path, blocks)) return -1;
-    file_identity(path, idx.file_size, idx.mtime);
-    const size_t nb = blocks.size();
-    std::vector<BlockLines> sum(nb);
-    std::string header;
-    // the header line: inflate serially from the first block until its newline
+    std::vector<BlockLines> sum;
+    std::string header;                    // part 0: the header line
+    bool header_done = false;
+};
+
+// Parses the member at file offset `off`: 1 = a BGZF block, 0 = end of file exactly at off, -1 = anything else.
+int bgzf_block_at(int fd, uint64_t file_size, uint64_t off, BgzfBlock &b)
+{
+    if (off == file_size) return 0;
+    unsigned char head[64], tail[4];
+    const ssize_t got = pread(fd, head, sizeof head, (off_t)off);
+    uint32_t hdr = 0;
+    const long sz = got > 0 ? bgzf_member_size(head, (size_t)got, &hdr) : 0;
+    if (sz <= 0 || off + (uint64_t)sz > file_size || pread(fd, tail, 4, (off_t)(off + (uint64_t)sz - 4)) != 4) return -1;
+    b.off = off;
+    b.csize = (uint32_t)sz;
+    b.hdr = hdr;
+    b.isize = tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+    return b.isize <= 65536 && b.csize >= hdr + 8 ? 1 : -1;
+}
+
+// First block boundary at or after `from` (from > 0): see above.  Returns file_size when the rest holds no block start.
+uint64_t bgzf_resync(int fd, uint64_t file_size, uint64_t from)
+{
+    std::vector<unsigned char> win(1u << 20);
+    for (uint64_t base = from; base < file_size;) {
+        const ssize_t got = pread(fd, win.data(), win.size(), (off_t)base);
+        if (got < 16) return file_size;
+        for (ssize_t i = 0; i + 16 <= got; ++i) {
+            const unsigned char *q = win.data() + i;
+            if (q[0] != 31 || q[1] != 139 || q[2] != 8 || q[3] != 4) continue;
+            uint64_t at = base + (uint64_t)i;
+            bool chain = true;
+            for (int hop = 0; hop < 4 && chain; ++hop) {
+                BgzfBlock b;
+                const int k = bgzf_block_at(fd, file_size, at, b);
+                if (k == 0) break;                            // the chain ends with the file: fine
+                chain = k > 0;
+                at += b.csize;
+            }
+            if (chain) return base + (uint64_t)i;
+        }
+        base += (uint64_t)got - 15;                           // a signature may straddle the window's end
+    }
+    return file_size;
+}
+
+// The blocks that START in [lo, hi), inflated and summarised: one thread's share.
+bool bgzf_part_thread(const char *path, uint64_t file_size, uint64_t lo, uint64_t hi, bool want_header, PartData &out)
+{
+    FILE *fp = fopen(path, "rb");
+    BlockInflater inf;
+    if (!fp || !inf.init()) {
+        if (fp) fclose(fp);
+        return false;
+    }
+    const int fd = fileno(fp);
+    uint64_t at = lo == 0 ? 0 : bgzf_resync(fd, file_size, lo);
+    out.first = at;
+    std::vector<unsigned char> cb(65536 + 4096), ob(65536);
+    bool ok = true;
+    while (at < hi && at < file_size) {
+        BgzfBlock b;
+        if (bgzf_block_at(fd, file_size, at, b) <= 0 || pread(fd, cb.data(), b.csize, (off_t)at) != (ssize_t)b.csize) {
+            ok = false;
+            break;
+        }
+        BgzfBlock rel = b;
+        rel.off = 0;
+        if (!inf.run(cb.data(), rel, ob.data())) {
+            ok = false;
+            break;
+        }
+        BlockLines bl;
+        summarise_block(ob.data(), b.isize, bl);
+        if (want_header && !out.header_done && b.isize > 0) {
+            const unsigned char *nl = (const unsigned char *)memchr(ob.data(), '\n', b.isize);
+            out.header.append((const char *)ob.data(), nl ? (size_t)(nl - ob.data()) : b.isize);
+            out.header_done = nl != nullptr;
+        }
+        out.blocks.push_back(b);
+        out.sum.push_back(bl);
+        at += b.csize;
+    }
+    out.next = at;
+    fclose(fp);
+    return ok;
+}
+
+// Part `part` of `nparts` (equal byte ranges of the file) on `threads` threads.  0 = ok, -1 = not BGZF / the sub-ranges
+// did not chain (the caller falls back to the serial hop), 1 = read error.
+int bgzf_collect_part(const char *path, int part, int nparts, int threads, PartData &out)
+{
+    uint64_t file_size = 0, mtime = 0;
+    if (!file_identity(path, file_size, mtime)) return 1;
     {
         FILE *fp = fopen(path, "rb");
-        if (!fp) return -1;
+        if (!fp) return 1;
+        BgzfBlock b;
+        const int k = bgzf_block_at(fileno(fp), file_size, 0, b);
+        fclose(fp);
+        if (k <= 0) return -1;
+    }
+    const uint64_t lo = file_size * (uint64_t)part / (uint64_t)nparts, hi = file_size * (uint64_t)(part + 1) / (uint64_t)nparts;
+    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(threads > 0 ? threads : 1), (hi - lo) >> 20));
+    std::vector<PartData> sub(T);
+    std::vector<char> ok(T, 1);
+    run_threads(T, [&](int t) {
+        const uint64_t a = lo + (hi - lo) * (uint64_t)t / (uint64_t)T, b = lo + (hi - lo) * (uint64_t)(t + 1) / (uint64_t)T;
+        ok[t] = bgzf_part_thread(path, file_size, a, b, part == 0 && t == 0, sub[t]);
+    });
+    for (char c : ok)
+        if (!c) return -1;
+    out = PartData();
+    out.first = sub[0].first;
+    for (int t = 0; t < T; ++t) {
+        if (t > 0 && sub[t].first != sub[t - 1].next) return -1;          // a sub-range started off the chain
+        out.blocks.insert(out.blocks.end(), sub[t].blocks.begin(), sub[t].blocks.end());
+        out.sum.insert(out.sum.end(), sub[t].sum.begin(), sub[t].sum.end());
+    }
+    out.next = sub[T - 1].next;
+    out.header = sub[0].header;
+    out.header_done = sub[0].header_done;
+    // a header line longer than the first thread's share: finish it serially
+    if (part == 0 && !out.header_done) {
+        out.header.clear();
+        FILE *fp = fopen(path, "rb");
         BlockInflater inf;
-        if (!inf.init()) {
-            fclose(fp);
-            return -1;
+        if (!fp || !inf.init()) {
+            if (fp) fclose(fp);
+            return 1;
         }
-        std::vector<unsigned char> cb(65536 + 1024), ob(65536);
-        for (size_t i = 0; i < nb; ++i) {
-            if (pread(fileno(fp), cb.data(), blocks[i].csize, (off_t)blocks[i].off) != (ssize_t)blocks[i].csize) break;
-            BgzfBlock b = blocks[i];
-            b.off = 0;
-            if (!inf.run(cb.data(), b, ob.data())) break;
+        std::vector<unsigned char> cb(65536 + 4096), ob(65536);
+        for (const BgzfBlock &b : out.blocks) {
+            if (pread(fileno(fp), cb.data(), b.csize, (off_t)b.off) != (ssize_t)b.csize) break;
+            BgzfBlock rel = b;
+            rel.off = 0;
+            if (!inf.run(cb.data(), rel, ob.data())) break;
             const unsigned char *nl = (const unsigned char *)memchr(ob.data(), '\n', b.isize);
-            header.append((const char *)ob.data(), nl ? (size_t)(nl - ob.data()) : b.isize);
+            out.header.append((const char *)ob.data(), nl ? (size_t)(nl - ob.data()) : b.isize);
             if (nl) break;
         }
         fclose(fp);
     }
-    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)(threads > 0 ? threads : 1), nb));
-    std::vector<char> ok(T, 1);
-    auto work = [&](int t) {
-        FILE *fp = fopen(path, "rb");
-        BlockInflater inf;
-        if (!fp || !inf.init()) {
-            ok[t] = 0;
-            if (fp) fclose(fp);
-            return;
-        }
-        const int fd = fileno(fp);
-        const size_t b0 = nb * (size_t)t / (size_t)T, b1 = nb * (size_t)(t + 1) / (size_t)T;
-        std::vector<unsigned char> cb(8u << 20), ob(65536);
-        for (size_t i = b0; i < b1 && ok[t];) {
-            // read a run of consecutive blocks with one pread
-            size_t j = i, bytes = 0;
-            while (j < b1 && bytes + blocks[j].csize <= cb.size()) bytes += blocks[j++].csize;
-            if (pread(fd, cb.data(), bytes, (off_t)blocks[i].off) != (ssize_t)bytes) {
-                ok[t] = 0;
-                break;
-            }
-            size_t at = 0;
-            for (; i < j; ++i) {
-                BgzfBlock b = blocks[i];
-                b.off = 0;
-                if (!inf.run(cb.data() + at, b, ob.data())) {
-                    ok[t] = 0;
-                    break;
-                }
-                summarise_block(ob.data(), b.isize, sum[i]);
-                at += b.csize;
-            }
-        }
-        fclose(fp);
-    };
-    if (T <= 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; ++t) th.emplace_back(work, t);
-        for (auto &x : th) x.join();
+    return 0;
+}
+
+// The serial pass over the block summaries of all parts, in file order: line numbers at every block start, access points.
+// -1 when the parts do not chain.
+int bgzf_merge_parts(const char *path, const std::vector<PartData> &parts, int64_t span, BeagleIndex &idx)
+{
+    uint64_t file_size = 0;
+    if (!file_identity(path, idx.file_size, idx.mtime)) return 1;
+    file_size = idx.file_size;
+    uint64_t expect = 0;
+    for (const PartData &p : parts) {
+        if (p.first != expect) return -1;
+        expect = p.next;
     }
-    for (char c : ok)
-        if (!c) {
-            wgs_set_error("read error in %s (corrupt BGZF block)", path);
-            return 1;
-        }
-    // serial pass over the summaries: line numbers at every block start
+    if (expect != file_size) return -1;
     int64_t lines = 0;              // non-blank lines completed
     bool content = false, at_line_start = true, header_done = false;
     uint64_t out = 0, last = 0;
-    for (size_t i = 0; i < nb; ++i) {
-        const BlockLines &bl = sum[i];
-        if (span > 0 && out > 0 && out - last >= (uint64_t)span && blocks[i].isize > 0 && header_done) {
-            AccessPoint ap;
-            ap.in = blocks[i].off;
-            ap.out = out;
-            ap.lines_before = lines;
-            ap.content = content;
-            ap.at_line_start = at_line_start;
-            ap.member_start = 1;
-            idx.points.push_back(std::move(ap));
-            last = out;
+    for (const PartData &p : parts) {
+        for (size_t i = 0; i < p.blocks.size(); ++i) {
+            const BgzfBlock &blk = p.blocks[i];
+            const BlockLines &bl = p.sum[i];
+            if (span > 0 && out > 0 && out - last >= (uint64_t)span && blk.isize > 0 && header_done) {
+                AccessPoint ap;
+                ap.in = blk.off;
+                ap.out = out;
+                ap.lines_before = lines;
+                ap.content = content;
+                ap.at_line_start = at_line_start;
+                ap.member_start = 1;
+                idx.points.push_back(std::move(ap));
+                last = out;
+            }
+            if (blk.isize == 0) continue;
+            if (bl.has_nl) {
+                // the header counts as a line even when it is empty (LineScan); every other line only when non-blank
+                lines += !header_done ? 1 : (content || bl.content_before);
+                header_done = true;
+                lines += bl.lines_after_first;
+                content = bl.content_after;
+                at_line_start = bl.last_is_nl;
+            } else {
+                content = content || bl.content_before;
+                at_line_start = false;
+            }
+            out += blk.isize;
         }
-        if (blocks[i].isize == 0) continue;
-        if (bl.has_nl) {
-            // the header counts as a line even when it is empty (LineScan); every other line only when non-blank
-            lines += !header_done ? 1 : (content || bl.content_before);
-            header_done = true;
-            lines += bl.lines_after_first;
-            content = bl.content_after;
-            at_line_start = bl.last_is_nl;
-        } else {
-            content = content || bl.content_before;
-            at_line_start = false;
-        }
-        out += blocks[i].isize;
     }
     if (!header_done) lines += 1;
     else if (content) lines += 1;   // last line without a newline
     idx.sites = lines > 0 ? lines - 1 : 0;
+    const std::string &header = parts.empty() ? std::string() : parts[0].header;
     parse_header(header.data(), header.data() + header.size(), idx.samples, idx.gl_cols);
     return 0;
+}
+
+// Returns 0 on success, -1 when the file is not (entirely) BGZF -- the caller then takes the serial pass.
+int scan_file_bgzf(const char *path, int64_t span, int threads, BeagleIndex &idx)
+{
+    std::vector<PartData> parts(1);
+    int rc = bgzf_collect_part(path, 0, 1, threads, parts[0]);
+    if (rc == 0) rc = bgzf_merge_parts(path, parts, span, idx);
+    if (rc == -1) {
+        // the sub-ranges did not chain (or this is not BGZF at all): the classic serial hop decides
+        std::vector<BgzfBlock> blocks;
+        if (!bgzf_block_table(path, blocks)) return -1;
+        idx = BeagleIndex();
+        parts.assign(1, PartData());
+        uint64_t file_size = 0, mtime = 0;
+        file_identity(path, file_size, mtime);
+        parts[0].first = 0;
+        if (!bgzf_part_thread(path, file_size, 0, file_size, true, parts[0])) {
+            wgs_set_error("read error in %s (corrupt BGZF block)", path);
+            return 1;
+        }
+        rc = bgzf_merge_parts(path, parts, span, idx);
+    }
+    if (rc == 1) wgs_set_error("read error in %s (corrupt BGZF block)", path);
+    return rc;
 }
 
 template <typename T>
@@ -1267,6 +1401,132 @@ int wgs_reader_build_index(const char *path, const char *index_path, const char 
             return 1;
         }
     }
+    return 0;
+}
+
+}   // extern "C"
+
+namespace {
+const char kPartMagic[8] = {'W', 'G', 'S', 'P', 'R', 'T', '1', 0};
+
+bool save_part(const char *path_out, const PartData &p, uint64_t file_size, uint64_t mtime)
+{
+    std::string tmp;
+    FILE *f = create_private(path_out, tmp);
+    if (!f) return false;
+    fwrite(kPartMagic, 1, 8, f);
+    put(f, file_size);
+    put(f, mtime);
+    put(f, p.first);
+    put(f, p.next);
+    const uint64_t nb = p.blocks.size(), hl = p.header.size();
+    put(f, nb);
+    put(f, hl);
+    fwrite(p.header.data(), 1, p.header.size(), f);
+    if (nb) {
+        fwrite(p.blocks.data(), sizeof(BgzfBlock), nb, f);
+        fwrite(p.sum.data(), sizeof(BlockLines), nb, f);
+    }
+    const bool ok = !ferror(f) && fflush(f) == 0;
+    fclose(f);
+    if (ok && rename(tmp.c_str(), path_out) == 0) return true;
+    unlink(tmp.c_str());
+    return false;
+}
+
+bool load_part(const char *path_in, PartData &p, uint64_t file_size, uint64_t mtime)
+{
+    FILE *f = open_private(path_in);
+    if (!f) return false;
+    char magic[8];
+    uint64_t fs = 0, mt = 0, nb = 0, hl = 0;
+    bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kPartMagic, 8) == 0 && get(f, fs) && get(f, mt) && get(f, p.first) && get(f, p.next) &&
+              get(f, nb) && get(f, hl) && fs == file_size && mt == mtime && hl < (1u << 30) && nb < (1ull << 40);
+    if (ok) {
+        p.header.resize((size_t)hl);
+        ok = fread(&p.header[0], 1, (size_t)hl, f) == (size_t)hl || hl == 0;
+        p.blocks.resize((size_t)nb);
+        p.sum.resize((size_t)nb);
+        if (ok && nb) ok = fread(p.blocks.data(), sizeof(BgzfBlock), (size_t)nb, f) == (size_t)nb && fread(p.sum.data(), sizeof(BlockLines), (size_t)nb, f) == (size_t)nb;
+    }
+    fclose(f);
+    return ok;
+}
+}  // namespace
+
+extern "C" {
+
+/* The index pass of a BGZF file split over the ranks of a node: rank `part` of `nparts` inflates and summarises the blocks
+ * of its byte range (on `threads` threads) into part_path; wgs_reader_index_merge (one rank, after a barrier) chains the
+ * parts into the index.  rc 3 = this file cannot be done in parts (not BGZF, or a range did not find the block chain): one
+ * rank then calls wgs_reader_build_index as before. */
+int wgs_reader_index_part(const char *path, const char *part_path, int part, int nparts, int threads)
+{
+    if (!path || !part_path || part < 0 || nparts < 1 || part >= nparts) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    PartData p;
+    const int rc = bgzf_collect_part(path, part, nparts, threads, p);
+    if (rc == -1) {
+        wgs_set_error("%s cannot be indexed in parts", path);
+        return 3;
+    }
+    if (rc) {
+        wgs_set_error("read error in %s (corrupt BGZF block)", path);
+        return 1;
+    }
+    uint64_t size = 0, mtime = 0;
+    file_identity(path, size, mtime);
+    if (!save_part(part_path, p, size, mtime)) {
+        wgs_set_error("cannot write %s", part_path);
+        return 1;
+    }
+    return 0;
+}
+
+int wgs_reader_index_merge(const char *path, const char *index_path, const char *parts_prefix, int nparts, int64_t span_bytes,
+                           int32_t max_points, int64_t *sites)
+{
+    if (!path || !index_path || !parts_prefix || nparts < 1 || !sites) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    uint64_t size = 0, mtime = 0;
+    if (!file_identity(path, size, mtime)) {
+        wgs_set_error("cannot open Beagle file %s", path);
+        return 2;
+    }
+    std::vector<PartData> parts((size_t)nparts);
+    for (int k = 0; k < nparts; ++k) {
+        const std::string pp = std::string(parts_prefix) + "." + std::to_string(k);
+        if (!load_part(pp.c_str(), parts[(size_t)k], size, mtime)) {
+            wgs_set_error("%s is not a part of the index of %s", pp.c_str(), path);
+            return 3;
+        }
+    }
+    BeagleIndex idx;
+    const int rc = bgzf_merge_parts(path, parts, std::max<int64_t>(span_bytes, (int64_t)GZ_WIN), idx);
+    if (rc == -1) {
+        wgs_set_error("the parts of the index of %s do not chain", path);
+        return 3;
+    }
+    if (rc) {
+        wgs_set_error("read error in %s", path);
+        return 1;
+    }
+    if (max_points > 0 && (int64_t)idx.points.size() > max_points) {
+        std::vector<AccessPoint> keep;
+        const double step = (double)idx.points.size() / max_points;
+        for (int i = 0; i < max_points; ++i) keep.push_back(std::move(idx.points[(size_t)(i * step)]));
+        idx.points.swap(keep);
+    }
+    if (!save_index(index_path, idx)) {
+        wgs_set_error("cannot write the Beagle index %s", index_path);
+        return 1;
+    }
+    *sites = idx.sites;
+    for (int k = 0; k < nparts; ++k) unlink((std::string(parts_prefix) + "." + std::to_string(k)).c_str());
     return 0;
 }
 
@@ -1566,18 +1826,6 @@ bool chunk_reserve(TextPipe *p, TextChunk *c, size_t want)
     c->data = q;
     c->cap = cap;
     return true;
-}
-
-template <typename F>
-void run_threads(int T, F work)
-{
-    if (T <= 1) {
-        work(0);
-        return;
-    }
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) th.emplace_back(work, t);
-    for (auto &x : th) x.join();
 }
 
 // The non-blank lines of data[0 .. len) -- every line ends with a newline, or (at the end of the file) with the buffer.

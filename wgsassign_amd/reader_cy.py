@@ -226,12 +226,38 @@ def ensure_index(path, comm=None, names=False):
         return ok, n.value
 
     ok, sites = valid()
-    if local_rank == 0 and not ok:
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", comm.world)) if comm is not None and comm.world > 1 else 1
+
+    def build_alone():
         n = ctypes.c_int64()
         _lib.check(lib.wgs_reader_build_index(os.fsencode(path), os.fsencode(idx), os.fsencode(nam) if names else None,
                                               INDEX_SPAN_BYTES, INDEX_MAX_POINTS, ctypes.byref(n)))
-    if comm is not None and comm.world > 1:
-        comm.barrier()
+
+    if comm is not None and comm.world > 1 and local_world > 1 and not names:
+        # BGZF (what ANGSD writes): the pass is split over the ranks of the node -- every rank inflates and summarises the
+        # blocks of its byte range, the first rank chains the parts (wgs_reader_index_part / _merge); anything else, or a
+        # range that did not find the block chain: the first rank alone, as before
+        need = comm.allreduce_sum(np.array([0.0 if ok else 1.0]))[0] > 0
+        if need:
+            prefix = idx + ".parts"
+            rc = 0
+            if not ok:
+                rc = lib.wgs_reader_index_part(os.fsencode(path), os.fsencode("%s.%d" % (prefix, local_rank)), local_rank, local_world,
+                                               host_threads())
+            failed = comm.allreduce_sum(np.array([1.0 if rc else 0.0]))[0] > 0      # also the barrier: all parts are written
+            if not ok and local_rank == 0:
+                if not failed:
+                    n = ctypes.c_int64()
+                    failed = lib.wgs_reader_index_merge(os.fsencode(path), os.fsencode(idx), os.fsencode(prefix), local_world,
+                                                        INDEX_SPAN_BYTES, INDEX_MAX_POINTS, ctypes.byref(n)) != 0
+                if failed:
+                    build_alone()
+            comm.barrier()
+    else:
+        if local_rank == 0 and not ok:
+            build_alone()
+        if comm is not None and comm.world > 1:
+            comm.barrier()
     ok, sites = valid()
     if not ok:
         raise RuntimeError("the index of %s could not be built or read (%s)" % (path, idx))
