@@ -343,6 +343,13 @@ const char *wgs_ingest_chunk_sites(wgs_ingest *g, int64_t *bytes);
  * (H2D + tokeniser); lines parsed on the host; text bytes; lines; chunks. */
 int wgs_ingest_stats(wgs_ingest *g, double *stats);
 
+/* BGZF inflate on the device (csrc/inflate.hip; RFC 1951, one lane per block): `nblocks` raw deflate streams -- BGZF members
+ * without header and trailer -- lying in the host buffer `comp` (in_off, in_len) are inflated into `out` (out_off, isize);
+ * status[i] != 0 marks a stream the device did not accept (the host inflates those).  *kernel_ms: the kernel alone. */
+int wgs_debug_inflate(wgs_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                      const uint64_t *out_off, const uint32_t *isize, int32_t nblocks, uint8_t *out, int64_t out_bytes,
+                      uint8_t *status, float *kernel_ms);
+
 /* Test hook, needs no GPU: drains the reader through the text hand-over (producer thread, carried partial lines,
  * parallel newline scan, row limit) with ordinary memory and the host parser in place of the device tokeniser. */
 int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit_rows, float *rows, int64_t max_rows, int64_t *nrows);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "wgs_ingest_next": (c_int, [c_vp, c_i64, c_vp, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "wgs_ingest_chunk_sites": (c_vp, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_ingest_stats": (c_int, [c_vp, c_f64p]),
+    "wgs_debug_inflate": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_f32p]),
     "wgs_debug_reader_text_rows": (c_int, [c_vp, c_i64, c_i64, c_f32p, c_i64, ctypes.POINTER(c_i64)]),
     "wgs_debug_reader_text_chunks": (c_i64, [c_vp]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),

@@ -1,0 +1,365 @@
+// BGZF inflate on the MI355X (RFC 1951, written from the specification).
+//
+// The ingest (ingest.hip) is bound by the host's inflate since the values are tokenised on the device; BGZF -- what ANGSD
+// writes -- is a series of INDEPENDENT deflate streams of at most 64 KiB of output, thousands per chunk of text, so the
+// streams can be decoded side by side: one LANE per block.  A deflate stream itself is serial (variable-length codes,
+// back-references into its own output); a lane decodes one symbol at a time through per-lane tables in device memory:
+//   * bits come from a 64-bit buffer refilled eight bytes at a time;
+//   * literal/length codes through an 11-bit table, distance codes through a 9-bit table (entry = length << 9 | symbol,
+//     filled from the canonical code of the block's code lengths, bit-reversed because deflate packs codes LSB first); the
+//     rare longer codes are found by the canonical count/first/offset walk of the remaining lengths;
+//   * literals and copies are written byte by byte into the block's slot of the text buffer (a lane's consecutive bytes
+//     share cache lines, L2 merges them); copies read the lane's own earlier output.
+// Every block is checked: the stream must end with its final block exactly at ISIZE bytes of output and inside its input;
+// anything else only marks the block, which the host then inflates itself (none for files bgzip or ANGSD wrote).
+// CRC32 is not checked (neither does the host path, reader.cpp: BlockInflater).
+#include "common.h"
+
+namespace {
+
+constexpr int LIT_BITS = 11, DIST_BITS = 9;
+constexpr int LIT_SIZE = 1 << LIT_BITS, DIST_SIZE = 1 << DIST_BITS;
+
+// per-lane scratch in device memory (one per block in flight)
+struct LaneTables {
+    uint16_t lit[LIT_SIZE];        // (code length << 9) | symbol; 0 = a longer code
+    uint16_t dist[DIST_SIZE];      // (code length << 9) | symbol; 0 = a longer code
+    uint16_t lit_sorted[288];      // symbols ordered by (length, symbol): the canonical walk for codes beyond the table
+    uint16_t dist_sorted[32];
+    uint16_t lit_count[16], dist_count[16];
+    uint16_t offs[16], next[16];   // build_table's running offsets / next codes per length
+    uint8_t lens[320];             // code lengths while a dynamic block's trees are read
+    uint8_t cl[20], dl[32];        // code-length code lengths / distance code lengths
+};
+
+struct InflateArgs {
+    const uint8_t *comp;           // compressed bytes of the chunk
+    const uint64_t *in_off;        // per block: first byte of the raw deflate stream (member header skipped)
+    const uint32_t *in_len;        // per block: bytes of the deflate stream
+    const uint64_t *out_off;       // per block: where its text goes
+    const uint32_t *isize;         // per block: bytes of text it must produce
+    uint8_t *out;
+    uint8_t *status;               // per block: 0 = ok, else the host inflates it
+    LaneTables *tables;            // one per lane of the launch
+    int32_t nblocks;
+};
+
+__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+__constant__ uint8_t kClenOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct BitReader {
+    const uint8_t *p, *end;
+    uint64_t buf = 0;
+    int cnt = 0;
+    bool overrun = false;
+    __device__ __forceinline__ void refill()
+    {
+#pragma nounroll
+        while (cnt <= 56) {
+            uint64_t byte = 0;
+            if (p < end) byte = *p;
+            else if (p >= end + 8) overrun = true;             // reading far past the stream: corrupt
+            ++p;
+            buf |= byte << cnt;
+            cnt += 8;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
+    __device__ __forceinline__ void drop(int n)
+    {
+        buf >>= n;
+        cnt -= n;
+    }
+    __device__ __forceinline__ uint32_t take(int n)
+    {
+        if (cnt < n) refill();
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+};
+
+__device__ __forceinline__ uint32_t reverse_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
+
+// Builds table (primary bits `bits`), sorted symbols and counts from n code lengths.  Returns false for an over-subscribed code.
+// (All arrays live in the lane's scratch in device memory and no loop is unrolled: registers buy nothing in code that waits
+// for its own previous load, occupancy does.)
+__device__ __noinline__ bool build_table(const uint8_t *lens, int n, uint16_t *table, int bits, uint16_t *sorted, uint16_t *count,
+                                         uint16_t *offs, uint16_t *next)
+{
+#pragma nounroll
+    for (int i = 0; i < 16; ++i) count[i] = 0;
+#pragma nounroll
+    for (int i = 0; i < n; ++i) ++count[lens[i]];
+    count[0] = 0;
+    int left = 1;
+#pragma nounroll
+    for (int len = 1; len < 16; ++len) {
+        left = (left << 1) - count[len];
+        if (left < 0) return false;
+    }
+    offs[1] = 0;
+    uint32_t code = 0;
+    next[0] = 0;
+#pragma nounroll
+    for (int len = 1; len < 16; ++len) {
+        if (len > 1) offs[len] = offs[len - 1] + count[len - 1];
+        code = (code + count[len - 1]) << 1;
+        next[len] = (uint16_t)code;
+    }
+    const int size = 1 << bits;
+#pragma nounroll
+    for (int i = 0; i < size; ++i) table[i] = 0;
+#pragma nounroll
+    for (int s = 0; s < n; ++s) {
+        const int len = lens[s];
+        if (!len) continue;
+        sorted[offs[len]++] = (uint16_t)s;
+        const uint32_t c = next[len]++;
+        if (len <= bits) {
+            const uint32_t r = reverse_bits(c, len);
+            const uint16_t e = (uint16_t)((len << 9) | s);
+#pragma nounroll
+            for (uint32_t i = r; i < (uint32_t)size; i += 1u << len) table[i] = e;
+        }
+    }
+    return true;
+}
+
+// One symbol: through the table, or the canonical walk for codes longer than the table's bits.  -1 = invalid code.
+__device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *table, int bits, const uint16_t *sorted, const uint16_t *count)
+{
+    if (br.cnt < 15) br.refill();
+    const uint16_t e = table[br.peek(bits)];
+    if (e) {
+        br.drop(e >> 9);
+        return e & 511;
+    }
+    // canonical walk (RFC 1951 3.2.2) over all lengths, bit by bit
+    int code = 0, first = 0, index = 0;
+    uint64_t b = br.buf;
+#pragma nounroll
+    for (int len = 1; len < 16; ++len) {
+        code |= (int)(b & 1);
+        b >>= 1;
+        const int c = count[len];
+        if (code - c < first) {
+            br.drop(len);
+            return sorted[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
+{
+    const int blk = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if (blk >= A.nblocks) return;
+    LaneTables &T = A.tables[blk];
+    BitReader br;
+    br.p = A.comp + A.in_off[blk];
+    br.end = br.p + A.in_len[blk];
+    uint8_t *const out0 = A.out + A.out_off[blk];
+    const uint32_t want = A.isize[blk];
+    uint32_t pos = 0;
+    bool bad = false, done = false;
+    while (!done && !bad) {
+        const uint32_t last = br.take(1), type = br.take(2);
+        if (type == 0) {                                          // stored
+            br.drop(br.cnt & 7);
+            const uint32_t len = br.take(16), nlen = br.take(16);
+            if ((len ^ 0xFFFFu) != nlen || pos + len > want) {
+                bad = true;
+                break;
+            }
+#pragma nounroll
+            for (uint32_t i = 0; i < len; ++i) out0[pos++] = (uint8_t)br.take(8);
+        } else if (type == 1 || type == 2) {
+            if (type == 1) {                                      // fixed codes
+#pragma nounroll
+                for (int i = 0; i < 288; ++i) T.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+                bad = !build_table(T.lens, 288, T.lit, LIT_BITS, T.lit_sorted, T.lit_count, T.offs, T.next);
+#pragma nounroll
+                for (int i = 0; i < 30; ++i) T.lens[i] = 5;
+                bad = bad || !build_table(T.lens, 30, T.dist, DIST_BITS, T.dist_sorted, T.dist_count, T.offs, T.next);
+            } else {                                              // dynamic codes
+                const int hlit = (int)br.take(5) + 257, hdist = (int)br.take(5) + 1, hclen = (int)br.take(4) + 4;
+                if (hlit > 286 || hdist > 30) {
+                    bad = true;
+                    break;
+                }
+                uint8_t *cl = T.cl;
+#pragma nounroll
+                for (int i = 0; i < 19; ++i) cl[i] = 0;
+#pragma nounroll
+                for (int i = 0; i < hclen; ++i) cl[kClenOrder[i]] = (uint8_t)br.take(3);
+                // the code-length code goes through the distance table's storage (it is rebuilt right after)
+                if (!build_table(cl, 19, T.dist, 7, T.dist_sorted, T.dist_count, T.offs, T.next)) {
+                    bad = true;
+                    break;
+                }
+                int i = 0;
+                while (i < hlit + hdist && !bad) {
+                    const int sym = decode_symbol(br, T.dist, 7, T.dist_sorted, T.dist_count);
+                    if (sym < 0) {
+                        bad = true;
+                    } else if (sym < 16) {
+                        T.lens[i++] = (uint8_t)sym;
+                    } else {
+                        int rep, val = 0;
+                        if (sym == 16) {
+                            if (i == 0) {
+                                bad = true;
+                                break;
+                            }
+                            val = T.lens[i - 1];
+                            rep = 3 + (int)br.take(2);
+                        } else if (sym == 17) {
+                            rep = 3 + (int)br.take(3);
+                        } else {
+                            rep = 11 + (int)br.take(7);
+                        }
+                        if (i + rep > hlit + hdist) {
+                            bad = true;
+                            break;
+                        }
+#pragma nounroll
+                        while (rep--) T.lens[i++] = (uint8_t)val;
+                    }
+                }
+                if (bad || T.lens[256] == 0) {
+                    bad = true;
+                    break;
+                }
+                // distance lengths follow the literal/length lengths: move them out before the tables are built over `lens`
+                uint8_t *dl = T.dl;
+#pragma nounroll
+                for (int d = 0; d < 30; ++d) dl[d] = d < hdist ? T.lens[hlit + d] : 0;
+                bad = !build_table(T.lens, hlit, T.lit, LIT_BITS, T.lit_sorted, T.lit_count, T.offs, T.next);
+                bool dist_ok = build_table(dl, 30, T.dist, DIST_BITS, T.dist_sorted, T.dist_count, T.offs, T.next);
+                bad = bad || !dist_ok;
+            }
+            while (!bad) {
+                const int sym = decode_symbol(br, T.lit, LIT_BITS, T.lit_sorted, T.lit_count);
+                if (sym < 0) {
+                    bad = true;
+                } else if (sym < 256) {
+                    if (pos >= want) {
+                        bad = true;
+                        break;
+                    }
+                    out0[pos++] = (uint8_t)sym;
+                } else if (sym == 256) {
+                    break;
+                } else {
+                    if (sym > 285) {
+                        bad = true;
+                        break;
+                    }
+                    const int li = sym - 257;
+                    const uint32_t len = kLenBase[li] + br.take(kLenExtra[li]);
+                    const int ds = decode_symbol(br, T.dist, DIST_BITS, T.dist_sorted, T.dist_count);
+                    if (ds < 0 || ds > 29) {
+                        bad = true;
+                        break;
+                    }
+                    const uint32_t dist = kDistBase[ds] + br.take(kDistExtra[ds]);
+                    if (dist > pos || pos + len > want) {
+                        bad = true;
+                        break;
+                    }
+                    const uint8_t *src = out0 + pos - dist;
+#pragma nounroll
+                    for (uint32_t i = 0; i < len; ++i) out0[pos + i] = src[i];
+                    pos += len;
+                }
+            }
+        } else {
+            bad = true;
+        }
+        if (last) done = true;
+    }
+    if (!bad && (pos != want || br.overrun)) bad = true;
+    A.status[blk] = bad ? 1 : 0;
+}
+
+}  // namespace
+
+size_t inflate_table_bytes(void) { return sizeof(LaneTables); }
+
+// Inflates nblocks BGZF deflate streams of d_comp into d_out (device pointers; tables: nblocks * inflate_table_bytes()).
+int launch_inflate(wgs_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len, const uint64_t *d_out_off,
+                   const uint32_t *d_isize, uint8_t *d_out, uint8_t *d_status, void *d_tables, int32_t nblocks)
+{
+    if (nblocks <= 0) return 0;
+    InflateArgs A;
+    A.comp = d_comp;
+    A.in_off = d_in_off;
+    A.in_len = d_in_len;
+    A.out_off = d_out_off;
+    A.isize = d_isize;
+    A.out = d_out;
+    A.status = d_status;
+    A.tables = reinterpret_cast<LaneTables *>(d_tables);
+    A.nblocks = nblocks;
+    hipLaunchKernelGGL(inflate_kernel, dim3((unsigned)((nblocks + 63) / 64)), dim3(64), 0, ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+/* Test hook and building block: inflate `nblocks` raw deflate streams (BGZF members without header and trailer) that lie in
+ * one host buffer `comp` (in_off / in_len) into `out` (out_off / isize), on the device; status[i] != 0 marks a stream the
+ * device did not accept.  *kernel_ms: the inflate kernel alone. */
+int wgs_debug_inflate(wgs_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
+                      const uint64_t *out_off, const uint32_t *isize, int32_t nblocks, uint8_t *out, int64_t out_bytes, uint8_t *status,
+                      float *kernel_ms)
+{
+    WGS_REQUIRE(ctx && comp && in_off && in_len && out_off && isize && out && status && nblocks >= 0, "bad argument");
+    for (int32_t i = 0; i < nblocks; ++i)
+        WGS_REQUIRE(in_off[i] + in_len[i] <= (uint64_t)comp_bytes && out_off[i] + isize[i] <= (uint64_t)out_bytes, "stream %d outside its buffer", i);
+    if (nblocks == 0) return 0;
+    HIP_TRY(hipSetDevice(ctx->device));
+    uint8_t *d_comp = nullptr, *d_out = nullptr, *d_status = nullptr;
+    uint64_t *d_io = nullptr, *d_oo = nullptr;
+    uint32_t *d_il = nullptr, *d_is = nullptr;
+    void *d_tab = nullptr;
+    auto guard = on_failure([&] {
+        for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_status, (void *)d_io, (void *)d_oo, (void *)d_il, (void *)d_is, d_tab})
+            if (p) (void)hipFree(p);
+    });
+    HIP_TRY(hipMalloc(&d_comp, (size_t)comp_bytes + 16));
+    HIP_TRY(hipMalloc(&d_out, (size_t)std::max<int64_t>(out_bytes, 1)));
+    HIP_TRY(hipMalloc(&d_status, (size_t)nblocks));
+    HIP_TRY(hipMalloc(&d_io, sizeof(uint64_t) * nblocks));
+    HIP_TRY(hipMalloc(&d_oo, sizeof(uint64_t) * nblocks));
+    HIP_TRY(hipMalloc(&d_il, sizeof(uint32_t) * nblocks));
+    HIP_TRY(hipMalloc(&d_is, sizeof(uint32_t) * nblocks));
+    HIP_TRY(hipMalloc(&d_tab, inflate_table_bytes() * (size_t)nblocks));
+    HIP_TRY(hipMemcpy(d_comp, comp, (size_t)comp_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_io, in_off, sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_oo, out_off, sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_il, in_len, sizeof(uint32_t) * nblocks, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_is, isize, sizeof(uint32_t) * nblocks, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(d_out, 0, (size_t)std::max<int64_t>(out_bytes, 1), ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (launch_inflate(ctx, d_comp, d_io, d_il, d_oo, d_is, d_out, d_status, d_tab, nblocks)) return 1;
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(status, d_status, (size_t)nblocks, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1);
+    guard.dismiss();
+    for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_status, (void *)d_io, (void *)d_oo, (void *)d_il, (void *)d_is, d_tab}) (void)hipFree(p);
+    return 0;
+}
+
+}  // extern "C"
