@@ -3,11 +3,11 @@
 // The ingest (ingest.hip) is bound by the host's inflate since the values are tokenised on the device; BGZF -- what ANGSD
 // writes -- is a series of INDEPENDENT deflate streams of at most 64 KiB of output, thousands per chunk of text, so the
 // streams can be decoded side by side: one LANE per block.  A deflate stream itself is serial (variable-length codes,
-// back-references into its own output); a lane decodes one symbol at a time through per-lane tables in device memory:
+// back-references into its own output); a lane decodes one symbol at a time through its own tables:
 //   * bits come from a 64-bit buffer refilled eight bytes at a time;
-//   * literal/length codes through an 11-bit table, distance codes through a 9-bit table (entry = length << 9 | symbol,
-//     filled from the canonical code of the block's code lengths, bit-reversed because deflate packs codes LSB first); the
-//     rare longer codes are found by the canonical count/first/offset walk of the remaining lengths;
+//   * literal/length codes through an 8-bit table, distance codes through a 7-bit table, both in LDS (entry = length << 9
+//     | symbol, filled from the canonical code of the block's code lengths, bit-reversed because deflate packs codes LSB
+//     first); the rare longer codes are found by the canonical count/first/offset walk of the remaining lengths;
 //   * literals and copies are written byte by byte into the block's slot of the text buffer (a lane's consecutive bytes
 //     share cache lines, L2 merges them); copies read the lane's own earlier output.
 // Every block is checked: the stream must end with its final block exactly at ISIZE bytes of output and inside its input;
@@ -17,16 +17,18 @@
 
 namespace {
 
-constexpr int LIT_BITS = 11, DIST_BITS = 9;
+// The decode tables live in LDS, entry-major with the lane fastest ([entry][lane]: a wave-wide lookup with per-lane entries
+// touches 32 banks evenly): device memory made every lookup a cache miss (tables of thousands of lanes, random entries --
+// 2.3 us per symbol measured).  8 + 7 bits of primary table, the per-length counts for the canonical walk of longer codes.
+constexpr int LIT_BITS = 8, DIST_BITS = 7;
 constexpr int LIT_SIZE = 1 << LIT_BITS, DIST_SIZE = 1 << DIST_BITS;
+constexpr int LDS_LIT = 0, LDS_DIST = LIT_SIZE * 64, LDS_LIT_COUNT = LDS_DIST + DIST_SIZE * 64, LDS_DIST_COUNT = LDS_LIT_COUNT + 16 * 64,
+              LDS_WORDS = LDS_DIST_COUNT + 16 * 64;      // uint16 words per wavefront: 52 KiB
 
-// per-lane scratch in device memory (one per block in flight)
+// per-lane scratch in device memory (one per block in flight): what is touched once per deflate block, not once per symbol
 struct LaneTables {
-    uint16_t lit[LIT_SIZE];        // (code length << 9) | symbol; 0 = a longer code
-    uint16_t dist[DIST_SIZE];      // (code length << 9) | symbol; 0 = a longer code
     uint16_t lit_sorted[288];      // symbols ordered by (length, symbol): the canonical walk for codes beyond the table
     uint16_t dist_sorted[32];
-    uint16_t lit_count[16], dist_count[16];
     uint16_t offs[16], next[16];   // build_table's running offsets / next codes per length
     uint8_t lens[320];             // code lengths while a dynamic block's trees are read
     uint8_t cl[20], dl[32];        // code-length code lengths / distance code lengths
@@ -54,18 +56,20 @@ struct BitReader {
     const uint8_t *p, *end;
     uint64_t buf = 0;
     int cnt = 0;
-    bool overrun = false;
+    // At least 56 valid bits afterwards.  Eight bytes are fetched as two aligned 64-bit words (the chunk is padded, so
+    // reading a little past a stream is harmless: a valid stream never CONSUMES those bits, see `consumed_past_end`);
+    // bytes of a partly used word are ORed in again at the same position by the next refill, which changes nothing.
     __device__ __forceinline__ void refill()
     {
-#pragma nounroll
-        while (cnt <= 56) {
-            uint64_t byte = 0;
-            if (p < end) byte = *p;
-            else if (p >= end + 8) overrun = true;             // reading far past the stream: corrupt
-            ++p;
-            buf |= byte << cnt;
-            cnt += 8;
-        }
+        const uintptr_t addr = (uintptr_t)p;
+        const uint64_t *a = reinterpret_cast<const uint64_t *>(addr & ~(uintptr_t)7);
+        const int sh = (int)(addr & 7) * 8;
+        const uint64_t lo = a[0], hi = a[1];
+        const uint64_t v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+        buf |= v << cnt;
+        const int nbytes = (63 - cnt) >> 3;
+        p += nbytes;
+        cnt += nbytes * 8;
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     __device__ __forceinline__ void drop(int n)
@@ -73,13 +77,14 @@ struct BitReader {
         buf >>= n;
         cnt -= n;
     }
-    __device__ __forceinline__ uint32_t take(int n)
+    __device__ __forceinline__ uint32_t take(int n)              // n <= 32
     {
         if (cnt < n) refill();
         const uint32_t v = peek(n);
         drop(n);
         return v;
     }
+    __device__ __forceinline__ bool consumed_past_end() const { return p - (cnt >> 3) > end; }
 };
 
 __device__ __forceinline__ uint32_t reverse_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
@@ -87,18 +92,19 @@ __device__ __forceinline__ uint32_t reverse_bits(uint32_t code, int len) { retur
 // Builds table (primary bits `bits`), sorted symbols and counts from n code lengths.  Returns false for an over-subscribed code.
 // (All arrays live in the lane's scratch in device memory and no loop is unrolled: registers buy nothing in code that waits
 // for its own previous load, occupancy does.)
+// `table` and `count` are this lane's columns of the LDS arrays: element i at [i * 64].
 __device__ __noinline__ bool build_table(const uint8_t *lens, int n, uint16_t *table, int bits, uint16_t *sorted, uint16_t *count,
                                          uint16_t *offs, uint16_t *next)
 {
 #pragma nounroll
-    for (int i = 0; i < 16; ++i) count[i] = 0;
+    for (int i = 0; i < 16; ++i) count[i * 64] = 0;
 #pragma nounroll
-    for (int i = 0; i < n; ++i) ++count[lens[i]];
+    for (int i = 0; i < n; ++i) ++count[lens[i] * 64];
     count[0] = 0;
     int left = 1;
 #pragma nounroll
     for (int len = 1; len < 16; ++len) {
-        left = (left << 1) - count[len];
+        left = (left << 1) - count[len * 64];
         if (left < 0) return false;
     }
     offs[1] = 0;
@@ -106,13 +112,13 @@ __device__ __noinline__ bool build_table(const uint8_t *lens, int n, uint16_t *t
     next[0] = 0;
 #pragma nounroll
     for (int len = 1; len < 16; ++len) {
-        if (len > 1) offs[len] = offs[len - 1] + count[len - 1];
-        code = (code + count[len - 1]) << 1;
+        if (len > 1) offs[len] = offs[len - 1] + count[(len - 1) * 64];
+        code = (code + count[(len - 1) * 64]) << 1;
         next[len] = (uint16_t)code;
     }
     const int size = 1 << bits;
 #pragma nounroll
-    for (int i = 0; i < size; ++i) table[i] = 0;
+    for (int i = 0; i < size; ++i) table[i * 64] = 0;
 #pragma nounroll
     for (int s = 0; s < n; ++s) {
         const int len = lens[s];
@@ -123,171 +129,198 @@ __device__ __noinline__ bool build_table(const uint8_t *lens, int n, uint16_t *t
             const uint32_t r = reverse_bits(c, len);
             const uint16_t e = (uint16_t)((len << 9) | s);
 #pragma nounroll
-            for (uint32_t i = r; i < (uint32_t)size; i += 1u << len) table[i] = e;
+            for (uint32_t i = r; i < (uint32_t)size; i += 1u << len) table[i * 64] = e;
         }
     }
     return true;
 }
 
-// One symbol: through the table, or the canonical walk for codes longer than the table's bits.  -1 = invalid code.
-__device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *table, int bits, const uint16_t *sorted, const uint16_t *count)
+// The canonical walk (RFC 1951 3.2.2) for a code the table does not hold: (length << 9) | symbol, or 0 for an invalid code.
+__device__ __noinline__ uint32_t walk_symbol(uint64_t b, const uint16_t *sorted, const uint16_t *count)
 {
-    if (br.cnt < 15) br.refill();
-    const uint16_t e = table[br.peek(bits)];
-    if (e) {
-        br.drop(e >> 9);
-        return e & 511;
-    }
-    // canonical walk (RFC 1951 3.2.2) over all lengths, bit by bit
     int code = 0, first = 0, index = 0;
-    uint64_t b = br.buf;
 #pragma nounroll
     for (int len = 1; len < 16; ++len) {
         code |= (int)(b & 1);
         b >>= 1;
-        const int c = count[len];
-        if (code - c < first) {
-            br.drop(len);
-            return sorted[index + (code - first)];
-        }
+        const int c = count[len * 64];
+        if (code - c < first) return ((uint32_t)len << 9) | sorted[index + (code - first)];
         index += c;
         first += c;
         first <<= 1;
         code <<= 1;
     }
-    return -1;
+    return 0;
 }
+
+// One symbol where lockstep does not matter (the trees of a dynamic block).  -1 = invalid code.
+__device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *table, int bits, const uint16_t *sorted, const uint16_t *count)
+{
+    if (br.cnt < 15) br.refill();
+    uint32_t e = table[br.peek(bits) * 64];
+    if (!e) e = walk_symbol(br.buf, sorted, count);
+    if (!e) return -1;
+    br.drop((int)(e >> 9));
+    return (int)(e & 511);
+}
+
+// Block header (and, for a dynamic block, its trees).  Returns the block type 0 / 1 / 2, or -1 for a corrupt header; for a
+// stored block *stored = its length.
+__device__ __noinline__ int read_block_header(BitReader &br, LaneTables &T, uint16_t *L, uint32_t *last, uint32_t *stored)
+{
+    uint16_t *const lit = L + LDS_LIT, *const dtab = L + LDS_DIST, *const lit_count = L + LDS_LIT_COUNT, *const dist_count = L + LDS_DIST_COUNT;
+    br.refill();
+    *last = br.take(1);
+    const uint32_t type = br.take(2);
+    if (type == 0) {
+        br.drop(br.cnt & 7);
+        const uint32_t len = br.take(16), nlen = br.take(16);
+        if ((len ^ 0xFFFFu) != nlen) return -1;
+        *stored = len;
+        return 0;
+    }
+    if (type == 1) {
+#pragma nounroll
+        for (int i = 0; i < 288; ++i) T.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
+        if (!build_table(T.lens, 288, lit, LIT_BITS, T.lit_sorted, lit_count, T.offs, T.next)) return -1;
+#pragma nounroll
+        for (int i = 0; i < 30; ++i) T.lens[i] = 5;
+        return build_table(T.lens, 30, dtab, DIST_BITS, T.dist_sorted, dist_count, T.offs, T.next) ? 1 : -1;
+    }
+    if (type != 2) return -1;
+    const int hlit = (int)br.take(5) + 257, hdist = (int)br.take(5) + 1, hclen = (int)br.take(4) + 4;
+    if (hlit > 286 || hdist > 30) return -1;
+    uint8_t *cl = T.cl;
+#pragma nounroll
+    for (int i = 0; i < 19; ++i) cl[i] = 0;
+#pragma nounroll
+    for (int i = 0; i < hclen; ++i) cl[kClenOrder[i]] = (uint8_t)br.take(3);
+    // the code-length code goes through the distance table's storage (it is rebuilt right after)
+    if (!build_table(cl, 19, dtab, 7, T.dist_sorted, dist_count, T.offs, T.next)) return -1;
+    int i = 0;
+    while (i < hlit + hdist) {
+        const int sym = decode_symbol(br, dtab, 7, T.dist_sorted, dist_count);
+        if (sym < 0) return -1;
+        if (sym < 16) {
+            T.lens[i++] = (uint8_t)sym;
+            continue;
+        }
+        int rep, val = 0;
+        if (sym == 16) {
+            if (i == 0) return -1;
+            val = T.lens[i - 1];
+            rep = 3 + (int)br.take(2);
+        } else if (sym == 17) {
+            rep = 3 + (int)br.take(3);
+        } else {
+            rep = 11 + (int)br.take(7);
+        }
+        if (i + rep > hlit + hdist) return -1;
+#pragma nounroll
+        while (rep--) T.lens[i++] = (uint8_t)val;
+    }
+    if (T.lens[256] == 0) return -1;
+    // distance lengths follow the literal/length lengths: move them out before the tables are built over `lens`
+    uint8_t *dl = T.dl;
+#pragma nounroll
+    for (int d = 0; d < 30; ++d) dl[d] = d < hdist ? T.lens[hlit + d] : 0;
+    if (!build_table(T.lens, hlit, lit, LIT_BITS, T.lit_sorted, lit_count, T.offs, T.next)) return -1;
+    return build_table(dl, 30, dtab, DIST_BITS, T.dist_sorted, dist_count, T.offs, T.next) ? 2 : -1;
+}
+
+// One lane per BGZF block, the 64 lanes of a wavefront in LOCKSTEP: every trip of the loop emits one step per lane
+// -- a literal, up to sixteen bytes of a copy, one byte of a stored block -- so lanes that are decoding symbols execute the same
+// instructions together, and so do the lanes that are copying.  (The first version let every lane run its own
+// symbol-by-symbol loop: 64 different instruction streams per wavefront, 5 GB/s.)  Only block headers -- a few per 64 KiB --
+// leave the common path, and the lanes that reach one at the same trip build their tables together.
+enum : int { ST_HEADER = 0, ST_SYMBOL = 1, ST_COPY = 2, ST_STORED = 3, ST_DONE = 4 };
 
 __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
 {
+    __shared__ uint16_t lds[LDS_WORDS];
+    uint16_t *const L = lds + threadIdx.x;                     // this lane's column of every table
     const int blk = (int)blockIdx.x * 64 + (int)threadIdx.x;
-    if (blk >= A.nblocks) return;
-    LaneTables &T = A.tables[blk];
+    const bool have = blk < A.nblocks;
+    LaneTables &T = A.tables[have ? blk : 0];
     BitReader br;
-    br.p = A.comp + A.in_off[blk];
-    br.end = br.p + A.in_len[blk];
-    uint8_t *const out0 = A.out + A.out_off[blk];
-    const uint32_t want = A.isize[blk];
-    uint32_t pos = 0;
-    bool bad = false, done = false;
-    while (!done && !bad) {
-        const uint32_t last = br.take(1), type = br.take(2);
-        if (type == 0) {                                          // stored
-            br.drop(br.cnt & 7);
-            const uint32_t len = br.take(16), nlen = br.take(16);
-            if ((len ^ 0xFFFFu) != nlen || pos + len > want) {
+    br.p = A.comp + (have ? A.in_off[blk] : 0);
+    br.end = br.p + (have ? A.in_len[blk] : 0);
+    uint8_t *const out0 = A.out + (have ? A.out_off[blk] : 0);
+    const uint32_t want = have ? A.isize[blk] : 0;
+    uint32_t pos = 0, last = 0, left = 0, dist = 0;
+    int state = have ? ST_HEADER : ST_DONE;
+    bool bad = false;
+    while (__any(state != ST_DONE)) {
+        if (state == ST_HEADER) {
+            uint32_t stored = 0;
+            const int type = read_block_header(br, T, L, &last, &stored);
+            if (type < 0 || (type == 0 && pos + stored > want)) {
                 bad = true;
-                break;
+                state = ST_DONE;
+            } else if (type == 0) {
+                left = stored;
+                state = stored ? ST_STORED : (last ? ST_DONE : ST_HEADER);
+            } else {
+                state = ST_SYMBOL;
             }
-#pragma nounroll
-            for (uint32_t i = 0; i < len; ++i) out0[pos++] = (uint8_t)br.take(8);
-        } else if (type == 1 || type == 2) {
-            if (type == 1) {                                      // fixed codes
-#pragma nounroll
-                for (int i = 0; i < 288; ++i) T.lens[i] = i < 144 ? 8 : (i < 256 ? 9 : (i < 280 ? 7 : 8));
-                bad = !build_table(T.lens, 288, T.lit, LIT_BITS, T.lit_sorted, T.lit_count, T.offs, T.next);
-#pragma nounroll
-                for (int i = 0; i < 30; ++i) T.lens[i] = 5;
-                bad = bad || !build_table(T.lens, 30, T.dist, DIST_BITS, T.dist_sorted, T.dist_count, T.offs, T.next);
-            } else {                                              // dynamic codes
-                const int hlit = (int)br.take(5) + 257, hdist = (int)br.take(5) + 1, hclen = (int)br.take(4) + 4;
-                if (hlit > 286 || hdist > 30) {
-                    bad = true;
-                    break;
-                }
-                uint8_t *cl = T.cl;
-#pragma nounroll
-                for (int i = 0; i < 19; ++i) cl[i] = 0;
-#pragma nounroll
-                for (int i = 0; i < hclen; ++i) cl[kClenOrder[i]] = (uint8_t)br.take(3);
-                // the code-length code goes through the distance table's storage (it is rebuilt right after)
-                if (!build_table(cl, 19, T.dist, 7, T.dist_sorted, T.dist_count, T.offs, T.next)) {
-                    bad = true;
-                    break;
-                }
-                int i = 0;
-                while (i < hlit + hdist && !bad) {
-                    const int sym = decode_symbol(br, T.dist, 7, T.dist_sorted, T.dist_count);
-                    if (sym < 0) {
-                        bad = true;
-                    } else if (sym < 16) {
-                        T.lens[i++] = (uint8_t)sym;
-                    } else {
-                        int rep, val = 0;
-                        if (sym == 16) {
-                            if (i == 0) {
-                                bad = true;
-                                break;
-                            }
-                            val = T.lens[i - 1];
-                            rep = 3 + (int)br.take(2);
-                        } else if (sym == 17) {
-                            rep = 3 + (int)br.take(3);
-                        } else {
-                            rep = 11 + (int)br.take(7);
-                        }
-                        if (i + rep > hlit + hdist) {
-                            bad = true;
-                            break;
-                        }
-#pragma nounroll
-                        while (rep--) T.lens[i++] = (uint8_t)val;
-                    }
-                }
-                if (bad || T.lens[256] == 0) {
-                    bad = true;
-                    break;
-                }
-                // distance lengths follow the literal/length lengths: move them out before the tables are built over `lens`
-                uint8_t *dl = T.dl;
-#pragma nounroll
-                for (int d = 0; d < 30; ++d) dl[d] = d < hdist ? T.lens[hlit + d] : 0;
-                bad = !build_table(T.lens, hlit, T.lit, LIT_BITS, T.lit_sorted, T.lit_count, T.offs, T.next);
-                bool dist_ok = build_table(dl, 30, T.dist, DIST_BITS, T.dist_sorted, T.dist_count, T.offs, T.next);
-                bad = bad || !dist_ok;
-            }
-            while (!bad) {
-                const int sym = decode_symbol(br, T.lit, LIT_BITS, T.lit_sorted, T.lit_count);
-                if (sym < 0) {
-                    bad = true;
-                } else if (sym < 256) {
-                    if (pos >= want) {
-                        bad = true;
-                        break;
-                    }
-                    out0[pos++] = (uint8_t)sym;
-                } else if (sym == 256) {
-                    break;
-                } else {
-                    if (sym > 285) {
-                        bad = true;
-                        break;
-                    }
-                    const int li = sym - 257;
-                    const uint32_t len = kLenBase[li] + br.take(kLenExtra[li]);
-                    const int ds = decode_symbol(br, T.dist, DIST_BITS, T.dist_sorted, T.dist_count);
-                    if (ds < 0 || ds > 29) {
-                        bad = true;
-                        break;
-                    }
-                    const uint32_t dist = kDistBase[ds] + br.take(kDistExtra[ds]);
-                    if (dist > pos || pos + len > want) {
-                        bad = true;
-                        break;
-                    }
-                    const uint8_t *src = out0 + pos - dist;
-#pragma nounroll
-                    for (uint32_t i = 0; i < len; ++i) out0[pos + i] = src[i];
-                    pos += len;
-                }
-            }
-        } else {
-            bad = true;
         }
-        if (last) done = true;
+        if (state != ST_DONE && br.cnt < 48) br.refill();
+        if (state == ST_SYMBOL) {
+            uint32_t e = L[LDS_LIT + br.peek(LIT_BITS) * 64];
+            if (!e) e = walk_symbol(br.buf, T.lit_sorted, L + LDS_LIT_COUNT);
+            const uint32_t sym = e & 511;
+            br.drop((int)(e >> 9));
+            if (!e || sym > 285) {
+                bad = true;
+                state = ST_DONE;
+            } else if (sym < 256) {
+                if (pos < want) out0[pos++] = (uint8_t)sym;
+                else bad = true, state = ST_DONE;
+            } else if (sym == 256) {
+                state = last ? ST_DONE : ST_HEADER;
+            } else {
+                const int li = (int)sym - 257;
+                const int xb = kLenExtra[li];
+                const uint32_t len = kLenBase[li] + br.peek(xb);
+                br.drop(xb);
+                uint32_t d = L[LDS_DIST + br.peek(DIST_BITS) * 64];
+                if (!d) d = walk_symbol(br.buf, T.dist_sorted, L + LDS_DIST_COUNT);
+                const uint32_t ds = d & 511;
+                br.drop((int)(d >> 9));
+                if (!d || ds > 29) {
+                    bad = true;
+                    state = ST_DONE;
+                } else {
+                    const int db = kDistExtra[ds];
+                    dist = kDistBase[ds] + br.peek(db);
+                    br.drop(db);
+                    left = len;
+                    if (dist > pos || pos + len > want) bad = true, state = ST_DONE;
+                    else state = ST_COPY;
+                }
+            }
+        } else if (state == ST_COPY) {
+            // matches in this kind of text are long (51 bytes on average) and come from far back (half of them from more
+            // than 2 KiB): sixteen bytes per trip whenever source and destination do not overlap within the sixteen and
+            // the slot has room for them (bytes past the match are overwritten by what follows); else one byte
+            if (dist >= 16 && pos + 16 <= want) {
+                struct __attribute__((packed)) B16 { uint64_t a, b; };
+                *reinterpret_cast<B16 *>(out0 + pos) = *reinterpret_cast<const B16 *>(out0 + pos - dist);
+                const uint32_t step = left < 16 ? left : 16;
+                pos += step;
+                left -= step;
+            } else {
+                out0[pos] = out0[pos - dist];
+                ++pos;
+                --left;
+            }
+            if (left == 0) state = ST_SYMBOL;
+        } else if (state == ST_STORED) {
+            out0[pos++] = (uint8_t)br.take(8);
+            if (--left == 0) state = last ? ST_DONE : ST_HEADER;
+        }
     }
-    if (!bad && (pos != want || br.overrun)) bad = true;
-    A.status[blk] = bad ? 1 : 0;
+    if (have) A.status[blk] = (bad || pos != want || br.consumed_past_end()) ? 1 : 0;
 }
 
 }  // namespace
