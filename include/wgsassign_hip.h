@@ -339,8 +339,11 @@ void wgs_ingest_destroy(wgs_ingest *g);
 int wgs_ingest_next(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64_t keep_len, int64_t *file_rows, int64_t *rows_written);
 /* Site names of that chunk's lines (kept or not), '\n'-terminated each, *bytes long. */
 const char *wgs_ingest_chunk_sites(wgs_ingest *g, int64_t *bytes);
-/* stats[0..7]: seconds the caller waited for text; producer seconds in inflate / in the newline scan; device ms
- * (H2D + tokeniser); lines parsed on the host; text bytes; lines; chunks. */
+/* stats[0..13]: seconds the caller waited for the producer thread; producer seconds in inflate / in the newline scan (host
+ * inflate); device ms (copies + kernels); lines parsed on the host; text bytes; lines; chunks; ms of the device inflate
+ * kernel; BGZF members inflated on the device (csrc/inflate.hip: BGZF files take the device-resident pipeline unless
+ * WGSASSIGN_INFLATE=host); members the device left to the host's inflater; producer seconds reading compressed members; seconds inside
+ * wgs_ingest_create and inside wgs_ingest_next. */
 int wgs_ingest_stats(wgs_ingest *g, double *stats);
 
 /* BGZF inflate on the device (csrc/inflate.hip; RFC 1951, one lane per block): `nblocks` raw deflate streams -- BGZF members

@@ -53,8 +53,9 @@ def test_bundled_files_through_the_device_tokeniser(golden, tmp_path, monkeypatc
     assert same_bits(rows, a["L"]) and samples == list(a["samples"]) and sites == list(a["sites"])
 
 
-def test_awkward_tokens_flag_lines_for_the_host(tmp_path, monkeypatch):
-    """Decimal tokens (with signs, exponents, odd widths, several delimiters, CRLF, blank lines, no final newline) are
+@pytest.mark.parametrize("container", ["gzip", "bgzf"])
+def test_awkward_tokens_flag_lines_for_the_host(tmp_path, monkeypatch, container):
+    """gzip: text inflated and listed on the host; BGZF: inflated and listed on the device.  Decimal tokens (with signs, exponents, odd widths, several delimiters, CRLF, blank lines, no final newline) are
     converted on the device; inf/nan, hex floats, 16+ digits and junk flag their line for the strtod-backed host
     parser.  Either way the bits are the host parser's."""
     from wgsassign_amd import reader_cy
@@ -80,15 +81,20 @@ def test_awkward_tokens_flag_lines_for_the_host(tmp_path, monkeypatch):
             lines.append("")
     text = "\r\n".join(lines)                                   # CRLF, no final newline
     p = str(tmp_path / "awkward.beagle.gz")
-    with gzip.open(p, "wt", newline="") as fh:
-        fh.write(text)
+
+    def write(t):
+        if container == "bgzf":
+            write_bgzf(p, t.encode(), block=5000)
+        else:
+            with gzip.open(p, "wt", newline="") as fh:
+                fh.write(t)
+    write(text)
     want, samples_h, sites_h = reader_cy.readBeagle(p)
     rows, samples, sites, stats = device_rows(p)
     assert same_bits(rows, want) and samples == samples_h and sites == sites_h == ["s%d" % s for s in range(400)]
     assert 0 < stats["host_lines"] <= sum(kinds)                # only lines that hold a hard token went to the host
     # a short line is reported like the host reader reports it
-    with gzip.open(p, "wt") as fh:
-        fh.write(head + "\n" + line("s0", plain) + "\ns1\tA\tC\t0.1\t0.2\n")
+    write(head + "\n" + line("s0", plain) + "\ns1\tA\tC\t0.1\t0.2\n")
     with pytest.raises(ValueError, match="Beagle data line 3 has fewer than %d" % (3 * n)):
         device_rows(p)
 

@@ -25,10 +25,18 @@ def main():
     ap.add_argument("--inds", type=int, default=2000)
     ap.add_argument("--sites", type=int, default=20000)
     ap.add_argument("--reblock", type=int, default=0, help="re-cut the text into BGZF blocks of this many bytes (0: the pool file's own blocks)")
+    ap.add_argument("--lowdepth", action="store_true", help="text of a simulated 2x matrix (tests/synth.make_beagle: few distinct likelihoods, "
+                                                            "long far matches, 10x compression) instead of the pool file's random digits (3x)")
     a = ap.parse_args()
     d = tempfile.mkdtemp()
     path = os.path.join(d, "x.beagle.gz")
-    synth.make_pool_file(path, a.inds, a.sites, pool=min(1024, a.sites))
+    if a.lowdepth:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_cli
+        L, IDs = synth.make_beagle(a.sites, a.inds, 5, seed=4242)
+        bench_cli.write_beagle(path, L, os.path.join(d, "ids.txt"), IDs, "bgzf")
+    else:
+        synth.make_pool_file(path, a.inds, a.sites, pool=min(1024, a.sites))
     raw = open(path, "rb").read()
     if a.reblock:
         import gzip

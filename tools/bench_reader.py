@@ -23,6 +23,10 @@ def main():
     ap.add_argument("--sites", type=int, default=3000)
     ap.add_argument("--device", action="store_true")
     ap.add_argument("--bgzf", action="store_true", help="write the file as BGZF (what ANGSD produces) instead of plain gzip")
+    ap.add_argument("--lowdepth", action="store_true", help="BGZF text of a simulated 2x matrix in 60 kB members (tests/synth.make_beagle "
+                                                            "through tools/bench_cli.write_beagle: few distinct likelihoods, ~11x compression, "
+                                                            "like the reference's bundled 2x files) instead of the pool file (random digits, 3x, "
+                                                            "two members per line)")
     a = ap.parse_args()
     n, m = a.inds, a.sites
     d = tempfile.mkdtemp()
@@ -32,7 +36,14 @@ def main():
     import synth
     # lines come from a pool of pre-made GL sections (a third of the genotypes missing, like low-depth ANGSD output):
     # formatting m x 3n numbers in Python would take longer than everything measured here
-    if a.bgzf:
+    if a.lowdepth:
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import bench_cli
+        a.bgzf = True
+        L, IDs = synth.make_beagle(m, n, 20, seed=4242)
+        text_bytes = bench_cli.write_beagle(path, L, os.path.join(d, "ids.txt"), IDs, "bgzf")
+        del L
+    elif a.bgzf:
         synth.make_pool_file(path, n, m, pool=min(1024, m))
         text_bytes = m * (27 * n + 1 + len("chr7_1\tA\tC")) + sum(len(str(s + 1)) - 1 for s in range(m))
     else:
@@ -65,8 +76,13 @@ def main():
     if a.device:
         from wgsassign_amd import device
         ctx = device.get_context()
-        for label, mode in (("into_slabs_device_tokeniser", "device"), ("into_slabs_host_parser", "host")):
+        for label, mode, inflate in (("into_slabs_device_inflate_and_tokeniser", "device", "device"),
+                                     ("into_slabs_host_inflate_device_tokeniser", "device", "host"),
+                                     ("into_slabs_host_parser", "host", "host")):
+            if inflate == "device" and not a.bgzf:
+                continue
             os.environ["WGSASSIGN_INGEST"] = mode
+            os.environ["WGSASSIGN_INFLATE"] = inflate
             best = None
             for _ in range(2):                      # the second run has the pinned buffers' pages and the file cache warm
                 t0 = time.perf_counter()
@@ -82,7 +98,12 @@ def main():
             if st:
                 res[label].update({"waited_for_inflate_s": round(st["wait_s"], 3), "producer_inflate_s": round(st["inflate_s"], 3),
                                    "producer_newline_scan_s": round(st["scan_s"], 3), "device_ms_h2d_plus_tokeniser": round(st["device_ms"], 1),
-                                   "lines_parsed_on_host": int(st["host_lines"]), "chunks": int(st["chunks"])})
+                                   "lines_parsed_on_host": int(st["host_lines"]), "chunks": int(st["chunks"]),
+                                   "device_inflate_kernel_ms": round(st["device_inflate_kernel_ms"], 1),
+                                   "members_inflated_on_device": int(st["blocks_inflated_on_device"]),
+                                   "members_left_to_host": int(st["blocks_left_to_host_inflater"]),
+                                   "producer_read_s": round(st["read_s"], 3), "ingest_create_s": round(st["create_s"], 3),
+                                   "ingest_next_s": round(st["next_s"], 3)})
     print(json.dumps(res))
 
 

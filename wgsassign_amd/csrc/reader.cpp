@@ -577,6 +577,7 @@ struct wgs_reader {
     int threads = 1;
     int64_t lines_read = 0;
     int64_t text_chunks = 0;           // chunks the last text hand-over produced
+    struct CompPipe *cpipe = nullptr;  // the compressed hand-over (reader_text.h: CompChunk), when started
     struct TextPipe *pipe = nullptr;   // the text hand-over to the device tokeniser (reader_text.h), when started
 };
 
@@ -710,6 +711,7 @@ int wgs_reader_open(const char *path, int threads, wgs_reader **out)
 void wgs_reader_close(wgs_reader *r)
 {
     if (!r) return;
+    reader_comp_stop(r);
     reader_text_stop(r);
     delete r;
 }
@@ -1983,6 +1985,8 @@ void text_producer(wgs_reader *r)
 
 }  // namespace
 
+bool reader_text_is_bgzf(const wgs_reader *r) { return r && r->src.bgzf; }
+
 int reader_text_start(wgs_reader *r, size_t chunk_bytes, int nbuf, TextAllocator a, int64_t limit_rows)
 {
     if (!r || r->pipe || !a.alloc || !a.release || nbuf < 1) {
@@ -1998,6 +2002,7 @@ int reader_text_start(wgs_reader *r, size_t chunk_bytes, int nbuf, TextAllocator
     r->pos = r->len = 0;
     for (int i = 0; i < nbuf; ++i) {
         TextChunk *c = new TextChunk();
+        c->slot = i;
         p->all.push_back(c);
         p->free_q.push_back(c);
     }
@@ -2056,6 +2061,238 @@ void reader_text_stop(wgs_reader *r)
     delete p;
     r->pipe = nullptr;
 }
+
+// ---- the compressed hand-over ----------------------------------------------------------------------------------
+struct CompPipe {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<CompChunk *> free_q, ready_q;
+    std::vector<CompChunk *> all;
+    TextAllocator alloc;
+    size_t text_cap = 0;
+    uint64_t file_off = 0;
+    bool finished = false, stop = false;
+    size_t pre_pos = 0, pre_end = 0;   // text the line-oriented calls had inflated already: [pre_pos, pre_end) of the reader's buffer
+    int rc = 0;
+    std::string err;
+};
+
+namespace {
+void comp_producer(wgs_reader *r)
+{
+    CompPipe *p = r->cpipe;
+    const int fd = fileno(r->src.fp);
+    auto fail = [&](const char *msg) {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->rc = 1;
+        p->err = msg;
+        p->finished = true;
+        p->cv.notify_all();
+    };
+    for (;;) {
+        CompChunk *c = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [&] { return p->stop || !p->free_q.empty(); });
+            if (p->stop) return;
+            c = p->free_q.front();
+            p->free_q.pop_front();
+        }
+        const double t0 = now_s();
+        c->in_off.clear();
+        c->in_len.clear();
+        c->isize.clear();
+        c->text_bytes = 0;
+        c->len = 0;
+        c->last = false;
+        c->pre_text = nullptr;
+        c->pre_len = 0;
+        if (p->pre_pos < p->pre_end) {                                     // first what was inflated already, a chunk's worth at a time
+            c->pre_text = r->buf.data() + p->pre_pos;
+            c->pre_len = std::min(p->pre_end - p->pre_pos, p->text_cap);
+            p->pre_pos += c->pre_len;
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->ready_q.push_back(c);
+            p->cv.notify_all();
+            continue;
+        }
+        // The file in slices (all threads copy their share out of the page cache), whole members counted off as they arrive,
+        // until the device's text buffer or this staging buffer is full; the slices shrink towards the end so that little
+        // is read twice.
+        size_t got = 0, at = 0;
+        bool file_end = false, full = false, corrupt = false;
+        while (!full && !file_end && !corrupt && got < c->cap) {
+            size_t slice = (size_t)64 << 20;
+            if (at > 0 && c->text_bytes > 0) {
+                const double per_text = (double)at / (double)c->text_bytes;
+                const double est = (double)(p->text_cap - c->text_bytes) * per_text * 1.03 + 262144.0 - (double)(got - at);
+                slice = (size_t)std::min<double>((double)slice, std::max<double>(est, (double)(1 << 20)));
+            }
+            slice = std::min(slice, c->cap - got);
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)r->threads, slice >> 20));
+            std::vector<size_t> part(T, 0);
+            run_threads(T, [&](int t) {
+                const size_t a = slice * (size_t)t / (size_t)T, b = slice * (size_t)(t + 1) / (size_t)T;
+                size_t done = 0;
+                while (a + done < b) {
+                    const ssize_t k = pread(fd, c->comp + got + a + done, b - a - done, (off_t)(p->file_off + got + a + done));
+                    if (k <= 0) break;
+                    done += (size_t)k;
+                }
+                part[t] = done;
+            });
+            size_t n = 0;
+            for (int t = 0; t < T; ++t) {
+                n += part[t];
+                if (part[t] < slice * (size_t)(t + 1) / (size_t)T - slice * (size_t)t / (size_t)T) {
+                    file_end = true;
+                    break;
+                }
+            }
+            got += n;
+            while (at < got) {
+                uint32_t hdr = 0;
+                const long sz = bgzf_member_size(c->comp + at, got - at, &hdr);
+                if (sz == 0) {
+                    corrupt = true;
+                    break;
+                }
+                if (sz < 0 || at + (size_t)sz > got) break;                    // a partial member: the next slice completes it
+                const unsigned char *tl = c->comp + at + sz - 4;
+                const uint32_t isz = tl[0] | ((uint32_t)tl[1] << 8) | ((uint32_t)tl[2] << 16) | ((uint32_t)tl[3] << 24);
+                if (isz > 65536 || (uint32_t)sz < hdr + 8) {
+                    corrupt = true;
+                    break;
+                }
+                if (c->text_bytes + isz > p->text_cap) {
+                    full = true;
+                    break;
+                }
+                if (isz) {
+                    c->in_off.push_back(at + hdr);
+                    c->in_len.push_back((uint32_t)sz - hdr - 8);
+                    c->isize.push_back(isz);
+                }
+                c->text_bytes += isz;
+                at += (size_t)sz;
+            }
+        }
+        if (corrupt || (file_end && at < got)) return fail("read error in the BGZF file (corrupt or truncated member)");
+        if (at == 0 && !file_end) return fail("a BGZF member larger than the staging buffer");
+        c->len = at;
+        p->file_off += at;
+        c->last = file_end;                                                // the file ended with this stretch
+        c->read_s = now_s() - t0;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->ready_q.push_back(c);
+            if (c->last) p->finished = true;
+            p->cv.notify_all();
+        }
+        if (c->last) return;
+    }
+}
+}  // namespace
+
+int reader_comp_start(wgs_reader *r, size_t comp_bytes, size_t text_cap, int nbuf, TextAllocator a)
+{
+    if (!r || r->pipe || r->cpipe || !r->src.bgzf || !a.alloc || !a.release || nbuf < 1) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    CompPipe *p = new CompPipe();
+    p->alloc = a;
+    p->text_cap = std::max<size_t>(text_cap, 1u << 20);
+    comp_bytes = std::max<size_t>(comp_bytes, 1u << 20);
+    p->pre_pos = r->pos;
+    p->pre_end = r->len;
+    // what the block-parallel host path had read ahead but not inflated is read again from the file
+    p->file_off = (uint64_t)ftello(r->src.fp) - (uint64_t)(r->src.clen - r->src.cpos);
+    for (int i = 0; i < nbuf; ++i) {
+        CompChunk *c = new CompChunk();
+        c->comp = (unsigned char *)a.alloc(comp_bytes, a.user);
+        c->cap = comp_bytes;
+        p->all.push_back(c);
+        if (!c->comp) {
+            for (CompChunk *x : p->all) {
+                if (x->comp) a.release(x->comp, a.user);
+                delete x;
+            }
+            delete p;
+            wgs_set_error("out of (pinned) memory for the compressed staging buffers");
+            return 1;
+        }
+        p->free_q.push_back(c);
+    }
+    r->cpipe = p;
+    p->th = std::thread(comp_producer, r);
+    return 0;
+}
+
+int reader_comp_next(wgs_reader *r, CompChunk **out, double *waited_s)
+{
+    CompPipe *p = r ? r->cpipe : nullptr;
+    if (!p || !out) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    const double t0 = now_s();
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv.wait(lk, [&] { return !p->ready_q.empty() || p->finished; });
+    if (waited_s) *waited_s = now_s() - t0;
+    *out = nullptr;
+    if (!p->ready_q.empty()) {
+        *out = p->ready_q.front();
+        p->ready_q.pop_front();
+        return 0;
+    }
+    if (p->rc) wgs_set_error("%s", p->err.c_str());
+    return p->rc;
+}
+
+void reader_comp_release(wgs_reader *r, CompChunk *c)
+{
+    CompPipe *p = r ? r->cpipe : nullptr;
+    if (!p || !c) return;
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->free_q.push_back(c);
+    p->cv.notify_all();
+}
+
+void reader_comp_stop(wgs_reader *r)
+{
+    CompPipe *p = r ? r->cpipe : nullptr;
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+        p->cv.notify_all();
+    }
+    if (p->th.joinable()) p->th.join();
+    for (CompChunk *c : p->all) {
+        if (c->comp) p->alloc.release(c->comp, p->alloc.user);
+        delete c;
+    }
+    delete p;
+    r->cpipe = nullptr;
+    r->pos = r->len = 0;               // the buffered text went to the device with the first chunk
+    r->eof = true;
+}
+
+bool reader_inflate_member(const unsigned char *deflate, uint32_t in_len, uint32_t isize, unsigned char *out)
+{
+    BlockInflater inf;
+    if (!inf.init()) return false;
+    BgzfBlock b;
+    b.off = 0;
+    b.hdr = 0;
+    b.csize = in_len + 8;
+    b.isize = isize;
+    return inf.run(deflate, b, out);
+}
+
+void reader_add_lines_read(wgs_reader *r, int64_t rows) { r->lines_read += rows; }
 
 int reader_text_parse_line(const wgs_reader *r, const char *b, const char *e, float *out)
 {

@@ -133,10 +133,11 @@ class BeagleStream:
                 consumed += nfile.value
                 row0 += nrows.value
                 yield nrows.value, names
-            st = (ctypes.c_double * 8)()
+            st = (ctypes.c_double * 14)()
             _lib.check(lib.wgs_ingest_stats(g, st))
             self.ingest_stats = dict(zip(("wait_s", "inflate_s", "scan_s", "device_ms", "host_lines", "text_bytes", "lines",
-                                          "chunks"), st))
+                                          "chunks", "device_inflate_kernel_ms", "blocks_inflated_on_device",
+                                          "blocks_left_to_host_inflater", "read_s", "create_s", "next_s"), st))
         finally:
             if self._ingest is not None:     # close() may have destroyed it already
                 self._ingest = None
