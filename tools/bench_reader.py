@@ -23,10 +23,9 @@ def main():
     ap.add_argument("--sites", type=int, default=3000)
     ap.add_argument("--device", action="store_true")
     ap.add_argument("--bgzf", action="store_true", help="write the file as BGZF (what ANGSD produces) instead of plain gzip")
-    ap.add_argument("--lowdepth", action="store_true", help="BGZF text of a simulated 2x matrix in 60 kB members (tests/synth.make_beagle "
-                                                            "through tools/bench_cli.write_beagle: few distinct likelihoods, ~11x compression, "
-                                                            "like the reference's bundled 2x files) instead of the pool file (random digits, 3x, "
-                                                            "two members per line)")
+    ap.add_argument("--lowdepth", action="store_true", help="BGZF text of a simulated 2x matrix, whole lines per member (tools/beagle_files.py: few "
+                                                            "distinct likelihoods per site, deflates 10-20x like the reference's bundled 2x files) "
+                                                            "instead of the pool file (random digits, 3x, two members per line)")
     a = ap.parse_args()
     n, m = a.inds, a.sites
     d = tempfile.mkdtemp()
@@ -38,11 +37,9 @@ def main():
     # formatting m x 3n numbers in Python would take longer than everything measured here
     if a.lowdepth:
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-        import bench_cli
+        import beagle_files
         a.bgzf = True
-        L, IDs = synth.make_beagle(m, n, 20, seed=4242)
-        text_bytes = bench_cli.write_beagle(path, L, os.path.join(d, "ids.txt"), IDs, "bgzf")
-        del L
+        text_bytes, _, _ = beagle_files.write_lowdepth_bgzf(path, n, m)
     elif a.bgzf:
         synth.make_pool_file(path, n, m, pool=min(1024, m))
         text_bytes = m * (27 * n + 1 + len("chr7_1\tA\tC")) + sum(len(str(s + 1)) - 1 for s in range(m))

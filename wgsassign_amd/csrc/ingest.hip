@@ -513,7 +513,9 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
 {
     wgs_beagle *b = g->b;
     hipStream_t st = b->ctx->stream;
+    static const bool trace = getenv("WGSASSIGN_INGEST_TRACE") != nullptr;       // per-chunk wall times on stderr
     while (!g->done) {
+        const double t_begin = now_s();
         CompChunk *c = nullptr;
         double waited = 0.0;
         if (int rc = reader_comp_next(g->r, &c, &waited)) return rc;
@@ -564,6 +566,7 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
             if (int rc = regrow(st, g->d_comp, c->len + 64)) return rc;
             g->comp_cap = c->len + 64;
         }
+        const double t_alloc = now_s();
         HIP_TRY(hipEventRecord(g->ev0, st));
         HIP_TRY(hipMemsetAsync(g->d_totals, 0, T_COUNT * sizeof(uint32_t), st));
         if (c->pre_len) HIP_TRY(hipMemcpyAsync(text + g->carry, c->pre_text, c->pre_len, hipMemcpyHostToDevice, st));
@@ -624,6 +627,7 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
             g->inflate_kernel_ms += ms;
             g->blocks_inflated += nb;
         }
+        const double t_inflated = now_s();
         reader_comp_release(g->r, c);                                   // the producer may refill it while the device works on
         release.c = nullptr;
         c = nullptr;
@@ -653,6 +657,7 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(g->h_totals, g->d_totals, T_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        const double t_listed = now_s();
         const size_t rows_here = g->h_totals[T_NONBLANK];
         size_t take = rows_here;
         if (g->limit >= 0 && (int64_t)take >= g->limit - g->rows_done) {
@@ -739,6 +744,10 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
         g->carry = left;
         g->rows_done += (int64_t)take;
         g->lines += (int64_t)take;
+        if (trace)
+            fprintf(stderr, "ingest chunk %lld: %zu B text, %d members, %zu lines | wait %.1f ms, buffers %.1f, copy+inflate %.1f, list %.1f, rows+names+tokenise %.1f\n",
+                    (long long)g->chunks, total, nb, nl, waited * 1e3, (t_alloc - t_begin - waited) * 1e3, (t_inflated - t_alloc) * 1e3,
+                    (t_listed - t_inflated) * 1e3, (now_s() - t_listed) * 1e3);
         if (take == 0) continue;
         *file_rows = (int64_t)take;
         *rows_written = written;
@@ -806,8 +815,18 @@ int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t 
         g->resident = true;
         if (limit_rows == 0) g->done = true;
         // page-locked staging for the compressed members: an eighth of the text (low-depth ANGSD output deflates 10 : 1 and
-        // more; where a file compresses less a chunk simply ends early) -- page-locking costs ~0.1 s per GB
-        else if (int rc = reader_comp_start(r, std::max<size_t>(g->chunk_text / 8, 1u << 20), g->chunk_text, 2, a)) return rc;
+        // more; where a file compresses less a chunk simply ends early), one buffer when the rest of the file fits into it --
+        // page-locking costs ~0.1 s per GB
+        else {
+            size_t staging = std::max<size_t>(g->chunk_text / 8, 1u << 20);
+            const int64_t left = reader_comp_bytes_left(r);
+            int nbuf = 2;
+            if (left >= 0 && (size_t)left + 4096 <= staging) {
+                staging = std::max<size_t>(((size_t)left + 4096 + 0xFFFFF) & ~(size_t)0xFFFFF, 1u << 20);
+                nbuf = 1;
+            }
+            if (int rc = reader_comp_start(r, staging, g->chunk_text, nbuf, a)) return rc;
+        }
     } else if (int rc = reader_text_start(r, (size_t)chunk_bytes, 3, a, limit_rows)) {
         return rc;
     }

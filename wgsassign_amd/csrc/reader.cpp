@@ -2280,6 +2280,16 @@ void reader_comp_stop(wgs_reader *r)
     r->eof = true;
 }
 
+// compressed bytes from the first member not yet inflated to the end of the file (-1: unknown)
+int64_t reader_comp_bytes_left(wgs_reader *r)
+{
+    if (!r || !r->src.fp) return -1;
+    struct stat sb;
+    if (fstat(fileno(r->src.fp), &sb) != 0) return -1;
+    const int64_t at = (int64_t)ftello(r->src.fp) - (int64_t)(r->src.clen - r->src.cpos);
+    return std::max<int64_t>(0, (int64_t)sb.st_size - at);
+}
+
 bool reader_inflate_member(const unsigned char *deflate, uint32_t in_len, uint32_t isize, unsigned char *out)
 {
     BlockInflater inf;

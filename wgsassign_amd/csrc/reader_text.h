@@ -51,6 +51,7 @@ void reader_comp_stop(wgs_reader *r);
 // One member through the host's inflater (for members the device rejects): comp + in_off .. -> out[isize]; false = corrupt.
 bool reader_inflate_member(const unsigned char *deflate, uint32_t in_len, uint32_t isize, unsigned char *out);
 void reader_add_lines_read(wgs_reader *r, int64_t rows);
+int64_t reader_comp_bytes_left(wgs_reader *r);   // compressed bytes not yet inflated (-1: unknown)
 
 // Starts the producer thread: it inflates ahead into `nbuf` buffers of `chunk_bytes` (grown when one line or one
 // batch of parallel-inflated stretches needs more) and stops after `limit_rows` data rows (< 0: the whole file).
