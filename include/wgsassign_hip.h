@@ -357,6 +357,11 @@ int wgs_debug_inflate(wgs_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, con
  * parallel newline scan, row limit) with ordinary memory and the host parser in place of the device tokeniser. */
 int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit_rows, float *rows, int64_t max_rows, int64_t *nrows);
 int64_t wgs_debug_reader_text_chunks(wgs_reader *r);   /* chunks that hand-over produced */
+/* Test hook, needs no GPU: the COMPRESSED hand-over of a BGZF file (what the device-resident ingest consumes: whole members
+ * in caller-allocated staging + the text the header calls had inflated already), inflated on the host into text[0 .. cap).
+ * info[0..3] = chunks, members, largest text of one chunk, chunks that carried pre-inflated text. */
+int wgs_debug_reader_comp_text(wgs_reader *r, int64_t comp_bytes, int64_t text_cap, int nbuf, char *text, int64_t cap, int64_t *bytes,
+                               int64_t *info);
 
 /* Test hooks for the convergence chain: wgs_rmse1d's value through the literal one-lane serial
  * kernel (serial != 0) or through the block-parallel exact emulation, reporting the number of

@@ -186,3 +186,49 @@ def test_n2000_bgzf_two_ranks_on_one_card(tmp_path, monkeypatch):
     assert done == cnt and b.download_rows(5, cnt).tobytes() == vals[pick[first:first + cnt]].tobytes()
     assert not b.download_rows(0, 5).any()
     b.close()
+
+
+def test_members_the_device_rejects_and_damaged_files(tmp_path, monkeypatch):
+    """Members the inflate kernel does not accept are inflated on the host and patched into the device text (forced here
+    for every third member, whose device text is wiped first): the same slabs.  A member with a damaged deflate stream --
+    rejected by the device AND by the host's inflater -- and a truncated file are errors, not short matrices."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import beagle_files
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    monkeypatch.setenv("WGSASSIGN_TEXT_CHUNK_BYTES", str(8 << 20))
+    n, m = 300, 14000                                            # 113 MB of text: the open call inflates the first 64
+    p = str(tmp_path / "r.beagle.gz")
+    _, vals, pick = beagle_files.write_lowdepth_bgzf(p, n, m, pool=128)
+    want = vals[pick]
+    rows, _, sites, stats = device_rows(p)
+    assert same_bits(rows, want) and stats["blocks_left_to_host_inflater"] == 0 and stats["blocks_inflated_on_device"] > 0
+    monkeypatch.setenv("WGSASSIGN_DEBUG_REJECT_MEMBERS", "3")
+    rows, _, sites2, stats = device_rows(p)
+    assert same_bits(rows, want) and sites2 == sites and stats["blocks_left_to_host_inflater"] >= stats["blocks_inflated_on_device"] // 3
+    monkeypatch.delenv("WGSASSIGN_DEBUG_REJECT_MEMBERS")
+    from wgsassign_amd import reader_cy
+    import shutil
+    reader_cy.ensure_index(p)
+    raw = bytearray(open(p, "rb").read())
+    k = bytes(raw).find(b"\x1f\x8b\x08\x04", len(raw) * 9 // 10)
+    for i in range(k + 40, k + 60):
+        raw[i] ^= 0x5A                                           # inside that member's deflate stream
+    dmg = str(tmp_path / "dmg.beagle.gz")
+    with open(dmg, "wb") as fh:
+        fh.write(bytes(raw))
+    # the damaged copy inherits the good file's index (same size, same modification time, same member layout), so that the
+    # damage is met by the ingest and not by the index pass
+    st = os.stat(p)
+    os.utime(dmg, ns=(st.st_atime_ns, st.st_mtime_ns))
+    for a, b in zip(reader_cy.index_paths(p), reader_cy.index_paths(dmg)):
+        if os.path.exists(a):
+            shutil.copyfile(a, b)
+            os.chmod(b, 0o600)
+    with pytest.raises(RuntimeError, match="corrupt block"):
+        device_rows(dmg)
+    cut = str(tmp_path / "cut.beagle.gz")
+    with open(cut, "wb") as fh:
+        fh.write(bytes(open(p, "rb").read()[:-3000]))
+    with pytest.raises(RuntimeError, match="read error|corrupt|truncated"):
+        device_rows(cut)

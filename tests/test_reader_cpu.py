@@ -628,3 +628,72 @@ def test_bgzf_parts_reject_a_planted_signature_and_a_plain_gzip_file(tmp_path):
     with gzip.open(g, "wb") as fh:
         fh.write(text_before)
     assert lib.wgs_reader_index_part(g.encode(), str(tmp_path / "g.0").encode(), 0, 2, 1) == 3
+
+
+# ------------------------------------------------------------------ the compressed hand-over (device-resident BGZF ingest)
+def _comp_text(path, comp_bytes, text_cap, nbuf=2, threads=3, index=None, first_row=0, cap=64 << 20):
+    import ctypes
+    from wgsassign_amd import _lib, reader_cy
+    with reader_cy.BeagleStream(path, threads=threads, index=index, first_row=first_row) as st:
+        buf = ctypes.create_string_buffer(cap)
+        nbytes = ctypes.c_int64()
+        info = (ctypes.c_int64 * 4)()
+        _lib.check(_lib.load().wgs_debug_reader_comp_text(st._h, comp_bytes, text_cap, nbuf, buf, cap, ctypes.byref(nbytes), info))
+        return buf.raw[:nbytes.value], list(info)
+
+
+@pytest.mark.parametrize("block", [900, 60000])
+def test_compressed_hand_over_delivers_the_rest_of_the_file(tmp_path, monkeypatch, block):
+    """What the device-resident ingest consumes (reader.cpp: comp_producer): the text the header calls had inflated
+    already, then whole BGZF members in staging buffers -- together exactly the file's text behind the header, whatever
+    the staging and text limits (one buffer or two, slices that end inside members, limits below one slice), from the
+    start and from a row in the middle through the index."""
+    from wgsassign_amd import reader_cy
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    m, n = 6000, 41
+    L, _ = synth.make_beagle(m, n, 2, seed=9)
+    text = _text_of(L, blank_lines=True, final_newline=False)
+    p = str(tmp_path / "c.beagle.gz")
+    synth.write_bgzf(p, text.encode(), block=block)
+    body = text.split("\n", 1)[1].encode()
+    for comp_bytes, text_cap, nbuf in [(1 << 20, 1 << 20, 2), (1 << 20, 3 << 20, 1), (4 << 20, 1 << 20, 3), (64 << 20, 64 << 20, 1)]:
+        got, info = _comp_text(p, comp_bytes, text_cap, nbuf)
+        assert got == body, (comp_bytes, text_cap)
+        assert info[2] <= max(text_cap, 1 << 20) and info[0] >= len(body) // max(text_cap, 1 << 20)
+    idx, _, sites = reader_cy.ensure_index(p)
+    assert sites == m
+    lines = body.split(b"\n")
+    data_lines = [i for i, x in enumerate(lines) if x.strip()]
+    for first in (1, 2999, m - 1):
+        got, info = _comp_text(p, 1 << 20, 1 << 20, 2, index=idx, first_row=first)
+        want = b"\n".join(lines[data_lines[first]:])
+        assert got.endswith(want) and len(got) - len(want) < 70000, first      # a reader opened at a row starts at its member
+        assert got[len(got) - len(want) - 1:len(got) - len(want)] in (b"\n", b"")
+
+
+def test_compressed_hand_over_reports_damaged_files(tmp_path, monkeypatch):
+    """A truncated file and a member whose header was overwritten -- beyond what the reader inflates while it reads the
+    header -- are errors of the hand-over, not silent ends; the undamaged file comes through whole."""
+    import gzip as gz
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import beagle_files
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    p = str(tmp_path / "d.beagle.gz")
+    total, _, _ = beagle_files.write_lowdepth_bgzf(p, 500, 12000, pool=64)       # 162 MB of text: the open call inflates 64 MB
+    got, info = _comp_text(p, 2 << 20, 8 << 20, threads=2, cap=200 << 20)
+    assert len(got) > 150 << 20 and got == gz.open(p).read()[-len(got):] and info[3] >= 1 and info[0] > 10
+    raw = open(p, "rb").read()
+    cut = str(tmp_path / "cut.beagle.gz")
+    with open(cut, "wb") as fh:
+        fh.write(raw[:len(raw) - 5000])
+    with pytest.raises(RuntimeError, match="corrupt or truncated"):
+        _comp_text(cut, 2 << 20, 8 << 20, threads=2, cap=200 << 20)
+    bad = bytearray(raw)
+    k = raw.find(b"\x1f\x8b\x08\x04", len(raw) * 3 // 4)
+    bad[k + 1] = 0x00                                             # not a gzip member any more
+    dmg = str(tmp_path / "dmg.beagle.gz")
+    with open(dmg, "wb") as fh:
+        fh.write(bytes(bad))
+    with pytest.raises(RuntimeError, match="corrupt or truncated"):
+        _comp_text(dmg, 2 << 20, 8 << 20, threads=2, cap=200 << 20)

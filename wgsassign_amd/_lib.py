@@ -106,6 +106,7 @@ SIGNATURES = {
     "wgs_debug_inflate": (c_int, [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i64, c_vp, c_f32p]),
     "wgs_debug_reader_text_rows": (c_int, [c_vp, c_i64, c_i64, c_f32p, c_i64, ctypes.POINTER(c_i64)]),
     "wgs_debug_reader_text_chunks": (c_i64, [c_vp]),
+    "wgs_debug_reader_comp_text": (c_int, [c_vp, c_i64, c_i64, c_int, c_vp, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "wgs_debug_rmse1d": (c_int, [c_vp, c_f32p, c_f32p, c_i64, c_f64p, c_int, ctypes.POINTER(c_int)]),
     "wgs_em_last_chain_serial_blocks": (c_int, [c_vp]),
     "wgs_debug_rcp_error": (c_int, [c_vp, c_int, c_f64p]),

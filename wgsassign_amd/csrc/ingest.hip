@@ -607,6 +607,13 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
             HIP_TRY(hipStreamSynchronize(st));
             if (pass) break;
             // members the device did not accept: the host's inflater, patched into the device text; the newlines are counted again
+            // (WGSASSIGN_DEBUG_REJECT_MEMBERS=k, tests: every k-th member is treated as rejected and its device text wiped first)
+            const char *reject_env = getenv("WGSASSIGN_DEBUG_REJECT_MEMBERS");
+            const int reject_every = reject_env ? atoi(reject_env) : 0;
+            for (int i = 0; reject_every > 0 && i < nb; i += reject_every) {
+                g->status[(size_t)i] = 1;
+                HIP_TRY(hipMemset(text + g->out_off[(size_t)i], '#', c->isize[(size_t)i]));
+            }
             bool patched = false;
             for (int i = 0; i < nb; ++i) {
                 if (!g->status[(size_t)i]) continue;

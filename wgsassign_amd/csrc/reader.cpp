@@ -2121,7 +2121,7 @@ void comp_producer(wgs_reader *r)
         // until the device's text buffer or this staging buffer is full; the slices shrink towards the end so that little
         // is read twice.
         size_t got = 0, at = 0;
-        bool file_end = false, full = false, corrupt = false;
+        bool file_end = false, full = false, corrupt = false, partial = false;
         while (!full && !file_end && !corrupt && got < c->cap) {
             size_t slice = (size_t)64 << 20;
             if (at > 0 && c->text_bytes > 0) {
@@ -2151,6 +2151,7 @@ void comp_producer(wgs_reader *r)
                 }
             }
             got += n;
+            partial = false;
             while (at < got) {
                 uint32_t hdr = 0;
                 const long sz = bgzf_member_size(c->comp + at, got - at, &hdr);
@@ -2158,7 +2159,10 @@ void comp_producer(wgs_reader *r)
                     corrupt = true;
                     break;
                 }
-                if (sz < 0 || at + (size_t)sz > got) break;                    // a partial member: the next slice completes it
+                if (sz < 0 || at + (size_t)sz > got) {                         // a partial member: the next slice completes it
+                    partial = true;
+                    break;
+                }
                 const unsigned char *tl = c->comp + at + sz - 4;
                 const uint32_t isz = tl[0] | ((uint32_t)tl[1] << 8) | ((uint32_t)tl[2] << 16) | ((uint32_t)tl[3] << 24);
                 if (isz > 65536 || (uint32_t)sz < hdr + 8) {
@@ -2178,11 +2182,11 @@ void comp_producer(wgs_reader *r)
                 at += (size_t)sz;
             }
         }
-        if (corrupt || (file_end && at < got)) return fail("read error in the BGZF file (corrupt or truncated member)");
+        if (corrupt || (file_end && partial)) return fail("read error in the BGZF file (corrupt or truncated member)");
         if (at == 0 && !file_end) return fail("a BGZF member larger than the staging buffer");
         c->len = at;
         p->file_off += at;
-        c->last = file_end;                                                // the file ended with this stretch
+        c->last = file_end && at == got;                                   // the file ended with this chunk's last member
         c->read_s = now_s() - t0;
         {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -2358,6 +2362,53 @@ int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit
     }
     reader_text_stop(r);
     *nrows = done;
+    return rc;
+}
+
+/* Debug / tests: the COMPRESSED hand-over (reader_text.h: CompChunk -- what the device-resident ingest consumes) driven on the
+ * host: every chunk's pre-inflated text and members (inflated here with the host's inflater) appended to text[0 .. cap);
+ * info[0] = chunks, info[1] = members, info[2] = largest text of one chunk, info[3] = chunks of pre-inflated text. */
+int wgs_debug_reader_comp_text(wgs_reader *r, int64_t comp_bytes, int64_t text_cap, int nbuf, char *text, int64_t cap, int64_t *bytes, int64_t *info)
+{
+    if (!r || !text || !bytes || !info) {
+        wgs_set_error("bad argument");
+        return 2;
+    }
+    TextAllocator a;
+    a.alloc = [](size_t n, void *) { return malloc(n); };
+    a.release = [](void *p, void *) { free(p); };
+    if (int rc = reader_comp_start(r, (size_t)comp_bytes, (size_t)text_cap, nbuf, a)) return rc;
+    int64_t at = 0;
+    int rc = 0;
+    info[0] = info[1] = info[2] = info[3] = 0;
+    for (;;) {
+        CompChunk *c = nullptr;
+        if ((rc = reader_comp_next(r, &c, nullptr)) != 0 || !c) break;
+        const int64_t here = (int64_t)c->pre_len + (int64_t)c->text_bytes;
+        if (at + here > cap) {
+            rc = 2;
+            wgs_set_error("more text than the caller has room for");
+        } else {
+            if (c->pre_len) memcpy(text + at, c->pre_text, c->pre_len);
+            at += (int64_t)c->pre_len;
+            for (size_t i = 0; i < c->isize.size() && !rc; ++i) {
+                if (!reader_inflate_member(c->comp + c->in_off[i], c->in_len[i], c->isize[i], reinterpret_cast<unsigned char *>(text + at))) {
+                    rc = 1;
+                    wgs_set_error("read error in the BGZF file (corrupt block)");
+                }
+                at += c->isize[i];
+            }
+        }
+        info[0] += 1;
+        info[1] += (int64_t)c->isize.size();
+        info[2] = std::max<int64_t>(info[2], here);
+        info[3] += c->pre_len ? 1 : 0;
+        const bool last = c->last;
+        reader_comp_release(r, c);
+        if (rc || last) break;
+    }
+    reader_comp_stop(r);
+    *bytes = at;
     return rc;
 }
 
