@@ -1,5 +1,7 @@
 // Sanitizer driver for csrc/reader.cpp (host code only): index, indexed opens at several rows and thread counts,
-// full reads; prints a checksum per configuration -- all must agree.
+// full reads; prints a checksum per configuration -- all must agree.  Then the two hand-overs of the device ingest, whose
+// producer threads run beside the consumer: inflated text (wgs_debug_reader_text_rows) and, for BGZF files, compressed
+// members (wgs_debug_reader_comp_text), both with small buffers so that many chunks change hands.
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -71,6 +73,34 @@ int main(int argc, char **argv)
         (void)h;
         wgs_reader_close(r);
         if (rows + skipped != sites) return 6;
+    }
+    for (int threads : {1, 3, 8}) {
+        const int64_t first = sites / 3;
+        wgs_reader *r = nullptr;
+        if (wgs_reader_open_indexed(path, idx.c_str(), first, threads, &r)) { fprintf(stderr, "open: %s\n", g_err); return 2; }
+        const int n = wgs_reader_n_individuals(r);
+        std::vector<float> rows((size_t)(sites - first) * 2 * n);
+        int64_t got = 0;
+        if (wgs_debug_reader_text_rows(r, 1 << 20, -1, rows.data(), sites - first, &got) || got != sites - first) {
+            fprintf(stderr, "text hand-over: %s (%lld rows)\n", g_err, (long long)got);
+            return 7;
+        }
+        wgs_reader_close(r);
+        if (wgs_reader_open_indexed(path, idx.c_str(), 0, threads, &r)) return 2;      // from the start: more text than the open call inflates
+        std::vector<char> text((size_t)256 << 20);
+        int64_t bytes = 0, info[4] = {0, 0, 0, 0};
+        const int rc = wgs_debug_reader_comp_text(r, 1 << 20, 2 << 20, 2, text.data(), (int64_t)text.size(), &bytes, info);
+        wgs_reader_close(r);
+        if (rc == 0) {
+            int64_t lines = 0;
+            for (int64_t i = 0; i < bytes; ++i) lines += text[(size_t)i] == '\n';
+            printf("threads %d: compressed hand-over %lld chunks, %lld members, %lld bytes, %lld lines\n", threads, (long long)info[0], (long long)info[1],
+                   (long long)bytes, (long long)lines);
+            if (lines < sites) return 8;
+        } else if (!strstr(g_err, "bad argument")) {       // a plain gzip file has no members to hand over: refused
+            fprintf(stderr, "compressed hand-over: %s\n", g_err);
+            return 8;
+        }
     }
     printf("ok\n");
     return 0;

@@ -6,7 +6,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 D=$(mktemp -d)
-python3 - "$D" "${1:-20000}" "${2:-60}" <<PY
+python3 - "$D" "${1:-60000}" "${2:-60}" <<PY
 import sys
 sys.path.insert(0, "$R/tests"); sys.path.insert(0, "$R/tools")
 import synth, bench_cli
