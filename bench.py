@@ -616,7 +616,7 @@ def committed_pmc(m, n, K, mode, coded_em=False, coded_score=False):
                 cur["em_traffic"] = e.get("traffic_bytes_per_launch")
                 cur["em_valu_busy_frac"] = e.get("valu_busy_frac")
                 cur["em_clock_ghz"] = e.get("effective_clock_ghz")
-            ck = re.search(r"score_coded_kernel<(\d+), (\d+)>", k)
+            ck = re.search(r"score_coded_kernel<(\d+), (\d+)(?:, \w+)?>", k)
             if coded_score and ck and int(ck.group(2)) == (0 if mode == "exact" else 1):
                 cur["assign_traffic"] = e.get("traffic_bytes_per_launch")
                 cur["assign_valu_busy_frac"] = e.get("valu_busy_frac")

@@ -48,6 +48,23 @@ def main():
     out1, _ = device.assign(b, afs)
     res["pop_like_coded_ms"] = round(device.assign.last_ms, 3)
     res["pop_like_identical"] = bool(out0.tobytes() == out1.tobytes())
+    from wgsassign_amd._lib import MODE_FAST
+    fast1, _ = device.assign(b, afs, mode=MODE_FAST)
+    fast1, _ = device.assign(b, afs, mode=MODE_FAST)
+    res["pop_like_coded_fast_ms"] = round(device.assign.last_ms, 3)
+    res["variants"] = {}
+    for v in os.environ.get("CHECK_CODES_VARIANTS", "").split(","):       # WGS_SCORE_CODED_VARIANT values to compare
+        if not v:
+            continue
+        os.environ["WGS_SCORE_CODED_VARIANT"] = v
+        o, _ = device.assign(b, afs)
+        o, _ = device.assign(b, afs)
+        ms = device.assign.last_ms
+        f, _ = device.assign(b, afs, mode=MODE_FAST)
+        f, _ = device.assign(b, afs, mode=MODE_FAST)
+        res["variants"][v] = {"exact_ms": round(ms, 3), "identical": bool(o.tobytes() == out0.tobytes()),
+                              "fast_ms": round(device.assign.last_ms, 3), "fast_identical": bool(f.tobytes() == fast1.tobytes())}
+    os.environ.pop("WGS_SCORE_CODED_VARIANT", None)
     em2 = device.EMBatch(b, np.arange(K, dtype=np.int32))
     t0 = time.perf_counter()
     iters2 = em2.run(200, 1e-4)

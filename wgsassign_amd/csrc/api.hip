@@ -204,6 +204,13 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b)
     for (size_t i = 0; i < rows; ++i) cmax = std::max<int>(cmax, h[i]);
     if (cmax > 64) return fail();                              // 255 marks a SNP with more than 64 classes
     c->cmax = cmax;
+    int rows16 = 16;
+    for (size_t i = 0; i < rows; i += 16) {
+        int sum = 0;
+        for (size_t k = i; k < i + 16 && k < rows; ++k) sum += h[k];
+        rows16 = std::max(rows16, sum);
+    }
+    c->rows16 = rows16;
     c->build_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3;
     b->codes_state = 1;
     return c;
@@ -1150,7 +1157,7 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     HIP_TRY(hipSetDevice(ctx->device));
     // shared columns + a codable matrix: the sweep through the class codes (same S, bit for bit)
     wgs_codes *codes = sc->per_ind ? nullptr : wgs_beagle_codes(sc->b);
-    if (codes && score_coded_lds_bytes(codes->cmax, 10) > 64 * 1024) codes = nullptr;
+    if (codes && score_coded_lds_bytes(codes->rows16, score_kb(sc->K)) > 64 * 1024) codes = nullptr;
     if (codes && sc->coded_for != codes) {
         std::vector<CodedSlabHost> tab;
         int quad0 = 0;

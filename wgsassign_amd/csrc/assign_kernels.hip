@@ -418,7 +418,6 @@ struct CodedScoreArgs {
     const uint8_t *ncls;
     const CodedSlab *slabs;
     int32_t n_slabs, cmax, total_quads;
-    uint32_t inv_rows;             // ceil(2^32 / (cmax * KB)): batch-local SNP index of a table element by multiplication
     const float *const *acol;
     int64_t m, cells;
     int32_t K, nblocks;
@@ -431,13 +430,30 @@ struct CodedScoreArgs {
 constexpr int CODED_BATCH = 16;    // SNPs per table: the code words of 16 SNPs of one quad are one 64-byte line
 constexpr int CODED_LOG_REP = 4;   // LDS copies of the log table here (phase 1 is a third of the kernel; 8 KiB instead of 32)
 
-template <int KB, int MODE>
+// Details of the table:
+//   * it holds only the classes a SNP HAS: row of (SNP j of the batch, class c) = rowoff[j] + c, rowoff = running sum of
+//     ncls over the batch's 16 SNPs (LDS sized for the richest aligned 16-SNP group of the matrix, wgs_codes::rows16; a
+//     first version walked cmax rows per SNP and left a third of its phase-1 lanes idle: 20.3 ms -> 15.9 at 10M x 1000 x 10);
+//   * a phase-1 work item is (row, half of the populations): the dictionary entry is fetched and widened once per item,
+//     the frequencies of the batch come from LDS (staged for the NEXT batch while this one is computed, together with
+//     the row offsets: two small buffers, no extra barrier);
+//   * TV = double: the table holds the widened values and phase 2 is an LDS read and an add per term, no conversion
+//     (-> 14.2 ms); TV = float where the float rows need no padding to 16 bytes (KB = 4, 8; 7 pads one): half the LDS
+//     traffic wins there.  WGS_SCORE_CODED_TABLE=float|double forces one (experiments).
+struct CodedPrep {
+    int rowoff[20];                // [j] = rows before SNP j of the batch, [16] = rows of the batch
+    float aval[CODED_BATCH][10];   // allele frequencies [SNP of the batch][population of this pass]
+};
+
+template <int KB, int MODE, typename TV>
 __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
 {
-    constexpr int KBP = (KB + 3) & ~3;                         // table rows padded to float4
+    constexpr int KBP = sizeof(TV) == 8 ? ((KB + 1) & ~1) : ((KB + 3) & ~3);      // table rows padded to 16 bytes
+    constexpr int KG = (KB + 1) / 2;                                                // populations per phase-1 item
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double2 *tab_lds = reinterpret_cast<double2 *>(lds_raw);
-    float *vtab = reinterpret_cast<float *>(lds_raw + sizeof(double2) * WGS_LOG_N * CODED_LOG_REP);
+    CodedPrep *prep = reinterpret_cast<CodedPrep *>(lds_raw + sizeof(double2) * WGS_LOG_N * CODED_LOG_REP);
+    TV *vtab = reinterpret_cast<TV *>(reinterpret_cast<unsigned char *>(prep) + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15));
     if (MODE == WGS_MODE_EXACT) {
         for (int e = threadIdx.x; e < WGS_LOG_N * CODED_LOG_REP; e += blockDim.x) tab_lds[e] = A.logtab[e / CODED_LOG_REP];
     }
@@ -448,8 +464,7 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
     const int tiles_per_part = WGS_BLOCK_TILES / A.parts;
     const int64_t t0 = blk * WGS_BLOCK_TILES + (int64_t)blockIdx.z * tiles_per_part;
     const int64_t t1 = t0 + tiles_per_part < ntiles ? t0 + tiles_per_part : ntiles;
-    double *const Sout = A.S + ((int64_t)blockIdx.z * A.nblocks + blk) * A.cells;      // parts == 1: S[block]
-    // this lane's quad
+    double *const Sout = A.S + ((int64_t)blockIdx.z * A.nblocks + blk) * A.cells;
     const int Q = (int)blockIdx.y * 256 + tid;
     const bool have = Q < A.total_quads;
     int g = 0;
@@ -465,79 +480,123 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
         ok[h] = have && col >= sl.col_lo && col < sl.col_hi;
         ind[h] = sl.members[ok[h] ? col : sl.col_lo];
     }
-    const uint4 *cptr = reinterpret_cast<const uint4 *>(sl.codes + (int64_t)q * 64);     // + tile * nquads * 64 + 16-SNP group
-    const int rows = A.cmax * KB;                              // table elements per SNP (before padding)
-    __syncthreads();
+    const uint4 *cptr = reinterpret_cast<const uint4 *>(sl.codes + (int64_t)q * 64);
+    const int64_t s_begin = t0 << 6;
+    const int64_t s_end = (t1 << 6) < A.m ? (t1 << 6) : A.m;
+    const int nbatch = s_end > s_begin ? (int)((s_end - s_begin + CODED_BATCH - 1) / CODED_BATCH) : 0;
 
     for (int kb = 0; kb < A.K; kb += KB) {
+        // what phase 1 needs of batch b, written by threads 0..15 (row offsets) and 16.. (frequencies)
+        auto prepare = [&](int b) {
+            CodedPrep &P = prep[b & 1];
+            const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
+            if (tid < 64) {                                    // the first wavefront: a 16-lane running sum of ncls
+                const int j = tid & 15;
+                const int n = tid < 16 && s0 + j < s_end ? (int)A.ncls[s0 + j] : 0;
+                int incl = n;
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    const int up = __shfl_up(incl, off, 64);
+                    if (j >= off) incl += up;
+                }
+                if (tid < 16) {
+                    P.rowoff[j] = incl - n;
+                    if (j == 15) P.rowoff[16] = incl;
+                }
+            } else if (tid - 64 < CODED_BATCH * KB) {
+                const int e = tid - 64, j = e / KB, k = e - j * KB;
+                const int kk = kb + k < A.K ? kb + k : A.K - 1;
+                P.aval[j][k] = s0 + j < s_end ? A.acol[kk][s0 + j] : 0.5f;
+            }
+        };
         double acc[4][KB];
 #pragma unroll
         for (int h = 0; h < 4; ++h)
 #pragma unroll
             for (int k = 0; k < KB; ++k) acc[h][k] = 0.0;
-        for (int64_t t = t0; t < t1; ++t) {
-            for (int sub = 0; sub < 4; ++sub) {
-                const int l0 = sub * CODED_BATCH;
-                const int64_t s0 = (t << 6) + l0;
-                if (s0 >= A.m) break;
-                const int nj = A.m - s0 < CODED_BATCH ? (int)(A.m - s0) : CODED_BATCH;
-                // this quad's code words for the 16 SNPs (one 64-byte line), in flight during phase 1
-                uint4 cw[4];
-                if (have) {
-                    const uint4 *line = cptr + (t * sl.nquads * 64 + l0) / 4;
+        __syncthreads();                                       // the log table (first pass); the previous pass's last phase 2
+        if (nbatch > 0) prepare(0);
+        __syncthreads();
+        for (int b = 0; b < nbatch; ++b) {
+            const CodedPrep &P = prep[b & 1];
+            const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
+            const int64_t t = s0 >> 6;
+            const int l0 = (int)(s0 & 63);
+            const int nj = s_end - s0 < CODED_BATCH ? (int)(s_end - s0) : CODED_BATCH;
+            uint4 cw[4];
+            if (have) {
+                const uint4 *line = cptr + (t * sl.nquads * 64 + l0) / 4;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) cw[x] = line[x];
-                } else {
+                for (int x = 0; x < 4; ++x) cw[x] = line[x];
+            } else {
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
-                }
-                // phase 1: vtab[j][c][k]
-                const int total = nj * rows;
-                for (int e = tid; e < total; e += 256) {
-                    const int j = (int)__umulhi((unsigned)e, A.inv_rows);
-                    const int r = e - j * rows;
-                    const int c = r / KB, k = r - c * KB;
-                    const int64_t s = s0 + j;
-                    if (c < (int)A.ncls[s]) {
-                        const float2 gl = A.dict[(t * WGS_CODE_ROWS + c) * 64 + l0 + j];
-                        const int kk = kb + k < A.K ? kb + k : A.K - 1;
-                        const float a = A.acol[kk][s];
+                for (int x = 0; x < 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
+            }
+            if (b + 1 < nbatch) prepare(b + 1);
+            // phase 1: vtab[rowoff[j] + c][k]
+            const int items = 2 * P.rowoff[16];
+            for (int it = tid; it < items; it += 256) {
+                const int r = it >> 1, half = it & 1;
+                int j = P.rowoff[8] <= r ? 8 : 0;
+                j += P.rowoff[j + 4] <= r ? 4 : 0;
+                j += P.rowoff[j + 2] <= r ? 2 : 0;
+                j += P.rowoff[j + 1] <= r ? 1 : 0;
+                const int c = r - P.rowoff[j];
+                const float2 gl = A.dict[(t * WGS_CODE_ROWS + c) * 64 + l0 + j];
+                const double g0d = (double)gl.x, g1d = (double)gl.y;
+                const double g1x2 = g1d * 2.0, g2d = (1.0 - g0d) - g1d;
+                const float g2f = (1.0f - gl.x) - gl.y;
+#pragma unroll
+                for (int kq = 0; kq < KG; ++kq) {
+                    const int k = half * KG + kq;
+                    if (k < KB) {
+                        const float a = P.aval[j][k];
                         float v;
                         if (MODE == WGS_MODE_EXACT) {
-                            const double g0d = (double)gl.x, g1d = (double)gl.y, ad = (double)a;
-                            const float ssum = like_sum_exact(g0d, g1d * 2.0, (1.0 - g0d) - g1d, ad, 1.0 - ad);
+                            const double ad = (double)a;
+                            const float ssum = like_sum_exact(g0d, g1x2, g2d, ad, 1.0 - ad);
                             const float plain = (float)log_f32arg<CODED_LOG_REP>((double)ssum, tab);
                             v = __builtin_isfpclass(ssum, FP_POS_FINITE) ? plain : __builtin_amdgcn_logf(ssum);
                         } else {
-                            v = site_ll_fast(gl.x, gl.y, (1.0f - gl.x) - gl.y, a);
+                            v = site_ll_fast(gl.x, gl.y, g2f, a);
                         }
-                        vtab[(j * A.cmax + c) * KBP + k] = v;
+                        vtab[r * KBP + k] = (TV)v;
                     }
                 }
-                __syncthreads();
-                // phase 2: look up and add
-                const unsigned *cwv = reinterpret_cast<const unsigned *>(cw);
+            }
+            __syncthreads();
+            // phase 2: look up and add
+            const unsigned *cwv = reinterpret_cast<const unsigned *>(cw);
 #pragma unroll
-                for (int j = 0; j < CODED_BATCH; ++j) {
-                    if (j < nj) {
-                        const unsigned w = cwv[j];
+            for (int j = 0; j < CODED_BATCH; ++j) {
+                if (j < nj) {
+                    const unsigned w = cwv[j];
+                    const TV *rows_j = vtab + P.rowoff[j] * KBP;
 #pragma unroll
-                        for (int h = 0; h < 4; ++h) {
-                            const int code = (w >> (8 * h)) & 255;
-                            const float4 *row = reinterpret_cast<const float4 *>(vtab + (j * A.cmax + code) * KBP);
-                            float vals[KBP];
+                    for (int h = 0; h < 4; ++h) {
+                        const int code = (w >> (8 * h)) & 255;
+                        TV vals[KBP];
+                        if (sizeof(TV) == 8) {
+                            const double2 *row = reinterpret_cast<const double2 *>(rows_j + code * KBP);
+#pragma unroll
+                            for (int x = 0; x < KBP / 2; ++x) {
+                                const double2 f = row[x];
+                                vals[2 * x] = (TV)f.x, vals[2 * x + 1] = (TV)f.y;
+                            }
+                        } else {
+                            const float4 *row = reinterpret_cast<const float4 *>(rows_j + code * KBP);
 #pragma unroll
                             for (int x = 0; x < KBP / 4; ++x) {
                                 const float4 f = row[x];
-                                vals[4 * x] = f.x, vals[4 * x + 1] = f.y, vals[4 * x + 2] = f.z, vals[4 * x + 3] = f.w;
+                                vals[4 * x] = (TV)f.x, vals[4 * x + 1] = (TV)f.y, vals[4 * x + 2] = (TV)f.z, vals[4 * x + 3] = (TV)f.w;
                             }
-#pragma unroll
-                            for (int k = 0; k < KB; ++k) acc[h][k] += (double)vals[k];
                         }
+#pragma unroll
+                        for (int k = 0; k < KB; ++k) acc[h][k] += (double)vals[k];
                     }
                 }
-                __syncthreads();
             }
+            __syncthreads();
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h)
@@ -1025,6 +1084,7 @@ static int pick_kb(int K, int kb_max = 10)
 }
 
 int score_pairs_per_wave(int K, bool per_ind) { return sweep_pairs(pick_kb(K), per_ind); }
+int score_kb(int K) { return pick_kb(K); }
 // The chain kernel keeps three float32 per (cell, lane) instead of one float64; with per-individual columns
 // its pointer and frequency tables leave room for one pair only.
 // It stays with batches of at most 8 populations (9 and 10 would spill).
@@ -1103,7 +1163,19 @@ __global__ __launch_bounds__(256) void combine_parts_kernel(const double *__rest
     S[e] = acc;
 }
 
-size_t score_coded_lds_bytes(int cmax, int kb) { return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + sizeof(float) * CODED_BATCH * cmax * ((kb + 3) & ~3); }
+// float table rows where they need (almost) no padding to 16 bytes, float64 rows (no conversion in phase 2) elsewhere
+static bool score_coded_wide(int kb)
+{
+    const char *e = getenv("WGS_SCORE_CODED_TABLE");
+    if (e && e[0] == 'f') return false;
+    if (e && e[0] == 'd') return true;
+    return ((kb + 3) & ~3) - kb > 1;
+}
+size_t score_coded_lds_bytes(int rows16, int kb)
+{
+    const size_t row = score_coded_wide(kb) ? sizeof(double) * ((kb + 1) & ~1) : sizeof(float) * ((kb + 3) & ~3);
+    return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15) + row * (size_t)rows16;
+}
 
 // The scoring sweep through the class codes (shared columns only).  d_slabs: n_slabs CodedSlab records in device memory.
 int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, int n_slabs, int total_quads, const float *const *d_acol,
@@ -1128,8 +1200,8 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(wgs_log_table_dev)));
     A.logtab = reinterpret_cast<const double2 *>(sym);
     const int kb = pick_kb(K);
-    A.inv_rows = (uint32_t)(((1ull << 32) + (uint64_t)(c->cmax * kb) - 1) / (uint64_t)(c->cmax * kb));
-    const size_t lds = score_coded_lds_bytes(c->cmax, kb);
+    const bool wide = score_coded_wide(kb);
+    const size_t lds = score_coded_lds_bytes(c->rows16, kb);
     WGS_REQUIRE(lds <= 64 * 1024, "class table too large for LDS");
     const unsigned ygroups = (unsigned)((total_quads + 255) / 256);
     int parts = 1;
@@ -1145,8 +1217,13 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     dim3 grid((unsigned)nblocks, ygroups, (unsigned)parts);
 #define WGS_CODED(KB)                                                                                                     \
     do {                                                                                                                  \
-        if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT>), grid, dim3(256), lds, ctx->stream, A); \
-        else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST>), grid, dim3(256), lds, ctx->stream, A);           \
+        if (wide) {                                                                                                       \
+            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, double>), grid, dim3(256), lds, ctx->stream, A); \
+            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, double>), grid, dim3(256), lds, ctx->stream, A); \
+        } else {                                                                                                          \
+            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, float>), grid, dim3(256), lds, ctx->stream, A); \
+            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, float>), grid, dim3(256), lds, ctx->stream, A); \
+        }                                                                                                                 \
     } while (0)
     WGS_FOR_KB(WGS_CODED, K)
 #undef WGS_CODED

@@ -91,6 +91,7 @@ struct SlabCodes {
 };
 struct wgs_codes {
     int32_t cmax = 0;
+    int32_t rows16 = 0;            // most classes summed over an aligned group of 16 SNPs (the coded scoring sweep's table rows)
     int32_t total_quads = 0;
     float2 *dict = nullptr;
     uint8_t *ncls = nullptr;
@@ -253,7 +254,8 @@ struct CodedSlabHost {             // = CodedSlab of assign_kernels.hip
     const int32_t *members;
     int32_t nquads, ncols, quad0, col_lo, col_hi;
 };
-size_t score_coded_lds_bytes(int cmax, int kb);
+int score_kb(int K);                                   // populations per pass of the scoring sweeps
+size_t score_coded_lds_bytes(int rows16, int kb);      // LDS of the coded sweep for a matrix whose richest 16-SNP group has rows16 classes
 int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, int n_slabs, int total_quads, const float *const *d_acol,
                        int64_t m, int64_t cells, int K, int nblocks, double *S, int mode);
 int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix, double *chunks);
