@@ -236,6 +236,8 @@ def main():
     gl_bytes = beagle.nbytes()
     # the class codes of the matrix (csrc/common.h: wgs_codes; built once per matrix like the slab layout itself, on first
     # use -- here explicitly, so that the build is never inside the timed region)
+    if args.mode == "exact":
+        beagle.prepare_codes(em=True)
     codes = beagle.codes_info() if args.mode == "exact" else {"available": False}
     em = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
 
@@ -283,7 +285,7 @@ def main():
     alg_bytes = (8.0 * n + 8.0 * K) * m
     k_avg = float(np.mean(kernel_ms)) * 1e-3
     achieved = alg_bytes / k_avg
-    coded_em = bool(codes.get("available")) and per >= 40 and os.environ.get("WGSASSIGN_CODES", "1") != "0"
+    coded_em = bool(codes.get("available")) and per >= 28 and os.environ.get("WGSASSIGN_CODES", "1") != "0"
     roofline = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
                 "kernel": "em_coded_kernel" if coded_em else "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
@@ -307,7 +309,9 @@ def main():
              "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
     if codes.get("available"):
         extra["class_codes"] = {"bytes": codes["bytes"], "build_ms_once_per_matrix": round(codes["build_ms"], 1), "mean_classes_per_snp":
-                                round(codes["mean_classes"], 2), "max_classes_per_snp": codes["max_classes"]}
+                                round(codes["mean_classes"], 2), "max_classes_per_snp": codes["max_classes"],
+                                "slab_numbering_ms_once_per_matrix": round(codes["slab_numbering_ms"], 1), "slab_numbering_bytes": codes["slab_numbering_bytes"],
+                                "em_table_rows": codes["em_table_rows"], "em_direct_tile_share": round(codes["em_direct_tile_share"], 5)}
     if coded_em:
         # the same iterations over the float32 slabs (WGSASSIGN_CODES=0): the kernel the HBM roofline of SURVEY 8d describes
         os.environ["WGSASSIGN_CODES"] = "0"
@@ -442,9 +446,12 @@ def whole_paths(ctx, device, mode_name):
         ctx.sync()
         # the class codes belong to the resident matrix like its slab layout (built once, on first use; a run from a
         # file builds them while the host is still inflating): outside the timed calls, reported per configuration
+        b.prepare_codes(em=int(min(np.bincount(group_of, minlength=K))) >= 28)
         info = b.codes_info()
         codes_note[0] = {"available": info["available"], "build_ms": round(info["build_ms"], 1), "bytes": info["bytes"],
-                         "mean_classes_per_snp": round(info["mean_classes"], 2)}
+                         "mean_classes_per_snp": round(info["mean_classes"], 2), "slab_numbering_ms": round(info["slab_numbering_ms"], 1),
+                         "slab_numbering_bytes": info["slab_numbering_bytes"], "em_table_rows": info["em_table_rows"],
+                         "em_direct_tile_share": round(info["em_direct_tile_share"], 5)}
         return b, group_of, np.bincount(group_of, minlength=K)
 
     def fit(b, K, counts):
@@ -455,7 +462,7 @@ def whole_paths(ctx, device, mode_name):
         dt = time.perf_counter() - t0
         st = em.fit_stats()                 # iterations enqueued, chain batches, seconds in wgs_em_fit, sweep kernels ms
         alg = float(np.sum([(8.0 * counts[k] + 8.0) * b.m * iters[k] for k in range(K)]))
-        coded = b.codes_info()["available"] and int(min(counts)) >= 40
+        coded = b.codes_info()["available"] and int(min(counts)) >= 28
         res = {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
                "sweep_kernel": "em_coded_kernel (class codes; hbm_frac counts the float32 matrix's algorithmic bytes and may exceed 1)" if coded
                else "em_sweep_kernel<exact>",

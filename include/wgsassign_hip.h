@@ -99,9 +99,13 @@ int64_t wgs_beagle_bytes(const wgs_beagle *b);
  * EM term's quotient / the per-site log-likelihood once per CLASS and SNP and look it up per individual -- same
  * values, same order of accumulation, same bits.  Built on first use (one byte per (SNP, individual) + a dictionary;
  * WGSASSIGN_CODES=0 disables them); a matrix with more than 64 classes in some SNP is not coded and takes the direct
- * kernels.  info[0..5] = available, classes of the richest SNP, bytes held, build milliseconds (allocations included),
- * mean classes per SNP, milliseconds of the encode kernel alone. */
+ * kernels.  info[0..9] = available, classes of the richest SNP, bytes held, build milliseconds (allocations included),
+ * mean classes per SNP, milliseconds of the encode kernel alone, milliseconds and bytes of the slabs' own class numbering
+ * (one more byte per (SNP, individual) + a dictionary per population slab, built by the first EM sweep through the codes), the
+ * rows of that sweep's quotient table, the share of (slab, tile) pairs with more classes than rows (swept directly). */
 int wgs_beagle_codes_info(wgs_beagle *b, double *info);
+/* Builds the codes now rather than at first use; em != 0: also the slabs' own class numbering of the coded EM sweep. */
+int wgs_beagle_codes_prepare(wgs_beagle *b, int em);
 
 /* A batch of EM fits (emMAF.py:15-27) over slabs of `b`.  Fit j estimates the frequency of
  * every SNP from the individuals of group fit_group[j], leaving out individual fit_skip[j]

@@ -71,7 +71,7 @@ def test_coded_kernels_equal_direct_kernels_and_oracle(dev, oracle, m, n, K, mon
     counts, frequencies and float64 sums; odd sizes, quads that straddle the end of a slab, short matrices (blocks split
     over several workgroups), K beyond one register batch."""
     if n < 200:
-        monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")      # populations below 40 individuals through the coded EM sweep too
+        monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")      # populations below 28 individuals through the coded EM sweep too
     rng = np.random.default_rng(m + n)
     labels = rng.integers(0, K, size=n)
     labels[:K] = np.arange(K)                                  # no empty population
@@ -187,4 +187,46 @@ def test_row_ranges_and_leave_one_out_are_unchanged(dev, oracle):
     assert same_nan(res[True], res[False]) and not res[True][:7].any() and not res[True][29:].any() and res[True][7:29].all()
     assert same_nan(res[True, "loo"][0], res[False, "loo"][0]) and same(res[True, "loo"][1], res[False, "loo"][1])
     afs.close()
+    b.close()
+
+
+def test_tiles_richer_than_the_quotient_table_are_swept_directly(dev, oracle, monkeypatch):
+    """The coded EM sweep sizes its table (rows per SNP) so that ~1 % of the tiles at most have a SNP with more classes in a
+    slab; those tiles are swept from the float32 slab inside the same kernel.  A matrix of low-depth sites with a few rich
+    ones (every individual its own likelihoods, but few enough classes to stay codable): same iterations and frequencies as
+    the direct kernels and the oracle, with and without a left-out individual."""
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")
+    m, n, K = 64 * 700 + 5, 90, 2
+    L, IDs = synth.make_beagle(m, n, K, seed=12)
+    rng = np.random.default_rng(5)
+    rich = rng.choice(m, size=12, replace=False)                # 12 sites in 12 of 701 tiles: the 1 % rule leaves them out
+    vals = np.round(rng.dirichlet((0.7, 0.7, 0.7), size=(len(rich), 30)), 6)      # 30 distinct pairs
+    pick = rng.integers(0, 30, size=(len(rich), n))
+    for a, s in enumerate(rich):
+        L[s, 0::2] = vals[a, pick[a], 0]
+        L[s, 1::2] = vals[a, pick[a], 1]
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    b = dev.DeviceBeagle.from_host(L, group_of, K)
+    with codes(False):
+        it0, af0, _ = fit_and_score(dev, b, K, counts)
+    with codes(True):
+        it1, af1, _ = fit_and_score(dev, b, K, counts)
+        info = b.codes_info()
+        assert info["available"] and 0 < info["em_direct_tile_share"] <= 0.01 and info["em_table_rows"] < 8 * ((info["max_classes"] + 7) // 8)
+        # leave-one-out style fits (a skipped column) of single slabs through the coded sweep
+        em = dev.EMBatch(b, np.array([0, 1], dtype=np.int32), skips=np.array([3, 50], dtype=np.int32))
+        its = [int(x) for x in em.run(200, 1e-4)]
+        f_skip = [em.get_f(0), em.get_f(1)]
+        em.close()
+    with codes(False):
+        em = dev.EMBatch(b, np.array([0, 1], dtype=np.int32), skips=np.array([3, 50], dtype=np.int32))
+        its0 = [int(x) for x in em.run(200, 1e-4)]
+        assert its == its0 and same(f_skip[0], em.get_f(0)) and same(f_skip[1], em.get_f(1))
+        em.close()
+    assert it1 == it0 and same(af1, af0)
+    with quiet():
+        _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+    assert it1 == [int(x) for x in it_o] and same(af1, af_o)
     b.close()

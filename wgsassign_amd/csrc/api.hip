@@ -139,6 +139,10 @@ void wgs_beagle_drop_codes(wgs_beagle *b)
             if (s.codes) (void)hipFree(s.codes);
             if (s.present) (void)hipFree(s.present);
         }
+        for (auto &l : c->local) {
+            if (l.lcodes) (void)hipFree(l.lcodes);
+            if (l.ldict) (void)hipFree(l.ldict);
+        }
         if (c->dict) (void)hipFree(c->dict);
         if (c->ncls) (void)hipFree(c->ncls);
         if (c->d_slabs) (void)hipFree(c->d_slabs);
@@ -216,20 +220,49 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b)
     return c;
 }
 
+// The slabs' own class numbering for the coded EM sweep (common.h: SlabLocal), built on first use: one more byte per (SNP,
+// individual) and a dictionary per slab.  No memory for it: false, and the direct sweep runs.
+bool wgs_beagle_local_codes(wgs_beagle *b, wgs_codes *c)
+{
+    if (!b || !c || c->local_state < 0) return false;
+    if (c->local_state > 0) return true;
+    c->local_state = -1;
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return false;
+    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (launch_local_encode(b, c)) {
+        (void)hipGetLastError();
+        for (auto &l : c->local) {
+            if (l.lcodes) (void)hipFree(l.lcodes);
+            if (l.ldict) (void)hipFree(l.ldict);
+        }
+        c->local.clear();
+        c->local_bytes = 0;
+        return false;
+    }
+    c->local_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3;
+    c->local_state = 1;
+    return true;
+}
+
 extern "C" {
 
 /* Class codes of the matrix (csrc/common.h: wgs_codes), built on first use by the kernels that look values up per
  * class: info[0..4] = available (0/1), classes of the richest SNP, bytes held, milliseconds the build took, mean classes
- * per SNP (computed on request).  Builds them if they have not been tried yet. */
+ * per SNP (computed on request), [5] = ms of the encode kernel alone, [6..9] = ms and bytes of the slabs' own numbering (built
+ * by the first coded EM sweep; 0 before), its table rows, the share of (slab, tile) pairs with a richer SNP (swept directly).  Builds the codes if they have not been tried yet. */
 int wgs_beagle_codes_info(wgs_beagle *b, double *info)
 {
     WGS_REQUIRE(b && info, "null argument");
     wgs_codes *c = wgs_beagle_codes(b);
-    for (int i = 0; i < 6; ++i) info[i] = 0.0;
+    for (int i = 0; i < 10; ++i) info[i] = 0.0;
     if (!c) return 0;
+    info[6] = c->local_ms;
+    info[7] = (double)c->local_bytes;
+    info[8] = c->lrows;
+    info[9] = c->local_direct_share;
     info[0] = 1.0;
     info[1] = c->cmax;
-    info[2] = (double)c->bytes;
+    info[2] = (double)(c->bytes + c->local_bytes);          // + the slabs' own numbering once a coded EM sweep has built it
     info[3] = c->build_ms;
     info[5] = c->kernel_ms;
     const size_t rows = (size_t)b->m;
@@ -238,6 +271,16 @@ int wgs_beagle_codes_info(wgs_beagle *b, double *info)
     double tot = 0.0;
     for (size_t i = 0; i < rows; ++i) tot += h[i];
     info[4] = rows ? tot / (double)rows : 0.0;
+    return 0;
+}
+
+/* Builds the class codes now instead of at their first use (and, with em != 0, the slabs' own numbering the coded EM sweep
+ * uses), e.g. while the host is still busy with something else.  Returns 0 also when the matrix cannot be coded. */
+int wgs_beagle_codes_prepare(wgs_beagle *b, int em)
+{
+    WGS_REQUIRE(b, "null argument");
+    wgs_codes *c = wgs_beagle_codes(b);
+    if (c && em) (void)wgs_beagle_local_codes(b, c);
     return 0;
 }
 
@@ -551,21 +594,25 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     // exact mode on a codable matrix: the sweep through the class codes (same frequencies, bit for bit)
     // -- for fits of different slabs; leave-one-out batches (several fits per slab) stay with em_sweep_group_kernel,
     // whose shared loads and conversions serve them better than a quotient table per fit
-    // -- and small populations stay with em_sweep_kernel too: below ~40 individuals the table costs more than it saves
-    // (measured: 20 individuals 0.68x, 62 1.14x, 100 1.39x)
+    // -- and small populations stay with em_sweep_kernel too: below ~28 individuals the table costs more than it saves
+    // (measured: 20 individuals 0.98x, 30 1.16x, 36 1.26x, 62 1.64x, 100 2.1x)
     bool worth = em->mode == WGS_MODE_EXACT && !shared;
     const char *min_env = getenv("WGSASSIGN_EM_CODES_MIN");    // tests lower it to run small populations through the codes
-    const int min_cols = min_env ? atoi(min_env) : 40;
+    const int min_cols = min_env ? atoi(min_env) : 28;
     for (int j : order) worth = worth && em->b->slabs[em->group[j]].ncols >= min_cols;
     wgs_codes *codes = worth ? wgs_beagle_codes(em->b) : nullptr;
-    if (codes && !em_coded_fits(codes->cmax)) codes = nullptr;
+    if (codes && !wgs_beagle_local_codes(em->b, codes)) codes = nullptr;
+    int coded_rows_max = 0;
     for (size_t i = 0; i < order.size(); ++i) {
         const int j = order[i];
         const Slab &s = em->b->slabs[em->group[j]];
         FitDesc &d = H[i];
-        d.codes = codes ? codes->slabs[em->group[j]].codes : nullptr;
+        d.lcodes = codes ? codes->local[em->group[j]].lcodes : nullptr;
+        d.ldict = codes ? codes->local[em->group[j]].ldict : nullptr;
+        d.lrows = codes ? codes->lrows : 0;
         d.present = codes ? codes->slabs[em->group[j]].present : nullptr;
         d.nquads = codes ? codes->slabs[em->group[j]].nquads : 0;
+        coded_rows_max = std::max(coded_rows_max, (int)d.lrows);
         d.slab = s.base;
         d.f_old = em_f(em, j, em->cur[j]);
         d.f_new = em_f(em, j, em->cur[j] ^ 1);
@@ -600,7 +647,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
         const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
         for (size_t off = 0; off < order.size(); off += max_fits) {
             const int cnt = (int)std::min<size_t>(max_fits, order.size() - off);
-            if (launch_em_coded(ctx, D + off, cnt, em->b->m, codes->dict, codes->cmax)) return 1;
+            if (launch_em_coded(ctx, D + off, cnt, em->b->m, coded_rows_max)) return 1;
         }
     } else if (shared) {
         for (size_t off = 0; off < (size_t)n_groups; off += max_units) {

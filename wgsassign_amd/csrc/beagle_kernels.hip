@@ -264,6 +264,53 @@ __global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
     }
 }
 
+// ---- the slabs' own class numbering (common.h: SlabLocal) --------------------------------------------------------
+// hist[slab * 8 + k] = tiles of the slab whose richest SNP shows 8 k + 1 .. 8 k + 8 classes among the slab's individuals
+__global__ __launch_bounds__(256) void slab_rows_hist_kernel(const SlabCodes *slabs, int64_t tiles, unsigned long long *hist)
+{
+    const SlabCodes sc = slabs[blockIdx.y];
+    if (sc.nquads == 0) return;
+    const int lane = threadIdx.x & 63;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += (int64_t)gridDim.x * 4) {
+        int best = __popcll(sc.present[t * 64 + lane]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
+        if (lane == 0) atomicAdd(hist + blockIdx.y * 8 + (best > 0 ? (best - 1) >> 3 : 0), 1ull);
+    }
+}
+
+// One wavefront per tile of one slab, lane <-> SNP: the dictionary rows of the classes present, in rank order; the code
+// words with every class replaced by its rank.
+__global__ __launch_bounds__(64) void local_encode_kernel(SlabCodes sc, const float2 *__restrict__ dict, uint32_t *__restrict__ lcodes,
+                                                          float2 *__restrict__ ldict, int rows)
+{
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const uint64_t present = sc.present[tile * 64 + lane];
+    uint64_t left = present;
+    for (int r = 0; r < rows; ++r) {                           // (a SNP with more classes than rows: its tile is swept directly)
+        float2 v = make_float2(0.0f, 0.0f);
+        if (left) {
+            const int c = __builtin_ctzll(left);
+            left &= left - 1;
+            v = dict[(tile * WGS_CODE_ROWS + c) * 64 + lane];
+        }
+        ldict[(tile * rows + r) * 64 + lane] = v;
+    }
+    const uint32_t *src = sc.codes + tile * sc.nquads * 64 + lane;
+    uint32_t *dst = lcodes + tile * sc.nquads * 64 + lane;
+    for (int q = 0; q < sc.nquads; ++q) {
+        const uint32_t w = src[(int64_t)q * 64];
+        uint32_t o = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const unsigned c = (w >> (8 * h)) & 255u;
+            o |= (uint32_t)__popcll(present & ((1ull << c) - 1ull)) << (8 * h);
+        }
+        dst[(int64_t)q * 64] = o;
+    }
+}
+
 inline unsigned grid_for(int64_t total)
 {
     int64_t blocks = (total + 255) / 256;
@@ -336,6 +383,46 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
     A.ncls = c->ncls;
     hipLaunchKernelGGL(class_encode_kernel, dim3((unsigned)wgs_ntiles(b->m)), dim3(64), 0, b->ctx->stream, A);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return 0;
+}
+
+// Allocates and fills wgs_codes::local for every slab (0 = done; a failed allocation is reported, the caller falls back).
+int launch_local_encode(wgs_beagle *b, wgs_codes *c)
+{
+    const int64_t tiles = wgs_ntiles(b->m);
+    const int G = b->n_groups;
+    void *ws = nullptr;
+    if (wgs_ctx_workspace(b->ctx, sizeof(unsigned long long) * 8 * G, &ws)) return 1;
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws);
+    HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 8 * G, b->ctx->stream));
+    hipLaunchKernelGGL(slab_rows_hist_kernel, dim3(grid_for(tiles * 64), (unsigned)G), dim3(256), 0, b->ctx->stream, c->d_slabs, tiles, d_hist);
+    HIP_TRY(hipGetLastError());
+    std::vector<unsigned long long> hist((size_t)8 * G, 0);
+    HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, sizeof(unsigned long long) * 8 * G, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    // table rows: the fewest (in eights) that leave at most 1 % of the (slab, tile) pairs to the direct path -- every row costs
+    // 512 bytes of LDS per wavefront, and the sweep is bound by the wavefronts a CU holds
+    unsigned long long total = 0, by_rows[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int g = 0; g < G; ++g)
+        for (int k = 0; k < 8; ++k) by_rows[k] += hist[(size_t)8 * g + k], total += hist[(size_t)8 * g + k];
+    int k_rows = 7;
+    unsigned long long above = 0;
+    while (k_rows > 0 && (above + by_rows[k_rows]) * 100 <= total) above += by_rows[k_rows--];
+    c->lrows = 8 * (k_rows + 1);
+    c->local_direct_share = total ? (double)above / (double)total : 0.0;
+    c->local.assign(G, SlabLocal());
+    for (int g = 0; g < G; ++g) {
+        const SlabCodes &sc = c->slabs[g];
+        SlabLocal &L = c->local[g];
+        if (sc.nquads == 0) continue;
+        const size_t words = (size_t)tiles * sc.nquads * 64, entries = (size_t)tiles * c->lrows * 64;
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&L.lcodes), words * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&L.ldict), entries * sizeof(float2)));
+        c->local_bytes += (int64_t)(words * sizeof(uint32_t) + entries * sizeof(float2));
+        hipLaunchKernelGGL(local_encode_kernel, dim3((unsigned)tiles), dim3(64), 0, b->ctx->stream, sc, c->dict, L.lcodes, L.ldict, c->lrows);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     return 0;
 }

@@ -89,7 +89,23 @@ struct SlabCodes {
     int32_t nquads = 0;
     int32_t quad0 = 0;             // first matrix-wide quad index of this slab
 };
+// The slab's own numbering of the classes (the EM sweep through the codes looks quotients up in a table with one row per class
+// PRESENT in the slab, not per class of the SNP): built on the first coded EM sweep from codes / present / dict.
+//   lcodes like SlabCodes::codes, a byte = rank of the individual's class among the set bits of present[SNP]
+//   ldict  [(tile * rows + rank) * 64 + lane]  (g0, g1) of the rank-th present class of SNP 64 * tile + lane
+// Table rows (wgs_codes::lrows, a multiple of 8, the same for all slabs) cover the richest SNP of all but ~1 % of the (slab, tile)
+// pairs; a tile with a richer SNP is swept directly from the float32 slab (its ranks >= lrows are never looked up).
+struct SlabLocal {
+    uint32_t *lcodes = nullptr;
+    float2 *ldict = nullptr;       // lrows rows per tile
+};
 struct wgs_codes {
+    std::vector<SlabLocal> local;  // per slab; local_state: 0 = not tried, 1 = available, -1 = no memory (direct kernels)
+    int local_state = 0;
+    int32_t lrows = 0;
+    double local_direct_share = 0.0;   // share of the (slab, tile) pairs that take the direct path
+    int64_t local_bytes = 0;
+    double local_ms = 0.0;
     int32_t cmax = 0;
     int32_t rows16 = 0;            // most classes summed over an aligned group of 16 SNPs (the coded scoring sweep's table rows)
     int32_t total_quads = 0;
@@ -140,10 +156,11 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     int32_t skip;      // local column left out (LOO) or -1
     int32_t n_eff;     // ncols - (skip >= 0)
     const int32_t *state;  // device: fit state (EM_ACTIVE / EM_CONVERGED / EM_UNDECIDED) or nullptr = always sweep
-    // the slab's class codes (common.h: wgs_codes), or nullptr: then only the direct kernels can take this fit
-    const uint32_t *codes;
+    // the slab's class codes in its own numbering (common.h: SlabLocal), or nullptr: then only the direct kernels can take this fit
+    const uint32_t *lcodes;
+    const float2 *ldict;
     const uint64_t *present;
-    int32_t nquads;
+    int32_t nquads, lrows;
 };
 enum { EM_ACTIVE = 0, EM_CONVERGED = 1, EM_UNDECIDED = 2 };
 // One exact convergence chain (emMAF_cy.pyx:30-31 over this shard): float32 running sum of (a-b)^2 from carry_in.
@@ -165,9 +182,12 @@ int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m
                          const int32_t *d_leaf_len, int nleaf, const int32_t *d_prog, int nprog, float *d_leaf_sums, const float *d_carry,
                          float *d_means);
 int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int mode);
-// the same sweep through the class codes (exact mode; every fit's descriptor carries its slab's codes)
-bool em_coded_fits(int cmax);
-int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, const float2 *dict, int cmax);
+// the same sweep through the class codes (exact mode; every fit's descriptor carries its slab's local codes; rows = the
+// largest SlabLocal::rows among the fits)
+int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int rows);
+// Builds wgs_codes::local (true = available).
+bool wgs_beagle_local_codes(wgs_beagle *b, wgs_codes *c);
+int launch_local_encode(wgs_beagle *b, wgs_codes *c);
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
 int ssq_reduce_chunks(void);

@@ -336,34 +336,36 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDes
     }
 }
 
-// ---- the sweep through the class codes (common.h: wgs_codes) --------------------------------------------------
+// ---- the sweep through the class codes (common.h: wgs_codes, SlabLocal) -----------------------------------------
 // The quotient q = (p1 + 2 p2) / ((p0 + p1) + p2) of a term depends on the individual only through its (g0, g1); a SNP has
-// few distinct (g0, g1) and a population slab fewer still (`present`).  Per (fit, tile), lane <-> SNP as before:
-//   phase 0  the tile's dictionary goes into LDS, [class][lane] (coalesced rows);
-//   phase 1  every lane replaces, for each class PRESENT in its slab, the (g0, g1) in its slot by the quotient q --
-//            the rounding sequence of term_exact_shared up to the divide, evaluated once per class instead of once per
-//            individual (lanes walk their own set bits; slot [class][lane] is touched by its lane only: no barrier);
-//   phase 2  the individuals are walked in order: tmp = (float)fma(0.5, q[code], (double)tmp) -- the serial float32
-//            accumulation of emMAF_cy.pyx:22 on the very same addends, with the leave-one-out skip and the column bound
-//            wave-uniform as in the direct kernels.
-// Leave-one-out fits of one population read the same dictionary and code words: workgroups are dealt to the XCDs so
-// that all fits of a tile meet in one L2 (as em_sweep_group_kernel does).
+// few distinct (g0, g1) and a population slab fewer still.  Per (fit, tile), lane <-> SNP as before, one wavefront per
+// workgroup (the table is private to it: no barriers):
+//   phase 1  the slab's own dictionary rows of the tile -- rank r = the r-th class PRESENT in the slab at that SNP -- are
+//            requested all at once (coalesced, only as many rows as the tile's richest SNP has) and every lane turns each
+//            (g0, g1) into the term's quotient: the rounding sequence of term_exact_shared up to the divide, evaluated once
+//            per class instead of once per individual, ILP classes at a time (the divide is a chain of dependent FP64
+//            operations); the quotients go to the table q[rank][lane] in LDS;
+//   phase 2  the individuals are walked in order: tmp = (float)fma(0.5, q[rank of its class], (double)tmp) -- the serial
+//            float32 accumulation of emMAF_cy.pyx:22 on the very same addends, with the leave-one-out skip and the column
+//            bound wave-uniform as in the direct kernels.
+// The table has one row per class present in the SLAB (<= 24 in 99 % of the tiles of 100 low-depth individuals), not per class
+// of the SNP (40): 12 KiB instead of 20 per wavefront, and the sweep is bound by how many wavefronts share a CU (measured with
+// padded LDS: 24.3 / 13.2 / 9.4 / 7.5 ms at 2 / 4 / 6 / 8 wavefronts per CU for the 10M x 1000 x K=10 sweep).  The rows
+// (wgs_codes::lrows) are chosen per matrix so that ~1 % of the tiles at most have a richer SNP; those take the direct path.
 
-template <int U, int WAVES_C, int ILP, int ROWS>
-__global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m,
-                                                                 const float2 *__restrict__ dict, int cmax)
+template <int U, int ILP, int ROWS>
+__global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m)
 {
     extern __shared__ __align__(16) double qtab_all[];
     const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
     const int fit = (int)(j % (unsigned)n_fits);
-    const int64_t tgroup = (int64_t)(j / (unsigned)n_fits) * 8 + xcd;
+    const int64_t tile = (int64_t)(j / (unsigned)n_fits) * 8 + xcd;
     const FitDesc fd = fits[fit];
     if (fd.state && *fd.state != EM_ACTIVE) return;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t tile = tgroup * WAVES_C + wave;
+    const int lane = threadIdx.x;
     const int64_t row0 = tile * 64;
     if (row0 >= m) return;                       // wave-uniform; no barriers below
-    double *q = qtab_all + (size_t)wave * ((cmax + 7) & ~7) * 64 + lane;      // slot of class c: q[c * 64]
+    double *q = qtab_all + lane;                 // slot of rank r: q[r * 64]
 
     const int64_t my_row = row0 + lane;
     const int64_t my_row_c = my_row < m ? my_row : m - 1;
@@ -373,68 +375,73 @@ __global__ __launch_bounds__(WAVES_C * 64) void em_coded_kernel(const FitDesc *_
     st.omf = 1.0 - st.fd;
     st.fd2 = 2.0 * st.fd;
 
-    // the first code words and the slab's class set: in flight while the dictionary is staged
+    // the first code words: in flight during phase 1
     const int nquads = fd.nquads;
-    const uint32_t *src = fd.codes + tile * nquads * 64 + lane;
+    const uint32_t *src = fd.lcodes + tile * nquads * 64 + lane;
     const int last = nquads - 1;
     uint32_t cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
-    uint64_t left = fd.present[row0 + lane];
-    // phase 0: dictionary rows -> LDS (as raw 8-byte words), eight loads in flight at a time; rows of classes that occur
-    // in none of the tile's 64 SNPs within this slab are skipped
-    uint64_t uni = left;
+    // rows of this tile: the most classes one of its 64 SNPs has in this slab
+    int nrows = __popcll(fd.present[row0 + lane]);
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) uni |= __shfl_xor(uni, off, 64);
+    for (int off = 32; off > 0; off >>= 1) nrows = max(nrows, __shfl_xor(nrows, off, 64));
+    if (nrows > ROWS) {
+        // a SNP of this tile shows more classes in this slab than the table has rows (~1 % of the tiles, launch_local_encode):
+        // the tile is swept from the float32 slab, term by term as em_sweep_kernel does
+        const int npairs = fd.npairs;
+        gf4_ptr gl = (gf4_ptr)fd.slab + tile * npairs * 64 + lane;
+        float tmp = 0.0f;
+        bool ok = true;
+        for (int p = 0; p < npairs; ++p) {
+            const f4 v = gl[(int64_t)p * 64];
+            if (2 * p < fd.ncols && 2 * p != fd.skip) term_exact<true>(v.x, v.y, st, tmp, ok);
+            if (2 * p + 1 < fd.ncols && 2 * p + 1 != fd.skip) term_exact<true>(v.z, v.w, st, tmp, ok);
+        }
+        const float f_new = tmp / (float)fd.n_eff;
+        double sq = 0.0;
+        if (my_row < m) {
+            ((gf32_wptr)fd.f_new)[my_row] = f_new;
+            const float d = f_new - f_old;
+            sq = (double)(d * d);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if (lane == 0) fd.ssq_part[tile] = sq;
+        return;
+    }
     {
-        // ALL rows are requested before the first is waited for (one memory latency per tile, not one per group of
-        // eight: with two or three waves per SIMD nothing else would hide the others); ROWS = the table's rows
-        const double *drow = reinterpret_cast<const double *>(dict) + tile * WGS_CODE_ROWS * 64 + lane;
+        const double *drow = reinterpret_cast<const double *>(fd.ldict) + tile * fd.lrows * 64 + lane;
         double r[ROWS];
 #pragma unroll
         for (int g8 = 0; g8 < ROWS / 8; ++g8) {
-            if ((uni >> (8 * g8)) & 0xFFull) {               // wave-uniform
+            if (8 * g8 < nrows) {                            // wave-uniform
 #pragma unroll
                 for (int u = 0; u < 8; ++u) r[8 * g8 + u] = drow[(int64_t)(8 * g8 + u) * 64];
             }
         }
+        auto quotient = [&](double raw) {
+            const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
+                        g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
+            const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
+            const float p0 = (float)((g0d * st.omf) * st.omf);
+            const float p1 = (float)((g1d * st.fd2) * st.omf);
+            const float p2 = (float)((g2d * st.fd) * st.fd);
+            const float ssum = (p0 + p1) + p2;
+            const double num = __builtin_fma(2.0, (double)p2, (double)p1);
+            return div_exact<true>(num, (double)ssum);
+        };
+        // (lanes whose SNP has fewer classes compute on the zero rows the encoder wrote there: never looked up)
 #pragma unroll
-        for (int g8 = 0; g8 < ROWS / 8; ++g8) {
-            if ((uni >> (8 * g8)) & 0xFFull) {
+        for (int r0 = 0; r0 < ROWS; r0 += ILP) {
+            if (r0 < nrows) {                                // wave-uniform
+                double qv[ILP];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) q[(8 * g8 + u) * 64] = r[8 * g8 + u];
+                for (int x = 0; x < ILP; ++x) qv[x] = quotient(r[r0 + x]);
+#pragma unroll
+                for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
             }
         }
-    }
-    // phase 1: (g0, g1) -> quotient, for the classes present in this slab (ILP classes per step: the divide is a chain of
-    // dependent FP64 operations, a second class gives the pipeline independent work)
-    auto quotient = [&](double raw) {
-        const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
-                    g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
-        const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
-        const float p0 = (float)((g0d * st.omf) * st.omf);
-        const float p1 = (float)((g1d * st.fd2) * st.omf);
-        const float p2 = (float)((g2d * st.fd) * st.fd);
-        const float ssum = (p0 + p1) + p2;
-        const double num = __builtin_fma(2.0, (double)p2, (double)p1);
-        return div_exact<true>(num, (double)ssum);
-    };
-    while (__any(left != 0)) {
-        bool on[ILP];
-        int c[ILP];
-        double raw[ILP], qv[ILP];
-#pragma unroll
-        for (int x = 0; x < ILP; ++x) {
-            on[x] = left != 0;
-            c[x] = on[x] ? __builtin_ctzll(left) : 0;
-            left &= left - 1;
-            raw[x] = q[c[x] * 64];
-        }
-#pragma unroll
-        for (int x = 0; x < ILP; ++x) qv[x] = quotient(raw[x]);
-#pragma unroll
-        for (int x = 0; x < ILP; ++x)
-            if (on[x]) q[c[x] * 64] = qv[x];
     }
     // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
     // table before the chain of that buffer starts
@@ -988,42 +995,28 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     return 0;
 }
 
-static int coded_rows(int cmax) { return (cmax + 7) & ~7; }      // table rows: whole groups of eight classes
-static int coded_variant()
-{
-    const char *e = getenv("WGS_EM_CODED_VARIANT");              // experiments: waves per workgroup * 10 + classes per step
-    return e ? atoi(e) : 12;
-}
-bool em_coded_fits(int cmax) { return cmax >= 1 && (size_t)(coded_variant() / 10) * coded_rows(cmax) * 512 <= 64 * 1024; }
-
-int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, const float2 *dict, int cmax)
+int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int rows)
 {
     if (n_fits <= 0 || m <= 0) return 0;
-    const int variant = coded_variant(), W = variant / 10;
+    WGS_REQUIRE(rows >= 8 && rows <= 64 && rows % 8 == 0, "em sweep: %d table rows", rows);
     const int64_t tiles = (m + 63) / 64;
-    const int64_t tgroups = ((tiles + W - 1) / W + 7) / 8 * 8;      // the XCD-aware order covers whole groups of 8
+    const int64_t tgroups = (tiles + 7) / 8 * 8;                    // the XCD-aware order covers whole groups of 8
     const int64_t blocks = tgroups * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
-    const size_t lds = (size_t)W * coded_rows(cmax) * 512;
-#define WGS_EMC2(WV, IL, RW) hipLaunchKernelGGL((em_coded_kernel<4, WV, IL, RW>), dim3((unsigned)blocks), dim3(WV * 64), lds, ctx->stream, d_descs, n_fits, m, dict, cmax)
-#define WGS_EMC(WV, IL)                            \
-    switch (coded_rows(cmax)) {                    \
-        case 8: WGS_EMC2(WV, IL, 8); break;        \
-        case 16: WGS_EMC2(WV, IL, 16); break;      \
-        case 24: WGS_EMC2(WV, IL, 24); break;      \
-        case 32: WGS_EMC2(WV, IL, 32); break;      \
-        case 40: WGS_EMC2(WV, IL, 40); break;      \
-        case 48: WGS_EMC2(WV, IL, 48); break;      \
-        case 56: WGS_EMC2(WV, IL, 56); break;      \
-        default: WGS_EMC2(WV, IL, 64); break;      \
-    }
-    switch (variant) {
-        case 11: WGS_EMC(1, 1); break;
-        case 12: WGS_EMC(1, 2); break;
-        default: WGS_EMC(2, 1); break;
+    const char *xl = getenv("WGS_EM_CODED_EXTRA_LDS");              // experiment: how the sweep depends on wavefronts per CU
+    const size_t lds = (size_t)rows * 512 + (xl ? (size_t)atoi(xl) : 0);
+#define WGS_EMC(RW) hipLaunchKernelGGL((em_coded_kernel<4, 2, RW>), dim3((unsigned)blocks), dim3(64), lds, ctx->stream, d_descs, n_fits, m)
+    switch (rows) {
+        case 8: WGS_EMC(8); break;
+        case 16: WGS_EMC(16); break;
+        case 24: WGS_EMC(24); break;
+        case 32: WGS_EMC(32); break;
+        case 40: WGS_EMC(40); break;
+        case 48: WGS_EMC(48); break;
+        case 56: WGS_EMC(56); break;
+        default: WGS_EMC(64); break;
     }
 #undef WGS_EMC
-#undef WGS_EMC2
     HIP_TRY(hipGetLastError());
     return 0;
 }

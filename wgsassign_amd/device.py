@@ -167,13 +167,18 @@ class DeviceBeagle:
     def nbytes(self):
         return int(_lib.load().wgs_beagle_bytes(self._h))
 
+    def prepare_codes(self, em=True):
+        """Build the class codes now (em: and the slabs' own numbering for the coded EM sweep) instead of at first use."""
+        check(_lib.load().wgs_beagle_codes_prepare(self._h, 1 if em else 0))
+
     def codes_info(self):
         """Class codes of the matrix (built on first use; csrc/common.h: wgs_codes): dict with `available`, `max_classes`
         (of the richest SNP), `bytes`, `build_ms`, `mean_classes`."""
-        info = (ctypes.c_double * 6)()
+        info = (ctypes.c_double * 10)()
         check(_lib.load().wgs_beagle_codes_info(self._h, info))
         return {"available": bool(info[0]), "max_classes": int(info[1]), "bytes": int(info[2]), "build_ms": info[3],
-                "encode_kernel_ms": info[5], "mean_classes": info[4]}
+                "encode_kernel_ms": info[5], "mean_classes": info[4], "slab_numbering_ms": info[6], "slab_numbering_bytes": int(info[7]),
+                "em_table_rows": int(info[8]), "em_direct_tile_share": info[9]}
 
     def close(self):
         if self._h:
