@@ -53,10 +53,10 @@ def main():
     fast1, _ = device.assign(b, afs, mode=MODE_FAST)
     res["pop_like_coded_fast_ms"] = round(device.assign.last_ms, 3)
     res["variants"] = {}
-    for v in os.environ.get("CHECK_CODES_VARIANTS", "").split(","):       # WGS_SCORE_CODED_VARIANT values to compare
+    for v in os.environ.get("CHECK_CODES_VARIANTS", "").split(","):       # WGS_SCORE_CODED_TABLE values to compare: float,double
         if not v:
             continue
-        os.environ["WGS_SCORE_CODED_VARIANT"] = v
+        os.environ["WGS_SCORE_CODED_TABLE"] = v
         o, _ = device.assign(b, afs)
         o, _ = device.assign(b, afs)
         ms = device.assign.last_ms
@@ -64,7 +64,7 @@ def main():
         f, _ = device.assign(b, afs, mode=MODE_FAST)
         res["variants"][v] = {"exact_ms": round(ms, 3), "identical": bool(o.tobytes() == out0.tobytes()),
                               "fast_ms": round(device.assign.last_ms, 3), "fast_identical": bool(f.tobytes() == fast1.tobytes())}
-    os.environ.pop("WGS_SCORE_CODED_VARIANT", None)
+    os.environ.pop("WGS_SCORE_CODED_TABLE", None)
     em2 = device.EMBatch(b, np.arange(K, dtype=np.int32))
     t0 = time.perf_counter()
     iters2 = em2.run(200, 1e-4)
