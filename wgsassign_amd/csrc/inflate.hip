@@ -195,11 +195,12 @@ __device__ __noinline__ int read_block_header(BitReader &br, LaneTables &T, uint
     for (int i = 0; i < 19; ++i) cl[i] = 0;
 #pragma nounroll
     for (int i = 0; i < hclen; ++i) cl[kClenOrder[i]] = (uint8_t)br.take(3);
-    // the code-length code goes through the distance table's storage (it is rebuilt right after)
-    if (!build_table(cl, 19, dtab, 7, T.dist_sorted, dist_count, T.offs, T.next)) return -1;
+    // the code-length code (at most 7 bits) goes through the literal table's storage (rebuilt right after)
+    static_assert(LIT_BITS >= 7, "the code-length code needs a 7-bit table");
+    if (!build_table(cl, 19, lit, 7, T.dist_sorted, dist_count, T.offs, T.next)) return -1;
     int i = 0;
     while (i < hlit + hdist) {
-        const int sym = decode_symbol(br, dtab, 7, T.dist_sorted, dist_count);
+        const int sym = decode_symbol(br, lit, 7, T.dist_sorted, dist_count);
         if (sym < 0) return -1;
         if (sym < 16) {
             T.lens[i++] = (uint8_t)sym;
