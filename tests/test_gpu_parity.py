@@ -34,11 +34,13 @@ def same_nan(a, b):
     return a[ok].tobytes() == b[ok].tobytes()
 
 
-def nearly_all_identical(a, b, frac=0.99):
+def nearly_all_identical(a, b, frac=1.0):
     """For matrices that do NOT start at a multiple of 8192 sites (windows cut out of a larger matrix): the per-site
     values are bit-identical but NumPy's float64 summation (chunks of 8192 sites from the window's first site) groups
-    them differently from the device (blocks of 4096 sites on the global grid) -- within 1e-6 everywhere and the very
-    same float32 in at least `frac` of the entries.  Everything that starts at site 0 is held to same_nan()."""
+    them differently from the device (blocks of 4096 sites on the global grid).  The float64 sums may then differ in
+    their last bit where a partial sum is not exact; rounded to float32 they are the same number unless such a sum
+    sits on a float32 rounding boundary -- with the seeded inputs of these tests it never does, so every entry is held
+    to the very same float32 (frac = 1).  Everything that starts at site 0 is held to same_nan() in float64."""
     a, b = np.asarray(a), np.asarray(b)
     return close(a, b) and np.mean(a.view(np.uint32) == b.view(np.uint32)) >= frac
 
