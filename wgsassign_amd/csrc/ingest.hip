@@ -788,7 +788,7 @@ void wgs_ingest_destroy(wgs_ingest *g)
     delete g;
 }
 
-/* chunk_bytes: text per chunk (<= 0: the default -- 256 MiB through the host inflater; 2 GiB when the device inflates, one
+/* chunk_bytes: text per chunk (<= 0: the default -- 256 MiB through the host inflater; 2.75 GiB when the device inflates, one
  * lane per BGZF member: the more members per launch, the better the chip is used). */
 int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t chunk_bytes, wgs_ingest **out)
 {
@@ -800,7 +800,9 @@ int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t 
     // BGZF (what ANGSD writes): inflated on the device unless WGSASSIGN_INFLATE says host / zlib
     const char *how = getenv("WGSASSIGN_INFLATE");
     const bool resident = reader_text_is_bgzf(r) && !(how && (strcmp(how, "host") == 0 || strcmp(how, "zlib") == 0));
-    if (chunk_bytes <= 0) chunk_bytes = resident ? (2ll << 30) : (256ll << 20);
+    // (one lane per member and three wavefronts per CU: a launch of up to 49 k members takes the time of one member, so the
+    // default chunk is 45 k members of 64 KiB)
+    if (chunk_bytes <= 0) chunk_bytes = resident ? (2816ll << 20) : (256ll << 20);
     chunk_bytes = std::min<int64_t>(chunk_bytes, resident ? (3ll << 30) : (1ll << 30));
     wgs_ingest *g = new wgs_ingest();
     g->b = b;
