@@ -46,30 +46,41 @@ struct InflateArgs {
     int32_t nblocks;
 };
 
-__constant__ uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t kClenOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct BitReader {
     const uint8_t *p, *end;
     uint64_t buf = 0;
     int cnt = 0;
-    // At least 56 valid bits afterwards.  Eight bytes are fetched as two aligned 64-bit words (the chunk is padded, so
-    // reading a little past a stream is harmless: a valid stream never CONSUMES those bits, see `consumed_past_end`);
-    // bytes of a partly used word are ORed in again at the same position by the next refill, which changes nothing.
+    // three aligned 64-bit words of input held in registers: the one `p` points into and the two behind it.  A refill takes
+    // its eight bytes from them and, when `p` moves on to the next word, requests the word after the window -- a load whose
+    // result is not needed for at least eight more bytes of input, so the trips in between do not wait for memory.
+    const uint64_t *a = nullptr;
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
+    __device__ __forceinline__ void start(const uint8_t *first, const uint8_t *last)
+    {
+        p = first;
+        end = last;
+        a = reinterpret_cast<const uint64_t *>((uintptr_t)first & ~(uintptr_t)7);
+        w0 = a[0], w1 = a[1], w2 = a[2];
+    }
+    // At least 56 valid bits afterwards.  (The chunk is padded, so reading a little past a stream is harmless: a valid stream
+    // never CONSUMES those bits, see `consumed_past_end`); bytes of a partly used word are ORed in again at the same position
+    // by the next refill, which changes nothing.
     __device__ __forceinline__ void refill()
     {
-        const uintptr_t addr = (uintptr_t)p;
-        const uint64_t *a = reinterpret_cast<const uint64_t *>(addr & ~(uintptr_t)7);
-        const int sh = (int)(addr & 7) * 8;
-        const uint64_t lo = a[0], hi = a[1];
-        const uint64_t v = sh ? (lo >> sh) | (hi << (64 - sh)) : lo;
+        const int sh = (int)((uintptr_t)p & 7) * 8;
+        const uint64_t v = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
         buf |= v << cnt;
         const int nbytes = (63 - cnt) >> 3;
         p += nbytes;
         cnt += nbytes * 8;
+        if (reinterpret_cast<const uint64_t *>((uintptr_t)p & ~(uintptr_t)7) != a) {     // at most one word further
+            ++a;
+            w0 = w1;
+            w1 = w2;
+            w2 = a[2];
+        }
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     __device__ __forceinline__ void drop(int n)
@@ -244,8 +255,10 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
     const bool have = blk < A.nblocks;
     LaneTables &T = A.tables[have ? blk : 0];
     BitReader br;
-    br.p = A.comp + (have ? A.in_off[blk] : 0);
-    br.end = br.p + (have ? A.in_len[blk] : 0);
+    {
+        const uint8_t *first = A.comp + (have ? A.in_off[blk] : 0);
+        br.start(first, first + (have ? A.in_len[blk] : 0));
+    }
     uint8_t *const out0 = A.out + (have ? A.out_off[blk] : 0);
     const uint32_t want = have ? A.isize[blk] : 0;
     uint32_t pos = 0, last = 0, left = 0, dist = 0;
@@ -280,9 +293,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
             } else if (sym == 256) {
                 state = last ? ST_DONE : ST_HEADER;
             } else {
+                // base and extra bits of the length code by arithmetic (RFC 1951 3.2.5: four codes per number of extra bits);
+                // a table in constant memory would be two more dependent loads per match
                 const int li = (int)sym - 257;
-                const int xb = kLenExtra[li];
-                const uint32_t len = kLenBase[li] + br.peek(xb);
+                const int xb = li < 8 || li == 28 ? 0 : (li >> 2) - 1;
+                const uint32_t lbase = li < 8 ? 3u + (uint32_t)li : li == 28 ? 258u : ((4u + ((uint32_t)li & 3u)) << xb) + 3u;
+                const uint32_t len = lbase + br.peek(xb);
                 br.drop(xb);
                 uint32_t d = L[LDS_DIST + br.peek(DIST_BITS) * 64];
                 if (!d) d = walk_symbol(br.buf, T.dist_sorted, L + LDS_DIST_COUNT);
@@ -292,8 +308,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
                     bad = true;
                     state = ST_DONE;
                 } else {
-                    const int db = kDistExtra[ds];
-                    dist = kDistBase[ds] + br.peek(db);
+                    const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;           // two distance codes per number of extra bits
+                    dist = (ds < 4 ? 1u + ds : ((2u + (ds & 1u)) << db) + 1u) + br.peek(db);
                     br.drop(db);
                     left = len;
                     if (dist > pos || pos + len > want) bad = true, state = ST_DONE;
@@ -302,12 +318,24 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
             }
         } else if (state == ST_COPY) {
             // matches in this kind of text are long (51 bytes on average) and come from far back (half of them from more
-            // than 2 KiB): sixteen bytes per trip whenever source and destination do not overlap within the sixteen and
-            // the slot has room for them (bytes past the match are overwritten by what follows); else one byte
-            if (dist >= 16 && pos + 16 <= want) {
-                struct __attribute__((packed)) B16 { uint64_t a, b; };
+            // than 2 KiB), or repeat a short period ("0.333333\t" three times per unobserved genotype: distance 9)
+            struct __attribute__((packed)) B16 { uint64_t a, b; };
+            if (dist >= 64 && left > 16 && pos + 64 <= want) {
+                // a long match from far back: sixty-four bytes in one trip (four loads in flight, then four stores)
+                const B16 *src = reinterpret_cast<const B16 *>(out0 + pos - dist);
+                const B16 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                B16 *dst = reinterpret_cast<B16 *>(out0 + pos);
+                dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3;
+                const uint32_t step = left < 64 ? left : 64;
+                pos += step;
+                left -= step;
+            } else if (pos + 16 <= want) {
+                // sixteen bytes are moved whatever the distance; the first min(dist, 16) of them are right (a source that
+                // overlaps the destination repeats with period dist), the rest -- and what lies past the match -- is
+                // overwritten by what follows
                 *reinterpret_cast<B16 *>(out0 + pos) = *reinterpret_cast<const B16 *>(out0 + pos - dist);
-                const uint32_t step = left < 16 ? left : 16;
+                uint32_t step = dist < 16 ? dist : 16;
+                step = left < step ? left : step;
                 pos += step;
                 left -= step;
             } else {
