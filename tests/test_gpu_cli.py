@@ -101,6 +101,47 @@ def test_cli_streams_in_many_chunks(tmp_path, golden, monkeypatch):
     assert gzip.open(out + ".pop_like_LOO_partitions_3.tsv.gz", "rt").read() == str(g["parts_tsv"])
 
 
+def test_cli_on_bgzf_copies_of_the_bundled_files(tmp_path, golden, monkeypatch):
+    """The bundled files re-written as BGZF (what ANGSD writes): the command line then reads them through the
+    device-resident ingest (members inflated, cut into lines and tokenised on the MI355X; a site filter applied while
+    streaming) -- same `.pop_af.npy` bytes, same stdout, same partition sums and downsampled TSV as the reference CLI."""
+    import synth
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    monkeypatch.setenv("WGSASSIGN_TEXT_CHUNK_BYTES", str(1 << 20))          # the 1 MB of text in two chunks
+    ds_src = os.path.join(DATA, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each_subset_80percent_sites.beagle.gz")
+    paths = {}
+    for name, src, block in (("breed", BREED, 20000), ("ds", ds_src, 60000), ("nonbreed", NONBREED, 3000)):
+        paths[name] = str(tmp_path / (name + ".beagle.gz"))
+        synth.write_bgzf(paths[name], gzip.open(src, "rb").read(), block=block)
+    g = golden("amre_cli.npz")
+    out = str(tmp_path / "ref")
+    stdout = run_cli(["--beagle", paths["breed"], "--pop_af_IDs", IDS, "--get_reference_af", "--loo", "--partition_sites", "3",
+                      "--out", out, "--threads", "2"])
+    assert np.load(out + ".pop_af.npy").tobytes() == g["pop_af_npy"].tobytes()
+    ref_lines = str(g["stdout_ref"]).replace("<TMP>/", "").splitlines()
+    got_lines = [l.replace(str(tmp_path) + "/", "") for l in stdout.splitlines()]
+    assert [l for l in got_lines if "Parsing" not in l] == [l for l in ref_lines if "Parsing" not in l]
+    assert gzip.open(out + ".pop_like_LOO_partitions_3.tsv.gz", "rt").read() == str(g["parts_tsv"])
+    out2 = str(tmp_path / "nb")
+    af = tmp_path / "ref.pop_af.npy"
+    np.save(af, g["pop_af_npy"])
+    run_cli(["--beagle", paths["nonbreed"], "--pop_af_file", str(af), "--get_pop_like", "--out", out2, "--threads", "2"])
+    got = np.loadtxt(out2 + ".pop_like.txt")
+    ref = np.loadtxt(io.StringIO(str(g["pop_like_txt"])))
+    assert got.shape == ref.shape and np.all(np.abs(got - ref) <= 1e-6 * np.abs(ref))
+    gd = golden("amre_cli_downsampled.npz")
+    out3 = str(tmp_path / "ds")
+    run_cli(["--beagle", paths["breed"], "--pop_af_IDs", IDS, "--get_reference_af", "--loo", "--loo_downsampled_beagle", paths["ds"],
+             "--out", out3, "--threads", "2"])
+    assert np.load(out3 + ".pop_af.npy").tobytes() == gd["pop_af_npy"].tobytes()
+    h_ref, r_ref = table(str(gd["loo_tsv"]))
+    h_got, r_got = table(open(out3 + ".pop_like_LOO_downsampled.tsv").read())
+    assert h_got == h_ref and [r[:2] for r in r_got] == [r[:2] for r in r_ref]
+    a = np.array([[float(x) for x in r[2:]] for r in r_got])
+    b = np.array([[float(x) for x in r[2:]] for r in r_ref])
+    assert np.all(np.abs(a - b) <= 1e-6 * np.abs(b) + 1.5e-6)
+
+
 @pytest.mark.parametrize("ranks, cases", [(1, 16), (3, 4)])
 def test_random_cases_through_the_command_line(ranks, cases):
     """tools/fuzz_cli.py: random shapes (populations of one, one SNP, tile edges, 1-7 partitions, --ne_obs), plain gzip or
