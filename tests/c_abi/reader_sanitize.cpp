@@ -86,7 +86,7 @@ int main(int argc, char **argv)
             return 7;
         }
         wgs_reader_close(r);
-        if (wgs_reader_open_indexed(path, idx.c_str(), 0, threads, &r)) return 2;      // from the start: more text than the open call inflates
+        if (wgs_reader_open_indexed(path, idx.c_str(), 0, threads, &r)) return 2;      // from the start of the data
         std::vector<char> text((size_t)256 << 20);
         int64_t bytes = 0, info[4] = {0, 0, 0, 0};
         const int rc = wgs_debug_reader_comp_text(r, 1 << 20, 2 << 20, 2, text.data(), (int64_t)text.size(), &bytes, info);

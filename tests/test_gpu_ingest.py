@@ -197,7 +197,7 @@ def test_members_the_device_rejects_and_damaged_files(tmp_path, monkeypatch):
     import beagle_files
     monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
     monkeypatch.setenv("WGSASSIGN_TEXT_CHUNK_BYTES", str(8 << 20))
-    n, m = 300, 14000                                            # 113 MB of text: the open call inflates the first 64
+    n, m = 300, 14000                                            # 113 MB of text, 14 chunks of 8 MiB
     p = str(tmp_path / "r.beagle.gz")
     _, vals, pick = beagle_files.write_lowdepth_bgzf(p, n, m, pool=128)
     want = vals[pick]

@@ -680,7 +680,7 @@ def test_compressed_hand_over_reports_damaged_files(tmp_path, monkeypatch):
     import beagle_files
     monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
     p = str(tmp_path / "d.beagle.gz")
-    total, _, _ = beagle_files.write_lowdepth_bgzf(p, 500, 12000, pool=64)       # 162 MB of text: the open call inflates 64 MB
+    total, _, _ = beagle_files.write_lowdepth_bgzf(p, 500, 12000, pool=64)       # 162 MB of text; the open call inflates ~1 MB of it on the host
     got, info = _comp_text(p, 2 << 20, 8 << 20, threads=2, cap=200 << 20)
     assert len(got) > 150 << 20 and got == gz.open(p).read()[-len(got):] and info[3] >= 1 and info[0] > 10
     raw = open(p, "rb").read()

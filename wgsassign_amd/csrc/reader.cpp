@@ -572,6 +572,9 @@ struct wgs_reader {
     int n_inds = 0;
     TextBuf buf;
     size_t len = 0, pos = 0;
+    size_t fill_cap = (size_t)-1;   // most bytes one fill() appends (BGZF, while a reader is opened: the header and the lines up to
+                                    // the first row need kilobytes, and what is left in the buffer reaches the device ingest
+                                    // as host-inflated text)
     bool eof = false;
     std::string chunk_sites;   // '\n'-joined site names of the last chunk
     int threads = 1;
@@ -593,9 +596,11 @@ static bool fill(wgs_reader *r)
     // points, must fit behind the tail
     const size_t want = r->src.want_room();
     if (r->buf.size() - r->len < want && !r->buf.resize(r->src.segmented ? r->len + want : r->buf.size() * 2)) return false;
-    while (!r->eof && r->len < r->buf.size()) {
+    const size_t room = r->buf.size() - r->len;
+    const size_t limit = r->len + std::min(room, std::max(r->fill_cap, want));
+    while (!r->eof && r->len < limit) {
         const bool batch = r->src.segmented;
-        const long got = r->src.read(r->buf.data() + r->len, r->buf.size() - r->len);
+        const long got = r->src.read(r->buf.data() + r->len, limit - r->len);
         if (got == -2) break;                                 // the next block does not fit any more; enough for now
         if (got < 0) return false;
         if (got == 0) {
@@ -690,6 +695,7 @@ int wgs_reader_open(const char *path, int threads, wgs_reader **out)
         delete r;
         return 1;
     }
+    if (r->src.bgzf) r->fill_cap = 1u << 20;
     if (!fill(r)) {
         wgs_set_error("read error in %s", path);
         delete r;
@@ -704,6 +710,7 @@ int wgs_reader_open(const char *path, int threads, wgs_reader **out)
     parse_header(r->buf.data(), hend, r->samples, r->gl_cols);
     r->n_inds = r->gl_cols / 3;
     r->pos = nl ? (size_t)(nl - r->buf.data()) + 1 : r->len;
+    r->fill_cap = (size_t)-1;
     *out = r;
     return 0;
 }
@@ -1586,6 +1593,7 @@ int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t fi
         return 2;
     }
     if (!best || best->member_start) r->src.try_bgzf(r->threads);
+    if (r->src.bgzf) r->fill_cap = 1u << 20;
     const bool have_best = best != nullptr;
     const int64_t best_lines = best ? best->lines_before : 0;
     const bool best_line_start = best ? best->at_line_start != 0 : true, best_content = best ? best->content != 0 : false;
@@ -1646,6 +1654,7 @@ int wgs_reader_open_indexed(const char *path, const char *index_path, int64_t fi
         return 1;
     }
     r->lines_read = first_row;
+    r->fill_cap = (size_t)-1;
     *out = r;
     return 0;
 }
