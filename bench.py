@@ -300,6 +300,9 @@ def main():
     roofline["traffic"], roofline["traffic_source"] = pmc.get("em_traffic"), pmc.get("source")
     if pmc.get("reason"):
         roofline["traffic_note"] = pmc["reason"]
+    if roofline.get("traffic") and roofline.get("kernel_ms_avg"):
+        # what the kernel really moves per launch (PMC) over its measured duration, as a fraction of the HBM peak
+        roofline["traffic_frac"] = round(roofline["traffic"] / (roofline["kernel_ms_avg"] * 1e-3) / HBM_PEAK, 4)
     if pmc.get("em_valu_busy_frac") is not None:
         # the exact-mode sweep sits on the FP64 issue roof as well: share of cycles the vector units were busy
         roofline["valu_busy_frac"] = round(pmc["em_valu_busy_frac"], 4)
