@@ -153,8 +153,9 @@ __global__ void synth_kernel(float4 *__restrict__ slab, int64_t m, int npairs, i
 // lane <-> SNP, one wavefront per tile: every lane walks the individuals of ITS SNP through all slabs (the slabs'
 // native coalesced loads) and keeps the distinct (g0, g1) bit patterns in a private open-addressing table of 64 slots
 // in LDS (slot-major, so a wave-wide access with per-lane slots is conflict-free); occupancy is a 64-bit mask in
-// registers.  A class's id is the number of occupied slots below its slot -- known once the walk is complete, hence
-// two walks: classes first, codes second.  More than 64 classes in one SNP: not codable (ncls = 255).
+// registers.  A class's id is the number of occupied slots below its slot -- known once the walk is complete: the walk
+// over the slabs writes slot numbers into the code words, a second walk over the code words alone (an eighth of the
+// bytes) turns them into ids.  More than 64 classes in one SNP: not codable (ncls = 255).
 struct ClassTable {
     uint64_t *keys;                // LDS: [slot * 64 + lane]
     uint64_t mask = 0;
@@ -202,38 +203,13 @@ __global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
     ClassTable T;
     T.keys = keys;
     constexpr int PF = 8;              // pair loads in flight (one wave per workgroup: nothing else hides their latency)
-    for (int g = 0; g < A.n_slabs; ++g) {
-        const int np = A.npairs[g], nc = A.ncols[g];
-        const float4 *src = A.base[g] + tile * np * 64 + lane;
-        for (int p0 = 0; p0 < np; p0 += PF) {
-            float4 v[PF];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) v[u] = src[(int64_t)(p0 + u < np ? p0 + u : np - 1) * 64];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                const int p = p0 + u;
-                if (p < np) {
-                    T.find_or_insert(gl_key(v[u].x, v[u].y), lane, true);
-                    if (2 * p + 1 < nc) T.find_or_insert(gl_key(v[u].z, v[u].w), lane, true);
-                }
-            }
-        }
-    }
-    const int n = T.overflow ? 255 : __popcll(T.mask);
-    A.ncls[snp] = (uint8_t)n;          // the arrays cover whole tiles
-    if (__any(T.overflow)) return;     // not codable: the host sees ncls = 255 and drops the codes
-    // the dictionary, class id = rank of the slot among the occupied ones
-    for (uint64_t left = T.mask; left;) {
-        const int slot = __builtin_ctzll(left);
-        left &= left - 1;
-        const uint64_t key = keys[slot * 64 + lane];
-        A.dict[(tile * WGS_CODE_ROWS + T.id_of(slot)) * 64 + lane] = make_float2(__uint_as_float((uint32_t)(key >> 32)), __uint_as_float((uint32_t)key));
-    }
+    // the walk over the float32 slabs: every (g0, g1) is looked up / inserted once and its SLOT goes into the code word; the
+    // slots each slab uses are remembered in its `present` word
     for (int g = 0; g < A.n_slabs; ++g) {
         const int np = A.npairs[g], nc = A.ncols[g];
         const SlabCodes sc = A.slabs[g];
         const float4 *src = A.base[g] + tile * np * 64 + lane;
-        uint64_t present = 0;
+        uint64_t used = 0;
         for (int q0 = 0; q0 < sc.nquads; q0 += PF / 2) {
             float4 v[PF];
 #pragma unroll
@@ -248,19 +224,56 @@ __global__ __launch_bounds__(64) void class_encode_kernel(EncodeArgs A)
                     const int p = 2 * q + h;
                     if (p >= np) break;
                     const float4 vv = v[2 * x + h];
-                    const int c0 = T.id_of(T.find_or_insert(gl_key(vv.x, vv.y), lane, false));
-                    word |= (uint32_t)c0 << (16 * h);
-                    present |= 1ull << c0;
+                    int s0 = T.find_or_insert(gl_key(vv.x, vv.y), lane, true);
+                    s0 = s0 < 0 ? 0 : s0;                        // (overflow: the codes are dropped by the host)
+                    word |= (uint32_t)s0 << (16 * h);
+                    used |= 1ull << s0;
                     if (2 * p + 1 < nc) {
-                        const int c1 = T.id_of(T.find_or_insert(gl_key(vv.z, vv.w), lane, false));
-                        word |= (uint32_t)c1 << (16 * h + 8);
-                        present |= 1ull << c1;
+                        int s1 = T.find_or_insert(gl_key(vv.z, vv.w), lane, true);
+                        s1 = s1 < 0 ? 0 : s1;
+                        word |= (uint32_t)s1 << (16 * h + 8);
+                        used |= 1ull << s1;
                     }
                 }
                 sc.codes[(tile * sc.nquads + q) * 64 + lane] = word;
             }
         }
+        sc.present[snp] = used;
+    }
+    const int n = T.overflow ? 255 : __popcll(T.mask);
+    A.ncls[snp] = (uint8_t)n;          // the arrays cover whole tiles
+    if (__any(T.overflow)) return;     // not codable: the host sees ncls = 255 and drops the codes
+    // the dictionary, class id = rank of the slot among the occupied ones
+    for (uint64_t left = T.mask; left;) {
+        const int slot = __builtin_ctzll(left);
+        left &= left - 1;
+        const uint64_t key = keys[slot * 64 + lane];
+        A.dict[(tile * WGS_CODE_ROWS + T.id_of(slot)) * 64 + lane] = make_float2(__uint_as_float((uint32_t)(key >> 32)), __uint_as_float((uint32_t)key));
+    }
+    // second walk, over the code words only (an eighth of the slabs' bytes, written moments ago): slot -> class id
+    for (int g = 0; g < A.n_slabs; ++g) {
+        const SlabCodes sc = A.slabs[g];
+        uint64_t present = 0;
+        for (uint64_t left = sc.present[snp]; left;) {
+            const int slot = __builtin_ctzll(left);
+            left &= left - 1;
+            present |= 1ull << T.id_of(slot);
+        }
         sc.present[snp] = present;
+        uint32_t *cw = sc.codes + tile * sc.nquads * 64 + lane;
+        for (int q0 = 0; q0 < sc.nquads; q0 += PF) {
+            uint32_t w[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) w[u] = cw[(int64_t)(q0 + u < sc.nquads ? q0 + u : sc.nquads - 1) * 64];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (q0 + u >= sc.nquads) break;
+                uint32_t o = 0;
+#pragma unroll
+                for (int h = 0; h < 4; ++h) o |= (uint32_t)T.id_of((int)((w[u] >> (8 * h)) & 63u)) << (8 * h);
+                cw[(int64_t)(q0 + u) * 64] = o;
+            }
+        }
     }
 }
 
