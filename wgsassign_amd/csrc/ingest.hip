@@ -800,9 +800,9 @@ int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t 
     // BGZF (what ANGSD writes): inflated on the device unless WGSASSIGN_INFLATE says host / zlib
     const char *how = getenv("WGSASSIGN_INFLATE");
     const bool resident = reader_text_is_bgzf(r) && !(how && (strcmp(how, "host") == 0 || strcmp(how, "zlib") == 0));
-    // (one lane per member and three wavefronts per CU: a launch of up to 49 k members takes the time of one member, so the
-    // default chunk is 45 k members of 64 KiB)
-    if (chunk_bytes <= 0) chunk_bytes = resident ? (2816ll << 20) : (256ll << 20);
+    // (one lane per member and three wavefronts per CU: a launch of up to 49 k members takes the time of one member, so a
+    // chunk is that many members -- see reader_comp_start below -- or 3 GiB of text, whichever comes first)
+    if (chunk_bytes <= 0) chunk_bytes = resident ? (3ll << 30) : (256ll << 20);
     chunk_bytes = std::min<int64_t>(chunk_bytes, resident ? (3ll << 30) : (1ll << 30));
     wgs_ingest *g = new wgs_ingest();
     g->b = b;
@@ -834,7 +834,12 @@ int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t 
                 staging = std::max<size_t>(((size_t)left + 4096 + 0xFFFFF) & ~(size_t)0xFFFFF, 1u << 20);
                 nbuf = 1;
             }
-            if (int rc = reader_comp_start(r, staging, g->chunk_text, nbuf, a)) return rc;
+            // one lane per member and three wavefronts per CU (52 KiB of tables each): members beyond that many wait for a
+            // second round of the launch
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDeviceProperties(&prop, b->ctx->device));
+            const size_t lanes = (size_t)std::max(1, prop.multiProcessorCount) * 3 * 64;
+            if (int rc = reader_comp_start(r, staging, g->chunk_text, nbuf, a, lanes)) return rc;
         }
     } else if (int rc = reader_text_start(r, (size_t)chunk_bytes, 3, a, limit_rows)) {
         return rc;

@@ -2079,7 +2079,7 @@ struct CompPipe {
     std::deque<CompChunk *> free_q, ready_q;
     std::vector<CompChunk *> all;
     TextAllocator alloc;
-    size_t text_cap = 0;
+    size_t text_cap = 0, max_members = 0;
     uint64_t file_off = 0;
     bool finished = false, stop = false;
     size_t pre_pos = 0, pre_end = 0;   // text the line-oriented calls had inflated already: [pre_pos, pre_end) of the reader's buffer
@@ -2178,7 +2178,7 @@ void comp_producer(wgs_reader *r)
                     corrupt = true;
                     break;
                 }
-                if (c->text_bytes + isz > p->text_cap) {
+                if (c->text_bytes + isz > p->text_cap || (p->max_members && isz && c->isize.size() >= p->max_members)) {
                     full = true;
                     break;
                 }
@@ -2208,7 +2208,7 @@ void comp_producer(wgs_reader *r)
 }
 }  // namespace
 
-int reader_comp_start(wgs_reader *r, size_t comp_bytes, size_t text_cap, int nbuf, TextAllocator a)
+int reader_comp_start(wgs_reader *r, size_t comp_bytes, size_t text_cap, int nbuf, TextAllocator a, size_t max_members)
 {
     if (!r || r->pipe || r->cpipe || !r->src.bgzf || !a.alloc || !a.release || nbuf < 1) {
         wgs_set_error("bad argument");
@@ -2217,6 +2217,7 @@ int reader_comp_start(wgs_reader *r, size_t comp_bytes, size_t text_cap, int nbu
     CompPipe *p = new CompPipe();
     p->alloc = a;
     p->text_cap = std::max<size_t>(text_cap, 1u << 20);
+    p->max_members = max_members;
     comp_bytes = std::max<size_t>(comp_bytes, 1u << 20);
     p->pre_pos = r->pos;
     p->pre_end = r->len;

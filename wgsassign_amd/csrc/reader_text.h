@@ -44,7 +44,8 @@ struct CompChunk {
     bool last = false;                  // nothing follows
     double read_s = 0.0;
 };
-int reader_comp_start(wgs_reader *r, size_t comp_bytes, size_t text_cap, int nbuf, TextAllocator a);
+// a chunk ends before its text would exceed text_cap or its non-empty members max_members (0: no limit)
+int reader_comp_start(wgs_reader *r, size_t comp_bytes, size_t text_cap, int nbuf, TextAllocator a, size_t max_members = 0);
 int reader_comp_next(wgs_reader *r, CompChunk **out, double *waited_s);
 void reader_comp_release(wgs_reader *r, CompChunk *c);
 void reader_comp_stop(wgs_reader *r);
