@@ -788,7 +788,7 @@ void wgs_ingest_destroy(wgs_ingest *g)
     delete g;
 }
 
-/* chunk_bytes: text per chunk (<= 0: the default -- 256 MiB through the host inflater; 2.75 GiB when the device inflates, one
+/* chunk_bytes: text per chunk (<= 0: the default -- 256 MiB through the host inflater; 3 GiB -- or the members one launch has lanes for -- when the device inflates, one
  * lane per BGZF member: the more members per launch, the better the chip is used). */
 int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t chunk_bytes, wgs_ingest **out)
 {
