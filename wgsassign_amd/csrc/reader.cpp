@@ -170,6 +170,7 @@ struct BgzfBlock {
     uint32_t csize = 0;     // whole member, header and trailer included
     uint32_t hdr = 0;       // bytes before the deflate data
     uint32_t isize = 0;     // uncompressed bytes
+    uint32_t unused = 0;    // (explicit padding: the part files of the split index pass hold these records verbatim)
 };
 
 // Parses the member header at p (n bytes available): 0 = not BGZF, -1 = need more bytes, else the member size.
