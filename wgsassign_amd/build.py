@@ -28,7 +28,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-KERNEL_SOURCES = ["em_kernels.hip", "assign_kernels.hip", "common.h", "log_table.h"]   # what the profiled kernels are made of
+KERNEL_SOURCES = ["em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "common.h", "log_table.h"]   # what the profiled kernels are made of
 
 
 def source_ids():
