@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # substrings of the kernel names whose counters are kept (every kernel of the hot path)
-KERNELS = ("em_sweep", "em_coded", "class_encode", "tokenise", "em_decide", "assign_", "score_", "parts_", "chain_", "ssq_reduce", "rmse", "fisher_", "block_prefix")
+KERNELS = ("em_sweep", "em_coded", "class_encode", "local_encode", "slab_rows", "tokenise", "em_decide", "assign_", "score_", "parts_", "chain_", "ssq_reduce", "rmse", "fisher_", "block_prefix")
 
 
 def main():
