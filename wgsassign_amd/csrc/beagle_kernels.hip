@@ -284,11 +284,19 @@ __global__ __launch_bounds__(256) void slab_rows_hist_kernel(const SlabCodes *sl
     const SlabCodes sc = slabs[blockIdx.y];
     if (sc.nquads == 0) return;
     const int lane = threadIdx.x & 63;
+    unsigned count[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // this wavefront's tiles per bin (kept in lane 0; one atomic per bin at the end)
     for (int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); t < tiles; t += (int64_t)gridDim.x * 4) {
         int best = __popcll(sc.present[t * 64 + lane]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) best = max(best, __shfl_xor(best, off, 64));
-        if (lane == 0) atomicAdd(hist + blockIdx.y * 8 + (best > 0 ? (best - 1) >> 3 : 0), 1ull);
+        const int bin = best > 0 ? (best - 1) >> 3 : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) count[k] += bin == k ? 1u : 0u;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (count[k]) atomicAdd(hist + blockIdx.y * 8 + k, (unsigned long long)count[k]);
     }
 }
 
