@@ -417,7 +417,9 @@ int launch_local_encode(wgs_beagle *b, wgs_codes *c)
     if (wgs_ctx_workspace(b->ctx, sizeof(unsigned long long) * 8 * G, &ws)) return 1;
     unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws);
     HIP_TRY(hipMemsetAsync(d_hist, 0, sizeof(unsigned long long) * 8 * G, b->ctx->stream));
-    hipLaunchKernelGGL(slab_rows_hist_kernel, dim3(grid_for(tiles * 64), (unsigned)G), dim3(256), 0, b->ctx->stream, c->d_slabs, tiles, d_hist);
+    // (a few hundred workgroups per slab: every wavefront then counts dozens of tiles before its eight atomic adds)
+    const unsigned hist_blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512, (tiles + 3) / 4));
+    hipLaunchKernelGGL(slab_rows_hist_kernel, dim3(hist_blocks, (unsigned)G), dim3(256), 0, b->ctx->stream, c->d_slabs, tiles, d_hist);
     HIP_TRY(hipGetLastError());
     std::vector<unsigned long long> hist((size_t)8 * G, 0);
     HIP_TRY(hipMemcpyAsync(hist.data(), d_hist, sizeof(unsigned long long) * 8 * G, hipMemcpyDeviceToHost, b->ctx->stream));
