@@ -234,11 +234,10 @@ def main():
     ctx.sync()
     t_gen = time.time() - t0
     gl_bytes = beagle.nbytes()
-    # the class codes of the matrix (csrc/common.h: wgs_codes; built once per matrix like the slab layout itself, on first
-    # use -- here explicitly, so that the build is never inside the timed region)
-    if args.mode == "exact":
-        beagle.prepare_codes(em=True)
-    codes = beagle.codes_info() if args.mode == "exact" else {"available": False}
+    # The headline is the sweep over the float32 matrix (8 bytes per (SNP, individual) read once): the class codes
+    # (csrc/codes.hip) are switched off for it and measured beside it in extra.coded, their one-time build included.
+    user_codes = os.environ.get("WGSASSIGN_CODES")
+    os.environ["WGSASSIGN_CODES"] = "0"
     em = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
 
     def barrier():
@@ -261,20 +260,20 @@ def main():
     # take the step-by-step protocol: sweep -> host all-reduce -> one readback per iteration.
     pipelined = not use_dist or getattr(comm, "handle", None) is not None
 
-    def run_steps(k):
+    def run_steps(e, k):
         if pipelined:
-            em.fit(k, 0.0, comm if use_dist else None, m_total)
-            return em.fit_stats()[3] / max(1, k)
+            e.fit(k, 0.0, comm if use_dist else None, m_total)
+            return e.fit_stats()[3] / max(1, k)
         ms = []
         for _ in range(k):
-            em.step_reduced(comm)
-            ms.append(em.last_sweep_ms())
+            e.step_reduced(comm)
+            ms.append(e.last_sweep_ms())
         return float(np.mean(ms)) if ms else 0.0
 
-    run_steps(args.warmup)
+    run_steps(em, args.warmup)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = [run_steps(args.steps)]
+    kernel_ms = [run_steps(em, args.steps)]
     barrier()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     ssq = em.step_reduced(comm if use_dist else None)       # untimed: the sums after warmup + steps + 1 updates
@@ -285,24 +284,15 @@ def main():
     alg_bytes = (8.0 * n + 8.0 * K) * m
     k_avg = float(np.mean(kernel_ms)) * 1e-3
     achieved = alg_bytes / k_avg
-    coded_em = bool(codes.get("available")) and per >= 28 and os.environ.get("WGSASSIGN_CODES", "1") != "0"
     roofline = {"bound": "hbm", "achieved": round(achieved / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
-                "kernel": "em_coded_kernel" if coded_em else "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
-                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_snp": 8 * n + 8 * K}
-    if coded_em:
-        roofline["note"] = ("achieved = ALGORITHMIC bytes (8 per (SNP, individual) of the float32 matrix, SURVEY 8d) / kernel time; the "
-                            "production sweep reads the matrix through its class codes -- 1 byte per (SNP, individual) + a per-SNP "
-                            "dictionary -- so it is not bound by those bytes and `frac` may exceed 1; `traffic` is what it really moves. "
-                            "Same frequencies bit for bit as the sweep over the float32 slabs (extra.direct_sweep).")
-
-    pmc = committed_pmc(m, n, K, args.mode, coded_em, bool(codes.get("available")))
+                "kernel": "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(k_avg * 1e3, 4),
+                "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_snp": 8 * n + 8 * K,
+                "achievable_copy_rate_GBps": 6300.0, "frac_of_achievable": round(achieved / 6.3e12, 4)}
+    pmc = committed_pmc(m, n, K, args.mode, False, False)
     roofline["traffic"], roofline["traffic_source"] = pmc.get("em_traffic"), pmc.get("source")
     if pmc.get("reason"):
         roofline["traffic_note"] = pmc["reason"]
-    if roofline.get("traffic") and roofline.get("kernel_ms_avg"):
-        # what the kernel really moves per launch (PMC) over its measured duration, as a fraction of the HBM peak
-        roofline["traffic_frac"] = round(roofline["traffic"] / (roofline["kernel_ms_avg"] * 1e-3) / HBM_PEAK, 4)
     if pmc.get("em_valu_busy_frac") is not None:
         # the exact-mode sweep sits on the FP64 issue roof as well: share of cycles the vector units were busy
         roofline["valu_busy_frac"] = round(pmc["em_valu_busy_frac"], 4)
@@ -310,24 +300,16 @@ def main():
 
     extra = {"gl_pair_terms_per_s": value * n_call, "synth_seconds": round(t_gen, 2),
              "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
-    if codes.get("available"):
-        extra["class_codes"] = {"bytes": codes["bytes"], "build_ms_once_per_matrix": round(codes["build_ms"], 1), "mean_classes_per_snp":
-                                round(codes["mean_classes"], 2), "max_classes_per_snp": codes["max_classes"],
-                                "slab_numbering_ms_once_per_matrix": round(codes["slab_numbering_ms"], 1), "slab_numbering_bytes": codes["slab_numbering_bytes"],
-                                "em_table_rows": codes["em_table_rows"], "em_direct_tile_share": round(codes["em_direct_tile_share"], 5)}
-    if coded_em:
-        # the same iterations over the float32 slabs (WGSASSIGN_CODES=0): the kernel the HBM roofline of SURVEY 8d describes
-        os.environ["WGSASSIGN_CODES"] = "0"
-        em_d = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
-        em_d.fit(2, 0.0, comm if use_dist else None, m_total)
-        em_d.fit(6, 0.0, comm if use_dist else None, m_total)
-        dk = em_d.fit_stats()[3] / 6 * 1e-3
-        ssq_d = em_d.step_reduced(comm if use_dist else None)
-        em_d.close()
-        os.environ["WGSASSIGN_CODES"] = "1"
-        extra["direct_sweep"] = {"kernel": "em_sweep_kernel<%s>" % args.mode, "kernel_ms_avg": round(dk * 1e3, 4),
-                                 "hbm_frac": round(alg_bytes / dk / HBM_PEAK, 4), "value_if_used": K * m_total / (dk * world) if dk > 0 else None,
-                                 "note": "float32 slabs, traffic = algorithmic bytes; identical frequencies (tests/test_gpu_codes.py)"}
+    if user_codes is None:
+        os.environ.pop("WGSASSIGN_CODES")
+    else:
+        os.environ["WGSASSIGN_CODES"] = user_codes
+    codes_on = args.mode == "exact" and os.environ.get("WGSASSIGN_CODES", "1") != "0"
+    codes = {"available": False}
+    if codes_on and not use_dist:
+        extra["coded"], codes = coded_em_leg(ctx, device, beagle, em, K, per, n, m, mode, args)
+        if "steady_state_sweep" in extra["coded"]:
+            extra["coded"]["steady_state_sweep"]["speedup_over_float32_sweep"] = round(k_avg * 1e3 / extra["coded"]["steady_state_sweep"]["kernel_ms_avg"], 3)
 
     # the same sweep in WGS_MODE_FAST (float32 term evaluation, ~1e-6 of the reference), for comparison
     if args.mode == "exact":
@@ -351,6 +333,8 @@ def main():
             em.clamp(k, per)
             afs.set_column_from_em(k, em, k)
         ctx.sync()
+        # the float32 matrix first (WGSASSIGN_CODES=0): the sweep SURVEY 8d's algorithmic bytes describe
+        os.environ["WGSASSIGN_CODES"] = "0"
         if args.warmup > 0:                       # like the EM leg: one untimed pass first (code objects, workspace, log table)
             device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
         barrier()
@@ -359,33 +343,54 @@ def main():
         barrier()
         t_as = max_over_ranks(time.perf_counter() - t0)
         as_ms = device.assign.last_ms
-        coded_score = bool(codes.get("available"))
+        if user_codes is None:
+            os.environ.pop("WGSASSIGN_CODES")
+        else:
+            os.environ["WGSASSIGN_CODES"] = user_codes
         extra["assign"] = {"metric": "assignment log-lik SNPs/s (all n x K terms of a SNP = 1)",
                            "value": m_total / t_as, "unit": "SNPs/s", "seconds": round(t_as, 4),
                            "terms_per_s": m_total * float(n) * K / t_as,
                            "kernel_ms": round(as_ms, 3),
                            "hbm_frac": round((8.0 * n + 4.0 * K) * m / (as_ms * 1e-3) / HBM_PEAK, 4) if as_ms > 0 else None,
-                           "kernel": ("score_coded_kernel<%s> (per-class value table in LDS)" if coded_score else "score_sweep_kernel<%s>") % args.mode
-                                     + " + block_prefix_kernel (one launch over all population slabs)",
-                           "checksum": float(np.sum(out))}
-        if coded_score:
-            os.environ["WGSASSIGN_CODES"] = "0"
-            out_d, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
-            os.environ["WGSASSIGN_CODES"] = "1"
-            extra["assign"]["direct_sweep"] = {"kernel": "score_sweep_kernel<%s>" % args.mode, "kernel_ms": round(device.assign.last_ms, 3),
-                                               "identical_sums": bool(out_d.tobytes() == out.tobytes())}
-        if args.mode == "exact":
-            # the float32 scoring sweep (WGSASSIGN_MODE=fast), validated against exact on this very matrix
-            out_f, _ = device.assign(beagle, afs, mode=MODE_FAST, comm=comm if use_dist else None)
-            dev_rel = float(np.max(np.abs(out_f - out) / np.abs(out)))
-            extra["assign"]["fast_mode"] = {"kernel_ms": round(device.assign.last_ms, 3), "snps_per_s": m_total / (device.assign.last_ms * 1e-3),
-                                            "max_rel_dev_of_sums_vs_exact": dev_rel, "within_1e-6": bool(dev_rel < 1e-6)}
+                           "kernel": "score_sweep_kernel<%s> + block_prefix_kernel (one launch over all population slabs; float32 matrix)" % args.mode,
+                           "bound": "valu_fp64_issue", "checksum": float(np.sum(out))}
         if pmc.get("assign_valu_busy_frac") is not None and pmc.get("assign_insts_valu"):
             # bound: FP64 vector issue (one double log per term), not HBM.  valu_frac = SQ_ACTIVE_INST_VALU * 4 /
             # (1024 SIMDs * GRBM_GUI_ACTIVE / 8) from the committed rocprofv3 PMC pass of this workload
-            extra["assign"].update({"bound": "valu_issue (+ LDS table reads)" if coded_score else "valu_fp64_issue", "valu_frac": round(pmc["assign_valu_busy_frac"], 4),
+            extra["assign"].update({"valu_frac": round(pmc["assign_valu_busy_frac"], 4),
                                     "valu_insts_per_term": round(pmc["assign_insts_valu"] * 64.0 / (float(m) * n * K), 2),
                                     "traffic": pmc.get("assign_traffic"), "pmc_source": pmc.get("source")})
+        if codes_on:
+            # through the class codes: the second call is the steady state; a cold call (codes built inside it) is
+            # extra.coded.pop_like_cold on a matrix whose codes were dropped
+            o1, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
+            o1, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
+            info = beagle.codes_info()
+            extra["assign"]["coded"] = {"available": info["available"], "kernel": "score_coded_kernel<%s> (per-class value table in LDS)" % args.mode,
+                                        "kernel_ms": round(device.assign.last_ms, 3), "snps_per_s_steady_state": m_total / (device.assign.last_ms * 1e-3) / 1.0 if device.assign.last_ms > 0 else None,
+                                        "identical_sums": bool(o1.tobytes() == out.tobytes()), "codes_build_ms_once_per_matrix": round(info["build_ms"], 1)}
+        if args.mode == "exact":
+            # the float32 scoring sweep (WGSASSIGN_MODE=fast), validated against exact on this very matrix
+            os.environ["WGSASSIGN_CODES"] = "0"
+            out_f, _ = device.assign(beagle, afs, mode=MODE_FAST, comm=comm if use_dist else None)
+            if user_codes is None:
+                os.environ.pop("WGSASSIGN_CODES")
+            else:
+                os.environ["WGSASSIGN_CODES"] = user_codes
+            dev_rel = float(np.max(np.abs(out_f - out) / np.abs(out)))
+            extra["assign"]["fast_mode"] = {"kernel_ms": round(device.assign.last_ms, 3), "snps_per_s": m_total / (device.assign.last_ms * 1e-3),
+                                            "max_rel_dev_of_sums_vs_exact": dev_rel, "within_1e-6": bool(dev_rel < 1e-6)}
+        if codes_on and not use_dist and "coded" in extra:
+            # --get_pop_like alone on a fresh matrix: the codes are built inside the call
+            beagle.synth(SEED, 2.0)
+            ctx.sync()
+            t0 = time.perf_counter()
+            o2, _ = device.assign(beagle, afs, mode=mode)
+            dt = time.perf_counter() - t0
+            info = beagle.codes_info()
+            extra["coded"]["pop_like_cold"] = {"seconds": round(dt, 4), "of_which_codes_build_ms": round(info["build_ms"], 1), "alloc_ms": round(info["alloc_ms"], 1),
+                                               "seconds_direct_sweep": round(t_as, 4), "identical_sums": bool(o2.tobytes() == out.tobytes()),
+                                               "note": "one call on a matrix without codes: sample pass + allocation + encode pass + coded sweep"}
         afs.close()
 
     cpu = None
@@ -425,6 +430,63 @@ def main():
             dist.destroy_process_group()
 
 
+def coded_em_leg(ctx, device, beagle, em_direct, K, per, n, m, mode, args):
+    """extra.coded: the EM fit through the class codes (csrc/codes.hip: one byte per (SNP, individual) + per-slab dictionaries, built
+    by one pass over the matrix; same frequencies bit for bit) with everything it costs: the COLD fit -- --get_reference_af as the
+    command line runs it: one fit per matrix, the codes built inside wgs_em_fit when its cost model expects them to pay -- beside
+    the same fit over the float32 slabs and the warm fit; the steady-state sweep with ITS algorithmic bytes."""
+    def fit(label):
+        e = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
+        t0 = time.perf_counter()
+        iters = e.run(200, 1e-4)
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        st = e.fit_stats()
+        return e, {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "sweep_kernels_ms": round(st[3], 2)}
+
+    res = {}
+    e_cold, res["fit_cold"] = fit("cold")                    # nothing built yet: the cost model decides inside wgs_em_fit
+    built_by_fit = beagle.codes_state() == 1
+    res["fit_cold"]["codes_built_inside_the_fit"] = built_by_fit
+    info = beagle.codes_info() if built_by_fit else None
+    e_warm, res["fit_warm"] = fit("warm")
+    os.environ["WGSASSIGN_CODES"] = "0"
+    e_dir, res["fit_direct"] = fit("direct")
+    os.environ.pop("WGSASSIGN_CODES")
+    same = all(e_cold.get_f(k).tobytes() == e_dir.get_f(k).tobytes() for k in (0, K - 1))
+    res["identical_frequencies"] = bool(same and res["fit_cold"]["iterations"] == res["fit_direct"]["iterations"])
+    for e in (e_cold, e_warm, e_dir):
+        e.close()
+    if info is None:
+        res["note"] = "the cost model (csrc/api.hip: em_codes_pay) kept the float32 slabs for this fit"
+        return res, {"available": False}
+    res["fit_cold"]["of_which_codes_build_ms"] = round(info["build_ms"], 1)
+    # steady state: exactly `steps` coded sweeps
+    e = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
+    e.fit(max(1, args.warmup), 0.0)
+    e.fit(args.steps, 0.0)
+    ck = e.fit_stats()[3] / args.steps * 1e-3
+    e.close()
+    its = float(np.mean(res["fit_cold"]["iterations"])) or 15.0
+    # what the coded sweep must read and write per SNP: a code byte per individual, the (g0, g1) of every class present in every
+    # slab (8 bytes each; the sample pass's mean), f in and out -- its own algorithmic bytes, not the float32 matrix's
+    alg = (float(n) + 8.0 * K * info["sample_mean_classes_per_slab"] + 8.0 * K) * m
+    res["steady_state_sweep"] = {"kernel": "em_coded_kernel", "kernel_ms_avg": round(ck * 1e3, 4), "snp_updates_per_s": K * float(m) / ck,
+                                 "algorithmic_bytes_per_launch": alg, "bytes_per_snp": alg / m, "hbm_frac_of_its_own_bytes": round(alg / ck / HBM_PEAK, 4),
+                                 "speedup_over_float32_sweep": None}
+    res["amortised_ms_per_iteration"] = {"iterations": its, "coded": round((info["build_ms"] + its * ck * 1e3) / its, 3),
+                                         "note": "(codes build + iterations x coded sweep) / iterations of the one fit --get_reference_af performs"}
+    res["class_codes"] = {"bytes": info["bytes"], "build_ms": round(info["build_ms"], 1), "encode_kernel_ms": round(info["encode_kernel_ms"], 1),
+                          "sample_ms": round(info["sample_ms"], 2), "alloc_ms": round(info["alloc_ms"], 2),
+                          "encode_hbm_frac": round(8.0 * n * m / (info["encode_kernel_ms"] * 1e-3) / HBM_PEAK, 4) if info["encode_kernel_ms"] > 0 else None,
+                          "mean_classes_per_snp": round(info["mean_classes"], 2), "max_classes_per_snp": info["max_classes"],
+                          "mean_classes_per_slab_and_snp": round(info["sample_mean_classes_per_slab"], 2), "hash_slots_per_snp": info["hash_slots"],
+                          "uncoded_snp_share": info["rich_snp_share"], "em_table_rows": info["em_table_rows"],
+                          "em_direct_tile_share": round(info["em_direct_tile_share"], 5), "slab_numbering_bytes": info["slab_numbering_bytes"],
+                          "probe_rounds_per_16_lookups": round(info["probe_rounds_per_buffer"], 2)}
+    return res, info
+
+
 FP64_ISSUE_CLOCK_GHZ = 2.4      # MI355X peak engine clock: issue fractions below are lower bounds of the busy share
 WAVE_ISSUE_PER_S = 1024 * FP64_ISSUE_CLOCK_GHZ * 1e9 / 4.0       # 1024 SIMDs, 4 cycles per wave-wide FP64-rate instruction
 # VALU wave-instructions per (SNP, individual[, population]) term of the FP64-issue-bound kernels, from the committed PMC
@@ -436,61 +498,105 @@ INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "score_sweep_kernel<exac
 def whole_paths(ctx, device, mode_name):
     """extra.paths: every other BASELINE.json configuration and the reference README's --loo shape (README.md:129-131:
     "30 min" at ~5M SNPs x 180 individuals) as WHOLE paths on device-generated data -- all kernel launches, readbacks,
-    exact chains and collectives-of-one included, file parsing excluded -- each with the roof that bounds its
-    dominant kernel: `hbm` (fraction of 8 TB/s the sweeps' algorithmic bytes / kernel time reach) or `valu_fp64_issue`
-    (wave-instructions of the committed PMC pass x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time): a lower bound
-    of the busy share, the chip clocks lower under FP64 load)."""
+    exact chains and collectives-of-one included, file parsing excluded.  Every fit and every --get_pop_like is timed COLD
+    (`seconds_cold`: a matrix nothing has been built for, as the command line meets it -- the class codes, when the cost
+    model of csrc/api.hip wants them, are built inside the timed call), WARM (`seconds_warm`: codes present) and over the
+    float32 slabs (`seconds_float32`: WGSASSIGN_CODES=0, the round-2 path).  Roofs of the dominant kernel: `hbm` (fraction of
+    8 TB/s the sweeps' algorithmic bytes / kernel time reach) or `valu_fp64_issue` (wave-instructions of the committed PMC pass
+    x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time): a lower bound of the busy share, the chip clocks lower under FP64 load)."""
     from wgsassign_amd import glassy
-    out = {"mode": mode_name, "note": "seconds = wall clock of the whole call(s) on one MI355X, matrix (and its class codes) resident in HBM"}
-    codes_note = [None]
+    out = {"mode": mode_name, "note": "seconds = wall clock of the whole call(s) on one MI355X, matrix resident in HBM; cold = nothing built for the "
+                                      "matrix before the call, warm = class codes present, float32 = WGSASSIGN_CODES=0"}
+
+    class codes_off:
+        def __enter__(self):
+            self.old = os.environ.get("WGSASSIGN_CODES")
+            os.environ["WGSASSIGN_CODES"] = "0"
+
+        def __exit__(self, *exc):
+            if self.old is None:
+                os.environ.pop("WGSASSIGN_CODES")
+            else:
+                os.environ["WGSASSIGN_CODES"] = self.old
 
     def matrix(m, n, K):
         group_of = np.minimum(np.arange(n) // (n // K), K - 1).astype(np.int32)
         b = device.DeviceBeagle(m, n, group_of, K, ctx=ctx)
         b.synth(SEED, 2.0)
         ctx.sync()
-        # the class codes belong to the resident matrix like its slab layout (built once, on first use; a run from a
-        # file builds them while the host is still inflating): outside the timed calls, reported per configuration
-        b.prepare_codes(em=int(min(np.bincount(group_of, minlength=K))) >= 28)
-        info = b.codes_info()
-        codes_note[0] = {"available": info["available"], "build_ms": round(info["build_ms"], 1), "bytes": info["bytes"],
-                         "mean_classes_per_snp": round(info["mean_classes"], 2), "slab_numbering_ms": round(info["slab_numbering_ms"], 1),
-                         "slab_numbering_bytes": info["slab_numbering_bytes"], "em_table_rows": info["em_table_rows"],
-                         "em_direct_tile_share": round(info["em_direct_tile_share"], 5)}
         return b, group_of, np.bincount(group_of, minlength=K)
 
-    def fit(b, K, counts):
+    def codes_note(b):
+        if b.codes_state() != 1:
+            return {"available": False}
+        info = b.codes_info()
+        return {"available": True, "build_ms": round(info["build_ms"], 2), "encode_kernel_ms": round(info["encode_kernel_ms"], 2), "alloc_ms": round(info["alloc_ms"], 2),
+                "bytes": info["bytes"], "mean_classes_per_snp": round(info["mean_classes"], 2), "em_table_rows": info["em_table_rows"],
+                "em_direct_tile_share": round(info["em_direct_tile_share"], 5), "uncoded_snp_share": info["rich_snp_share"], "hash_slots_per_snp": info["hash_slots"]}
+
+    def one_fit(b, K):
         t0 = time.perf_counter()
         em = device.EMBatch(b, np.arange(K, dtype=np.int32))
         iters = em.run(200, 1e-4)
         ctx.sync()
-        dt = time.perf_counter() - t0
-        st = em.fit_stats()                 # iterations enqueued, chain batches, seconds in wgs_em_fit, sweep kernels ms
+        return em, time.perf_counter() - t0, iters, em.fit_stats()
+
+    def fit(b, K, counts):
+        """--get_reference_af: cold, warm, float32"""
+        em, dt, iters, st = one_fit(b, K)
+        built = b.codes_state() == 1
         alg = float(np.sum([(8.0 * counts[k] + 8.0) * b.m * iters[k] for k in range(K)]))
-        coded = b.codes_info()["available"] and int(min(counts)) >= 28
-        res = {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
-               "sweep_kernel": "em_coded_kernel (class codes; hbm_frac counts the float32 matrix's algorithmic bytes and may exceed 1)" if coded
-               else "em_sweep_kernel<exact>",
-               "sweep_kernels_ms": round(st[3], 3), "bound": "hbm",
-               "hbm_frac_of_sweeps": round(alg / (st[3] * 1e-3) / HBM_PEAK, 4) if st[3] > 0 else None,
-               "snp_updates_per_s": float(b.m) * float(np.sum(iters)) / dt}
+        res = {"seconds_cold": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
+               "codes_built_inside_the_cold_fit": built, "cold_sweep_kernels_ms": round(st[3], 3), "class_codes": codes_note(b)}
+        em2, dt2, it2, st2 = one_fit(b, K)
+        res["seconds_warm"] = round(dt2, 4)
+        res["warm_sweep_kernel"] = "em_coded_kernel" if built else "em_sweep_kernel<exact>"
+        res["warm_sweep_kernels_ms"] = round(st2[3], 3)
+        em2.close()
+        with codes_off():
+            em3, dt3, it3, st3 = one_fit(b, K)
+        res["seconds_float32"] = round(dt3, 4)
+        res["float32_sweep_kernels_ms"] = round(st3[3], 3)
+        res["bound"] = "hbm"
+        res["hbm_frac_of_float32_sweeps"] = round(alg / (st3[3] * 1e-3) / HBM_PEAK, 4) if st3[3] > 0 else None
+        res["identical_frequencies"] = bool(list(it3) == list(iters) and em3.get_f(0).tobytes() == em.get_f(0).tobytes())
+        res["snp_updates_per_s_cold"] = float(b.m) * float(np.sum(iters)) / dt
+        em3.close()
         return em, res
 
     def pop_like(b, em, K, counts):
+        """--get_pop_like after the fit (the codes are there if the fit built them), over the float32 slabs, and alone on a
+        fresh matrix (cold)"""
         afs = device.AFSet(b.m, K, ctx=ctx)
         for k in range(K):
             em.clamp(k, int(counts[k]))
             afs.set_column_from_em(k, em, k)
         ctx.sync()
+        had = b.codes_state() == 1
         t0 = time.perf_counter()
         o, _ = device.assign(b, afs)
         dt = time.perf_counter() - t0
-        ms = device.assign.last_ms
         terms = float(b.m) * b.n * K
-        kern = "score_coded_kernel<exact>" if b.codes_info()["available"] else "score_sweep_kernel<exact>"
-        res = {"seconds": round(dt, 4), "kernel": kern, "kernel_ms": round(ms, 3), "snps_per_s": b.m / dt, "bound": "valu_fp64_issue",
-               "fp64_issue_frac": round(terms * INSTS_PER_TERM[kern] / 64.0 / WAVE_ISSUE_PER_S / (ms * 1e-3), 4),
-               "hbm_frac": round((8.0 * b.n + 4.0 * K) * b.m / (ms * 1e-3) / HBM_PEAK, 4), "checksum": float(np.sum(o))}
+        coded = b.codes_state() == 1
+        kern = "score_coded_kernel<exact>" if coded else "score_sweep_kernel<exact>"
+        res = {"seconds_after_the_fit": round(dt, 4), "codes_present_before_the_call": had, "kernel": kern}
+        o, _ = device.assign(b, afs)
+        ms = device.assign.last_ms
+        res.update({"kernel_ms_warm": round(ms, 3), "snps_per_s_warm": b.m / (ms * 1e-3), "bound": "valu_issue (+ LDS table reads)" if coded else "valu_fp64_issue",
+                    "fp64_issue_frac": round(terms * INSTS_PER_TERM[kern] / 64.0 / WAVE_ISSUE_PER_S / (ms * 1e-3), 4), "checksum": float(np.sum(o))})
+        with codes_off():
+            t0 = time.perf_counter()
+            od, _ = device.assign(b, afs)
+            res["seconds_float32"] = round(time.perf_counter() - t0, 4)
+            res["float32_kernel_ms"] = round(device.assign.last_ms, 3)
+            res["float32_hbm_frac"] = round((8.0 * b.n + 4.0 * K) * b.m / (device.assign.last_ms * 1e-3) / HBM_PEAK, 4)
+        b.synth(SEED, 2.0)                       # the same matrix again, nothing built for it
+        ctx.sync()
+        t0 = time.perf_counter()
+        oc, _ = device.assign(b, afs)
+        res["seconds_cold"] = round(time.perf_counter() - t0, 4)
+        res["class_codes_cold"] = codes_note(b)
+        res["identical_sums"] = bool(od.tobytes() == o.tobytes() == oc.tobytes())
         af = afs.to_host()
         afs.close()
         return af, res
@@ -508,6 +614,7 @@ def whole_paths(ctx, device, mode_name):
                 "partition_chain_seconds": round(tm.get("chain_seconds", 0.0), 4), "em_sweep_kernels_ms": round(kms, 2),
                 "em_batches": tm.get("em_batches"), "iterations_min_max": [int(it.min()), int(it.max())], "bound": "valu_fp64_issue",
                 "fp64_issue_frac_of_em_sweeps": round(terms * INSTS_PER_TERM["em_sweep_group_kernel<exact>"] / 64.0 / WAVE_ISSUE_PER_S / (kms * 1e-3), 4) if kms > 0 else None,
+                "note": "leave-one-out re-fits share slabs and score through per-individual columns: the float32 slabs, no class codes",
                 "self_assignment_accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of)),
                 "checksum": float(np.sum(ll.astype(np.float64))), "partitions_checksum": float(np.sum(parts.astype(np.float64))) if P > 1 else None}
 
@@ -516,10 +623,6 @@ def whole_paths(ctx, device, mode_name):
     b, g, c = matrix(1_000_000, 200, 5)
     em, r = fit(b, 5, c)
     em.close()
-    em2, r2 = fit(b, 5, c)                       # second run: allocations and code objects warm
-    em2.close()
-    r["seconds_second_run"] = r2["seconds"]
-    r["class_codes"] = codes_note[0]
     out["config2_1Mx200_K5_get_reference_af"] = r
     b.close()
     # BASELINE configs[3]: 2M x 500, K=8, --get_reference_af --loo --partition_sites 3 (+ --get_pop_like)
@@ -527,29 +630,57 @@ def whole_paths(ctx, device, mode_name):
     em, r = fit(b, 8, c)
     af, rp = pop_like(b, em, 8, c)
     em.close()
-    out["config4_2Mx500_K8"] = {"get_reference_af": r, "get_pop_like": rp, "loo_partition_sites_3": loo(b, g, c, af, 3), "class_codes": codes_note[0]}
+    out["config4_2Mx500_K8"] = {"get_reference_af": r, "get_pop_like": rp, "loo_partition_sites_3": loo(b, g, c, af, 3)}
     b.close()
     # the reference README's timing claim (README.md:129-131): --loo at ~5M SNPs x 180 individuals, "30 min"
     b, g, c = matrix(5_000_000, 180, 5)
     em, r = fit(b, 5, c)
     af, rp = pop_like(b, em, 5, c)
     em.close()
-    out["readme_5Mx180_K5"] = {"get_reference_af": r, "loo": loo(b, g, c, af, 1), "reference_readme_claim": "30 min (hardware and threads not stated)",
-                               "class_codes": codes_note[0]}
+    out["readme_5Mx180_K5"] = {"get_reference_af": r, "loo": loo(b, g, c, af, 1), "reference_readme_claim": "30 min (hardware and threads not stated)"}
     b.close()
     # BASELINE configs[4]: one GPU's shard of 50M x 2000, K=20 on 8 GPUs = 6.25M SNPs (100 GB of genotype likelihoods)
     b, g, c = matrix(6_250_000, 2000, 20)
     em, r = fit(b, 20, c)
     af, rp = pop_like(b, em, 20, c)
     em.close()
-    out["config5_shard_6.25Mx2000_K20"] = {"get_reference_af": r, "get_pop_like": rp, "gl_bytes": b.nbytes(), "class_codes": codes_note[0]}
+    out["config5_shard_6.25Mx2000_K20"] = {"get_reference_af": r, "get_pop_like": rp, "gl_bytes": b.nbytes()}
     b.close()
+    # quality-dependent likelihoods (every read its own error rate, four base-quality bins as current instruments write them):
+    # 80-100 classes per SNP among 1000 individuals instead of 27 -- what real ANGSD files look like to the class codes
+    out["realistic_gl_2Mx1000_K10"] = realistic_gl(ctx, device, fit, pop_like)
     # BASELINE configs[4], the streamed reader: a BGZF Beagle file of n = 2000 individuals (tools/beagle_files.py: simulated
     # 2x data, whole lines per member) from the page cache into a resident matrix -- compressed members H2D, inflate, line
     # listing and tokeniser on the device (csrc/inflate.hip, csrc/ingest.hip); and the same with the host inflating
     out["config5_streamed_ingest_100kx2000"] = ingest_path(ctx, device, 2000, 100_000, 20)
     out["seconds_total"] = round(time.perf_counter() - t_all, 2)
     return out
+
+
+def realistic_gl(ctx, device, fit, pop_like, m=2_000_000, n=1000, K=10):
+    """Class codes on likelihoods computed from per-read base qualities (wgs_beagle_synth_quality; Q in {12, 23, 37} with
+    probabilities 3 / 12 / 85 %): the encoder's larger hash tables, fewer SNPs per table of the coded scoring sweep, SNPs and
+    tiles beyond the tables taken from the float32 slabs.  --get_reference_af and --get_pop_like cold / warm / float32."""
+    group_of = np.minimum(np.arange(n) // (n // K), K - 1).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    b = device.DeviceBeagle(m, n, group_of, K, ctx=ctx)
+    b.synth_quality(SEED, 2.0)
+    ctx.sync()
+    synth_orig = b.synth
+    b.synth = lambda seed, depth=2.0: b.synth_quality(seed, depth)      # (pop_like re-generates the matrix for its cold call)
+    em, r = fit(b, K, counts)
+    af, rp = pop_like(b, em, K, counts)
+    em.close()
+    b.synth = synth_orig
+    info = b.codes_info()
+    res = {"generator": "per-read qualities 12/23/37 (3/12/85 %), depth Poisson(2), likelihoods rounded to 6 decimals",
+           "get_reference_af": r, "get_pop_like": rp,
+           "classes_per_snp_mean_max": [round(info["mean_classes"], 1), info["max_classes"]] if info["available"] else None,
+           "classes_per_slab_and_snp_mean": round(info["sample_mean_classes_per_slab"], 1) if info["available"] else None,
+           "hash_slots_per_snp": info.get("hash_slots"), "snps_per_scoring_table": info.get("score_batch_snps"),
+           "uncoded_snp_share": info.get("rich_snp_share"), "em_table_rows": info.get("em_table_rows"), "em_direct_tile_share": info.get("em_direct_tile_share")}
+    b.close()
+    return res
 
 
 def ingest_path(ctx, device, n, m, K):

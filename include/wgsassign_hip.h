@@ -41,6 +41,11 @@ typedef struct wgs_em wgs_em;         /* a batch of EM fits over one wgs_beagle 
 
 /* ------------------------------------------------------------------ context */
 const char *wgs_last_error(void);
+/* ABI version of this header (WGS_ABI_VERSION).  2 (round 4): wgs_assign lost its `P` / `parts` arguments and
+ * wgs_fisher_obs_ind was removed in round 3 while the number stayed 1 -- a caller built against the older header must
+ * compare wgs_version() with the WGS_ABI_VERSION it was compiled with and refuse to run on a mismatch (the ctypes shim does:
+ * wgsassign_amd/_lib.py); wgs_beagle_codes_info fills 20 entries; wgs_comm_info is new. */
+#define WGS_ABI_VERSION 2
 int wgs_version(void);
 /* sha256[:16] over every source of the library / over the sources of the EM and scoring kernels (em_kernels.hip,
  * assign_kernels.hip, common.h, log_table.h), fixed at build time: profiles record them, bench.py quotes hardware
@@ -93,18 +98,30 @@ int wgs_beagle_download_rows(wgs_beagle *b, float *L_rows, int64_t row0, int64_t
  * Philox-4x32-10 counter RNG keyed by (seed, global SNP, individual), HWE genotypes from
  * per-group frequencies, Poisson(depth) reads, error 0.01, GLs rounded to 6 decimals). */
 int wgs_beagle_synth(wgs_beagle *b, uint64_t seed, double depth);
+/* The same with QUALITY-DEPENDENT likelihoods, as ANGSD's -GL 2 writes them for real reads: every read draws its base quality
+ * from n_bins bins (Phred values quals[], probabilities probs[]; n_bins <= 8) and enters with its own error rate -- 80-100
+ * distinct (g0, g1) per SNP among 1000 individuals with the four bins of current instruments instead of the 27 of the fixed
+ * error of wgs_beagle_synth (bench.py: extra.realistic_gl; the NumPy twin of the model is tests/synth.py: make_beagle_quality). */
+int wgs_beagle_synth_quality(wgs_beagle *b, uint64_t seed, double depth, int32_t n_bins, const double *quals, const double *probs);
 int64_t wgs_beagle_bytes(const wgs_beagle *b);
 /* Class codes of the matrix: low-depth genotype likelihoods take few distinct (g0, g1) values per SNP (29 on average in
- * the bundled 85-individual data, 27 among 1000 individuals of the 2x synthetic matrices), so the kernels evaluate the
- * EM term's quotient / the per-site log-likelihood once per CLASS and SNP and look it up per individual -- same
- * values, same order of accumulation, same bits.  Built on first use (one byte per (SNP, individual) + a dictionary;
- * WGSASSIGN_CODES=0 disables them); a matrix with more than 64 classes in some SNP is not coded and takes the direct
- * kernels.  info[0..9] = available, classes of the richest SNP, bytes held, build milliseconds (allocations included),
- * mean classes per SNP, milliseconds of the encode kernel alone, milliseconds and bytes of the slabs' own class numbering
- * (one more byte per (SNP, individual) + a dictionary per population slab, built by the first EM sweep through the codes), the
- * rows of that sweep's quotient table, the share of (slab, tile) pairs with more classes than rows (swept directly). */
+ * the bundled 85-individual data, 27 among 1000 individuals of the 2x synthetic matrices, ~80 with binned base qualities), so
+ * the kernels evaluate the EM term's quotient / the per-site log-likelihood once per CLASS and SNP and look it up per
+ * individual -- same values, same order of accumulation, same bits.  Built by ONE pass over the matrix when a sweep that
+ * profits asks for them (a scoring sweep with shared columns; an EM fit with enough iterations ahead): one byte per (SNP,
+ * individual) + a dictionary, and the same again in every population slab's own numbering (csrc/codes.hip).
+ * WGSASSIGN_CODES=0 disables them.  A SNP with more classes than the tables hold is left uncoded and taken from the
+ * float32 slab by every sweep (nothing matrix-wide depends on it); a matrix whose typical SNP has that many is not coded.
+ * info[0..19] = available, classes of the richest coded SNP, bytes held, build milliseconds (sample pass, allocation and
+ * encode pass), mean classes per coded SNP, milliseconds of the encode pass alone, of the sample pass, bytes of the slabs' own
+ * numbering, rows of the coded EM sweep's quotient table, share of (slab, tile) pairs with more classes than rows (swept
+ * directly), hash slots per SNP of the encoder (64 / 128 / 256), share of SNPs left uncoded, dictionary rows per tile, hash
+ * probe rounds beyond the first per 16 lookups, milliseconds of the allocation, rows of the coded scoring sweep's table, mean classes
+ * per SNP and per (population slab, SNP) in the sample pass, SNPs per table of the coded scoring sweep, [19] reserved. */
 int wgs_beagle_codes_info(wgs_beagle *b, double *info);
-/* Builds the codes now rather than at first use; em != 0: also the slabs' own class numbering of the coded EM sweep. */
+/* 1: the codes exist, 0: nothing has asked for them yet, -1: the matrix was found not worth coding (or no memory).  Builds nothing. */
+int wgs_beagle_codes_state(wgs_beagle *b);
+/* Builds the codes now rather than at the first sweep that asks.  (`em` is ignored since version 2: one pass builds all.) */
 int wgs_beagle_codes_prepare(wgs_beagle *b, int em);
 
 /* A batch of EM fits (emMAF.py:15-27) over slabs of `b`.  Fit j estimates the frequency of

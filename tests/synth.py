@@ -82,6 +82,61 @@ def make_beagle_for_labels(m, labels, K, seed=SEED, depth=2.0):
     return np.ascontiguousarray(L), IDs
 
 
+# Base-quality bins of a current Illumina instrument (RTA3 bins qualities to four values; share of bases per bin as in a
+# typical 2 x 150 run) -- the per-read error rates of make_beagle_quality below.
+QUAL_BINS = ((12, 23, 37), (0.03, 0.12, 0.85))
+
+
+def make_beagle_quality(m, n, K, seed=SEED, depth=2.0, quals=QUAL_BINS, dmax=15, labels=None):
+    """Like make_beagle, with QUALITY-DEPENDENT genotype likelihoods -- what ANGSD's -GL 2 (GATK model) writes for real
+    reads: every read has its own error rate e = 10^(-Q/10), Q drawn per read (quals = (values, probabilities), or
+    (lo, hi) for a uniform integer quality), P(base | genotype) = 1-e / e/3 for the homozygotes and their mean for the
+    heterozygote, likelihoods multiplied over the reads, normalised, rounded to 6 decimals.  The fixed e = 0.01 of
+    make_beagle gives ~27 distinct (g0, g1) pairs per SNP among 1000 individuals; binned qualities give ~80 (the bundled
+    85-individual AMRE file has 29 on average, this model 26 at n = 85), a uniform Q20-40 draw ~530.
+    Returns (L float32 (m, 2n), IDs (n, 2) str)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919 * m + 104729 * n + K + 17))
+    p_anc = rng.beta(0.8, 0.8, size=m)
+    p_pop = np.clip(p_anc[:, None] + rng.normal(0.0, 0.08, size=(m, K)), 0.01, 0.99)
+    if labels is None:
+        IDs = pop_labels(n, K)
+        pops = np.unique(IDs[:, 1])
+        pop_of = np.searchsorted(pops, IDs[:, 1])
+    else:
+        pop_of = np.asarray(labels)
+        IDs = np.array([["Ind%d" % i, "pop%02d" % pop_of[i]] for i in range(n)], dtype=str)
+    L = np.empty((m, 2 * n), dtype=np.float32)
+    step = max(1, 4_000_000 // max(1, n * dmax))              # rows per slice: the (rows, n, dmax) temporaries stay small
+    for r0 in range(0, m, step):
+        r1 = min(m, r0 + step)
+        geno = rng.binomial(2, p_pop[r0:r1][:, pop_of])
+        d = np.minimum(rng.poisson(depth, size=geno.shape), dmax)
+        shape = geno.shape + (dmax,)
+        if np.isscalar(quals[0]):
+            Q = rng.integers(quals[0], quals[1] + 1, size=shape)
+        else:
+            Q = rng.choice(np.asarray(quals[0]), p=np.asarray(quals[1], dtype=float), size=shape)
+        e = 10.0 ** (-Q / 10.0)
+        is_alt = (rng.random(shape) < geno[:, :, None] * 0.5) ^ (rng.random(shape) < e)
+        live = np.arange(dmax)[None, None, :] < d[:, :, None]
+        pm, px = 1.0 - e, e / 3.0
+        l0 = np.where(live, np.where(is_alt, px, pm), 1.0).prod(axis=2)
+        l1 = np.where(live, 0.5 * pm + 0.5 * px, 1.0).prod(axis=2)
+        l2 = np.where(live, np.where(is_alt, pm, px), 1.0).prod(axis=2)
+        tot = l0 + l1 + l2
+        L[r0:r1, 0::2] = np.round(l0 / tot, 6)
+        L[r0:r1, 1::2] = np.round(l1 / tot, 6)
+    return np.ascontiguousarray(L), IDs
+
+
+def classes_per_snp(L):
+    """Distinct (g0, g1) bit patterns per row of an (m, 2n) float32 matrix."""
+    L = np.ascontiguousarray(L, dtype=np.float32)
+    key = (L[:, 0::2].view(np.uint32).astype(np.uint64) << np.uint64(32)) | L[:, 1::2].view(np.uint32)
+    key.sort(axis=1)
+    return 1 + (key[:, 1:] != key[:, :-1]).sum(axis=1)
+
+
 def digest(a):
     """sha256[:16] of the array bytes (same convention as BASELINE.md section 2)."""
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()[:16]

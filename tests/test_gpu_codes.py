@@ -1,6 +1,8 @@
 """The kernels that go through the class codes (csrc/common.h: wgs_codes -- per-SNP dictionaries of the distinct (g0, g1)
-pairs, one byte per (SNP, individual)) against the direct kernels and the oracle: the same bits everywhere, for matrices
-that can be coded, and an unnoticed fall-back to the direct kernels for matrices that cannot."""
+pairs, one byte per (SNP, individual)) against the direct kernels and the oracle: the same bits everywhere -- for every
+geometry of the encoder's hash tables, for quality-dependent likelihoods with many classes per SNP, for SNPs and tiles
+with more classes than the tables hold (taken from the float32 slabs, SNP by SNP / tile by tile), and an unnoticed
+fall-back to the direct kernels for matrices that are not worth coding."""
 import os
 
 import numpy as np
@@ -64,12 +66,16 @@ def fit_and_score(dev, b, K, counts, mode=None):
     return [int(x) for x in iters], np.stack(cols, axis=1), out
 
 
-@pytest.mark.parametrize("m,n,K", [(1, 3, 1), (63, 9, 2), (4097, 37, 4), (20_011, 61, 5), (70_003, 103, 7), (300_017, 64, 10), (40_000, 130, 13),
-                                   (9_000, 257, 20), (20_000, 230, 3), (6_000, 499, 4)])
-def test_coded_kernels_equal_direct_kernels_and_oracle(dev, oracle, m, n, K, monkeypatch):
+@pytest.mark.parametrize("m,n,K,slots", [(1, 3, 1, 64), (63, 9, 2, 128), (4097, 37, 4, 256), (20_011, 61, 5, 64), (70_003, 103, 7, 128), (300_017, 64, 10, 64),
+                                         (40_000, 130, 13, 256), (9_000, 257, 20, 64), (20_000, 230, 3, 128), (6_000, 499, 4, 256), (6_000, 499, 4, 0)])
+def test_coded_kernels_equal_direct_kernels_and_oracle(dev, oracle, m, n, K, slots, monkeypatch):
     """EM fit (all populations to convergence) and the n x K sums, through the codes and directly: identical iteration
     counts, frequencies and float64 sums; odd sizes, quads that straddle the end of a slab, short matrices (blocks split
-    over several workgroups), K beyond one register batch."""
+    over several workgroups), K beyond one register batch; every geometry of the encoder (64 / 128 / 256 hash slots per SNP =
+    64 / 32 / 16 SNPs per wavefront; 0: its own choice)."""
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")       # the EM fit asks for the codes from its first sweep
+    if slots:
+        monkeypatch.setenv("WGSASSIGN_CODES_TABLE", str(slots))    # (also codes matrices too small to be worth it)
     if n < 200:
         monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")      # populations below 28 individuals through the coded EM sweep too
     rng = np.random.default_rng(m + n)
@@ -85,6 +91,7 @@ def test_coded_kernels_equal_direct_kernels_and_oracle(dev, oracle, m, n, K, mon
     with codes(True):
         info = b.codes_info()
         assert info["available"] and 1 <= info["max_classes"] <= 64 and info["mean_classes"] <= info["max_classes"]
+        assert info["rich_snp_share"] == 0 and info["hash_slots"] == (slots or 64) and info["em_table_rows"] > 0
         it1, af1, out1 = fit_and_score(dev, b, K, counts)
         from wgsassign_amd._lib import MODE_FAST
         _, _, fast1 = fit_and_score(dev, b, K, counts, mode=MODE_FAST)
@@ -129,10 +136,13 @@ def test_special_values_through_the_class_table(dev, oracle):
     b.close()
 
 
-def test_matrices_that_cannot_be_coded_take_the_direct_kernels(dev, oracle):
-    """More than 64 distinct (g0, g1) pairs in a SNP (deep coverage: every individual its own likelihoods): no codes, the
-    direct kernels run, the results are the oracle's.  A matrix that becomes codable after its rows are replaced is coded
-    then, and the other way round."""
+def test_matrices_not_worth_coding_take_the_direct_kernels(dev, oracle, monkeypatch):
+    """Deep coverage -- every individual its own likelihoods, as many classes per SNP as individuals: the sample pass says
+    so, no codes are built, the direct kernels run, the results are the oracle's.  A matrix that becomes worth coding after
+    its rows are replaced is coded then; ten deep-coverage rows among the others stay UNCODED rows of a coded matrix
+    (round 3 dropped the whole matrix's codes for one such row) and every result still is the oracle's."""
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")
     m, n, K = 3000, 80, 2
     rng = np.random.default_rng(4)
     g = rng.dirichlet((0.7, 0.7, 0.7), size=(m, n))
@@ -149,18 +159,143 @@ def test_matrices_that_cannot_be_coded_take_the_direct_kernels(dev, oracle):
             _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
         assert it == [int(x) for x in it_o] and same(af, af_o)
         assert same_nan(out.astype(np.float32), oracle.assignLL(L, af_o.copy(), 4))
-        # replace the rows by low-depth data: codable now, and the codes follow the new contents
+        # replace the rows by low-depth data: worth coding now, and the codes follow the new contents
         L2, _ = synth.make_beagle(m, n, K, seed=2)
         b.upload_rows(L2, 0)
-        assert b.codes_info()["available"]
+        info = b.codes_info()
+        assert info["available"] and info["rich_snp_share"] == 0
         it2, af2, out2 = fit_and_score(dev, b, K, np.bincount(group_of))
         with quiet():
             _, af_o2, _, it_o2 = oracle.fit_reference_af(L2, IDs, t=4)
         assert it2 == [int(x) for x in it_o2] and same(af2, af_o2)
         assert same_nan(out2.astype(np.float32), oracle.assignLL(L2, af_o2.copy(), 4))
-        b.upload_rows(L[:10], 5)                                 # ten deep-coverage rows: not codable any more
-        assert not b.codes_info()["available"]
+        # ten deep-coverage rows: ten uncoded SNPs in ONE tile (rows 5..14), everything else stays coded
+        b.upload_rows(L[:10], 5)
+        L3 = L2.copy()
+        L3[5:15] = L[:10]
+        info = b.codes_info()
+        assert info["available"] and abs(info["rich_snp_share"] - 10 / m) < 1e-9 and 0 < info["em_direct_tile_share"] <= 2 / 47
+        it3, af3, out3 = fit_and_score(dev, b, K, np.bincount(group_of))
+        with quiet():
+            _, af_o3, _, it_o3 = oracle.fit_reference_af(L3, IDs, t=4)
+        assert it3 == [int(x) for x in it_o3] and same(af3, af_o3)
+        assert same_nan(out3.astype(np.float32), oracle.assignLL(L3, af_o3.copy(), 4))
     b.close()
+
+
+@pytest.mark.parametrize("m,n,K,quals,coded", [(6_000, 400, 4, synth.QUAL_BINS, True), (3_000, 1000, 10, synth.QUAL_BINS, True),
+                                               (40_000, 200, 5, synth.QUAL_BINS, True), (3_000, 600, 3, (30, 34), False)])
+def test_quality_dependent_likelihoods(dev, oracle, m, n, K, quals, coded, monkeypatch):
+    """Likelihoods as ANGSD writes them for real reads (every read its own error rate, tests/synth.py: make_beagle_quality):
+    40-100 classes per SNP instead of the ~27 of the fixed-error generator -- larger hash tables, 8 or 4 SNPs per table of
+    the coded scoring sweep, some SNPs and tiles beyond the tables.  Same iterations, frequencies and sums as the direct
+    kernels and the oracle.  (The last case, five equally likely qualities: 150 classes among 600 individuals -- the sample
+    pass finds the largest table overflowing and the matrix stays uncoded.)"""
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")
+    L, IDs = synth.make_beagle_quality(m, n, K, seed=5, quals=quals)
+    ncls = synth.classes_per_snp(L)
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    b = dev.DeviceBeagle.from_host(L, group_of, K)
+    with codes(False):
+        it0, af0, out0 = fit_and_score(dev, b, K, counts)
+    with codes(True):
+        info = b.codes_info()
+        assert info["available"] == coded
+        if coded:
+            assert info["hash_slots"] >= (128 if ncls.mean() > 40 else 64)
+            # the dictionary agrees with a NumPy count wherever the SNP was coded
+            assert info["max_classes"] <= ncls.max() and abs(info["mean_classes"] - ncls.mean()) < 0.05 * ncls.mean() + 20 * info["rich_snp_share"]
+        it1, af1, out1 = fit_and_score(dev, b, K, counts)
+    assert it1 == it0 and same(af1, af0) and same_nan(out1, out0)
+    b.close()
+    with quiet():
+        _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+    assert it1 == [int(x) for x in it_o] and same(af1, af_o)
+    with np.errstate(all="ignore"):
+        assert same_nan(out1.astype(np.float32), oracle.assignLL(L, af_o.copy(), 4))
+
+
+def test_snps_beyond_the_tables_are_scored_from_the_slab(dev, oracle, monkeypatch):
+    """A low-depth matrix in which every 250th SNP has as many classes as individuals: those SNPs are left uncoded (ncls = 0)
+    and the coded scoring sweep takes exactly them from the float32 slab, inside the same launch; the EM sweep takes
+    their tiles directly.  The bits of the direct kernels and of the oracle, in both arithmetic modes."""
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")
+    m, n, K = 20_000, 160, 4
+    L, IDs = synth.make_beagle(m, n, K, seed=21)
+    rng = np.random.default_rng(2)
+    deep = np.arange(7, m, 250)
+    g = rng.dirichlet((0.7, 0.7, 0.7), size=(len(deep), n))
+    L[deep, 0::2] = np.round(g[:, :, 0], 6)
+    L[deep, 1::2] = np.round(g[:, :, 1], 6)
+    L[deep[3], 0] = np.float32(np.nan)                          # special values on the direct path of the coded sweep
+    L[deep[4], 2:4] = [0.0, 0.0]
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    b = dev.DeviceBeagle.from_host(L, group_of, K)
+    from wgsassign_amd._lib import MODE_FAST
+    with codes(False):
+        it0, af0, out0 = fit_and_score(dev, b, K, counts)
+        _, _, fast0 = fit_and_score(dev, b, K, counts, mode=MODE_FAST)
+    with codes(True):
+        info = b.codes_info()
+        assert info["available"] and abs(info["rich_snp_share"] - len(deep) / m) < 1e-9
+        it1, af1, out1 = fit_and_score(dev, b, K, counts)
+        _, _, fast1 = fit_and_score(dev, b, K, counts, mode=MODE_FAST)
+    assert it1 == it0 and same(af1, af0) and same_nan(out1, out0) and same_nan(fast1, fast0)
+    b.close()
+    with quiet():
+        _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+    assert it1 == [int(x) for x in it_o] and same_nan(af1, af_o)
+    with np.errstate(all="ignore"):
+        assert same_nan(out1.astype(np.float32), oracle.assignLL(L, af_o.copy(), 4))
+
+
+def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
+    """The cost model of csrc/api.hip: em_codes_pay (a 6.4 GB device-generated matrix, 100 individuals per population: the
+    encode pass costs about four direct sweeps, a coded sweep saves half of one) -- a fit with three iterations ahead sweeps the
+    float32 slabs and builds nothing; a fit with many builds the codes at its first sweep; a step-by-step caller gets them after
+    three direct sweeps; a scoring sweep with shared columns always builds them; a small matrix (fixed costs dominate) never
+    builds them for an EM fit.  Same frequencies either way (the tests above)."""
+    monkeypatch.delenv("WGSASSIGN_EM_CODES_SWEEPS", raising=False)
+    m, n, K = 2_000_000, 400, 4
+    group_of = (np.arange(n) // (n // K)).astype(np.int32)
+
+    def matrix(m=m):
+        b = dev.DeviceBeagle(m, n, group_of, K)
+        b.synth(77, 2.0)
+        return b
+
+    with codes(True):
+        b = matrix()
+        em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+        em.fit(3, 0.0)                                           # three iterations at most: not worth an encode pass
+        assert b.codes_state() == 0
+        em.fit(50, 0.0)                                          # fifty: built at the first sweep
+        assert b.codes_state() == 1
+        em.close()
+        b.close()
+        b = matrix()
+        em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+        for i in range(6):                                       # step by step: direct at first, coded once the run is long
+            em.step()
+            assert (b.codes_state() == 1) == (i >= 3), i
+        em.close()
+        b.close()
+        b = matrix()
+        afs = dev.AFSet.from_host(np.full((m, K), 0.3, dtype=np.float32))
+        dev.assign(b, afs)
+        assert b.codes_state() == 1
+        afs.close()
+        b.close()
+        b = matrix(20_000)                                       # 64 MB: the encode pass's fixed costs exceed what 14 sweeps save
+        em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+        em.fit(200, 0.0)
+        assert b.codes_state() == 0
+        em.close()
+        b.close()
 
 
 def test_row_ranges_and_leave_one_out_are_unchanged(dev, oracle):
@@ -196,10 +331,11 @@ def test_tiles_richer_than_the_quotient_table_are_swept_directly(dev, oracle, mo
     ones (every individual its own likelihoods, but few enough classes to stay codable): same iterations and frequencies as
     the direct kernels and the oracle, with and without a left-out individual."""
     monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")
     m, n, K = 64 * 700 + 5, 90, 2
     L, IDs = synth.make_beagle(m, n, K, seed=12)
     rng = np.random.default_rng(5)
-    rich = rng.choice(m, size=12, replace=False)                # 12 sites in 12 of 701 tiles: the 1 % rule leaves them out
+    rich = rng.choice(m, size=6, replace=False)                 # 6 sites in 6 of 701 tiles: the 1 % rule leaves them out
     vals = np.round(rng.dirichlet((0.7, 0.7, 0.7), size=(len(rich), 30)), 6)      # 30 distinct pairs
     pick = rng.integers(0, 30, size=(len(rich), n))
     for a, s in enumerate(rich):

@@ -46,8 +46,10 @@ SIGNATURES = {
     "wgs_beagle_download_rows": (c_int, [c_vp, c_f32p, c_i64, c_i64]),
     "wgs_beagle_synth": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_double]),
     "wgs_beagle_bytes": (c_i64, [c_vp]),
+    "wgs_beagle_synth_quality": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_double, c_i32, c_f64p, c_f64p]),
     "wgs_beagle_codes_info": (c_int, [c_vp, c_f64p]),
     "wgs_beagle_codes_prepare": (c_int, [c_vp, c_int]),
+    "wgs_beagle_codes_state": (c_int, [c_vp]),
     "wgs_em_create": (c_int, [c_vp, c_i32, c_i32p, c_i32p, c_int, ctypes.POINTER(c_vp)]),
     "wgs_em_destroy": (None, [c_vp]),
     "wgs_em_step": (c_int, [c_vp, c_f64p]),
@@ -132,6 +134,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2      # = WGS_ABI_VERSION of include/wgsassign_hip.h
 
 
 def load():
@@ -149,6 +152,9 @@ def load():
             fn = getattr(lib, name)   # AttributeError if the .so does not export it
             fn.restype = res
             fn.argtypes = args
+        if lib.wgs_version() != ABI_VERSION:      # signatures above are those of include/wgsassign_hip.h's WGS_ABI_VERSION
+            raise RuntimeError("wgsassign_amd: %s has ABI version %d, this shim binds version %d -- rebuild the library "
+                               "(python -m wgsassign_amd.build)" % (LIB_PATH, lib.wgs_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

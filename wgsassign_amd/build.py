@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwgsassign_hip.so")
-SOURCES = ["api.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "ingest.hip", "inflate.hip", "rccl_comm.hip", "reader.cpp"]
+SOURCES = ["api.hip", "codes.hip", "codes_kernels.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "ingest.hip", "inflate.hip", "rccl_comm.hip", "reader.cpp"]
 # -ffp-contract=off: the exact-mode kernels restate the reference's rounding sequence operation by
 # operation; hipcc's default (fast) contraction would fuse a*b+c and change results.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -28,7 +28,7 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-KERNEL_SOURCES = ["em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "common.h", "log_table.h"]   # what the profiled kernels are made of
+KERNEL_SOURCES = ["em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "codes_kernels.hip", "common.h", "log_table.h"]   # what the profiled kernels are made of
 
 
 def source_ids():

@@ -27,7 +27,7 @@ void wgs_set_error(const char *fmt, ...)
 extern "C" {
 
 const char *wgs_last_error(void) { return g_err.c_str(); }
-int wgs_version(void) { return 1; }
+int wgs_version(void) { return WGS_ABI_VERSION; }
 const char *wgs_build_id(void) { return WGS_BUILD_ID; }
 const char *wgs_kernels_id(void) { return WGS_KERNELS_ID; }
 
@@ -129,160 +129,9 @@ int wgs_ctx_info(wgs_ctx *ctx, char *name, int name_len, int *cus, int64_t *mem_
 
 }   // extern "C"
 
-void wgs_beagle_drop_codes(wgs_beagle *b)
-{
-    if (!b) return;
-    if (wgs_codes *c = b->codes) {
-        (void)hipSetDevice(b->ctx->device);
-        (void)hipStreamSynchronize(b->ctx->stream);
-        for (auto &s : c->slabs) {
-            if (s.codes) (void)hipFree(s.codes);
-            if (s.present) (void)hipFree(s.present);
-        }
-        for (auto &l : c->local) {
-            if (l.lcodes) (void)hipFree(l.lcodes);
-            if (l.ldict) (void)hipFree(l.ldict);
-        }
-        if (c->dict) (void)hipFree(c->dict);
-        if (c->ncls) (void)hipFree(c->ncls);
-        if (c->d_slabs) (void)hipFree(c->d_slabs);
-        delete c;
-    }
-    b->codes = nullptr;
-    b->codes_state = 0;
-}
-
-// Builds the class codes on first use (two walks over the matrix: ~3 x its streaming time, once).  Not codable -- a SNP
-// with more than 64 distinct (g0, g1) pairs, or no memory for the codes (an eighth of the matrix + the dictionary) --
-// returns nullptr and the direct kernels run; WGSASSIGN_CODES=0 turns the codes off altogether.
-wgs_codes *wgs_beagle_codes(wgs_beagle *b)
-{
-    if (!b || b->codes_state < 0) return nullptr;
-    if (b->codes_state > 0) {
-        const char *env = getenv("WGSASSIGN_CODES");
-        return env && env[0] == '0' ? nullptr : b->codes;
-    }
-    {
-        const char *env = getenv("WGSASSIGN_CODES");          // read at every use, so one process can compare both paths
-        if (env && env[0] == '0') return nullptr;
-    }
-    b->codes_state = -1;
-    if (hipSetDevice(b->ctx->device) != hipSuccess) return nullptr;
-    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    const size_t rows = (size_t)wgs_ntiles(b->m) * 64;
-    wgs_codes *c = new wgs_codes();
-    b->codes = c;
-    auto fail = [&]() -> wgs_codes * {
-        (void)hipGetLastError();
-        wgs_beagle_drop_codes(b);
-        b->codes_state = -1;
-        return nullptr;
-    };
-    if (hipMalloc(&c->ncls, rows) != hipSuccess) return fail();
-    c->bytes += (int64_t)rows;
-    if (hipMalloc(&c->dict, rows * (size_t)WGS_CODE_ROWS * sizeof(float2)) != hipSuccess) return fail();
-    c->bytes += (int64_t)(rows * (size_t)WGS_CODE_ROWS * sizeof(float2));
-    c->slabs.resize(b->n_groups);
-    int quad0 = 0;
-    for (int g = 0; g < b->n_groups; ++g) {
-        SlabCodes &s = c->slabs[g];
-        s.nquads = (b->slabs[g].ncols + 3) / 4;
-        s.quad0 = quad0;
-        quad0 += s.nquads;
-        if (s.nquads == 0) continue;
-        const size_t words = (size_t)wgs_ntiles(b->m) * s.nquads * 64;
-        if (hipMalloc(&s.codes, words * sizeof(uint32_t)) != hipSuccess || hipMalloc(&s.present, rows * sizeof(uint64_t)) != hipSuccess) return fail();
-        c->bytes += (int64_t)(words * sizeof(uint32_t) + rows * sizeof(uint64_t));
-    }
-    c->total_quads = quad0;
-    if (hipMalloc(&c->d_slabs, sizeof(SlabCodes) * b->n_groups) != hipSuccess ||
-        hipMemcpy(c->d_slabs, c->slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) != hipSuccess)
-        return fail();
-    c->cmax = WGS_CODE_ROWS;                                   // row stride of the dictionary while encoding
-    const double tk = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (launch_class_encode(b, c)) return fail();
-    c->kernel_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tk) * 1e3;
-    std::vector<uint8_t> h(rows);
-    if (hipMemcpy(h.data(), c->ncls, rows, hipMemcpyDeviceToHost) != hipSuccess) return fail();
-    int cmax = 1;
-    for (size_t i = 0; i < rows; ++i) cmax = std::max<int>(cmax, h[i]);
-    if (cmax > 64) return fail();                              // 255 marks a SNP with more than 64 classes
-    c->cmax = cmax;
-    int rows16 = 16;
-    for (size_t i = 0; i < rows; i += 16) {
-        int sum = 0;
-        for (size_t k = i; k < i + 16 && k < rows; ++k) sum += h[k];
-        rows16 = std::max(rows16, sum);
-    }
-    c->rows16 = rows16;
-    c->build_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3;
-    b->codes_state = 1;
-    return c;
-}
-
-// The slabs' own class numbering for the coded EM sweep (common.h: SlabLocal), built on first use: one more byte per (SNP,
-// individual) and a dictionary per slab.  No memory for it: false, and the direct sweep runs.
-bool wgs_beagle_local_codes(wgs_beagle *b, wgs_codes *c)
-{
-    if (!b || !c || c->local_state < 0) return false;
-    if (c->local_state > 0) return true;
-    c->local_state = -1;
-    if (hipSetDevice(b->ctx->device) != hipSuccess) return false;
-    const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-    if (launch_local_encode(b, c)) {
-        (void)hipGetLastError();
-        for (auto &l : c->local) {
-            if (l.lcodes) (void)hipFree(l.lcodes);
-            if (l.ldict) (void)hipFree(l.ldict);
-        }
-        c->local.clear();
-        c->local_bytes = 0;
-        return false;
-    }
-    c->local_ms = (std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0) * 1e3;
-    c->local_state = 1;
-    return true;
-}
+// (class codes: codes.hip)
 
 extern "C" {
-
-/* Class codes of the matrix (csrc/common.h: wgs_codes), built on first use by the kernels that look values up per
- * class: info[0..4] = available (0/1), classes of the richest SNP, bytes held, milliseconds the build took, mean classes
- * per SNP (computed on request), [5] = ms of the encode kernel alone, [6..9] = ms and bytes of the slabs' own numbering (built
- * by the first coded EM sweep; 0 before), its table rows, the share of (slab, tile) pairs with a richer SNP (swept directly).  Builds the codes if they have not been tried yet. */
-int wgs_beagle_codes_info(wgs_beagle *b, double *info)
-{
-    WGS_REQUIRE(b && info, "null argument");
-    wgs_codes *c = wgs_beagle_codes(b);
-    for (int i = 0; i < 10; ++i) info[i] = 0.0;
-    if (!c) return 0;
-    info[6] = c->local_ms;
-    info[7] = (double)c->local_bytes;
-    info[8] = c->lrows;
-    info[9] = c->local_direct_share;
-    info[0] = 1.0;
-    info[1] = c->cmax;
-    info[2] = (double)(c->bytes + c->local_bytes);          // + the slabs' own numbering once a coded EM sweep has built it
-    info[3] = c->build_ms;
-    info[5] = c->kernel_ms;
-    const size_t rows = (size_t)b->m;
-    std::vector<uint8_t> h(rows);
-    HIP_TRY(hipMemcpy(h.data(), c->ncls, rows, hipMemcpyDeviceToHost));
-    double tot = 0.0;
-    for (size_t i = 0; i < rows; ++i) tot += h[i];
-    info[4] = rows ? tot / (double)rows : 0.0;
-    return 0;
-}
-
-/* Builds the class codes now instead of at their first use (and, with em != 0, the slabs' own numbering the coded EM sweep
- * uses), e.g. while the host is still busy with something else.  Returns 0 also when the matrix cannot be coded. */
-int wgs_beagle_codes_prepare(wgs_beagle *b, int em)
-{
-    WGS_REQUIRE(b, "null argument");
-    wgs_codes *c = wgs_beagle_codes(b);
-    if (c && em) (void)wgs_beagle_local_codes(b, c);
-    return 0;
-}
 
 void wgs_beagle_destroy(wgs_beagle *b)
 {
@@ -438,6 +287,14 @@ int wgs_beagle_synth(wgs_beagle *b, uint64_t seed, double depth)
     return launch_synth(b, seed, depth);
 }
 
+int wgs_beagle_synth_quality(wgs_beagle *b, uint64_t seed, double depth, int32_t n_bins, const double *quals, const double *probs)
+{
+    WGS_REQUIRE(b, "null argument");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    wgs_beagle_drop_codes(b);
+    return launch_synth_quality(b, seed, depth, n_bins, quals, probs);
+}
+
 /* ------------------------------------------------------------------ EM */
 
 struct wgs_em {
@@ -573,13 +430,38 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
 
 static float *em_f(wgs_em *em, int fit, int which) { return em->fbuf[which] + (size_t)fit * em->b->m; }
 
+/* Whether building the class codes pays for the EM sweeps still to come (codes.hip builds them in one pass over the matrix):
+ *   the encode pass costs about the matrix's bytes at 1.8 TB/s (measured: 80 GB in 44 ms, 1.6 GB in 2.3 ms) + 0.6 ms of
+ *   sample pass, allocation and readbacks;
+ *   a coded sweep saves a share of the direct sweep (the slabs' bytes at ~6 TB/s) that grows with the population size --
+ *   measured 14 % at 30 individuals, 21 % at 36, 39 % at 62, 52 % at 100;
+ *   sweeps to come: what the caller knows -- wgs_em_fit its iteration limit, of which a fit rarely uses more than ~14 (the
+ *   reference's default tolerance: 13-17 iterations on every data set here); a step-by-step caller nothing, so there a matrix
+ *   that has been swept directly three times is taken to be in a long run.
+ * WGSASSIGN_EM_CODES_SWEEPS=k replaces the model by "k or more sweeps ahead" (0: always; tests). */
+static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, int fewest_cols, int sweeps_ahead)
+{
+    const wgs_beagle *b = em->b;
+    if (const char *sw = getenv("WGSASSIGN_EM_CODES_SWEEPS")) return sweeps_ahead >= atoi(sw) || b->direct_sweeps >= 3;
+    double ahead = std::min(sweeps_ahead, 14);
+    if (sweeps_ahead <= 0 && b->direct_sweeps >= 3) ahead = 12;
+    static const double at[5] = {28, 36, 62, 100, 1e9}, share[5] = {0.10, 0.21, 0.39, 0.52, 0.52};
+    double saves = share[0];
+    for (int i = 0; i + 1 < 5; ++i)
+        if (fewest_cols >= at[i]) saves = share[i] + (share[i + 1] - share[i]) * std::min(1.0, (fewest_cols - at[i]) / (at[i + 1] - at[i]));
+    double swept = 0.0;
+    for (int j : order) swept += 8.0 * (double)b->slabs[em->group[j]].ncols * (double)b->m;
+    const double direct_ms = swept / 6.0e9, build_ms = (double)b->bytes / 1.8e9 + 0.6;
+    return ahead * saves * direct_ms > build_ms;
+}
+
 /* Enqueue one sweep (+ the fixed-order reduction of its sums) for the fits in `list`: descriptors into the pinned
  * array H and from there to D.  Fits of different populations stream their slabs once (nontemporal loads); when
  * several fits share a slab (leave-one-out batches) they are ordered by slab and swept in groups of up to
  * em_fits_per_group() per wavefront (group table Hg -> Dg), which share the tile's loads and conversions.
  * ssq_base[j] receives fit j's sum; state_base (device, may be NULL) holds the fit states a sweep honours. */
 static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDesc *H, FitDesc *D, int32_t *Hg, int32_t *Dg,
-                            double *ssq_base, int32_t *state_base, hipEvent_t ev0, hipEvent_t ev1)
+                            double *ssq_base, int32_t *state_base, hipEvent_t ev0, hipEvent_t ev1, int sweeps_ahead)
 {
     wgs_ctx *ctx = em->b->ctx;
     const int64_t ntiles = wgs_ntiles(em->b->m);
@@ -591,26 +473,32 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
         seen[em->group[j]] = 1;
     }
     if (shared) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return em->group[x] < em->group[y]; });
-    // exact mode on a codable matrix: the sweep through the class codes (same frequencies, bit for bit)
+    // exact mode on a coded matrix: the sweep through the class codes (same frequencies, bit for bit)
     // -- for fits of different slabs; leave-one-out batches (several fits per slab) stay with em_sweep_group_kernel,
     // whose shared loads and conversions serve them better than a quotient table per fit
     // -- and small populations stay with em_sweep_kernel too: below ~28 individuals the table costs more than it saves
     // (measured: 20 individuals 0.98x, 30 1.16x, 36 1.26x, 62 1.64x, 100 2.1x)
+    // -- and the codes are BUILT for it only when the sweeps still to come repay the encode pass (em_codes_pay below).
+    // Codes that exist already (a scoring sweep built them, or wgs_beagle_codes_prepare) are used at once.
     bool worth = em->mode == WGS_MODE_EXACT && !shared;
     const char *min_env = getenv("WGSASSIGN_EM_CODES_MIN");    // tests lower it to run small populations through the codes
     const int min_cols = min_env ? atoi(min_env) : 28;
-    for (int j : order) worth = worth && em->b->slabs[em->group[j]].ncols >= min_cols;
-    wgs_codes *codes = worth ? wgs_beagle_codes(em->b) : nullptr;
-    if (codes && !wgs_beagle_local_codes(em->b, codes)) codes = nullptr;
+    int fewest = INT32_MAX;
+    for (int j : order) fewest = std::min(fewest, (int)em->b->slabs[em->group[j]].ncols);
+    worth = worth && fewest >= min_cols;
+    const bool build = worth && em_codes_pay(em, order, fewest, sweeps_ahead);
+    wgs_codes *codes = worth ? wgs_beagle_codes(em->b, build) : nullptr;
+    if (codes && codes->lrows == 0) codes = nullptr;
+    if (worth && !codes) ++em->b->direct_sweeps;          // (a sweep the codes could have served)
     int coded_rows_max = 0;
     for (size_t i = 0; i < order.size(); ++i) {
         const int j = order[i];
         const Slab &s = em->b->slabs[em->group[j]];
         FitDesc &d = H[i];
-        d.lcodes = codes ? codes->local[em->group[j]].lcodes : nullptr;
-        d.ldict = codes ? codes->local[em->group[j]].ldict : nullptr;
+        d.lcodes = codes ? codes->slabs[em->group[j]].lcodes : nullptr;
+        d.ldict = codes ? codes->slabs[em->group[j]].ldict : nullptr;
         d.lrows = codes ? codes->lrows : 0;
-        d.present = codes ? codes->slabs[em->group[j]].present : nullptr;
+        d.tile_rows = codes ? codes->slabs[em->group[j]].tile_rows : nullptr;
         d.nquads = codes ? codes->slabs[em->group[j]].nquads : 0;
         coded_rows_max = std::max(coded_rows_max, (int)d.lrows);
         d.slab = s.base;
@@ -680,7 +568,7 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
     if (em->last.empty()) return 0;
     // h_descs / h_groups (pinned) stay untouched until the next step, which the caller only starts after
     // consuming this step's sums
-    if (em_enqueue_sweep(em, em->last, em->h_descs, em->d_descs, em->h_groups, em->d_groups, ssq_dev, nullptr, em->ev0, em->ev1)) return 1;
+    if (em_enqueue_sweep(em, em->last, em->h_descs, em->d_descs, em->h_groups, em->d_groups, ssq_dev, nullptr, em->ev0, em->ev1, 0)) return 1;
     for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
     return 0;
 }
@@ -840,7 +728,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
             if (!fin[j] && sweeps[j] < max_iter) L.push_back(j);
         if (!L.empty()) {
             if (em_enqueue_sweep(em, L, em->h_descs2[slot], em->d_descs2[slot], em->h_groups2[slot], em->d_groups2[slot], em->d_ssq2,
-                                 em->d_state, em->ev_sw0[slot], em->ev_sw1[slot]))
+                                 em->d_state, em->ev_sw0[slot], em->ev_sw1[slot], max_iter - t + 1))
                 return 1;
             // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
             // in the same way on every rank (all ranks take the same decisions).
@@ -1076,7 +964,7 @@ struct wgs_score {
     int32_t last_serial_blocks = 0;
     CodedSlabHost *d_coded = nullptr;     // slab table of the sweep through the class codes (shared columns)
     int n_coded = 0, coded_quads = 0;
-    const wgs_codes *coded_for = nullptr; // the codes d_coded was built from
+    int64_t coded_generation = -1;        // wgs_codes::generation of the build d_coded was made from
     int last_path = 0;                    // 1: the last wgs_score_sums went through the class codes
 };
 
@@ -1204,8 +1092,8 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     HIP_TRY(hipSetDevice(ctx->device));
     // shared columns + a codable matrix: the sweep through the class codes (same S, bit for bit)
     wgs_codes *codes = sc->per_ind ? nullptr : wgs_beagle_codes(sc->b);
-    if (codes && score_coded_lds_bytes(codes->rows16, score_kb(sc->K)) > 64 * 1024) codes = nullptr;
-    if (codes && sc->coded_for != codes) {
+    if (codes && score_coded_lds_bytes(codes->rows_batch, score_kb(sc->K), codes->score_batch) > 64 * 1024) codes = nullptr;
+    if (codes && sc->coded_generation != codes->generation) {     // (keyed on the build, not on the object's address: a rebuilt wgs_codes may reuse it)
         std::vector<CodedSlabHost> tab;
         int quad0 = 0;
         for (int g = 0; g < sc->b->n_groups; ++g) {
@@ -1217,6 +1105,8 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
             CodedSlabHost e;
             e.codes = codes->slabs[g].codes;
             e.members = s.d_members;
+            e.slab = s.base;
+            e.npairs = s.npairs;
             e.nquads = codes->slabs[g].nquads;
             e.ncols = s.ncols;
             e.quad0 = quad0;
@@ -1233,7 +1123,7 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
             HIP_TRY(hipMalloc(&sc->d_coded, sizeof(CodedSlabHost) * tab.size()));
             HIP_TRY(hipMemcpy(sc->d_coded, tab.data(), sizeof(CodedSlabHost) * tab.size(), hipMemcpyHostToDevice));
         }
-        sc->coded_for = codes;
+        sc->coded_generation = codes->generation;
     }
     HIP_TRY(hipMemsetAsync(sc->d_S, 0, sizeof(double) * (size_t)sc->nblocks * sc->cells, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));

@@ -411,13 +411,14 @@ __global__ __launch_bounds__(256, sweep_waves_per_simd(KB, NP, MODE, PER_IND)) v
 struct CodedSlab {
     const uint32_t *codes;
     const int32_t *members;
-    int32_t nquads, ncols, quad0, col_lo, col_hi;
+    const float4 *slab;            // the float32 slab, for the SNPs the encoder left uncoded (ncls = 0: too many classes)
+    int32_t nquads, ncols, quad0, col_lo, col_hi, npairs;
 };
 struct CodedScoreArgs {
     const float2 *dict;
     const uint8_t *ncls;
     const CodedSlab *slabs;
-    int32_t n_slabs, cmax, total_quads;
+    int32_t n_slabs, drows, total_quads;
     const float *const *acol;
     int64_t m, cells;
     int32_t K, nblocks;
@@ -427,7 +428,8 @@ struct CodedScoreArgs {
     double *S;
     const double2 *logtab;         // the log table in device memory (wgs_log_table_dev)
 };
-constexpr int CODED_BATCH = 16;    // SNPs per table: the code words of 16 SNPs of one quad are one 64-byte line
+constexpr int CODED_BATCH_MAX = 16; // SNPs per table: the code words of 16 SNPs of one quad are one 64-byte line; matrices with many
+                                    // classes per SNP take 8 or 4 at a time (wgs_codes::score_batch) so that a batch's rows fit the table
 constexpr int CODED_LOG_REP = 4;   // LDS copies of the log table here (phase 1 is a third of the kernel; 8 KiB instead of 32)
 
 // Details of the table:
@@ -441,13 +443,14 @@ constexpr int CODED_LOG_REP = 4;   // LDS copies of the log table here (phase 1 
 //     (-> 14.2 ms); TV = float where the float rows need no padding to 16 bytes (KB = 4, 8; 7 pads one): half the LDS
 //     traffic wins there.  WGS_SCORE_CODED_TABLE=float|double forces one (experiments).
 struct CodedPrep {
-    int rowoff[20];                // [j] = rows before SNP j of the batch, [16] = rows of the batch
-    float aval[CODED_BATCH][10];   // allele frequencies [SNP of the batch][population of this pass]
+    int rowoff[20];                // [j] = rows before SNP j of the batch, [batch size] = rows of the batch, [17] = an uncoded SNP in the batch
+    float aval[CODED_BATCH_MAX][10];   // allele frequencies [SNP of the batch][population of this pass]
 };
 
-template <int KB, int MODE, typename TV>
+template <int KB, int MODE, typename TV, int CODED_BATCH>
 __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
 {
+    static_assert(CODED_BATCH == 16 || CODED_BATCH == 8 || CODED_BATCH == 4, "SNPs per table");
     constexpr int KBP = sizeof(TV) == 8 ? ((KB + 1) & ~1) : ((KB + 3) & ~3);      // table rows padded to 16 bytes
     constexpr int KG = (KB + 1) / 2;                                                // populations per phase-1 item
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -490,19 +493,21 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
         auto prepare = [&](int b) {
             CodedPrep &P = prep[b & 1];
             const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
-            if (tid < 64) {                                    // the first wavefront: a 16-lane running sum of ncls
+            if (tid < 64) {                                    // the first wavefront: a running sum of ncls over the batch's SNPs
                 const int j = tid & 15;
-                const int n = tid < 16 && s0 + j < s_end ? (int)A.ncls[s0 + j] : 0;
+                const int n = tid < CODED_BATCH && s0 + j < s_end ? (int)A.ncls[s0 + j] : 0;
                 int incl = n;
 #pragma unroll
-                for (int off = 1; off < 16; off <<= 1) {
+                for (int off = 1; off < CODED_BATCH; off <<= 1) {
                     const int up = __shfl_up(incl, off, 64);
                     if (j >= off) incl += up;
                 }
-                if (tid < 16) {
+                if (tid < CODED_BATCH) {
                     P.rowoff[j] = incl - n;
-                    if (j == 15) P.rowoff[16] = incl;
+                    if (j == CODED_BATCH - 1) P.rowoff[CODED_BATCH] = incl;
                 }
+                const unsigned long long uncoded = __ballot(tid < CODED_BATCH && s0 + j < s_end && n == 0);
+                if (tid == 0) P.rowoff[17] = uncoded != 0;     // the batch holds a SNP the encoder left uncoded
             } else if (tid - 64 < CODED_BATCH * KB) {
                 const int e = tid - 64, j = e / KB, k = e - j * KB;
                 const int kk = kb + k < A.K ? kb + k : A.K - 1;
@@ -523,26 +528,25 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
             const int64_t t = s0 >> 6;
             const int l0 = (int)(s0 & 63);
             const int nj = s_end - s0 < CODED_BATCH ? (int)(s_end - s0) : CODED_BATCH;
-            uint4 cw[4];
+            uint4 cw[CODED_BATCH / 4];
             if (have) {
                 const uint4 *line = cptr + (t * sl.nquads * 64 + l0) / 4;
 #pragma unroll
-                for (int x = 0; x < 4; ++x) cw[x] = line[x];
+                for (int x = 0; x < CODED_BATCH / 4; ++x) cw[x] = line[x];
             } else {
 #pragma unroll
-                for (int x = 0; x < 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
+                for (int x = 0; x < CODED_BATCH / 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
             }
             if (b + 1 < nbatch) prepare(b + 1);
             // phase 1: vtab[rowoff[j] + c][k]
-            const int items = 2 * P.rowoff[16];
+            const int items = 2 * P.rowoff[CODED_BATCH];
             for (int it = tid; it < items; it += 256) {
                 const int r = it >> 1, half = it & 1;
-                int j = P.rowoff[8] <= r ? 8 : 0;
-                j += P.rowoff[j + 4] <= r ? 4 : 0;
-                j += P.rowoff[j + 2] <= r ? 2 : 0;
-                j += P.rowoff[j + 1] <= r ? 1 : 0;
+                int j = 0;
+#pragma unroll
+                for (int step = CODED_BATCH / 2; step >= 1; step >>= 1) j += P.rowoff[j + step] <= r ? step : 0;
                 const int c = r - P.rowoff[j];
-                const float2 gl = A.dict[(t * WGS_CODE_ROWS + c) * 64 + l0 + j];
+                const float2 gl = A.dict[(t * A.drows + c) * 64 + l0 + j];
                 const double g0d = (double)gl.x, g1d = (double)gl.y;
                 const double g1x2 = g1d * 2.0, g2d = (1.0 - g0d) - g1d;
                 const float g2f = (1.0f - gl.x) - gl.y;
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
             const unsigned *cwv = reinterpret_cast<const unsigned *>(cw);
 #pragma unroll
             for (int j = 0; j < CODED_BATCH; ++j) {
-                if (j < nj) {
+                if (j < nj && P.rowoff[j + 1] != P.rowoff[j]) {
                     const unsigned w = cwv[j];
                     const TV *rows_j = vtab + P.rowoff[j] * KBP;
 #pragma unroll
@@ -593,6 +597,41 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
                         }
 #pragma unroll
                         for (int k = 0; k < KB; ++k) acc[h][k] += (double)vals[k];
+                    }
+                }
+            }
+            // SNPs the encoder left uncoded (more classes than its tables hold; ncls = 0): their terms straight from the float32
+            // slab with the direct sweep's arithmetic -- the same float32 per-site values, added to the same float64 sums
+#pragma unroll 1
+            for (int j = 0; j < (P.rowoff[17] ? nj : 0); ++j) {
+                if (P.rowoff[j + 1] == P.rowoff[j]) {
+                    if (have) {
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const int pair = 2 * q + pr < sl.npairs ? 2 * q + pr : sl.npairs - 1;
+                            const float4 g = sl.slab[(t * sl.npairs + pair) * 64 + l0 + j];
+#pragma unroll
+                            for (int hh = 0; hh < 2; ++hh) {
+                                const float g0 = hh ? g.z : g.x, g1 = hh ? g.w : g.y;
+                                const double g0d = (double)g0, g1d = (double)g1;
+                                const double g1x2 = g1d * 2.0, g2d = (1.0 - g0d) - g1d;
+                                const float g2f = (1.0f - g0) - g1;
+#pragma unroll
+                                for (int k = 0; k < KB; ++k) {
+                                    const float a = P.aval[j][k];
+                                    float v;
+                                    if (MODE == WGS_MODE_EXACT) {
+                                        const double ad = (double)a;
+                                        const float ssum = like_sum_exact(g0d, g1x2, g2d, ad, 1.0 - ad);
+                                        const float plain = (float)log_f32arg<CODED_LOG_REP>((double)ssum, tab);
+                                        v = __builtin_isfpclass(ssum, FP_POS_FINITE) ? plain : __builtin_amdgcn_logf(ssum);
+                                    } else {
+                                        v = site_ll_fast(g0, g1, g2f, a);
+                                    }
+                                    acc[2 * pr + hh][k] += (double)v;
+                                }
+                            }
+                        }
                     }
                 }
             }
@@ -1171,10 +1210,10 @@ static bool score_coded_wide(int kb)
     if (e && e[0] == 'd') return true;
     return ((kb + 3) & ~3) - kb > 1;
 }
-size_t score_coded_lds_bytes(int rows16, int kb)
+size_t score_coded_lds_bytes(int rows, int kb, int batch)
 {
-    const size_t row = score_coded_wide(kb) ? sizeof(double) * ((kb + 1) & ~1) : sizeof(float) * ((kb + 3) & ~3);
-    return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15) + row * (size_t)rows16;
+    const size_t row = (batch < 16 || score_coded_wide(kb)) ? sizeof(double) * ((kb + 1) & ~1) : sizeof(float) * ((kb + 3) & ~3);
+    return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15) + row * (size_t)rows;
 }
 
 // The scoring sweep through the class codes (shared columns only).  d_slabs: n_slabs CodedSlab records in device memory.
@@ -1188,7 +1227,7 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     A.ncls = c->ncls;
     A.slabs = reinterpret_cast<const CodedSlab *>(d_slabs);
     A.n_slabs = n_slabs;
-    A.cmax = c->cmax;
+    A.drows = c->drows;
     A.total_quads = total_quads;
     A.acol = d_acol;
     A.m = m;
@@ -1200,8 +1239,9 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(wgs_log_table_dev)));
     A.logtab = reinterpret_cast<const double2 *>(sym);
     const int kb = pick_kb(K);
-    const bool wide = score_coded_wide(kb);
-    const size_t lds = score_coded_lds_bytes(c->rows16, kb);
+    const int batch = c->score_batch;
+    const bool wide = batch < 16 || score_coded_wide(kb);          // (the 8- and 4-SNP tables exist with float64 rows only)
+    const size_t lds = score_coded_lds_bytes(c->rows_batch, kb, batch);
     WGS_REQUIRE(lds <= 64 * 1024, "class table too large for LDS");
     const unsigned ygroups = (unsigned)((total_quads + 255) / 256);
     int parts = 1;
@@ -1217,12 +1257,18 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     dim3 grid((unsigned)nblocks, ygroups, (unsigned)parts);
 #define WGS_CODED(KB)                                                                                                     \
     do {                                                                                                                  \
-        if (wide) {                                                                                                       \
-            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, double>), grid, dim3(256), lds, ctx->stream, A); \
-            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, double>), grid, dim3(256), lds, ctx->stream, A); \
+        if (batch == 8) {                                                                                                 \
+            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, double, 8>), grid, dim3(256), lds, ctx->stream, A); \
+            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, double, 8>), grid, dim3(256), lds, ctx->stream, A); \
+        } else if (batch == 4) {                                                                                          \
+            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, double, 4>), grid, dim3(256), lds, ctx->stream, A); \
+            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, double, 4>), grid, dim3(256), lds, ctx->stream, A); \
+        } else if (wide) {                                                                                                \
+            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, double, 16>), grid, dim3(256), lds, ctx->stream, A); \
+            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, double, 16>), grid, dim3(256), lds, ctx->stream, A); \
         } else {                                                                                                          \
-            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, float>), grid, dim3(256), lds, ctx->stream, A); \
-            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, float>), grid, dim3(256), lds, ctx->stream, A); \
+            if (mode == WGS_MODE_EXACT) hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_EXACT, float, 16>), grid, dim3(256), lds, ctx->stream, A); \
+            else hipLaunchKernelGGL((score_coded_kernel<KB, WGS_MODE_FAST, float, 16>), grid, dim3(256), lds, ctx->stream, A); \
         }                                                                                                                 \
     } while (0)
     WGS_FOR_KB(WGS_CODED, K)

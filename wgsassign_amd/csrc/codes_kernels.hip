@@ -1,0 +1,525 @@
+// The class encoder (common.h: wgs_codes): ONE pass over the float32 slabs that leaves everything both coded sweeps need --
+// the per-SNP dictionary and class ids of every individual (scoring), and per population slab its own numbering of the
+// classes with its own dictionary rows (EM).  Round 3 did this in two kernels (77 + 14 ms at 10M x 1000) whose walk was a
+// chain of dependent LDS probes, one wavefront per tile; here the probes are LDS compare-and-swaps issued sixteen at a
+// time, so the walk is bound by issue slots and HBM instead of LDS latency.
+//
+//   hash table   per SNP, T slots of 8 bytes (the (g0, g1) bit pattern) in LDS, open addressing, linear probing, insert-only.
+//                A lookup-or-insert at slot h is ONE ds_cmpst_rtn_b64 (expect EMPTY, store the key): it returns EMPTY (inserted),
+//                the key (found) or another key (probe h + 1).  An insert-only table gives every key the same slot whatever the
+//                order of the operations, and LDS operations of a wavefront execute in issue order, so the sixteen lookups of a
+//                buffer are issued back to back without waiting for each other -- also when two of them insert the same new key.
+//   geometry     a wavefront owns 2048 slots (20 KiB of LDS with the marks: two wavefronts per SIMD, the second hides the first's
+//                waits): SNPS SNPs x T slots, (32, 64), (16, 128) or (8, 256), chosen per matrix from a sample (low-depth data
+//                with fixed error has ~27 classes per SNP among 1000 individuals, likelihoods from binned base qualities
+//                80-100).  The 64 / SNPS lanes of a SNP share its table (real atomics) and take alternate quads of individuals.
+//   walk         per slab: the lane's quads, two 16-byte loads each (the slab's native layout, lane <-> SNP), 4 lookups per
+//                quad, the four SLOT numbers written as the quad's code word, a byte per (slot, SNP) in LDS marked "seen in
+//                this slab".
+//   slab end     the seen slots of each SNP are ranked in slot order (32 slots per lane, prefix over the lanes of the SNP):
+//                that rank is the slab's OWN class number; the slab's dictionary rows are written coalesced (ldict), its
+//                code words re-read (they were written moments ago) and written as local ranks (lcodes), the most local
+//                classes of the tile's SNPs goes to tile_rows (what the coded EM sweep sizes its table by).
+//   end          the occupied slots are ranked the same way: dictionary rows (dict), ncls, and every slab's code words
+//                rewritten in place from slot numbers to class ids.
+// A SNP whose table overflows (more than RMAX probes, i.e. too many classes for T), with more classes than the dictionary
+// has rows, or holding the one bit pattern used as EMPTY is RICH: ncls = 0 and tile_rows = 255 tell the sweeps to take that
+// SNP (scoring) / that tile of that slab (EM) from the float32 slab.  Nothing about a rich SNP affects the others.
+#include "common.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));   // plain vector type (nontemporal loads take it)
+typedef const f4 __attribute__((address_space(1))) *gf4_ptr;
+
+constexpr unsigned long long KEY_EMPTY = ~0ull;            // (g0, g1) = two NaNs with all payload bits set: no parser makes it
+constexpr int ENC_SLOTS = 2048;                            // hash slots per wavefront (16 KiB of keys + 4 KiB of marks: 8 wavefronts per CU)
+constexpr int ENC_RMAX = 24;                               // probe rounds per buffer before the SNP is given up as rich
+constexpr int ENC_UQ = 4;                                  // quads per lane and buffer: 8 loads of 16 bytes, 16 lookups in flight
+
+__device__ __forceinline__ unsigned hash32(unsigned g0, unsigned g1)
+{
+    // two 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate) over all 32 bits of a mix of both values
+    const unsigned x = g0 ^ __builtin_rotateleft32(g1, 13);
+    return __umul24(x, 0x9E3779u) ^ __builtin_rotateleft32(__umul24(x >> 8, 0x85EBCBu), 3);
+}
+
+struct EncodeArgs {
+    float4 *const *base;           // device: slab bases
+    const int32_t *npairs, *ncols; // device: per slab
+    const SlabCodes *slabs;        // device
+    int32_t n_slabs;
+    int64_t m, tiles;
+    float2 *dict;
+    uint8_t *ncls;
+    int32_t drows, lrows;          // dictionary rows per tile / rows of a slab's own dictionary per tile (0: no local numbering)
+    int32_t batch, batch_cap;      // the coded scoring sweep tables `batch` (16, 8 or 4) consecutive SNPs at a time: most classes such an
+                                   // aligned group may sum to (its LDS table)
+    int64_t unit_stride;           // sample pass: work unit = blockIdx.x * unit_stride
+    uint8_t *sample;               // sample pass: [unit][slab, then all][SNP of the unit] classes found (0: beyond the last SNP, 255: overflow)
+    unsigned long long *stats;     // see EncStat
+};
+
+// stats[]: what the host reads back after a pass
+enum EncStat {
+    ST_SUM_NCLS = 0,      // sum of ncls over the coded SNPs
+    ST_RICH = 1,          // rich SNPs
+    ST_CMAX = 2,          // most classes of a coded SNP
+    ST_ROWS_BATCH = 3,    // most classes summed over an aligned group of `batch` SNPs
+    ST_UNUSED = 4,
+    ST_ROUNDS = 5,        // probe rounds beyond the first, summed over buffers
+    ST_BUFFERS = 6,       // buffers walked
+    ST_DIRECT = 7,        // (slab, tile) pairs with more classes than the EM sweep's table has rows
+    ST_COUNT = 8
+};
+
+template <int SNPS, bool SAMPLE>
+__global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
+{
+    constexpr int COLS = 64 / SNPS, T = ENC_SLOTS / SNPS, SCAN = ENC_SLOTS / 64;    // SCAN slots per lane when a table is ranked
+    constexpr unsigned TMASK = T - 1, HSHIFT = T == 64 ? 26 : (T == 128 ? 25 : 24);
+    constexpr int NL = 4 * ENC_UQ;                         // lookups per lane and buffer
+    __shared__ unsigned long long keys[ENC_SLOTS];         // [slot * SNPS + s]
+    __shared__ __align__(16) uint8_t flag[ENC_SLOTS];      // [slot * SNPS + s]: seen in the current slab; then the slot's rank
+    __shared__ __align__(16) uint8_t order[ENC_SLOTS];     // [rank * SNPS + s]: the slot of the rank-th class
+    const int lane = threadIdx.x;
+    const int s = lane & (SNPS - 1), col = lane / SNPS;
+    const int64_t unit = (int64_t)blockIdx.x * A.unit_stride;
+    const int64_t tile = unit / (64 / SNPS);
+    const int sub = (int)(unit - tile * (64 / SNPS));
+    if (tile >= A.tiles) return;
+    const int ls = sub * SNPS + s;                         // this lane's SNP within the tile
+    const int64_t snp = tile * 64 + ls;
+
+    auto clear_flags = [&]() {
+#pragma unroll
+        for (int i = 0; i < ENC_SLOTS / 1024; ++i) reinterpret_cast<uint4 *>(flag)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < ENC_SLOTS / 64; ++i) keys[i * 64 + lane] = KEY_EMPTY;
+    clear_flags();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+
+    bool rich = false;                                     // this lane gave up on its SNP (combined over the SNP's lanes at slab ends)
+    unsigned n_rounds = 0, n_buffers = 0;
+
+    // lanes of one SNP: col = 0 .. COLS-1 at lane distance SNPS
+    auto snp_or = [&](bool v) {
+        int x = v ? 1 : 0;
+#pragma unroll
+        for (int d = SNPS; d < 64; d <<= 1) x |= __shfl_xor(x, d, 64);
+        return x != 0;
+    };
+    // (exclusive prefix over the SNP's lanes in col order, total)
+    auto snp_scan = [&](int cnt, int &pre, int &tot) {
+        pre = 0;
+        tot = 0;
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) {
+            const int v = __shfl(cnt, c * SNPS + s, 64);
+            if (c < col) pre += v;
+            tot += v;
+        }
+    };
+    auto wave_max = [&](int v) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+        return v;
+    };
+    // one probe of lookup `key` at `slot`: true when it ended there (inserted or found)
+    auto probe = [&](unsigned slot, unsigned long long key) {
+        const unsigned long long old = atomicCAS(&keys[slot * SNPS + s], KEY_EMPTY, key);
+        return old;
+    };
+
+    for (int g = 0; g < A.n_slabs; ++g) {
+        const int np = A.npairs[g], nc = A.ncols[g];
+        const SlabCodes sc = A.slabs[g];
+        const int nquads = sc.nquads;
+        if (nquads == 0) continue;
+        gf4_ptr src = (gf4_ptr)A.base[g] + tile * np * 64 + ls;
+        uint32_t *cw = sc.codes + tile * nquads * 64 + ls;
+        // ---- the walk: this lane's quads col, col + COLS, ...; the loads of the next buffer are in flight while this one is hashed
+        f4 nxt[ENC_UQ][2];
+        auto fetch = [&](int qb) {
+#pragma unroll
+            for (int u = 0; u < ENC_UQ; ++u) {
+                const int q = qb + u * COLS + col;
+                nxt[u][0] = __builtin_nontemporal_load(src + (int64_t)min(2 * q, np - 1) * 64);
+                nxt[u][1] = __builtin_nontemporal_load(src + (int64_t)min(2 * q + 1, np - 1) * 64);
+            }
+        };
+        fetch(0);
+        for (int qb = 0; qb < nquads; qb += COLS * ENC_UQ) {
+            f4 v[ENC_UQ][2];
+#pragma unroll
+            for (int u = 0; u < ENC_UQ; ++u) v[u][0] = nxt[u][0], v[u][1] = nxt[u][1];
+            if (qb + COLS * ENC_UQ < nquads) fetch(qb + COLS * ENC_UQ);
+            unsigned long long key[NL], old[NL];
+            unsigned slot[NL];
+#pragma unroll
+            for (int u = 0; u < ENC_UQ; ++u) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const f4 vv = v[u][h >> 1];
+                    const unsigned g0 = __float_as_uint((h & 1) ? vv.z : vv.x), g1 = __float_as_uint((h & 1) ? vv.w : vv.y);
+                    key[4 * u + h] = ((unsigned long long)g1 << 32) | g0;          // = the float2 (g0, g1) as the slab holds it
+                    slot[4 * u + h] = hash32(g0, g1) >> HSHIFT;
+                }
+            }
+            bool pend[NL];                                 // lane masks in scalar registers
+            // a buffer whose 4 x ENC_UQ x COLS individuals all exist, in a wavefront without a rich SNP: no per-lookup predicates
+            const bool plain = 4 * (qb + COLS * ENC_UQ) <= nc && !__any(rich);
+            if (plain) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) old[i] = probe(slot[i], key[i]);
+#pragma unroll
+                for (int i = 0; i < NL; ++i) pend[i] = old[i] != KEY_EMPTY && old[i] != key[i];
+            } else {
+#pragma unroll
+                for (int u = 0; u < ENC_UQ; ++u) {
+                    const int q = qb + u * COLS + col;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int i = 4 * u + h;
+                        const bool live = 4 * q + h < nc && !rich;
+                        old[i] = key[i];
+                        if (live) old[i] = probe(slot[i], key[i]);
+                        pend[i] = live;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NL; ++i) pend[i] = pend[i] && !rich && old[i] != KEY_EMPTY && old[i] != key[i];
+            }
+            bool any_pend = false;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) any_pend = any_pend || pend[i];
+            int rounds = 0;
+            while (__any(any_pend)) {
+                if (++rounds > ENC_RMAX) {                 // too many classes for this table: the SNP is rich
+                    rich = rich || any_pend;
+                    break;
+                }
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    if (__any(pend[i])) {                  // (most lookups are settled by their first probe: skipped as a wave)
+                        if (pend[i]) {
+                            slot[i] = (slot[i] + 1) & TMASK;
+                            old[i] = probe(slot[i], key[i]);
+                        }
+                    }
+                }
+                any_pend = false;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    pend[i] = pend[i] && old[i] != KEY_EMPTY && old[i] != key[i];
+                    any_pend = any_pend || pend[i];
+                }
+            }
+            n_rounds += (unsigned)rounds;
+            ++n_buffers;
+            // seen marks and code words (slot numbers for now); a rich SNP's are never read
+            if (plain) {
+#pragma unroll
+                for (int i = 0; i < NL; ++i) flag[slot[i] * SNPS + s] = 1;
+            } else {
+#pragma unroll
+                for (int u = 0; u < ENC_UQ; ++u)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h)
+                        if (4 * (qb + u * COLS + col) + h < nc) flag[slot[4 * u + h] * SNPS + s] = 1;
+            }
+            if (!SAMPLE) {
+#pragma unroll
+                for (int u = 0; u < ENC_UQ; ++u) {
+                    const int q = qb + u * COLS + col;
+                    if (plain || q < nquads) cw[(int64_t)q * 64] = slot[4 * u] | (slot[4 * u + 1] << 8) | (slot[4 * u + 2] << 16) | (slot[4 * u + 3] << 24);
+                }
+            }
+        }
+        // ---- slab end: the slab's own numbering
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN; ++k) {
+            const int f = flag[(col * SCAN + k) * SNPS + s];
+            cnt += f;
+            // a slot marked seen that holds no key: the one bit pattern used as EMPTY was looked up -- that SNP cannot be coded
+            if (f && keys[(col * SCAN + k) * SNPS + s] == KEY_EMPTY) rich = true;
+        }
+        rich = snp_or(rich);
+        int pre, nloc;
+        snp_scan(cnt, pre, nloc);
+        if (SAMPLE) {
+            if (col == 0) A.sample[((int64_t)blockIdx.x * (A.n_slabs + 1) + g) * SNPS + s] = (uint8_t)(snp < A.m ? (rich ? 255 : min(nloc, 254)) : 0);
+        } else {
+            const int wmax = wave_max(rich ? 255 : nloc);
+            if (lane == 0) atomicMax(sc.tile_rows + tile, (unsigned)wmax);
+            if (A.lrows > 0 && wmax <= A.lrows) {          // wave-uniform: this wave's SNPs fit the EM sweep's table
+                int r = pre;
+#pragma unroll 8
+                for (int k = 0; k < SCAN; ++k) {
+                    const int sl = col * SCAN + k;
+                    if (flag[sl * SNPS + s]) {
+                        flag[sl * SNPS + s] = (uint8_t)r;
+                        order[r * SNPS + s] = (uint8_t)sl;
+                        ++r;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                // dictionary rows: as many as the richest of this wave's SNPs has (the EM sweep requests rows eight at a time and never
+                // looks at a row beyond a SNP's own classes: what it finds in the unwritten ones does not matter)
+                const int rows_w = wmax;
+                unsigned long long *ld = reinterpret_cast<unsigned long long *>(sc.ldict) + (tile * A.lrows) * 64 + ls;
+                for (int r0 = col; r0 < rows_w; r0 += COLS) {
+                    unsigned long long e = 0;
+                    if (r0 < nloc) e = keys[(unsigned)order[r0 * SNPS + s] * SNPS + s];
+                    ld[(int64_t)r0 * 64] = e;
+                }
+                // the code words again, as local ranks
+                uint32_t *lw = sc.lcodes + tile * nquads * 64 + ls;
+                constexpr int PF = 8;
+                for (int q0 = col; q0 < nquads; q0 += COLS * PF) {
+                    uint32_t w[PF];
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) w[u] = cw[(int64_t)min(q0 + u * COLS, nquads - 1) * 64];
+#pragma unroll
+                    for (int u = 0; u < PF; ++u) {
+                        if (q0 + u * COLS < nquads) {
+                            uint32_t o = 0;
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) o |= (uint32_t)flag[((w[u] >> (8 * h)) & 255u) * SNPS + s] << (8 * h);
+                            lw[(int64_t)(q0 + u * COLS) * 64] = o;
+                        }
+                    }
+                }
+            }
+        }
+        // the marks of this slab are done with
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        clear_flags();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+
+    // ---- end: the SNP's classes = the occupied slots, ranked in slot order
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN; ++k) cnt += keys[(col * SCAN + k) * SNPS + s] != KEY_EMPTY ? 1 : 0;
+    int pre, ncls;
+    snp_scan(cnt, pre, ncls);
+    if (ncls > A.drows || ncls > 254) rich = true;
+    rich = snp_or(rich);
+    if (SAMPLE) {
+        if (col == 0) A.sample[((int64_t)blockIdx.x * (A.n_slabs + 1) + A.n_slabs) * SNPS + s] = (uint8_t)(snp < A.m ? (rich ? 255 : min(ncls, 254)) : 0);
+        if (lane == 0) {
+            atomicAdd(A.stats + ST_ROUNDS, (unsigned long long)n_rounds);
+            atomicAdd(A.stats + ST_BUFFERS, (unsigned long long)n_buffers);
+        }
+        return;
+    }
+    int eff = rich ? 0 : ncls;
+    // the scoring sweep's table holds the classes of `batch` consecutive SNPs: a group that would not fit loses its
+    // richest SNPs to the direct path.  (Every group of `batch` lanes holds `batch` consecutive SNPs of one column, and all
+    // columns of a SNP see the same numbers and take the same decision.)
+    auto group_sum = [&](int v) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1)
+            if (off < A.batch && off < SNPS) v += __shfl_xor(v, off, 64);
+        return v;
+    };
+    for (int it = 0; it < 16; ++it) {
+        const int sum = group_sum(eff);
+        if (!__any(sum > A.batch_cap)) break;
+        int best = (eff << 8) | (63 - (lane & 15));        // the richest SNP of the group (lowest lane on ties)
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1)
+            if (off < A.batch && off < SNPS) best = max(best, __shfl_xor(best, off, 64));
+        if (sum > A.batch_cap && (best & 255) == 63 - (lane & 15)) {
+            eff = 0;
+            rich = true;
+        }
+    }
+    if (col == 0) A.ncls[snp] = (uint8_t)eff;
+    {
+        const int mb = wave_max(group_sum(eff)), mc = wave_max(eff);
+        unsigned long long tot = (unsigned long long)((col == 0 && snp < A.m) ? eff : 0), nrich = (col == 0 && snp < A.m && rich) ? 1ull : 0ull;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            tot += __shfl_xor(tot, off, 64);
+            nrich += __shfl_xor(nrich, off, 64);
+        }
+        if (lane == 0) {
+            atomicAdd(A.stats + ST_SUM_NCLS, tot);
+            if (nrich) atomicAdd(A.stats + ST_RICH, nrich);
+            atomicMax(A.stats + ST_CMAX, (unsigned long long)mc);
+            atomicMax(A.stats + ST_ROWS_BATCH, (unsigned long long)mb);
+            atomicAdd(A.stats + ST_ROUNDS, (unsigned long long)n_rounds);
+            atomicAdd(A.stats + ST_BUFFERS, (unsigned long long)n_buffers);
+        }
+    }
+    int r = pre;
+#pragma unroll 8
+    for (int k = 0; k < SCAN; ++k) {
+        const int sl = col * SCAN + k;
+        if (keys[sl * SNPS + s] != KEY_EMPTY) {
+            flag[sl * SNPS + s] = (uint8_t)min(r, 255);
+            order[min(r, 255) * SNPS + s] = (uint8_t)sl;
+            ++r;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int wmax = min(wave_max(eff), A.drows);
+    unsigned long long *dd = reinterpret_cast<unsigned long long *>(A.dict) + (tile * A.drows) * 64 + ls;
+    for (int r0 = col; r0 < wmax; r0 += COLS)
+        if (r0 < eff) dd[(int64_t)r0 * 64] = keys[(unsigned)order[r0 * SNPS + s] * SNPS + s];
+    // every slab's code words: slot numbers -> class ids, in place
+    for (int g = 0; g < A.n_slabs; ++g) {
+        const SlabCodes sc = A.slabs[g];
+        const int nquads = sc.nquads;
+        uint32_t *cw = sc.codes + tile * nquads * 64 + ls;
+        constexpr int PF = 8;
+        for (int q0 = col; q0 < nquads; q0 += COLS * PF) {
+            uint32_t w[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) w[u] = cw[(int64_t)min(q0 + u * COLS, nquads - 1) * 64];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                if (q0 + u * COLS < nquads) {
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) o |= (uint32_t)flag[((w[u] >> (8 * h)) & 255u) * SNPS + s] << (8 * h);
+                    cw[(int64_t)(q0 + u * COLS) * 64] = o;
+                }
+            }
+        }
+    }
+}
+
+// (slab, tile) pairs whose SNPs do not fit the EM sweep's table: counted after the encode pass
+__global__ __launch_bounds__(256) void tile_rows_count_kernel(const SlabCodes *slabs, int64_t tiles, unsigned lrows, unsigned long long *out)
+{
+    const SlabCodes sc = slabs[blockIdx.y];
+    if (sc.nquads == 0) return;
+    unsigned long long c = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tiles; t += (int64_t)gridDim.x * 256) c += sc.tile_rows[t] > lrows ? 1u : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+}  // namespace
+
+static EncodeArgs encode_args(wgs_beagle *b, wgs_codes *c, const int32_t *d_ncols, unsigned long long *d_stats)
+{
+    EncodeArgs A;
+    A.base = b->d_base;
+    A.npairs = b->d_npairs;
+    A.ncols = d_ncols;
+    A.slabs = c->d_slabs;
+    A.n_slabs = b->n_groups;
+    A.m = b->m;
+    A.tiles = wgs_ntiles(b->m);
+    A.dict = c->dict;
+    A.ncls = c->ncls;
+    A.drows = c->drows;
+    A.lrows = c->lrows;
+    A.batch = c->score_batch;
+    A.batch_cap = WGS_BATCH_ROWS_CAP;
+    A.unit_stride = 1;
+    A.sample = nullptr;
+    A.stats = d_stats;
+    return A;
+}
+
+// Device scratch of an encode pass: the slabs' column counts and the statistics block.
+static int encode_scratch(wgs_beagle *b, int32_t **d_ncols, unsigned long long **d_stats, size_t extra = 0)
+{
+    std::vector<int32_t> ncols(b->n_groups);
+    for (int g = 0; g < b->n_groups; ++g) ncols[g] = b->slabs[g].ncols;
+    void *ws = nullptr;
+    const size_t stat_bytes = sizeof(unsigned long long) * ST_COUNT;
+    if (wgs_ctx_workspace(b->ctx, stat_bytes + sizeof(int32_t) * (b->n_groups + 64) + extra, &ws)) return 1;
+    *d_stats = reinterpret_cast<unsigned long long *>(ws);
+    *d_ncols = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(ws) + stat_bytes);
+    HIP_TRY(hipMemsetAsync(*d_stats, 0, stat_bytes, b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(*d_ncols, ncols.data(), sizeof(int32_t) * b->n_groups, hipMemcpyHostToDevice, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));        // (ncols is a local)
+    return 0;
+}
+
+// The sample pass: up to `max_units` groups of 8 SNPs spread over the matrix through the (8, 256) table; hist_g[c] = SNPs
+// with c classes, hist_l[c] = (slab, SNP) pairs with c classes in the slab (255 = overflow), 256 entries each.
+int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned long long *hist_g, unsigned long long *hist_l, double *rounds_per_buffer)
+{
+    int32_t *d_ncols = nullptr;
+    unsigned long long *d_stats = nullptr;
+    const int64_t units = wgs_ntiles(b->m) * 8;
+    const int64_t stride = std::max<int64_t>(1, units / std::max(1, max_units));
+    const int64_t grid = (units + stride - 1) / stride;
+    const size_t sample_bytes = (size_t)grid * (b->n_groups + 1) * 8;
+    if (encode_scratch(b, &d_ncols, &d_stats, sample_bytes)) return 1;
+    EncodeArgs A = encode_args(b, c, d_ncols, d_stats);
+    A.drows = 254;
+    A.lrows = 0;
+    A.unit_stride = stride;
+    A.sample = reinterpret_cast<uint8_t *>(d_ncols + b->n_groups + 64);
+    hipLaunchKernelGGL((class_encode_kernel<8, true>), dim3((unsigned)grid), dim3(64), 0, b->ctx->stream, A);
+    HIP_TRY(hipGetLastError());
+    std::vector<uint8_t> h(sample_bytes);
+    unsigned long long st[ST_COUNT];
+    HIP_TRY(hipMemcpyAsync(h.data(), A.sample, sample_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    for (int i = 0; i < 256; ++i) hist_g[i] = hist_l[i] = 0;
+    const int G = b->n_groups;
+    for (int64_t u = 0; u < grid; ++u) {
+        const uint8_t *row = h.data() + (size_t)u * (G + 1) * 8;
+        for (int x = 0; x < 8; ++x) {
+            if (row[(size_t)G * 8 + x] == 0) continue;     // beyond the last SNP
+            ++hist_g[row[(size_t)G * 8 + x]];
+            for (int g = 0; g < G; ++g)
+                if (b->slabs[g].ncols) ++hist_l[row[(size_t)g * 8 + x]];
+        }
+    }
+    if (rounds_per_buffer) *rounds_per_buffer = st[ST_BUFFERS] ? (double)st[ST_ROUNDS] / (double)st[ST_BUFFERS] : 0.0;
+    return 0;
+}
+
+// The encode pass over the whole matrix with c->snps_per_wave SNPs per wavefront; fills the arrays of `c` and its statistics.
+int launch_class_encode(wgs_beagle *b, wgs_codes *c)
+{
+    int32_t *d_ncols = nullptr;
+    unsigned long long *d_stats = nullptr;
+    if (encode_scratch(b, &d_ncols, &d_stats)) return 1;
+    const int64_t tiles = wgs_ntiles(b->m);
+    for (int g = 0; g < b->n_groups; ++g)
+        if (c->slabs[g].tile_rows) HIP_TRY(hipMemsetAsync(c->slabs[g].tile_rows, 0, sizeof(uint32_t) * tiles, b->ctx->stream));
+    EncodeArgs A = encode_args(b, c, d_ncols, d_stats);
+    const int64_t units = tiles * (64 / c->snps_per_wave);
+    WGS_REQUIRE(units < (1ll << 31), "class encoder: %lld work units exceed one launch", (long long)units);
+    switch (c->snps_per_wave) {
+        case 32: hipLaunchKernelGGL((class_encode_kernel<32, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
+        case 16: hipLaunchKernelGGL((class_encode_kernel<16, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
+        default: hipLaunchKernelGGL((class_encode_kernel<8, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
+    }
+    HIP_TRY(hipGetLastError());
+    unsigned long long *d_direct = d_stats + ST_DIRECT;
+    if (c->lrows > 0) {
+        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (tiles + 255) / 256));
+        hipLaunchKernelGGL(tile_rows_count_kernel, dim3(gx, (unsigned)b->n_groups), dim3(256), 0, b->ctx->stream, c->d_slabs, tiles, (unsigned)c->lrows, d_direct);
+        HIP_TRY(hipGetLastError());
+    }
+    unsigned long long h[8];
+    HIP_TRY(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    c->sum_ncls = (double)h[ST_SUM_NCLS];
+    c->rich_snps = (int64_t)h[ST_RICH];
+    c->cmax = (int32_t)h[ST_CMAX];
+    c->rows_batch = std::max<int32_t>(c->score_batch, (int32_t)h[ST_ROWS_BATCH]);
+    c->probe_rounds = h[ST_BUFFERS] ? (double)h[ST_ROUNDS] / (double)h[ST_BUFFERS] : 0.0;
+    int64_t slab_tiles = 0;
+    for (int g = 0; g < b->n_groups; ++g) slab_tiles += c->slabs[g].nquads ? tiles : 0;
+    c->local_direct_share = c->lrows > 0 && slab_tiles ? (double)h[ST_DIRECT] / (double)slab_tiles : 1.0;
+    return 0;
+}

@@ -70,51 +70,54 @@ struct Slab {
 static inline int64_t wgs_ntiles(int64_t m) { return (m + 63) / 64; }
 
 // Class codes of a matrix (wgs_beagle_codes): low-depth genotype likelihoods take few distinct (g0, g1) values per SNP
-// -- the bundled 85-individual data 29 on average, the 2x synthetic matrices 27 among 1000 individuals -- and both hot
-// kernels evaluate an expensive function of (g0, g1, per-SNP parameter) per individual: the EM term's quotient, the
-// per-site log-likelihood.  With the classes known, that function is evaluated once per CLASS and SNP and looked up per
-// individual; the serial float32 accumulation / the float64 sums run over the individuals exactly as before, on the
-// very same values, so every result keeps its bits.
-//   dict   [(tile * 64 + class) * 64 + lane]    the (g0, g1) of class `class` of SNP 64 * tile + lane (tile-interleaved;
-//                                               WGS_CODE_ROWS = 64 rows per tile, so one launch encodes without knowing cmax)
-//   ncls   [SNP]                                classes of the SNP (<= cmax <= 64)
+// -- the bundled 85-individual data 29 on average, the 2x synthetic matrices 27 among 1000 individuals, likelihoods from
+// binned base qualities ~80 -- and both hot kernels evaluate an expensive function of (g0, g1, per-SNP parameter) per
+// individual: the EM term's quotient, the per-site log-likelihood.  With the classes known, that function is evaluated once
+// per CLASS and SNP and looked up per individual; the serial float32 accumulation / the float64 sums run over the
+// individuals exactly as before, on the very same values, so every result keeps its bits.  Built by ONE pass of
+// class_encode_kernel (codes_kernels.hip); policy (when to build, table geometry) in codes.hip.
+//   dict   [(tile * drows + class) * 64 + lane]  the (g0, g1) of class `class` of SNP 64 * tile + lane (tile-interleaved)
+//   ncls   [SNP]                                 classes of the SNP (<= drows <= 254); 0: the SNP is RICH (too many classes
+//                                                for the tables) and every sweep takes it from the float32 slab
 //   codes  per slab: [(tile * nquads + quad) * 64 + lane]  the classes of individuals 4 quad .. 4 quad + 3 (one byte
 //          each, low byte first) of the slab for SNP 64 * tile + lane: coalesced for lane <-> SNP kernels, and 16
 //          consecutive SNPs of one quad are one 64-byte line for lane <-> quad kernels
-//   present per slab: [SNP] bit c = class c occurs among the slab's individuals
-constexpr int WGS_CODE_ROWS = 64;  // dictionary rows per tile = the most classes a SNP may have
+// and the slab's OWN numbering of the classes (the EM sweep through the codes looks quotients up in a table with one row per
+// class PRESENT in the slab, not per class of the SNP):
+//   lcodes like codes, a byte = rank of the individual's class among the classes present in the slab at that SNP
+//   ldict  [(tile * lrows + rank) * 64 + lane]  (g0, g1) of the rank-th present class of SNP 64 * tile + lane
+//   tile_rows [tile]  most classes present in the slab at one of the tile's 64 SNPs; 255 when one of them is rich.  A tile
+//          with more than lrows is swept directly from the float32 slab by the coded EM sweep.
+constexpr int WGS_BATCH_ROWS_CAP = 672;  // classes the SNPs of one batch of the coded scoring sweep may sum to: 672 rows of 80 bytes + the log table fit 64 KiB of LDS
 struct SlabCodes {
     uint32_t *codes = nullptr;
-    uint64_t *present = nullptr;
+    uint32_t *lcodes = nullptr;
+    float2 *ldict = nullptr;
+    uint32_t *tile_rows = nullptr;
     int32_t nquads = 0;
     int32_t quad0 = 0;             // first matrix-wide quad index of this slab
 };
-// The slab's own numbering of the classes (the EM sweep through the codes looks quotients up in a table with one row per class
-// PRESENT in the slab, not per class of the SNP): built on the first coded EM sweep from codes / present / dict.
-//   lcodes like SlabCodes::codes, a byte = rank of the individual's class among the set bits of present[SNP]
-//   ldict  [(tile * rows + rank) * 64 + lane]  (g0, g1) of the rank-th present class of SNP 64 * tile + lane
-// Table rows (wgs_codes::lrows, a multiple of 8, the same for all slabs) cover the richest SNP of all but ~1 % of the (slab, tile)
-// pairs; a tile with a richer SNP is swept directly from the float32 slab (its ranks >= lrows are never looked up).
-struct SlabLocal {
-    uint32_t *lcodes = nullptr;
-    float2 *ldict = nullptr;       // lrows rows per tile
-};
 struct wgs_codes {
-    std::vector<SlabLocal> local;  // per slab; local_state: 0 = not tried, 1 = available, -1 = no memory (direct kernels)
-    int local_state = 0;
-    int32_t lrows = 0;
-    double local_direct_share = 0.0;   // share of the (slab, tile) pairs that take the direct path
-    int64_t local_bytes = 0;
-    double local_ms = 0.0;
-    int32_t cmax = 0;
-    int32_t rows16 = 0;            // most classes summed over an aligned group of 16 SNPs (the coded scoring sweep's table rows)
+    void *pool = nullptr;          // one allocation behind every array below
+    int32_t snps_per_wave = 32;    // encoder geometry: 32 / 16 / 8 SNPs per wavefront = hash tables of 64 / 128 / 256 slots
+    int32_t drows = 0;             // dictionary rows per tile
+    int32_t lrows = 0;             // rows of a slab's own dictionary per tile = rows of the coded EM sweep's table; 0: no local numbering
+    int32_t cmax = 0;              // most classes of a coded SNP
+    int32_t score_batch = 16;      // SNPs per table of the coded scoring sweep: 16, 8 or 4 (fewer when the SNPs have many classes)
+    int32_t rows_batch = 0;        // most classes summed over an aligned group of score_batch SNPs (that sweep's table rows)
     int32_t total_quads = 0;
     float2 *dict = nullptr;
     uint8_t *ncls = nullptr;
     std::vector<SlabCodes> slabs;
-    SlabCodes *d_slabs = nullptr;  // device copy (+ per-slab member tables come from wgs_beagle)
-    int64_t bytes = 0;
-    double build_ms = 0.0, kernel_ms = 0.0;
+    SlabCodes *d_slabs = nullptr;  // device copy
+    int64_t bytes = 0, local_bytes = 0;
+    int64_t generation = 0;        // distinguishes this build from any earlier one of the same matrix (caches of derived tables)
+    double build_ms = 0.0, kernel_ms = 0.0, sample_ms = 0.0, alloc_ms = 0.0;
+    double sum_ncls = 0.0;         // over the coded SNPs
+    int64_t rich_snps = 0;
+    double local_direct_share = 0.0;   // share of the (slab, tile) pairs the coded EM sweep takes from the float32 slab
+    double probe_rounds = 0.0;     // hash probe rounds beyond the first per buffer of 16 lookups (encoder diagnostics)
+    double sample_mean_g = 0.0, sample_mean_l = 0.0;   // classes per SNP / per (slab, SNP) in the sample
 };
 
 struct wgs_beagle {
@@ -127,14 +130,18 @@ struct wgs_beagle {
     int32_t *d_group_of = nullptr, *d_col_of = nullptr, *d_npairs = nullptr;
     float4 **d_base = nullptr;
     int64_t bytes = 0;
-    // class codes, built on first use (wgs_beagle_codes) and dropped when rows change; codes_state: 0 = not tried,
-    // 1 = available, -1 = not codable (a SNP with more than 64 classes, or no memory): the direct kernels run
+    // class codes, built when a sweep that profits from them asks (wgs_beagle_codes) and dropped when rows change; codes_state:
+    // 0 = not tried, 1 = available, -1 = not worth coding (too many classes per SNP in the sample, or no memory): the direct kernels run
     wgs_codes *codes = nullptr;
     int codes_state = 0;
+    int64_t codes_generation = 0;  // counts builds and drops
+    int64_t direct_sweeps = 0;     // EM sweeps over the float32 slabs so far (wgs_em_step callers: the codes are built once a run is long)
 };
-// The matrix's class codes, or nullptr when it is not codable (then the direct kernels are used).
-wgs_codes *wgs_beagle_codes(wgs_beagle *b);
+// The matrix's class codes, or nullptr when they are switched off (WGSASSIGN_CODES=0) or the matrix is not worth coding (then the
+// direct kernels are used).  build = false only returns codes that exist already.
+wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true);
 void wgs_beagle_drop_codes(wgs_beagle *b);
+int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned long long *hist_g, unsigned long long *hist_l, double *rounds_per_buffer);
 int launch_class_encode(wgs_beagle *b, wgs_codes *c);
 
 struct wgs_afset {
@@ -159,7 +166,7 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     // the slab's class codes in its own numbering (common.h: SlabLocal), or nullptr: then only the direct kernels can take this fit
     const uint32_t *lcodes;
     const float2 *ldict;
-    const uint64_t *present;
+    const uint32_t *tile_rows;
     int32_t nquads, lrows;
 };
 enum { EM_ACTIVE = 0, EM_CONVERGED = 1, EM_UNDECIDED = 2 };
@@ -185,9 +192,6 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 // the same sweep through the class codes (exact mode; every fit's descriptor carries its slab's local codes; rows = the
 // largest SlabLocal::rows among the fits)
 int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int rows);
-// Builds wgs_codes::local (true = available).
-bool wgs_beagle_local_codes(wgs_beagle *b, wgs_codes *c);
-int launch_local_encode(wgs_beagle *b, wgs_codes *c);
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
 int ssq_reduce_chunks(void);
@@ -272,10 +276,11 @@ int launch_score_sweep(wgs_ctx *ctx, const ScoreArgs &a, int mode);
 struct CodedSlabHost {             // = CodedSlab of assign_kernels.hip
     const uint32_t *codes;
     const int32_t *members;
-    int32_t nquads, ncols, quad0, col_lo, col_hi;
+    const float4 *slab;            // the float32 slab: SNPs the encoder left uncoded (ncls = 0) are scored from it
+    int32_t nquads, ncols, quad0, col_lo, col_hi, npairs;
 };
 int score_kb(int K);                                   // populations per pass of the scoring sweeps
-size_t score_coded_lds_bytes(int rows16, int kb);      // LDS of the coded sweep for a matrix whose richest 16-SNP group has rows16 classes
+size_t score_coded_lds_bytes(int rows, int kb, int batch);   // LDS of the coded sweep for a matrix whose richest batch of SNPs has `rows` classes
 int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, int n_slabs, int total_quads, const float *const *d_acol,
                        int64_t m, int64_t cells, int K, int nblocks, double *S, int mode);
 int launch_block_prefix(wgs_ctx *ctx, double *S, int nblocks, int64_t cells, double *out, int keep_prefix, double *chunks);
@@ -290,5 +295,6 @@ int launch_loglike_site(wgs_ctx *ctx, const float2 *g, const float *a, float *ve
 int launch_scatter_rows(wgs_beagle *b, const float *d_rows, int64_t row0, int64_t nrows);
 int launch_gather_rows(wgs_beagle *b, float *d_rows, int64_t row0, int64_t nrows);
 int launch_synth(wgs_beagle *b, uint64_t seed, double depth);
+int launch_synth_quality(wgs_beagle *b, uint64_t seed, double depth, int nq, const double *quals, const double *probs);
 int launch_transpose_mK_to_Km(wgs_ctx *ctx, const float *src_mK, float *dst_Km, int64_t m, int32_t K);
 int launch_transpose_Km_to_mK(wgs_ctx *ctx, const float *src_Km, float *dst_mK, int64_t m, int32_t K);

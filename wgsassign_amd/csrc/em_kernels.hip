@@ -382,12 +382,10 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
     uint32_t cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
-    // rows of this tile: the most classes one of its 64 SNPs has in this slab
-    int nrows = __popcll(fd.present[row0 + lane]);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) nrows = max(nrows, __shfl_xor(nrows, off, 64));
-    if (nrows > ROWS) {
-        // a SNP of this tile shows more classes in this slab than the table has rows (~1 % of the tiles, launch_local_encode):
+    // rows of this tile: the most classes one of its 64 SNPs has in this slab (255: a SNP the encoder gave up on)
+    const int nrows = (int)__builtin_amdgcn_readfirstlane((int)fd.tile_rows[tile]);
+    if (nrows > ROWS || nrows > fd.lrows) {
+        // a SNP of this tile shows more classes in this slab than the table has rows (~1 % of the tiles, codes.hip):
         // the tile is swept from the float32 slab, term by term as em_sweep_kernel does
         const int npairs = fd.npairs;
         gf4_ptr gl = (gf4_ptr)fd.slab + tile * npairs * 64 + lane;

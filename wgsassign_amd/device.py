@@ -164,6 +164,12 @@ class DeviceBeagle:
     def synth(self, seed, depth=2.0):
         check(_lib.load().wgs_beagle_synth(self._h, int(seed), float(depth)))
 
+    def synth_quality(self, seed, depth=2.0, quals=(12, 23, 37), probs=(0.03, 0.12, 0.85)):
+        """Synthetic matrix with quality-dependent likelihoods (every read its own error rate, drawn from the given bins)."""
+        q = np.ascontiguousarray(quals, dtype=np.float64)
+        p = np.ascontiguousarray(probs, dtype=np.float64)
+        check(_lib.load().wgs_beagle_synth_quality(self._h, int(seed), float(depth), len(q), f64p(q), f64p(p)))
+
     def nbytes(self):
         return int(_lib.load().wgs_beagle_bytes(self._h))
 
@@ -171,14 +177,22 @@ class DeviceBeagle:
         """Build the class codes now (em: and the slabs' own numbering for the coded EM sweep) instead of at first use."""
         check(_lib.load().wgs_beagle_codes_prepare(self._h, 1 if em else 0))
 
+    def codes_state(self):
+        """1: the class codes exist, 0: nothing has asked for them yet, -1: not worth coding.  Builds nothing."""
+        return int(_lib.load().wgs_beagle_codes_state(self._h))
+
     def codes_info(self):
-        """Class codes of the matrix (built on first use; csrc/common.h: wgs_codes): dict with `available`, `max_classes`
-        (of the richest SNP), `bytes`, `build_ms`, `mean_classes`."""
-        info = (ctypes.c_double * 10)()
+        """Class codes of the matrix (built on first use; csrc/common.h: wgs_codes, csrc/codes.hip): what they hold and what
+        they cost.  `build_ms` is the whole build (sample pass, one allocation, the encode pass); `rich_snp_share` the SNPs
+        left uncoded (too many classes: every sweep takes them from the float32 slab), `em_direct_tile_share` the (slab, tile)
+        pairs the coded EM sweep takes from the float32 slab."""
+        info = (ctypes.c_double * 20)()
         check(_lib.load().wgs_beagle_codes_info(self._h, info))
         return {"available": bool(info[0]), "max_classes": int(info[1]), "bytes": int(info[2]), "build_ms": info[3],
-                "encode_kernel_ms": info[5], "mean_classes": info[4], "slab_numbering_ms": info[6], "slab_numbering_bytes": int(info[7]),
-                "em_table_rows": int(info[8]), "em_direct_tile_share": info[9]}
+                "encode_kernel_ms": info[5], "mean_classes": info[4], "sample_ms": info[6], "slab_numbering_bytes": int(info[7]),
+                "em_table_rows": int(info[8]), "em_direct_tile_share": info[9], "hash_slots": int(info[10]), "rich_snp_share": info[11],
+                "dict_rows": int(info[12]), "probe_rounds_per_buffer": info[13], "alloc_ms": info[14], "score_table_rows": int(info[15]),
+                "sample_mean_classes": info[16], "sample_mean_classes_per_slab": info[17], "score_batch_snps": int(info[18])}
 
     def close(self):
         if self._h:
