@@ -125,10 +125,11 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
         off.push_back(take(slab_tab));
         off.push_back(take(rows));                                             // ncls
         off.push_back(take((size_t)tiles * c->drows * 64 * sizeof(float2)));   // dict
+        off.push_back(take(sizeof(uint4) * 2 * (size_t)tiles * (64 / c->snps_per_wave)));   // wave_stats
         for (int g = 0; g < b->n_groups; ++g) {
             const size_t words = (size_t)tiles * c->slabs[g].nquads * 64;
             off.push_back(take(words * sizeof(uint32_t)));                      // codes
-            off.push_back(take(sizeof(uint32_t) * (size_t)tiles));              // tile_rows
+            off.push_back(take(8 * (size_t)tiles));                             // tile_rows
             off.push_back(take(with_local ? words * sizeof(uint32_t) : 0));     // lcodes
             off.push_back(take(with_local ? (size_t)tiles * c->lrows * 64 * sizeof(float2) : 0));   // ldict
         }
@@ -153,22 +154,21 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
     c->d_slabs = reinterpret_cast<SlabCodes *>(base + off[0]);
     c->ncls = reinterpret_cast<uint8_t *>(base + off[1]);
     c->dict = reinterpret_cast<float2 *>(base + off[2]);
+    c->wave_stats = reinterpret_cast<uint4 *>(base + off[3]);
     for (int g = 0; g < b->n_groups; ++g) {
         SlabCodes &s = c->slabs[g];
         if (s.nquads == 0) continue;
-        s.codes = reinterpret_cast<uint32_t *>(base + off[3 + 4 * g]);
-        s.tile_rows = reinterpret_cast<uint32_t *>(base + off[4 + 4 * g]);
+        s.codes = reinterpret_cast<uint32_t *>(base + off[4 + 4 * g]);
+        s.tile_rows = reinterpret_cast<uint8_t *>(base + off[5 + 4 * g]);
         if (c->lrows > 0) {
-            s.lcodes = reinterpret_cast<uint32_t *>(base + off[5 + 4 * g]);
-            s.ldict = reinterpret_cast<float2 *>(base + off[6 + 4 * g]);
+            s.lcodes = reinterpret_cast<uint32_t *>(base + off[6 + 4 * g]);
+            s.ldict = reinterpret_cast<float2 *>(base + off[7 + 4 * g]);
             c->local_bytes += (int64_t)((size_t)tiles * s.nquads * 64 * sizeof(uint32_t) + (size_t)tiles * c->lrows * 64 * sizeof(float2));
         }
     }
     c->bytes = (int64_t)total - c->local_bytes;
     if (hipMemcpy(c->d_slabs, c->slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) != hipSuccess) return fail();
-    const double tk = now_s();
-    if (launch_class_encode(b, c)) return fail();
-    c->kernel_ms = (now_s() - tk) * 1e3;
+    if (launch_class_encode(b, c)) return fail();          // (sets kernel_ms from HIP events around the kernel)
     c->build_ms = (now_s() - t0) * 1e3;
     b->codes_state = 1;
     return c;

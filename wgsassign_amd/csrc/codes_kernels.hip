@@ -31,10 +31,16 @@ namespace {
 
 typedef float f4 __attribute__((ext_vector_type(4)));   // plain vector type (nontemporal loads take it)
 typedef const f4 __attribute__((address_space(1))) *gf4_ptr;
+// Pointers read out of the slab table are generic to the compiler (-> flat_load / flat_store, which count as LDS operations
+// too and stall the probes' counted waits); they are device-global by construction.
+typedef uint32_t __attribute__((address_space(1))) *gu32_ptr;
+typedef unsigned long long __attribute__((address_space(1))) *gu64_ptr;
+typedef uint8_t __attribute__((address_space(1))) *gu8_ptr;
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;            // (g0, g1) = two NaNs with all payload bits set: no parser makes it
 constexpr int ENC_SLOTS = 2048;                            // hash slots per wavefront (16 KiB of keys + 4 KiB of marks: 8 wavefronts per CU)
 constexpr int ENC_RMAX = 24;                               // probe rounds per buffer before the SNP is given up as rich
+constexpr int ENC_PD = 2;                                  // buffers requested ahead of the one being hashed
 constexpr int ENC_UQ = 4;                                  // quads per lane and buffer: 8 loads of 16 bytes, 16 lookups in flight
 
 __device__ __forceinline__ unsigned hash32(unsigned g0, unsigned g1)
@@ -56,8 +62,10 @@ struct EncodeArgs {
     int32_t batch, batch_cap;      // the coded scoring sweep tables `batch` (16, 8 or 4) consecutive SNPs at a time: most classes such an
                                    // aligned group may sum to (its LDS table)
     int64_t unit_stride;           // sample pass: work unit = blockIdx.x * unit_stride
+    int32_t dbg;                   // experiments (WGS_ENC_DBG)
     uint8_t *sample;               // sample pass: [unit][slab, then all][SNP of the unit] classes found (0: beyond the last SNP, 255: overflow)
     unsigned long long *stats;     // see EncStat
+    uint4 *wave_stats;             // full pass: two records per work unit (sum of ncls, rich SNPs, most classes, most rows of a batch | rounds, buffers)
 };
 
 // stats[]: what the host reads back after a pass
@@ -73,7 +81,7 @@ enum EncStat {
     ST_COUNT = 8
 };
 
-template <int SNPS, bool SAMPLE>
+template <int SNPS, bool SAMPLE, int VARIANT = 0>
 __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
 {
     constexpr int COLS = 64 / SNPS, T = ENC_SLOTS / SNPS, SCAN = ENC_SLOTS / 64;    // SCAN slots per lane when a table is ranked
@@ -138,23 +146,32 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
         const int nquads = sc.nquads;
         if (nquads == 0) continue;
         gf4_ptr src = (gf4_ptr)A.base[g] + tile * np * 64 + ls;
-        uint32_t *cw = sc.codes + tile * nquads * 64 + ls;
+        gu32_ptr cw = (gu32_ptr)sc.codes + tile * nquads * 64 + ls;
         // ---- the walk: this lane's quads col, col + COLS, ...; the loads of the next buffer are in flight while this one is hashed
-        f4 nxt[ENC_UQ][2];
-        auto fetch = [&](int qb) {
+        // (two buffers ahead: the walk is bound by memory latency -- a wavefront has few loads in flight -- and that latency varies
+        // with how the driver could place the matrix; 16 KiB in flight per wavefront while 8 KiB are being hashed)
+        f4 nxt[ENC_PD][ENC_UQ][2];
+        auto fetch = [&](int qb, f4 (&dst)[ENC_UQ][2]) {
 #pragma unroll
             for (int u = 0; u < ENC_UQ; ++u) {
                 const int q = qb + u * COLS + col;
-                nxt[u][0] = __builtin_nontemporal_load(src + (int64_t)min(2 * q, np - 1) * 64);
-                nxt[u][1] = __builtin_nontemporal_load(src + (int64_t)min(2 * q + 1, np - 1) * 64);
+                dst[u][0] = __builtin_nontemporal_load(src + (int64_t)min(2 * q, np - 1) * 64);
+                dst[u][1] = __builtin_nontemporal_load(src + (int64_t)min(2 * q + 1, np - 1) * 64);
             }
         };
-        fetch(0);
-        for (int qb = 0; qb < nquads; qb += COLS * ENC_UQ) {
+        constexpr int QSTEP = COLS * ENC_UQ;
+#pragma unroll
+        for (int d = 0; d < ENC_PD; ++d)
+            if (d == 0 || d * QSTEP < nquads) fetch(d * QSTEP, nxt[d]);
+        for (int qb = 0; qb < nquads; qb += QSTEP) {
             f4 v[ENC_UQ][2];
 #pragma unroll
-            for (int u = 0; u < ENC_UQ; ++u) v[u][0] = nxt[u][0], v[u][1] = nxt[u][1];
-            if (qb + COLS * ENC_UQ < nquads) fetch(qb + COLS * ENC_UQ);
+            for (int u = 0; u < ENC_UQ; ++u) v[u][0] = nxt[0][u][0], v[u][1] = nxt[0][u][1];
+#pragma unroll
+            for (int d = 0; d + 1 < ENC_PD; ++d)
+#pragma unroll
+                for (int u = 0; u < ENC_UQ; ++u) nxt[d][u][0] = nxt[d + 1][u][0], nxt[d][u][1] = nxt[d + 1][u][1];
+            if (qb + ENC_PD * QSTEP < nquads) fetch(qb + ENC_PD * QSTEP, nxt[ENC_PD - 1]);
             unsigned long long key[NL], old[NL];
             unsigned slot[NL];
 #pragma unroll
@@ -167,6 +184,13 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
                     slot[4 * u + h] = hash32(g0, g1) >> HSHIFT;
                 }
             }
+            if (A.dbg & 32) {                              // (experiment: the loads alone)
+                unsigned acc = 0;
+#pragma unroll
+                for (int i = 0; i < NL; ++i) acc ^= slot[i];
+                if (acc == 0x7fffffffu) flag[0] = 1;
+                continue;
+            }
             bool pend[NL];                                 // lane masks in scalar registers
             // a buffer whose 4 x ENC_UQ x COLS individuals all exist, in a wavefront without a rich SNP: no per-lookup predicates
             const bool plain = 4 * (qb + COLS * ENC_UQ) <= nc && !__any(rich);
@@ -174,7 +198,10 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
 #pragma unroll
                 for (int i = 0; i < NL; ++i) old[i] = probe(slot[i], key[i]);
 #pragma unroll
-                for (int i = 0; i < NL; ++i) pend[i] = old[i] != KEY_EMPTY && old[i] != key[i];
+                for (int i = 0; i < NL; ++i) {
+                    pend[i] = old[i] != KEY_EMPTY && old[i] != key[i];
+                    if (VARIANT == 1) rich = rich || key[i] == KEY_EMPTY;
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < ENC_UQ; ++u) {
@@ -245,7 +272,7 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
             const int f = flag[(col * SCAN + k) * SNPS + s];
             cnt += f;
             // a slot marked seen that holds no key: the one bit pattern used as EMPTY was looked up -- that SNP cannot be coded
-            if (f && keys[(col * SCAN + k) * SNPS + s] == KEY_EMPTY) rich = true;
+            if (VARIANT == 0 && f && keys[(col * SCAN + k) * SNPS + s] == KEY_EMPTY) rich = true;
         }
         rich = snp_or(rich);
         int pre, nloc;
@@ -254,8 +281,9 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
             if (col == 0) A.sample[((int64_t)blockIdx.x * (A.n_slabs + 1) + g) * SNPS + s] = (uint8_t)(snp < A.m ? (rich ? 255 : min(nloc, 254)) : 0);
         } else {
             const int wmax = wave_max(rich ? 255 : nloc);
-            if (lane == 0) atomicMax(sc.tile_rows + tile, (unsigned)wmax);
-            if (A.lrows > 0 && wmax <= A.lrows) {          // wave-uniform: this wave's SNPs fit the EM sweep's table
+            // one byte per group of 8 SNPs of the tile (this wave's SNPS / 8 of them): plain stores, the EM sweep takes the largest
+            if (lane < SNPS / 8) ((gu8_ptr)sc.tile_rows)[tile * 8 + sub * (SNPS / 8) + lane] = (uint8_t)wmax;
+            if (A.lrows > 0 && wmax <= A.lrows && !(A.dbg & 8)) {          // wave-uniform: this wave's SNPs fit the EM sweep's table
                 int r = pre;
 #pragma unroll 8
                 for (int k = 0; k < SCAN; ++k) {
@@ -269,15 +297,15 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // dictionary rows: as many as the richest of this wave's SNPs has (the EM sweep requests rows eight at a time and never
                 // looks at a row beyond a SNP's own classes: what it finds in the unwritten ones does not matter)
-                const int rows_w = wmax;
-                unsigned long long *ld = reinterpret_cast<unsigned long long *>(sc.ldict) + (tile * A.lrows) * 64 + ls;
+                const int rows_w = (A.dbg & 2) ? min(A.lrows, (wmax + 7) & ~7) : wmax;
+                gu64_ptr ld = (gu64_ptr)sc.ldict + (tile * A.lrows) * 64 + ls;
                 for (int r0 = col; r0 < rows_w; r0 += COLS) {
                     unsigned long long e = 0;
                     if (r0 < nloc) e = keys[(unsigned)order[r0 * SNPS + s] * SNPS + s];
                     ld[(int64_t)r0 * 64] = e;
                 }
                 // the code words again, as local ranks
-                uint32_t *lw = sc.lcodes + tile * nquads * 64 + ls;
+                gu32_ptr lw = (gu32_ptr)sc.lcodes + tile * nquads * 64 + ls;
                 constexpr int PF = 8;
                 for (int q0 = col; q0 < nquads; q0 += COLS * PF) {
                     uint32_t w[PF];
@@ -312,10 +340,6 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
     rich = snp_or(rich);
     if (SAMPLE) {
         if (col == 0) A.sample[((int64_t)blockIdx.x * (A.n_slabs + 1) + A.n_slabs) * SNPS + s] = (uint8_t)(snp < A.m ? (rich ? 255 : min(ncls, 254)) : 0);
-        if (lane == 0) {
-            atomicAdd(A.stats + ST_ROUNDS, (unsigned long long)n_rounds);
-            atomicAdd(A.stats + ST_BUFFERS, (unsigned long long)n_buffers);
-        }
         return;
     }
     int eff = rich ? 0 : ncls;
@@ -340,7 +364,7 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
             rich = true;
         }
     }
-    if (col == 0) A.ncls[snp] = (uint8_t)eff;
+    if (col == 0) ((gu8_ptr)A.ncls)[snp] = (uint8_t)eff;
     {
         const int mb = wave_max(group_sum(eff)), mc = wave_max(eff);
         unsigned long long tot = (unsigned long long)((col == 0 && snp < A.m) ? eff : 0), nrich = (col == 0 && snp < A.m && rich) ? 1ull : 0ull;
@@ -349,13 +373,14 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
             tot += __shfl_xor(tot, off, 64);
             nrich += __shfl_xor(nrich, off, 64);
         }
+        // this wavefront's record (no atomics on shared counters: 312 500 wavefronts adding to one cache line queue up behind each
+        // other in its memory channel; encode_stats_kernel adds the records up)
         if (lane == 0) {
-            atomicAdd(A.stats + ST_SUM_NCLS, tot);
-            if (nrich) atomicAdd(A.stats + ST_RICH, nrich);
-            atomicMax(A.stats + ST_CMAX, (unsigned long long)mc);
-            atomicMax(A.stats + ST_ROWS_BATCH, (unsigned long long)mb);
-            atomicAdd(A.stats + ST_ROUNDS, (unsigned long long)n_rounds);
-            atomicAdd(A.stats + ST_BUFFERS, (unsigned long long)n_buffers);
+            typedef unsigned u4 __attribute__((ext_vector_type(4)));
+            typedef u4 __attribute__((address_space(1))) *gu4_ptr;
+            gu4_ptr rec = (gu4_ptr)A.wave_stats + 2 * (int64_t)blockIdx.x;
+            rec[0] = u4{(unsigned)tot, (unsigned)nrich, (unsigned)mc, (unsigned)mb};
+            rec[1] = u4{n_rounds, n_buffers, 0u, 0u};
         }
     }
     int r = pre;
@@ -370,14 +395,14 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int wmax = min(wave_max(eff), A.drows);
-    unsigned long long *dd = reinterpret_cast<unsigned long long *>(A.dict) + (tile * A.drows) * 64 + ls;
+    gu64_ptr dd = (gu64_ptr)A.dict + (tile * A.drows) * 64 + ls;
     for (int r0 = col; r0 < wmax; r0 += COLS)
         if (r0 < eff) dd[(int64_t)r0 * 64] = keys[(unsigned)order[r0 * SNPS + s] * SNPS + s];
     // every slab's code words: slot numbers -> class ids, in place
-    for (int g = 0; g < A.n_slabs; ++g) {
+    for (int g = 0; g < ((A.dbg & 16) ? 0 : A.n_slabs); ++g) {
         const SlabCodes sc = A.slabs[g];
         const int nquads = sc.nquads;
-        uint32_t *cw = sc.codes + tile * nquads * 64 + ls;
+        gu32_ptr cw = (gu32_ptr)sc.codes + tile * nquads * 64 + ls;
         constexpr int PF = 8;
         for (int q0 = col; q0 < nquads; q0 += COLS * PF) {
             uint32_t w[PF];
@@ -396,16 +421,43 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
     }
 }
 
-// (slab, tile) pairs whose SNPs do not fit the EM sweep's table: counted after the encode pass
-__global__ __launch_bounds__(256) void tile_rows_count_kernel(const SlabCodes *slabs, int64_t tiles, unsigned lrows, unsigned long long *out)
+// After the encode pass: the wavefronts' records added up, and the (slab, tile) pairs whose SNPs do not fit the EM sweep's table counted.
+__global__ __launch_bounds__(256) void encode_stats_kernel(const uint4 *wave_stats, int64_t units, const SlabCodes *slabs, int n_slabs, int64_t tiles,
+                                                           unsigned lrows, unsigned long long *out)
 {
-    const SlabCodes sc = slabs[blockIdx.y];
-    if (sc.nquads == 0) return;
-    unsigned long long c = 0;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tiles; t += (int64_t)gridDim.x * 256) c += sc.tile_rows[t] > lrows ? 1u : 0u;
+    unsigned long long sum = 0, rich = 0, rounds = 0, buffers = 0, direct = 0;
+    unsigned cmax = 0, rows = 0;
+    const int64_t step = (int64_t)gridDim.x * 256;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += step) {
+        const uint4 a = wave_stats[2 * u], b = wave_stats[2 * u + 1];
+        sum += a.x, rich += a.y, cmax = max(cmax, a.z), rows = max(rows, a.w), rounds += b.x, buffers += b.y;
+    }
+    for (int g = 0; g < n_slabs; ++g) {
+        if (slabs[g].nquads == 0) continue;
+        const unsigned long long *tr = reinterpret_cast<const unsigned long long *>(slabs[g].tile_rows);
+        for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tiles; t += step) {
+            const unsigned long long w = tr[t];
+            unsigned mx = 0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+            for (int k = 0; k < 8; ++k) mx = max(mx, (unsigned)((w >> (8 * k)) & 255u));
+            direct += mx > lrows ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64), rich += __shfl_xor(rich, off, 64), rounds += __shfl_xor(rounds, off, 64);
+        buffers += __shfl_xor(buffers, off, 64), direct += __shfl_xor(direct, off, 64);
+        cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, off, 64)), rows = max(rows, (unsigned)__shfl_xor((int)rows, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(out + ST_SUM_NCLS, sum);
+        atomicAdd(out + ST_RICH, rich);
+        atomicMax(out + ST_CMAX, (unsigned long long)cmax);
+        atomicMax(out + ST_ROWS_BATCH, (unsigned long long)rows);
+        atomicAdd(out + ST_ROUNDS, rounds);
+        atomicAdd(out + ST_BUFFERS, buffers);
+        atomicAdd(out + ST_DIRECT, direct);
+    }
 }
 
 }  // namespace
@@ -428,7 +480,9 @@ static EncodeArgs encode_args(wgs_beagle *b, wgs_codes *c, const int32_t *d_ncol
     A.batch_cap = WGS_BATCH_ROWS_CAP;
     A.unit_stride = 1;
     A.sample = nullptr;
+    A.dbg = getenv("WGS_ENC_DBG") ? atoi(getenv("WGS_ENC_DBG")) : 0;
     A.stats = d_stats;
+    A.wave_stats = nullptr;
     return A;
 }
 
@@ -482,7 +536,8 @@ int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned lon
                 if (b->slabs[g].ncols) ++hist_l[row[(size_t)g * 8 + x]];
         }
     }
-    if (rounds_per_buffer) *rounds_per_buffer = st[ST_BUFFERS] ? (double)st[ST_ROUNDS] / (double)st[ST_BUFFERS] : 0.0;
+    (void)st;
+    if (rounds_per_buffer) *rounds_per_buffer = 0.0;
     return 0;
 }
 
@@ -493,26 +548,32 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
     unsigned long long *d_stats = nullptr;
     if (encode_scratch(b, &d_ncols, &d_stats)) return 1;
     const int64_t tiles = wgs_ntiles(b->m);
-    for (int g = 0; g < b->n_groups; ++g)
-        if (c->slabs[g].tile_rows) HIP_TRY(hipMemsetAsync(c->slabs[g].tile_rows, 0, sizeof(uint32_t) * tiles, b->ctx->stream));
     EncodeArgs A = encode_args(b, c, d_ncols, d_stats);
     const int64_t units = tiles * (64 / c->snps_per_wave);
+    A.wave_stats = c->wave_stats;
     WGS_REQUIRE(units < (1ll << 31), "class encoder: %lld work units exceed one launch", (long long)units);
+    HIP_TRY(hipEventRecord(b->ctx->ev0, b->ctx->stream));
     switch (c->snps_per_wave) {
-        case 32: hipLaunchKernelGGL((class_encode_kernel<32, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
+        case 32:
+            if (A.dbg & 4) hipLaunchKernelGGL((class_encode_kernel<32, false, 1>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
+            else hipLaunchKernelGGL((class_encode_kernel<32, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
+            break;
         case 16: hipLaunchKernelGGL((class_encode_kernel<16, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
         default: hipLaunchKernelGGL((class_encode_kernel<8, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
     }
     HIP_TRY(hipGetLastError());
-    unsigned long long *d_direct = d_stats + ST_DIRECT;
-    if (c->lrows > 0) {
-        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(256, (tiles + 255) / 256));
-        hipLaunchKernelGGL(tile_rows_count_kernel, dim3(gx, (unsigned)b->n_groups), dim3(256), 0, b->ctx->stream, c->d_slabs, tiles, (unsigned)c->lrows, d_direct);
+    HIP_TRY(hipEventRecord(b->ctx->ev1, b->ctx->stream));
+    {
+        const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512, (units + 255) / 256));
+        hipLaunchKernelGGL(encode_stats_kernel, dim3(gx), dim3(256), 0, b->ctx->stream, c->wave_stats, units, c->d_slabs, (int)b->n_groups, tiles,
+                           (unsigned)(c->lrows > 0 ? c->lrows : 255), d_stats);
         HIP_TRY(hipGetLastError());
     }
     unsigned long long h[8];
     HIP_TRY(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    float ev_ms = 0.0f;
+    if (hipEventElapsedTime(&ev_ms, b->ctx->ev0, b->ctx->ev1) == hipSuccess) c->kernel_ms = ev_ms;     // the encode kernel alone (HIP events)
     c->sum_ncls = (double)h[ST_SUM_NCLS];
     c->rich_snps = (int64_t)h[ST_RICH];
     c->cmax = (int32_t)h[ST_CMAX];

@@ -86,14 +86,15 @@ static inline int64_t wgs_ntiles(int64_t m) { return (m + 63) / 64; }
 // class PRESENT in the slab, not per class of the SNP):
 //   lcodes like codes, a byte = rank of the individual's class among the classes present in the slab at that SNP
 //   ldict  [(tile * lrows + rank) * 64 + lane]  (g0, g1) of the rank-th present class of SNP 64 * tile + lane
-//   tile_rows [tile]  most classes present in the slab at one of the tile's 64 SNPs; 255 when one of them is rich.  A tile
-//          with more than lrows is swept directly from the float32 slab by the coded EM sweep.
+//   tile_rows [tile * 8 + k]  most classes present in the slab at one of SNPs 8 k .. 8 k + 7 of the tile (as the encoder's wavefronts,
+//          which own 8, 16 or 32 SNPs, saw it); 255 when one of them is rich.  A tile whose largest entry exceeds lrows is swept
+//          directly from the float32 slab by the coded EM sweep.
 constexpr int WGS_BATCH_ROWS_CAP = 672;  // classes the SNPs of one batch of the coded scoring sweep may sum to: 672 rows of 80 bytes + the log table fit 64 KiB of LDS
 struct SlabCodes {
     uint32_t *codes = nullptr;
     uint32_t *lcodes = nullptr;
     float2 *ldict = nullptr;
-    uint32_t *tile_rows = nullptr;
+    uint8_t *tile_rows = nullptr;  // [tile * 8 + k]: for SNPs 8 k .. 8 k + 7 of the tile
     int32_t nquads = 0;
     int32_t quad0 = 0;             // first matrix-wide quad index of this slab
 };
@@ -110,6 +111,7 @@ struct wgs_codes {
     uint8_t *ncls = nullptr;
     std::vector<SlabCodes> slabs;
     SlabCodes *d_slabs = nullptr;  // device copy
+    uint4 *wave_stats = nullptr;   // the encoder's per-wavefront records (two per work unit)
     int64_t bytes = 0, local_bytes = 0;
     int64_t generation = 0;        // distinguishes this build from any earlier one of the same matrix (caches of derived tables)
     double build_ms = 0.0, kernel_ms = 0.0, sample_ms = 0.0, alloc_ms = 0.0;
@@ -166,7 +168,7 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     // the slab's class codes in its own numbering (common.h: SlabLocal), or nullptr: then only the direct kernels can take this fit
     const uint32_t *lcodes;
     const float2 *ldict;
-    const uint32_t *tile_rows;
+    const uint8_t *tile_rows;
     int32_t nquads, lrows;
 };
 enum { EM_ACTIVE = 0, EM_CONVERGED = 1, EM_UNDECIDED = 2 };

@@ -383,7 +383,14 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
     // rows of this tile: the most classes one of its 64 SNPs has in this slab (255: a SNP the encoder gave up on)
-    const int nrows = (int)__builtin_amdgcn_readfirstlane((int)fd.tile_rows[tile]);
+    int nrows;
+    {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long *>(fd.tile_rows + tile * 8);   // one byte per 8 SNPs
+        unsigned mx = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mx = max(mx, (unsigned)((w >> (8 * k)) & 255u));
+        nrows = (int)__builtin_amdgcn_readfirstlane((int)mx);
+    }
     if (nrows > ROWS || nrows > fd.lrows) {
         // a SNP of this tile shows more classes in this slab than the table has rows (~1 % of the tiles, codes.hip):
         // the tile is swept from the float32 slab, term by term as em_sweep_kernel does
