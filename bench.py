@@ -220,6 +220,9 @@ def main():
         comm = wcomm.LocalComm()
     comm.force_device = True
     watchdog.cancel()
+    # what the communicator is by RCCL's own account (ncclCommCount / ncclCommUserRank / ncclCommCuDevice through wgs_comm_info;
+    # wgs_comm_init refuses a communicator that differs from what was asked for)
+    comm_info = comm.info() if use_dist and hasattr(comm, "info") and getattr(comm, "handle", None) is not None else None
 
     m_total, n, K = args.m, args.n, args.K
     lo, hi = wcomm.shard_range(m_total, rank, world)
@@ -300,6 +303,13 @@ def main():
 
     extra = {"gl_pair_terms_per_s": value * n_call, "synth_seconds": round(t_gen, 2),
              "ssq_last": [float(x) for x in np.asarray(ssq)[:3]]}
+    if use_dist:
+        # every rank's own sweep time (the slowest decides a step), and the device time of the collectives the sharded path uses
+        slots = np.zeros(world)
+        slots[rank] = k_avg * 1e3
+        extra["per_rank_sweep_kernel_ms"] = [round(float(x), 4) for x in comm.allreduce_sum(slots)]
+        if comm_info is not None:
+            extra["collectives"] = comm.time_collectives(reps=20, n=max(16, K))
     if user_codes is None:
         os.environ.pop("WGSASSIGN_CODES")
     else:
@@ -415,6 +425,8 @@ def main():
                 "config": {"workload": "synthetic Beagle %d SNPs x %d ind, K=%d, --get_reference_af EM sweep (+ --get_pop_like sweep), SNP-sharded over %d GPU(s)"
                                        % (m_total, n, K, world), "mode": args.mode, "snps_per_gpu": m,
                            "gl_bytes_per_gpu": gl_bytes, "comm": comm_note,
+                           "rccl_ranks_seen": comm_info["rccl_ranks_seen"] if comm_info and comm_info["native"] else None,
+                           "comm_native_rccl": bool(comm_info and comm_info["native"]),
                            "step": ("wgs_em_fit iteration (enqueued ahead of the host)" if not use_dist or getattr(comm, "native", False)
                                     else "wgs_em_fit iteration, all-reduce staged through the host (TCP)") if pipelined
                            else "sweep + host all-reduce + readback"},

@@ -280,6 +280,13 @@ int wgs_comm_bcast_dev(wgs_comm *c, void *dev_buf, int64_t bytes, int root);
 /* stats[0..3]: all-reduces, broadcasts, payload bytes, host round trips (stream synchronisations) of this
  * communicator's collectives so far. */
 int wgs_comm_stats(wgs_comm *c, int64_t *stats);
+/* info[0..7]: 1 = RCCL communicator / 0 = host-backed; the number of ranks, this rank and the device as RCCL ITSELF reports
+ * them for the communicator it built (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 where unavailable) -- wgs_comm_init
+ * fails when they differ from what was asked for --; world and rank as given at creation; two reserved entries. */
+int wgs_comm_info(wgs_comm *c, int64_t *info);
+/* Mean device microseconds (HIP events on the context's stream) of `reps` sum all-reduces of n float64 and of `reps`
+ * broadcasts of n float64 from rank 0: us_out[0..1].  Collective. */
+int wgs_comm_time_collectives(wgs_comm *c, int32_t reps, int64_t n, double *us_out);
 /* Same for a host buffer (staged through the device); returns when the result is back. */
 int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n);
 /* The communicator's device bounce buffer (>= n float64), e.g. as the target of wgs_em_step_dev;

@@ -34,6 +34,30 @@ def test_bench_json_line():
     assert abs(d["value"] - 5 * 200000 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-6
 
 
+def test_bench_line_says_what_rccl_saw():
+    """WGS_FORCE_DIST=1 sends the one-GPU run down the N > 1 path over a real RCCL communicator of one rank: the line carries
+    RCCL's own count of the communicator's ranks (ncclCommCount -- what tells an N-rank RCCL run from a socket fall-back), every
+    rank's sweep time and the device time of the collectives; the headline stays the float32 sweep with frac < 1, and the
+    class-coded leg reports the fit cold, warm and over the float32 slabs."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--snps", "200000", "--inds", "100", "--pops", "5",
+                        "--steps", "3", "--warmup", "1", "--no-cpu", "--no-paths"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, WGS_FORCE_DIST="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d["config"]["rccl_ranks_seen"] == 1 and d["config"]["comm_native_rccl"] is True
+    assert len(d["extra"]["per_rank_sweep_kernel_ms"]) == 1 and d["extra"]["per_rank_sweep_kernel_ms"][0] > 0
+    assert d["extra"]["collectives"]["allreduce_us"] > 0
+    assert d["roofline"]["kernel"] == "em_sweep_kernel<exact>" and 0 < d["roofline"]["frac"] < 1
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--snps", "200000", "--inds", "100", "--pops", "5",
+                          "--steps", "3", "--warmup", "1", "--no-cpu", "--no-paths"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.strip().startswith("{")][0])
+    assert d1["config"]["rccl_ranks_seen"] is None and "collectives" not in d1["extra"]
+    c = d1["extra"]["coded"]
+    assert c["identical_frequencies"] and c["fit_cold"]["seconds"] > 0 and c["fit_warm"]["seconds"] > 0 and c["fit_direct"]["seconds"] > 0
+    assert d1["extra"]["assign"]["kernel"].startswith("score_sweep_kernel") and d1["extra"]["assign"]["coded"]["identical_sums"]
+
+
 @pytest.mark.parametrize("comm_env", [{"WGSASSIGN_COMM": "socket"}, {"WGSASSIGN_BACKEND": "gloo"}])
 def test_bench_self_launches_two_ranks(comm_env):
     """`python bench.py --gpus 2` with no launcher: bench.py starts the two ranks itself (both on the one

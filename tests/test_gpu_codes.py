@@ -253,6 +253,40 @@ def test_snps_beyond_the_tables_are_scored_from_the_slab(dev, oracle, monkeypatc
         assert same_nan(out1.astype(np.float32), oracle.assignLL(L, af_o.copy(), 4))
 
 
+@pytest.mark.parametrize("slots", [64, 128, 256])
+def test_small_quotient_table_sends_many_tiles_to_the_direct_path(dev, oracle, slots, monkeypatch):
+    """WGSASSIGN_EM_TABLE_ROWS=16 on 30 individuals per population (~10 classes per slab and SNP): one tile in thirteen has a SNP with more
+    classes than rows and are swept from the float32 slab inside the coded sweep, the others through the table -- same
+    iterations and frequencies as the direct kernels and the oracle, and the reported share of direct tiles says so."""
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")
+    monkeypatch.setenv("WGSASSIGN_EM_TABLE_ROWS", "16")
+    monkeypatch.setenv("WGSASSIGN_CODES_TABLE", str(slots))
+    m, n, K = 50_000, 60, 2
+    L, IDs = synth.make_beagle(m, n, K, seed=31)
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")
+    group_of = (np.arange(n) // (n // K)).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    # how many (slab, tile) pairs NumPy sees with more than 16 classes in some SNP
+    tiles = (m + 63) // 64
+    over = 0
+    for k in range(K):
+        cl = synth.classes_per_snp(L[:, 2 * 30 * k:2 * 30 * (k + 1)])
+        cl = np.concatenate([cl, np.ones(tiles * 64 - m, dtype=cl.dtype)])
+        over += int((cl.reshape(tiles, 64).max(axis=1) > 16).sum())
+    b = dev.DeviceBeagle.from_host(L, group_of, K)
+    with codes(False):
+        it0, af0, _ = fit_and_score(dev, b, K, counts)
+    with codes(True):
+        it1, af1, _ = fit_and_score(dev, b, K, counts)
+        info = b.codes_info()
+    assert info["em_table_rows"] == 16 and abs(info["em_direct_tile_share"] - over / (K * tiles)) < 1e-9 and 0.02 < info["em_direct_tile_share"] < 0.98
+    assert it1 == it0 and same(af1, af0)
+    with quiet():
+        _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+    assert it1 == [int(x) for x in it_o] and same(af1, af_o)
+    b.close()
+
+
 def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
     """The cost model of csrc/api.hip: em_codes_pay (a 6.4 GB device-generated matrix, 100 individuals per population: the
     encode pass costs about four direct sweeps, a coded sweep saves half of one) -- a fit with three iterations ahead sweeps the

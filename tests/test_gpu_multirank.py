@@ -333,6 +333,12 @@ def test_native_rccl_single_rank():
     assert c.allgather_object({"a": 1}) == [{"a": 1}]
     big = np.arange(200_000, dtype=np.float64)
     assert np.array_equal(c.allreduce_sum(big), big)
+    # what RCCL itself says about the communicator it built (wgs_comm_init refuses one that differs from what was asked for)
+    info = c.info()
+    assert info["native"] and info["rccl_ranks_seen"] == 1 and info["rccl_rank"] == 0 and info["world"] == 1
+    assert info["rccl_device"] == device.get_context().device
+    t = c.time_collectives(reps=10, n=16)
+    assert t["allreduce_us"] > 0 and t["bcast_us"] >= 0 and t["calls"] == 10
     c.barrier()
     c.close()
 

@@ -80,6 +80,8 @@ SIGNATURES = {
     "wgs_comm_allreduce_f64_dev": (c_int, [c_vp, c_vp, c_i64]),
     "wgs_comm_allreduce_f64": (c_int, [c_vp, c_f64p, c_i64]),
     "wgs_comm_bcast_dev": (c_int, [c_vp, c_vp, c_i64, c_int]),
+    "wgs_comm_info": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
+    "wgs_comm_time_collectives": (c_int, [c_vp, c_i32, c_i64, c_f64p]),
     "wgs_comm_stats": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_comm_buffer": (c_vp, [c_vp, c_i64]),
     "wgs_comm_allreduce_buffer": (c_int, [c_vp, c_i64, c_f64p]),

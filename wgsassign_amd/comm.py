@@ -343,6 +343,21 @@ class RcclComm(SocketComm):
         self._lib.check(lib.wgs_comm_allreduce_buffer(self._h, int(n_fits), self._lib.f64p(out)))
         return out
 
+    def info(self):
+        """What the communicator is, by RCCL's own account: dict with `native`, `rccl_ranks_seen` (ncclCommCount),
+        `rccl_rank`, `rccl_device` (-1 for the socket fall-back), `world`, `rank`."""
+        h = self.handle
+        out = (self._ct.c_int64 * 8)()
+        self._lib.check(self._lib.load().wgs_comm_info(h, out))
+        return {"native": bool(out[0]), "rccl_ranks_seen": int(out[1]), "rccl_rank": int(out[2]), "rccl_device": int(out[3]),
+                "world": int(out[4]), "rank": int(out[5])}
+
+    def time_collectives(self, reps=20, n=16):
+        """Mean device microseconds of a sum all-reduce / a broadcast of n float64 on the context's stream (collective)."""
+        us = np.zeros(2)
+        self._lib.check(self._lib.load().wgs_comm_time_collectives(self.handle, int(reps), int(n), self._lib.f64p(us)))
+        return {"allreduce_us": float(us[0]), "bcast_us": float(us[1]), "float64_per_call": int(n), "calls": int(reps)}
+
     @property
     def handle(self):
         """wgs_comm* for the C entry points that run whole loops (wgs_em_fit, wgs_loo): RCCL, or the host-backed one."""

@@ -116,6 +116,10 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
         const int l_hi = hist_quantile(hl, 1.0 - 1.0 / 6400.0);
         c->lrows = (std::max(l_hi, 1) + 7) & ~7;
         if (c->lrows > 64 || l_hi >= 255) c->lrows = 0;
+        if (const char *rows_env = getenv("WGSASSIGN_EM_TABLE_ROWS")) {    // experiments / tests: 8 .. 64, a multiple of 8
+            const int r = atoi(rows_env);
+            if (r >= 8 && r <= 64 && r % 8 == 0) c->lrows = r;
+        }
     }
     // ---- one allocation for everything
     auto plan = [&](bool with_local, std::vector<size_t> &off) -> size_t {

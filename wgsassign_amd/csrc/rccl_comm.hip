@@ -26,6 +26,10 @@ struct Api {
     int (*Broadcast)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t) = nullptr;
     int (*CommDestroy)(rcclComm_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    // what RCCL itself says about a communicator (optional symbols: a librccl without them only loses the cross-check)
+    int (*CommCount)(rcclComm_t, int *) = nullptr;
+    int (*CommUserRank)(rcclComm_t, int *) = nullptr;
+    int (*CommCuDevice)(rcclComm_t, int *) = nullptr;
 };
 
 Api *api()
@@ -46,6 +50,9 @@ Api *api()
             a.Broadcast = (int (*)(const void *, void *, size_t, int, int, rcclComm_t, hipStream_t))dlsym(a.handle, "ncclBroadcast");
             a.CommDestroy = (int (*)(rcclComm_t))dlsym(a.handle, "ncclCommDestroy");
             a.GetErrorString = (const char *(*)(int))dlsym(a.handle, "ncclGetErrorString");
+            a.CommCount = (int (*)(rcclComm_t, int *))dlsym(a.handle, "ncclCommCount");
+            a.CommUserRank = (int (*)(rcclComm_t, int *))dlsym(a.handle, "ncclCommUserRank");
+            a.CommCuDevice = (int (*)(rcclComm_t, int *))dlsym(a.handle, "ncclCommCuDevice");
         }
     }
     if (!a.handle || !a.GetUniqueId || !a.CommInitRank || !a.AllReduce || !a.Broadcast || !a.CommDestroy) return nullptr;
@@ -67,6 +74,9 @@ struct wgs_comm {
     size_t host_elems = 0;
     // what crossed ranks so far (wgs_comm_stats): collectives, their payload, host round trips they cost
     int64_t n_allreduce = 0, n_bcast = 0, bytes_moved = 0, n_syncs = 0;
+    // what RCCL reports about the communicator it built (-1: not asked / not available)
+    int rccl_count = -1, rccl_rank = -1, rccl_device = -1;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // wgs_comm_time_collectives
 };
 
 #define RCCL_TRY(expr)                                                                              \
@@ -105,6 +115,18 @@ int wgs_comm_init(wgs_ctx *ctx, const uint8_t *id128, int rank, int world, wgs_c
     rcclUniqueId id;
     memcpy(id.internal, id128, 128);
     RCCL_TRY(A->CommInitRank(&c->comm, world, id, rank));
+    // the communicator RCCL built must be the one asked for: `world` ranks, this one at `rank`, on this context's device -- a
+    // launcher that reports N ranks over a communicator of fewer (or over a fallback transport) cannot pass for an N-GPU run
+    if (A->CommCount) RCCL_TRY(A->CommCount(c->comm, &c->rccl_count));
+    if (A->CommUserRank) RCCL_TRY(A->CommUserRank(c->comm, &c->rccl_rank));
+    if (A->CommCuDevice) RCCL_TRY(A->CommCuDevice(c->comm, &c->rccl_device));
+    if ((c->rccl_count >= 0 && c->rccl_count != world) || (c->rccl_rank >= 0 && c->rccl_rank != rank) ||
+        (c->rccl_device >= 0 && c->rccl_device != ctx->device)) {
+        wgs_set_error("RCCL built a communicator of %d ranks with this one at %d on device %d; asked for %d ranks, rank %d, device %d",
+                      c->rccl_count, c->rccl_rank, c->rccl_device, world, rank, ctx->device);
+        (void)A->CommDestroy(c->comm);
+        return 1;
+    }
     guard.dismiss();
     *out = c;
     return 0;
@@ -143,6 +165,8 @@ void wgs_comm_destroy(wgs_comm *c)
     if (A && c->comm) (void)A->CommDestroy(c->comm);
     if (c->buf) (void)hipFree(c->buf);
     if (c->host_stage) (void)hipHostFree(c->host_stage);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
     delete c;
 }
 
@@ -246,6 +270,49 @@ int wgs_comm_stats(wgs_comm *c, int64_t *stats)
     stats[1] = c->n_bcast;
     stats[2] = c->bytes_moved;
     stats[3] = c->n_syncs;
+    return 0;
+}
+
+/* info[0..7]: 1 = RCCL communicator / 0 = host-backed; ranks, this rank and the device as RCCL ITSELF reports them
+ * (ncclCommCount, ncclCommUserRank, ncclCommCuDevice; -1 where not available or host-backed); world and rank as given at
+ * creation; [6..7] reserved.  bench.py and the command line put these into what they report for N > 1. */
+int wgs_comm_info(wgs_comm *c, int64_t *info)
+{
+    WGS_REQUIRE(c && info, "null argument");
+    info[0] = c->comm ? 1 : 0;
+    info[1] = c->rccl_count;
+    info[2] = c->rccl_rank;
+    info[3] = c->rccl_device;
+    info[4] = c->world;
+    info[5] = c->rank;
+    info[6] = info[7] = 0;
+    return 0;
+}
+
+/* Device time of the two collectives the sharded path uses, measured with HIP events on the context's stream: `reps`
+ * back-to-back sum all-reduces of n float64 (the per-iteration exchange of the EM fit) and `reps` broadcasts of n float64 from
+ * rank 0 (the hand-over of a running total); us_out[0..1] = mean microseconds of each.  Collective: every rank calls it. */
+int wgs_comm_time_collectives(wgs_comm *c, int32_t reps, int64_t n, double *us_out)
+{
+    WGS_REQUIRE(c && us_out && reps > 0 && n > 0, "bad argument");
+    HIP_TRY(hipSetDevice(c->ctx->device));
+    if (!c->ev0) HIP_TRY(hipEventCreate(&c->ev0));
+    if (!c->ev1) HIP_TRY(hipEventCreate(&c->ev1));
+    double *buf = wgs_comm_buffer(c, n);
+    if (!buf) return 1;
+    HIP_TRY(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)n, c->ctx->stream));
+    for (int which = 0; which < 2; ++which) {
+        // one untimed call first (connection set-up of the first collective of a kind)
+        if (which == 0 ? wgs_comm_allreduce_f64_dev(c, buf, n) : wgs_comm_bcast_dev(c, buf, n * 8, 0)) return 1;
+        HIP_TRY(hipEventRecord(c->ev0, c->ctx->stream));
+        for (int r = 0; r < reps; ++r)
+            if (which == 0 ? wgs_comm_allreduce_f64_dev(c, buf, n) : wgs_comm_bcast_dev(c, buf, n * 8, 0)) return 1;
+        HIP_TRY(hipEventRecord(c->ev1, c->ctx->stream));
+        HIP_TRY(hipEventSynchronize(c->ev1));
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        us_out[which] = (double)ms * 1e3 / reps;
+    }
     return 0;
 }
 
