@@ -48,10 +48,12 @@ const char *wgs_last_error(void);
 #define WGS_ABI_VERSION 2
 int wgs_version(void);
 /* sha256[:16] over every source of the library / over the sources of the EM and scoring kernels (em_kernels.hip,
- * assign_kernels.hip, common.h, log_table.h), fixed at build time: profiles record them, bench.py quotes hardware
+ * assign_kernels.hip, beagle_kernels.hip, codes_kernels.hip, common.h, log_table.h), fixed at build time: profiles record them, bench.py quotes hardware
  * counters only from a profile whose kernels id equals the loaded library's. */
 const char *wgs_build_id(void);
 const char *wgs_kernels_id(void);
+/* ... and over the sources of the ingest kernels (ingest.hip, inflate.hip, common.h): recorded with the ingest profiles. */
+const char *wgs_ingest_kernels_id(void);
 int wgs_device_count(int *count);
 int wgs_ctx_create(int device, wgs_ctx **out);
 void wgs_ctx_destroy(wgs_ctx *ctx);
@@ -253,11 +255,8 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
  * batched chain resolutions of the re-fits; EM iterations enqueued. */
 int wgs_loo_stats(double *stats);
 
-/* Test hooks: (chain, block) pairs of the last walk that took the literal serial loop / walked in all;
- * the literal one-lane-per-chain kernel behind wgs_assign_parts_exact, whatever P. */
+/* (chain, block) pairs of the last walk that took the literal serial loop / walked in all (diagnostics). */
 int wgs_score_last_serial_blocks(wgs_score *sc, int64_t *total_blocks);
-int wgs_debug_parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P,
-                                  const float *carry_in, float *parts_out);
 
 /* ------------------------------------------------------------------ RCCL communicator (SNP shards)
  * The one collective of the sharded path -- a sum all-reduce of a few float64 over xGMI -- without
@@ -374,50 +373,8 @@ const char *wgs_ingest_chunk_sites(wgs_ingest *g, int64_t *bytes);
  * wgs_ingest_create and inside wgs_ingest_next. */
 int wgs_ingest_stats(wgs_ingest *g, double *stats);
 
-/* BGZF inflate on the device (csrc/inflate.hip; RFC 1951, one lane per block): `nblocks` raw deflate streams -- BGZF members
- * without header and trailer -- lying in the host buffer `comp` (in_off, in_len) are inflated into `out` (out_off, isize);
- * status[i] != 0 marks a stream the device did not accept (the host inflates those).  *kernel_ms: the kernel alone. */
-int wgs_debug_inflate(wgs_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, const uint64_t *in_off, const uint32_t *in_len,
-                      const uint64_t *out_off, const uint32_t *isize, int32_t nblocks, uint8_t *out, int64_t out_bytes,
-                      uint8_t *status, float *kernel_ms);
-
-/* Test hook, needs no GPU: drains the reader through the text hand-over (producer thread, carried partial lines,
- * parallel newline scan, row limit) with ordinary memory and the host parser in place of the device tokeniser. */
-int wgs_debug_reader_text_rows(wgs_reader *r, int64_t chunk_bytes, int64_t limit_rows, float *rows, int64_t max_rows, int64_t *nrows);
-int64_t wgs_debug_reader_text_chunks(wgs_reader *r);   /* chunks that hand-over produced */
-/* Test hook, needs no GPU: the COMPRESSED hand-over of a BGZF file (what the device-resident ingest consumes: whole members
- * in caller-allocated staging + the text the header calls had inflated already), inflated on the host into text[0 .. cap).
- * info[0..3] = chunks, members, largest text of one chunk, chunks that carried pre-inflated text. */
-int wgs_debug_reader_comp_text(wgs_reader *r, int64_t comp_bytes, int64_t text_cap, int nbuf, char *text, int64_t cap, int64_t *bytes,
-                               int64_t *info);
-
-/* Test hooks for the convergence chain: wgs_rmse1d's value through the literal one-lane serial
- * kernel (serial != 0) or through the block-parallel exact emulation, reporting the number of
- * 4096-element blocks that fell back to the serial loop; the same count for the last
- * wgs_em_rmse_chain of an EM batch. */
-int wgs_debug_rmse1d(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m, double *out, int serial,
-                     int *serial_blocks);
+/* Blocks of 4096 elements that fell back to the serial loop in the last wgs_em_rmse_chain of an EM batch (diagnostics). */
 int wgs_em_last_chain_serial_blocks(wgs_em *em);
-
-/* Test hook for the EM kernel's correctly rounded divide (csrc/em_kernels.hip: div_exact): number of
- * 2^20 x per_thread pseudo-random EM-shaped operand pairs whose quotient differs bitwise from the
- * compiler's IEEE double divide. */
-int wgs_debug_div_mismatch(wgs_ctx *ctx, uint64_t seed, uint64_t per_thread, uint64_t *mismatch);
-/* ... and the accuracy of its once-refined reciprocal: the largest relative error over ALL 2^23 float32 mantissas of
- * the denominator at binary exponent `exponent` (its exactness argument needs < 2^-48; see em_kernels.hip). */
-int wgs_debug_rcp_error(wgs_ctx *ctx, int exponent, double *max_rel);
-
-/* Test hooks for the assignment kernel's double-precision log of float32 arguments
- * (csrc/assign_kernels.hip: log_f32arg): number of float32 bit patterns in [b0, b1) whose
- * float32-rounded log differs from the device math library's, and the values themselves. */
-int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first);
-int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, int use_libm);
-
-/* Cross-check only: FLOAT64 partition sums parts[(i*P + p)*K + k] (labels = global site index % P) and totals from the
- * round-1 kernel (lanes <-> pairs of individuals, tile ranges combined with float64 atomics): ~1e-5 from the
- * reference's serial float32 partition sums, not reproducible run to run.  Not on the product path. */
-int wgs_debug_assign_parts_f64(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, int mode,
-                               double *out, double *parts);
 
 /* Kernel time (HIP events on the context's stream) of the context's last wgs_assign / wgs_score_* call. */
 int wgs_assign_last_ms(wgs_ctx *ctx, float *ms);

@@ -8,10 +8,20 @@ import pytest
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "wgsassign_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(wgs_[a-z0-9_]+)\s*\(", text)) - {"wgs_reduce_fn"})
+def declared_symbols(headers=("wgsassign_hip.h", "wgsassign_hip_debug.h")):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(wgs_[a-z0-9_]+)\s*\(", text))
+    return sorted(names - {"wgs_reduce_fn"})
+
+
+def test_test_hooks_live_in_their_own_header():
+    """The drop-in boundary (include/wgsassign_hip.h) declares no wgs_debug_* entry point; the test hooks have their own header."""
+    assert not [n for n in declared_symbols(("wgsassign_hip.h",)) if n.startswith("wgs_debug_")]
+    dbg = declared_symbols(("wgsassign_hip_debug.h",))
+    assert len(dbg) >= 10 and all(n.startswith("wgs_debug_") for n in dbg)
 
 
 def test_library_exports_every_declared_symbol():

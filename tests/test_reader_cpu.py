@@ -630,6 +630,47 @@ def test_bgzf_parts_reject_a_planted_signature_and_a_plain_gzip_file(tmp_path):
     assert lib.wgs_reader_index_part(g.encode(), str(tmp_path / "g.0").encode(), 0, 2, 1) == 3
 
 
+def test_damaged_part_files_are_refused_and_removed(tmp_path):
+    """A part file of the split index pass whose block count or header length has been damaged (the counts sized
+    two vectors before being checked against the file -- std::bad_alloc through an extern "C" call): the merge answers rc 3 with
+    a message, and the part files are gone afterwards whether the merge succeeded or not."""
+    import ctypes
+    import struct
+    from wgsassign_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    n, m = 6, 400
+    head = "marker\tallele1\tallele2\t" + "\t".join("I%d\tI%d\tI%d" % (i, i, i) for i in range(n))
+    lines = [head] + ["s%d\tA\tC\t" % s + "\t".join("%.6f" % v for v in rng.random(3 * n)) for s in range(m)]
+    p = str(tmp_path / "d.beagle.gz")
+    _bgzf_write(p, "\n".join(lines) + "\n", block=900)
+    nparts = 3
+    for damage in ("blocks", "header", "truncate", None):
+        prefix = str(tmp_path / ("part_%s" % damage))
+        for k in range(nparts):
+            assert lib.wgs_reader_index_part(p.encode(), ("%s.%d" % (prefix, k)).encode(), k, nparts, 1) == 0
+        victim = "%s.1" % prefix
+        raw = bytearray(open(victim, "rb").read())
+        # layout: magic[8], file size, mtime, first, next, nb, hl (six uint64)
+        if damage == "blocks":
+            raw[8 + 4 * 8:8 + 5 * 8] = struct.pack("<Q", (1 << 39) + 7)
+        elif damage == "header":
+            raw[8 + 5 * 8:8 + 6 * 8] = struct.pack("<Q", (1 << 29) + 3)
+        elif damage == "truncate":
+            raw = raw[:len(raw) - 5]
+        if damage:
+            os.chmod(victim, 0o600)
+            with open(victim, "wb") as fh:
+                fh.write(bytes(raw))
+        got = ctypes.c_int64()
+        rc = lib.wgs_reader_index_merge(p.encode(), str(tmp_path / ("m_%s.idx" % damage)).encode(), prefix.encode(), nparts, 40_000, 1000, ctypes.byref(got))
+        if damage:
+            assert rc == 3 and b"is not a part of the index" in lib.wgs_last_error()
+        else:
+            assert rc == 0 and got.value == m
+        assert not [f for f in os.listdir(tmp_path) if f.startswith("part_%s." % damage)]
+
+
 # ------------------------------------------------------------------ the compressed hand-over (device-resident BGZF ingest)
 def _comp_text(path, comp_bytes, text_cap, nbuf=2, threads=3, index=None, first_row=0, cap=64 << 20):
     import ctypes

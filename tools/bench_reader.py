@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--inds", type=int, default=2000)
     ap.add_argument("--sites", type=int, default=3000)
     ap.add_argument("--device", action="store_true")
+    ap.add_argument("--only-device-inflate", action="store_true", help="with --device: only the device-resident path (inflate, listing and tokeniser "
+                                                                     "on the device), twice -- what tools/prof_ingest.sh profiles")
     ap.add_argument("--bgzf", action="store_true", help="write the file as BGZF (what ANGSD produces) instead of plain gzip")
     ap.add_argument("--lowdepth", action="store_true", help="BGZF text of a simulated 2x matrix, whole lines per member (tools/beagle_files.py: few "
                                                             "distinct likelihoods per site, deflates 10-20x like the reference's bundled 2x files) "
@@ -63,7 +65,7 @@ def main():
     idx, _, sites = reader_cy.ensure_index(path)
     t = time.perf_counter() - t0
     res["index_pass"] = {"seconds": round(t, 3), "text_MB_per_s": round(text_bytes / 1e6 / t, 1), "sites_per_s": round(m / t)}
-    for label, first in (("parse_from_start", 0), ("parse_second_half_via_index", m // 2)):
+    for label, first in (() if a.only_device_inflate else (("parse_from_start", 0), ("parse_second_half_via_index", m // 2))):
         t0 = time.perf_counter()
         with reader_cy.BeagleStream(path, index=idx, first_row=first) as st:
             rows = sum(r.shape[0] for r, _ in st.chunks())
@@ -77,6 +79,8 @@ def main():
                                      ("into_slabs_host_inflate_device_tokeniser", "device", "host"),
                                      ("into_slabs_host_parser", "host", "host")):
             if inflate == "device" and not a.bgzf:
+                continue
+            if a.only_device_inflate and inflate != "device":
                 continue
             os.environ["WGSASSIGN_INGEST"] = mode
             os.environ["WGSASSIGN_INFLATE"] = inflate

@@ -30,6 +30,7 @@ SIGNATURES = {
     "wgs_version": (c_int, []),
     "wgs_build_id": (ctypes.c_char_p, []),
     "wgs_kernels_id": (ctypes.c_char_p, []),
+    "wgs_ingest_kernels_id": (ctypes.c_char_p, []),
     "wgs_device_count": (c_int, [ctypes.POINTER(c_int)]),
     "wgs_ctx_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
     "wgs_ctx_destroy": (None, [c_vp]),

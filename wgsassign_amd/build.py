@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libwgsassign_hip.so")
-SOURCES = ["api.hip", "codes.hip", "codes_kernels.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "ingest.hip", "inflate.hip", "rccl_comm.hip", "reader.cpp"]
+SOURCES = ["api.hip", "em_api.hip", "score_api.hip", "codes.hip", "codes_kernels.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "ingest.hip", "inflate.hip", "rccl_comm.hip", "reader.cpp"]
 # -ffp-contract=off: the exact-mode kernels restate the reference's rounding sequence operation by
 # operation; hipcc's default (fast) contraction would fuse a*b+c and change results.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
@@ -31,9 +31,12 @@ def _stale(target, deps):
 KERNEL_SOURCES = ["em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "codes_kernels.hip", "common.h", "log_table.h"]   # what the profiled kernels are made of
 
 
+INGEST_SOURCES = ["ingest.hip", "inflate.hip", "common.h"]   # the device side of the streamed reader: tokeniser, line listing, BGZF inflate
+
+
 def source_ids():
-    """(build id, kernels id): sha256[:16] over every source of the library / over the sources of the EM and scoring
-    kernels.  Compiled into the library (wgs_build_id, wgs_kernels_id) and written into every profile summary
+    """(build id, kernels id, ingest kernels id): sha256[:16] over every source of the library / over the sources of the EM,
+    scoring and encoder kernels / over the sources of the ingest kernels.  Compiled into the library (wgs_build_id, wgs_kernels_id) and written into every profile summary
     (tools/summarize_profile.py), so that bench.py quotes counters only from a profile of the kernels it is timing."""
     import hashlib
 
@@ -45,15 +48,15 @@ def source_ids():
         return h.hexdigest()[:16]
     every = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")) and f != "build_id.h")
     every.append(os.path.join(HERE, "..", "include", "wgsassign_hip.h"))
-    return digest(every), digest([os.path.join(CSRC, f) for f in KERNEL_SOURCES])
+    return digest(every), digest([os.path.join(CSRC, f) for f in KERNEL_SOURCES]), digest([os.path.join(CSRC, f) for f in INGEST_SOURCES])
 
 
 def build(force=False, verbose=False):
     cc = hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "log_table.h"), os.path.join(CSRC, "reader_text.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "em_state.h"), os.path.join(CSRC, "log_table.h"), os.path.join(CSRC, "reader_text.h"),
                os.path.join(HERE, "..", "include", "wgsassign_hip.h")]
     id_header = os.path.join(CSRC, "build_id.h")
-    text = '#define WGS_BUILD_ID "%s"\n#define WGS_KERNELS_ID "%s"\n' % source_ids()
+    text = '#define WGS_BUILD_ID "%s"\n#define WGS_KERNELS_ID "%s"\n#define WGS_INGEST_KERNELS_ID "%s"\n' % source_ids()
     if not os.path.exists(id_header) or open(id_header).read() != text:
         with open(id_header, "w") as fh:
             fh.write(text)

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/wgsassign_hip.h"
+#include "../../include/wgsassign_hip_debug.h"
 
 void wgs_set_error(const char *fmt, ...);
 

@@ -1,0 +1,555 @@
+// The EM fits of the C ABI (include/wgsassign_hip.h: wgs_em_*): emMAF.py:15-27 as ONE call per batch of fits (wgs_em_fit: iterations
+// enqueued ahead of the host, decisions on the device), the step-by-step twin, the exact convergence chain, and the policy that decides
+// which sweep kernel a batch takes (direct, grouped leave-one-out, class-coded -- and when the codes are worth building).
+// Host-side orchestration only; the arithmetic is in em_kernels.hip.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <string>
+
+#include "common.h"
+#include "em_state.h"
+
+extern "C" {
+
+/* ------------------------------------------------------------------ EM */
+
+// (struct wgs_em: em_state.h)
+
+
+void wgs_em_destroy(wgs_em *em)
+{
+    if (!em) return;
+    (void)hipSetDevice(em->b->ctx->device);
+    for (int i = 0; i < 2; ++i)
+        if (em->fbuf[i]) (void)hipFree(em->fbuf[i]);
+    if (em->d_descs) (void)hipFree(em->d_descs);
+    if (em->h_descs) (void)hipHostFree(em->h_descs);
+    if (em->d_groups) (void)hipFree(em->d_groups);
+    if (em->h_groups) (void)hipHostFree(em->h_groups);
+    for (int i = 0; i < 2; ++i) {
+        if (em->d_groups2[i]) (void)hipFree(em->d_groups2[i]);
+        if (em->h_groups2[i]) (void)hipHostFree(em->h_groups2[i]);
+    }
+    if (em->d_ssq) (void)hipFree(em->d_ssq);
+    if (em->d_part) (void)hipFree(em->d_part);
+    if (em->d_part2) (void)hipFree(em->d_part2);
+    if (em->d_carry) (void)hipFree(em->d_carry);
+    if (em->d_chain_work) (void)hipFree(em->d_chain_work);
+    if (em->ev0) (void)hipEventDestroy(em->ev0);
+    if (em->ev1) (void)hipEventDestroy(em->ev1);
+    for (int i = 0; i < 2; ++i) {
+        if (em->d_descs2[i]) (void)hipFree(em->d_descs2[i]);
+        if (em->h_descs2[i]) (void)hipHostFree(em->h_descs2[i]);
+        if (em->h_state[i]) (void)hipHostFree(em->h_state[i]);
+        if (em->ev_it[i]) (void)hipEventDestroy(em->ev_it[i]);
+        if (em->ev_sw0[i]) (void)hipEventDestroy(em->ev_sw0[i]);
+        if (em->ev_sw1[i]) (void)hipEventDestroy(em->ev_sw1[i]);
+    }
+    for (void *p : {(void *)em->d_state, (void *)em->d_ssq2, (void *)em->d_jobs, (void *)em->d_chain_out, em->d_chain_batch})
+        if (p) (void)hipFree(p);
+    for (void *p : {(void *)em->h_jobs, (void *)em->h_chain_out, (void *)em->h_setstate})
+        if (p) (void)hipHostFree(p);
+    delete em;
+}
+
+int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const int32_t *fit_skip, int mode, wgs_em **out)
+{
+    WGS_REQUIRE(b && fit_group && out, "null argument");
+    WGS_REQUIRE(n_fits > 0, "n_fits must be positive");
+    WGS_REQUIRE(mode == WGS_MODE_EXACT || mode == WGS_MODE_FAST, "unknown mode %d", mode);
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    wgs_em *em = new wgs_em();
+    auto guard = on_failure([&] { wgs_em_destroy(em); });
+    em->b = b;
+    em->n_fits = n_fits;
+    em->mode = mode;
+    em->group.resize(n_fits);
+    em->skip_local.resize(n_fits);
+    em->n_eff.resize(n_fits);
+    em->cur.assign(n_fits, 0);
+    em->active.assign(n_fits, 1);
+    for (int j = 0; j < n_fits; ++j) {
+        const int g = fit_group[j];
+        if (g < 0 || g >= b->n_groups || b->slabs[g].ncols == 0) {
+            wgs_set_error("fit %d: group %d is out of range or empty", j, g);
+            return 2;
+        }
+        int skip = -1;
+        if (fit_skip && fit_skip[j] >= 0) {
+            const int i = fit_skip[j];
+            if (i >= b->n || b->group_of[i] != g) {
+                wgs_set_error("fit %d: left-out individual %d does not belong to group %d", j, i, g);
+                return 2;
+            }
+            skip = b->col_of[i];
+        }
+        em->group[j] = g;
+        em->skip_local[j] = skip;
+        em->n_eff[j] = b->slabs[g].ncols - (skip >= 0 ? 1 : 0);
+    }
+    const size_t fbytes = (size_t)n_fits * b->m * sizeof(float);
+    for (int i = 0; i < 2; ++i) {
+        if (hipMalloc(&em->fbuf[i], fbytes) != hipSuccess) {
+            wgs_set_error("hipMalloc of %zu bytes for EM frequencies failed", fbytes);
+            return 1;
+        }
+    }
+    HIP_TRY(hipMalloc(&em->d_descs, sizeof(FitDesc) * n_fits));
+    HIP_TRY(hipMalloc(&em->d_ssq, sizeof(double) * n_fits));
+    HIP_TRY(hipMalloc(&em->d_part, sizeof(double) * (size_t)n_fits * wgs_ntiles(b->m)));
+    HIP_TRY(hipMalloc(&em->d_part2, sizeof(double) * (size_t)n_fits * ssq_reduce_chunks()));
+    HIP_TRY(hipMalloc(&em->d_carry, 2 * sizeof(float)));
+    HIP_TRY(hipMalloc(&em->d_chain_work, rmse_chain_workspace_bytes(b->m)));
+    HIP_TRY(hipEventCreate(&em->ev0));
+    HIP_TRY(hipEventCreate(&em->ev1));
+    HIP_TRY(hipHostMalloc(&em->h_descs, sizeof(FitDesc) * n_fits, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&em->d_groups, sizeof(int32_t) * 2 * n_fits));
+    HIP_TRY(hipHostMalloc(&em->h_groups, sizeof(int32_t) * 2 * n_fits, hipHostMallocDefault));
+    if (launch_fill(b->ctx, em->fbuf[0], (int64_t)n_fits * b->m, 0.25f)) return 1;   // emMAF.py:17-18
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    guard.dismiss();
+    *out = em;
+    return 0;
+}
+
+
+/* Whether building the class codes pays for the EM sweeps still to come (codes.hip builds them in one pass over the matrix):
+ *   the encode pass costs about the matrix's bytes at 1.8 TB/s (measured: 80 GB in 44 ms, 1.6 GB in 2.3 ms) + 0.6 ms of
+ *   sample pass, allocation and readbacks;
+ *   a coded sweep saves a share of the direct sweep (the slabs' bytes at ~6 TB/s) that grows with the population size --
+ *   measured 14 % at 30 individuals, 21 % at 36, 39 % at 62, 52 % at 100;
+ *   sweeps to come: what the caller knows -- wgs_em_fit its iteration limit, of which a fit rarely uses more than ~14 (the
+ *   reference's default tolerance: 13-17 iterations on every data set here); a step-by-step caller nothing, so there a matrix
+ *   that has been swept directly three times is taken to be in a long run.
+ * WGSASSIGN_EM_CODES_SWEEPS=k replaces the model by "k or more sweeps ahead" (0: always; tests). */
+static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, int fewest_cols, int sweeps_ahead)
+{
+    const wgs_beagle *b = em->b;
+    if (const char *sw = getenv("WGSASSIGN_EM_CODES_SWEEPS")) return sweeps_ahead >= atoi(sw) || b->direct_sweeps >= 3;
+    double ahead = std::min(sweeps_ahead, 14);
+    if (sweeps_ahead <= 0 && b->direct_sweeps >= 3) ahead = 12;
+    static const double at[5] = {28, 36, 62, 100, 1e9}, share[5] = {0.10, 0.21, 0.39, 0.52, 0.52};
+    double saves = share[0];
+    for (int i = 0; i + 1 < 5; ++i)
+        if (fewest_cols >= at[i]) saves = share[i] + (share[i + 1] - share[i]) * std::min(1.0, (fewest_cols - at[i]) / (at[i + 1] - at[i]));
+    double swept = 0.0;
+    for (int j : order) swept += 8.0 * (double)b->slabs[em->group[j]].ncols * (double)b->m;
+    const double direct_ms = swept / 6.0e9, build_ms = (double)b->bytes / 1.8e9 + 0.6;
+    return ahead * saves * direct_ms > build_ms;
+}
+
+/* Enqueue one sweep (+ the fixed-order reduction of its sums) for the fits in `list`: descriptors into the pinned
+ * array H and from there to D.  Fits of different populations stream their slabs once (nontemporal loads); when
+ * several fits share a slab (leave-one-out batches) they are ordered by slab and swept in groups of up to
+ * em_fits_per_group() per wavefront (group table Hg -> Dg), which share the tile's loads and conversions.
+ * ssq_base[j] receives fit j's sum; state_base (device, may be NULL) holds the fit states a sweep honours. */
+static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDesc *H, FitDesc *D, int32_t *Hg, int32_t *Dg,
+                            double *ssq_base, int32_t *state_base, hipEvent_t ev0, hipEvent_t ev1, int sweeps_ahead)
+{
+    wgs_ctx *ctx = em->b->ctx;
+    const int64_t ntiles = wgs_ntiles(em->b->m);
+    std::vector<int32_t> order(list);
+    std::vector<char> seen(em->b->n_groups, 0);
+    bool shared = false;
+    for (int j : order) {
+        shared = shared || seen[em->group[j]];
+        seen[em->group[j]] = 1;
+    }
+    if (shared) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return em->group[x] < em->group[y]; });
+    // exact mode on a coded matrix: the sweep through the class codes (same frequencies, bit for bit)
+    // -- for fits of different slabs; leave-one-out batches (several fits per slab) stay with em_sweep_group_kernel,
+    // whose shared loads and conversions serve them better than a quotient table per fit
+    // -- and small populations stay with em_sweep_kernel too: below ~28 individuals the table costs more than it saves
+    // (measured: 20 individuals 0.98x, 30 1.16x, 36 1.26x, 62 1.64x, 100 2.1x)
+    // -- and the codes are BUILT for it only when the sweeps still to come repay the encode pass (em_codes_pay below).
+    // Codes that exist already (a scoring sweep built them, or wgs_beagle_codes_prepare) are used at once.
+    bool worth = em->mode == WGS_MODE_EXACT && !shared;
+    const char *min_env = getenv("WGSASSIGN_EM_CODES_MIN");    // tests lower it to run small populations through the codes
+    const int min_cols = min_env ? atoi(min_env) : 28;
+    int fewest = INT32_MAX;
+    for (int j : order) fewest = std::min(fewest, (int)em->b->slabs[em->group[j]].ncols);
+    worth = worth && fewest >= min_cols;
+    const bool build = worth && em_codes_pay(em, order, fewest, sweeps_ahead);
+    wgs_codes *codes = worth ? wgs_beagle_codes(em->b, build) : nullptr;
+    if (codes && codes->lrows == 0) codes = nullptr;
+    if (worth && !codes) ++em->b->direct_sweeps;          // (a sweep the codes could have served)
+    int coded_rows_max = 0;
+    for (size_t i = 0; i < order.size(); ++i) {
+        const int j = order[i];
+        const Slab &s = em->b->slabs[em->group[j]];
+        FitDesc &d = H[i];
+        d.lcodes = codes ? codes->slabs[em->group[j]].lcodes : nullptr;
+        d.ldict = codes ? codes->slabs[em->group[j]].ldict : nullptr;
+        d.lrows = codes ? codes->lrows : 0;
+        d.tile_rows = codes ? codes->slabs[em->group[j]].tile_rows : nullptr;
+        d.nquads = codes ? codes->slabs[em->group[j]].nquads : 0;
+        coded_rows_max = std::max(coded_rows_max, (int)d.lrows);
+        d.slab = s.base;
+        d.f_old = em_f(em, j, em->cur[j]);
+        d.f_new = em_f(em, j, em->cur[j] ^ 1);
+        d.ssq = ssq_base + j;
+        d.ssq_part = em->d_part + (size_t)j * ntiles;
+        d.npairs = s.npairs;
+        d.ncols = s.ncols;
+        d.skip = em->skip_local[j];
+        d.n_eff = em->n_eff[j];
+        d.state = state_base ? state_base + j : nullptr;
+    }
+    // H (pinned) stays untouched until the caller has waited for this sweep
+    HIP_TRY(hipMemcpyAsync(D, H, sizeof(FitDesc) * order.size(), hipMemcpyHostToDevice, ctx->stream));
+    int32_t n_groups = 0;
+    if (shared && !codes) {
+        const int fg = em_fits_per_group();
+        for (size_t i = 0; i < order.size();) {
+            size_t k = i + 1;
+            while (k < order.size() && (int)(k - i) < fg && em->group[order[k]] == em->group[order[i]]) ++k;
+            Hg[2 * n_groups] = (int32_t)i;
+            Hg[2 * n_groups + 1] = (int32_t)(k - i);
+            ++n_groups;
+            i = k;
+        }
+        HIP_TRY(hipMemcpyAsync(Dg, Hg, sizeof(int32_t) * 2 * n_groups, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (ev0) HIP_TRY(hipEventRecord(ev0, ctx->stream));
+    const int64_t per_unit = ((ntiles + 3) / 4 + 7) / 8 * 8 + 8;       // workgroups per fit / per group: slices stay below 2^31
+    const size_t max_units = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_unit);
+    if (codes) {
+        const int64_t per_fit = (ntiles + 7) / 8 * 8 + 8;            // at least one tile per workgroup
+        const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
+        for (size_t off = 0; off < order.size(); off += max_fits) {
+            const int cnt = (int)std::min<size_t>(max_fits, order.size() - off);
+            if (launch_em_coded(ctx, D + off, cnt, em->b->m, coded_rows_max)) return 1;
+        }
+    } else if (shared) {
+        for (size_t off = 0; off < (size_t)n_groups; off += max_units) {
+            const int cnt = (int)std::min<size_t>(max_units, (size_t)n_groups - off);
+            if (launch_em_sweep_groups(ctx, D, Dg + 2 * off, cnt, em->b->m, em->mode)) return 1;
+        }
+    } else {
+        for (size_t off = 0; off < order.size(); off += max_units) {
+            const int cnt = (int)std::min<size_t>(max_units, order.size() - off);
+            if (launch_em_sweep(ctx, D + off, cnt, em->b->m, em->mode)) return 1;
+        }
+    }
+    if (ev1) HIP_TRY(hipEventRecord(ev1, ctx->stream));
+    for (size_t off = 0; off < order.size(); off += 65535) {
+        const int cnt = (int)std::min<size_t>(65535, order.size() - off);
+        if (launch_ssq_reduce(ctx, D + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
+    }
+    return 0;
+}
+
+int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
+{
+    WGS_REQUIRE(em && ssq_dev, "null argument");
+    wgs_ctx *ctx = em->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    em->last.clear();
+    for (int j = 0; j < em->n_fits; ++j)
+        if (em->active[j]) em->last.push_back(j);
+    HIP_TRY(hipMemsetAsync(ssq_dev, 0, sizeof(double) * em->n_fits, ctx->stream));
+    if (em->last.empty()) return 0;
+    // h_descs / h_groups (pinned) stay untouched until the next step, which the caller only starts after
+    // consuming this step's sums
+    if (em_enqueue_sweep(em, em->last, em->h_descs, em->d_descs, em->h_groups, em->d_groups, ssq_dev, nullptr, em->ev0, em->ev1, 0)) return 1;
+    for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
+    return 0;
+}
+
+int wgs_em_step(wgs_em *em, double *ssq_host)
+{
+    WGS_REQUIRE(em, "null argument");
+    if (wgs_em_step_dev(em, em->d_ssq)) return 1;
+    wgs_ctx *ctx = em->b->ctx;
+    if (ssq_host) {
+        HIP_TRY(hipMemcpyAsync(ssq_host, em->d_ssq, sizeof(double) * em->n_fits, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out)
+{
+    WGS_REQUIRE(em && carry_out, "null argument");
+    WGS_REQUIRE(fit >= 0 && fit < em->n_fits, "fit index out of range");
+    wgs_ctx *ctx = em->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (launch_rmse_chain(ctx, em_f(em, fit, em->cur[fit]), em_f(em, fit, em->cur[fit] ^ 1), em->b->m, carry_in, em->d_carry,
+                          em->d_chain_work, reinterpret_cast<int *>(em->d_carry + 1)))
+        return 1;
+    float host[2];
+    HIP_TRY(hipMemcpyAsync(host, em->d_carry, 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *carry_out = host[0];
+    memcpy(&em->last_chain_serial_blocks, &host[1], sizeof(int));
+    return 0;
+}
+
+/* ---- emMAF.py:15-27 for every fit of the batch in ONE call ------------------------------------------
+ * The host enqueues iteration t (sweep, sum reduction, [RCCL all-reduce], decision kernel, state readback)
+ * BEFORE it reads the decisions of iteration t-1, so the GPU never waits for the host:
+ *   - the decision kernel settles the clear cases on the device (EM_CONVERGED / EM_ACTIVE) and parks the
+ *     fits whose float64 sum lies in the guard band (EM_UNDECIDED);
+ *   - a sweep skips every fit that is not EM_ACTIVE, so a fit that converged at t-1 keeps the frequencies of
+ *     update t-1 (emMAF.py:23-25 breaks after the update) and a parked fit keeps both vectors its exact
+ *     chain needs;
+ *   - the host, one iteration behind, resolves parked fits with the exact serial float32 chain (all of them
+ *     in one batched launch; across SNP shards the float32 carries travel in rank order) and either
+ *     finishes them or re-activates them -- such a fit simply runs its next sweep one iteration later.
+ * Decisions use only all-reduced sums, so every rank takes the same path. */
+static int em_fit_alloc(wgs_em *em)
+{
+    if (em->d_state) return 0;
+    const size_t n = (size_t)em->n_fits;
+    HIP_TRY(hipMalloc(&em->d_state, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc(&em->d_ssq2, sizeof(double) * n));
+    HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&em->d_jobs, sizeof(ChainJob) * n));
+    HIP_TRY(hipMalloc(&em->d_chain_out, sizeof(float) * 2 * n));
+    // workspace of the exact chains for all fits at once (60 bytes per fit and block of 4096 SNPs): no allocation
+    // inside the convergence loop
+    HIP_TRY(hipMalloc(&em->d_chain_batch, rmse_chain_workspace_bytes(em->b->m) * n));
+    em->chain_batch_jobs = n;
+    HIP_TRY(hipHostMalloc(&em->h_jobs, sizeof(ChainJob) * n, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&em->h_chain_out, sizeof(float) * 2 * n, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&em->h_setstate, sizeof(int32_t) * n, hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipMalloc(&em->d_descs2[i], sizeof(FitDesc) * n));
+        HIP_TRY(hipHostMalloc(&em->h_descs2[i], sizeof(FitDesc) * n, hipHostMallocDefault));
+        HIP_TRY(hipMalloc(&em->d_groups2[i], sizeof(int32_t) * 2 * n));
+        HIP_TRY(hipHostMalloc(&em->h_groups2[i], sizeof(int32_t) * 2 * n, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
+        HIP_TRY(hipEventCreateWithFlags(&em->ev_it[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreate(&em->ev_sw0[i]));
+        HIP_TRY(hipEventCreate(&em->ev_sw1[i]));
+    }
+    return 0;
+}
+
+/* Exact chains of `fits` (all at once): converged[i] = the reference's `diff < tole` for fits[i]. */
+static int em_resolve_chains(wgs_em *em, const std::vector<int32_t> &fits, double tole, int64_t m_total, wgs_comm *comm,
+                             std::vector<char> &converged)
+{
+    wgs_ctx *ctx = em->b->ctx;
+    const int nj = (int)fits.size();
+    converged.assign(nj, 0);
+    if (nj == 0) return 0;
+    int world = 1, rank = 0;
+    if (comm) wgs_comm_rank(comm, &rank, &world);
+    // The serial float32 chain crosses the SNP shards in rank order ON THE STREAM: rank r walks its blocks from the
+    // running values it received and broadcasts the result (`world` broadcasts of nj float32, one readback at the end).
+    for (int i = 0; i < nj; ++i) {
+        const int j = fits[i];
+        em->h_jobs[i] = ChainJob{em_f(em, j, em->cur[j]), em_f(em, j, em->cur[j] ^ 1), 0.0f};
+    }
+    HIP_TRY(hipMemcpyAsync(em->d_jobs, em->h_jobs, sizeof(ChainJob) * nj, hipMemcpyHostToDevice, ctx->stream));
+    for (int r = 0; r < world; ++r) {
+        if (r == rank) {
+            if (r > 0 && launch_chain_set_carry(ctx, em->d_jobs, em->d_chain_out, nj)) return 1;
+            if (launch_rmse_chain_batch(ctx, em->d_jobs, nj, em->b->m, em->d_chain_out, em->d_chain_batch,
+                                        reinterpret_cast<int *>(em->d_chain_out + em->n_fits)))
+                return 1;
+        }
+        if (world > 1 && wgs_comm_bcast_dev(comm, em->d_chain_out, (int64_t)sizeof(float) * nj, r)) return 1;
+    }
+    HIP_TRY(hipMemcpyAsync(em->h_chain_out, em->d_chain_out, sizeof(float) * nj, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));       // also: h_jobs has been consumed
+    const float *carry = em->h_chain_out;
+    ++em->fit_chain_batches;
+    for (int i = 0; i < nj; ++i) {
+        const float res = carry[i] / (float)m_total;         // emMAF_cy.pyx:32
+        converged[i] = sqrt((double)res) < tole;             // emMAF_cy.pyx:33, emMAF.py:23
+    }
+    return 0;
+}
+
+int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm, double guard_floor, int32_t *iters_out)
+{
+    WGS_REQUIRE(em && iters_out, "null argument");
+    WGS_REQUIRE(m_total >= em->b->m, "m_total (%lld) is smaller than this shard (%lld SNPs)", (long long)m_total, (long long)em->b->m);
+    wgs_ctx *ctx = em->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (em_fit_alloc(em)) return 1;
+    const int n = em->n_fits;
+    // the band of device.py: guard_band / decide_converged
+    double lo = -1.0, hi = -INFINITY;                        // tole <= 0 or NaN: `diff < tole` never holds
+    if (tole > 0) {
+        const double thresh = tole * tole * (double)m_total;
+        const double g = std::max(guard_floor, (double)m_total * 0x1p-24) + 1e-6;
+        lo = g < 1.0 ? thresh * (1.0 - g) : -1.0;
+        hi = thresh * (1.0 + g);
+    }
+    std::vector<char> fin(n, 0), skipped(n, 0);
+    std::vector<int32_t> sweeps(n, 0), init(n), ran, parked, lists[2];
+    for (int j = 0; j < n; ++j) {
+        iters_out[j] = 0;
+        fin[j] = !em->active[j];
+        init[j] = em->active[j] ? EM_ACTIVE : EM_CONVERGED;
+    }
+    HIP_TRY(hipMemcpyAsync(em->d_state, init.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    em->fit_iterations = em->fit_chain_batches = 0;
+    em->fit_sweep_ms = 0.0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    bool launched_prev = false;
+    for (int t = 1;; ++t) {
+        const int slot = t & 1;
+        // Who ran at t-1 is known now: its list minus the fits found finished or parked when the decisions
+        // of t-2 were read (those sweeps returned at once).
+        ran.clear();
+        for (int j : lists[slot ^ 1]) {
+            if (skipped[j]) continue;
+            ++sweeps[j];
+            em->cur[j] ^= 1;                                 // the new frequencies are current; 1-cur holds f_prev
+            ran.push_back(j);
+        }
+        std::fill(skipped.begin(), skipped.end(), 0);
+        // ---- enqueue iteration t (fits that turn out to have converged at t-1 return at once)
+        std::vector<int32_t> &L = lists[slot];
+        L.clear();
+        for (int j = 0; j < n; ++j)
+            if (!fin[j] && sweeps[j] < max_iter) L.push_back(j);
+        if (!L.empty()) {
+            if (em_enqueue_sweep(em, L, em->h_descs2[slot], em->d_descs2[slot], em->h_groups2[slot], em->d_groups2[slot], em->d_ssq2,
+                                 em->d_state, em->ev_sw0[slot], em->ev_sw1[slot], max_iter - t + 1))
+                return 1;
+            // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
+            // in the same way on every rank (all ranks take the same decisions).
+            if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, n)) return 1;
+            if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
+            HIP_TRY(hipMemcpyAsync(em->h_state[slot], em->d_state, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipEventRecord(em->ev_it[slot], ctx->stream));
+            ++em->fit_iterations;
+        }
+        // ---- read the decisions of iteration t-1 while the GPU works on iteration t
+        if (launched_prev) {
+            const int ps = slot ^ 1;
+            HIP_TRY(hipEventSynchronize(em->ev_it[ps]));     // also: the pinned descriptors of t-1 have been consumed
+            float sweep_ms = 0.0f;
+            if (hipEventElapsedTime(&sweep_ms, em->ev_sw0[ps], em->ev_sw1[ps]) == hipSuccess) em->fit_sweep_ms += sweep_ms;
+            parked.clear();
+            for (int j : ran) {
+                const int st = em->h_state[ps][j];
+                if (st == EM_CONVERGED) {
+                    fin[j] = 1;
+                    skipped[j] = 1;                          // its sweep t (if enqueued) returned at once
+                    iters_out[j] = sweeps[j];
+                } else if (st == EM_UNDECIDED) {
+                    parked.push_back(j);
+                    skipped[j] = 1;
+                } else if (sweeps[j] >= max_iter) {
+                    fin[j] = 1;                              // exhausted: the reference prints nothing, iters stays 0
+                }
+            }
+            if (!parked.empty()) {
+                std::vector<char> conv;
+                if (em_resolve_chains(em, parked, tole, m_total, comm, conv)) return 1;
+                for (size_t i = 0; i < parked.size(); ++i) {
+                    const int j = parked[i];
+                    if (conv[i]) {
+                        fin[j] = 1;
+                        iters_out[j] = sweeps[j];
+                    } else if (sweeps[j] >= max_iter) {
+                        fin[j] = 1;
+                    }
+                    // stream-ordered behind iteration t (whose sweep must see the fit parked throughout)
+                    em->h_setstate[j] = conv[i] ? EM_CONVERGED : EM_ACTIVE;
+                    HIP_TRY(hipMemcpyAsync(em->d_state + j, em->h_setstate + j, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+                }
+            }
+        }
+        launched_prev = !L.empty();
+        if (!launched_prev) break;                           // nothing in flight: every fit finished or exhausted
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int j = 0; j < n; ++j)
+        if (iters_out[j] > 0) em->active[j] = 0;             // frozen, as wgs_em_set_active(j, 0) would
+    em->fit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    return 0;
+}
+
+/* Diagnostics of the last wgs_em_fit: iterations enqueued, batched exact-chain resolutions, wall seconds, and the
+ * summed duration of its sweep kernels (HIP events on the context's stream around each iteration's sweep). */
+int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds, double *sweep_ms)
+{
+    WGS_REQUIRE(em, "null argument");
+    if (iterations) *iterations = em->fit_iterations;
+    if (chain_batches) *chain_batches = em->fit_chain_batches;
+    if (seconds) *seconds = em->fit_seconds;
+    if (sweep_ms) *sweep_ms = em->fit_sweep_ms;
+    return 0;
+}
+
+int wgs_em_last_chain_serial_blocks(wgs_em *em) { return em ? em->last_chain_serial_blocks : -1; }
+
+int wgs_em_last_sweep_ms(wgs_em *em, float *ms)
+{
+    WGS_REQUIRE(em && ms, "null argument");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    HIP_TRY(hipEventSynchronize(em->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, em->ev0, em->ev1));
+    return 0;
+}
+
+int wgs_em_set_active(wgs_em *em, int32_t fit, int active)
+{
+    WGS_REQUIRE(em && fit >= 0 && fit < em->n_fits, "fit index out of range");
+    em->active[fit] = active ? 1 : 0;
+    return 0;
+}
+
+int wgs_em_n_active(wgs_em *em)
+{
+    int c = 0;
+    for (int j = 0; j < em->n_fits; ++j) c += em->active[j];
+    return c;
+}
+
+int wgs_em_clamp(wgs_em *em, int32_t fit, float lo, float hi)
+{
+    WGS_REQUIRE(em && fit >= 0 && fit < em->n_fits, "fit index out of range");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    return launch_clamp(em->b->ctx, em_f(em, fit, em->cur[fit]), em->b->m, lo, hi);
+}
+
+int wgs_em_get_f(wgs_em *em, int32_t fit, float *f_host)
+{
+    WGS_REQUIRE(em && f_host && fit >= 0 && fit < em->n_fits, "bad argument");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    HIP_TRY(hipMemcpyAsync(f_host, em_f(em, fit, em->cur[fit]), sizeof(float) * em->b->m, hipMemcpyDeviceToHost, em->b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(em->b->ctx->stream));
+    return 0;
+}
+
+int wgs_em_get_f_range(wgs_em *em, int32_t fit, int previous, int64_t row0, int64_t nrows, float *f_host)
+{
+    WGS_REQUIRE(em && f_host && fit >= 0 && fit < em->n_fits, "bad argument");
+    WGS_REQUIRE(row0 >= 0 && nrows >= 0 && row0 + nrows <= em->b->m, "row range [%lld, %lld) outside 0..%lld", (long long)row0,
+                (long long)(row0 + nrows), (long long)em->b->m);
+    if (nrows == 0) return 0;
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    const float *src = em_f(em, fit, previous ? em->cur[fit] ^ 1 : em->cur[fit]) + row0;
+    HIP_TRY(hipMemcpyAsync(f_host, src, sizeof(float) * nrows, hipMemcpyDeviceToHost, em->b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(em->b->ctx->stream));
+    return 0;
+}
+
+int wgs_em_set_f(wgs_em *em, int32_t fit, const float *f_host)
+{
+    WGS_REQUIRE(em && f_host && fit >= 0 && fit < em->n_fits, "bad argument");
+    HIP_TRY(hipSetDevice(em->b->ctx->device));
+    HIP_TRY(hipMemcpyAsync(em_f(em, fit, em->cur[fit]), f_host, sizeof(float) * em->b->m, hipMemcpyHostToDevice, em->b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(em->b->ctx->stream));
+    return 0;
+}
+
+const float *wgs_em_f_dev(wgs_em *em, int32_t fit)
+{
+    if (!em || fit < 0 || fit >= em->n_fits) return nullptr;
+    return em_f(em, fit, em->cur[fit]);
+}
+
+}   // extern "C"

@@ -96,6 +96,10 @@ struct BitReader {
         return v;
     }
     __device__ __forceinline__ bool consumed_past_end() const { return p - (cnt >> 3) > end; }
+    // The read pointer runs at most eight bytes ahead of the bits consumed: further than that behind the stream's end means the
+    // stream has consumed input that is not its own (a damaged or truncated member) -- checked once per trip and per symbol of
+    // a header, so that a lane never reads more than a few words past its stream (the chunk is padded by 128 zero bytes).
+    __device__ __forceinline__ bool ran_past_end() const { return p > end + 8; }
 };
 
 __device__ __forceinline__ uint32_t reverse_bits(uint32_t code, int len) { return __brev(code) >> (32 - len); }
@@ -212,7 +216,7 @@ __device__ __noinline__ int read_block_header(BitReader &br, LaneTables &T, uint
     int i = 0;
     while (i < hlit + hdist) {
         const int sym = decode_symbol(br, lit, 7, T.dist_sorted, dist_count);
-        if (sym < 0) return -1;
+        if (sym < 0 || br.ran_past_end()) return -1;
         if (sym < 16) {
             T.lens[i++] = (uint8_t)sym;
             continue;
@@ -279,6 +283,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
             }
         }
         if (state != ST_DONE && br.cnt < 48) br.refill();
+        if (state != ST_DONE && br.ran_past_end()) {
+            // input that belongs to the next member (or to nobody): a damaged stream -- e.g. empty stored blocks or end-of-block
+            // codes that never set the final bit -- would otherwise decode on through the following members and past the chunk
+            bad = true;
+            state = ST_DONE;
+        }
         if (state == ST_SYMBOL) {
             uint32_t e = L[LDS_LIT + br.peek(LIT_BITS) * 64];
             if (!e) e = walk_symbol(br.buf, T.lit_sorted, L + LDS_LIT_COUNT);
@@ -398,7 +408,8 @@ int wgs_debug_inflate(wgs_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, con
         for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_status, (void *)d_io, (void *)d_oo, (void *)d_il, (void *)d_is, d_tab})
             if (p) (void)hipFree(p);
     });
-    HIP_TRY(hipMalloc(&d_comp, (size_t)comp_bytes + 16));
+    HIP_TRY(hipMalloc(&d_comp, (size_t)comp_bytes + 128));
+    HIP_TRY(hipMemset(d_comp + comp_bytes, 0, 128));
     HIP_TRY(hipMalloc(&d_out, (size_t)std::max<int64_t>(out_bytes, 1)));
     HIP_TRY(hipMalloc(&d_status, (size_t)nblocks));
     HIP_TRY(hipMalloc(&d_io, sizeof(uint64_t) * nblocks));

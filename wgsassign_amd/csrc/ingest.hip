@@ -30,6 +30,7 @@
 #include "reader_text.h"
 
 size_t inflate_table_bytes(void);
+constexpr size_t INFLATE_PAD = 128;   // bytes the compressed chunk is padded by on the device (inflate.hip reads a 24-byte window ahead)
 int launch_inflate(wgs_ctx *ctx, const uint8_t *d_comp, const uint64_t *d_in_off, const uint32_t *d_in_len, const uint64_t *d_out_off,
                    const uint32_t *d_isize, uint8_t *d_out, uint8_t *d_status, void *d_tables, int32_t nblocks);
 
@@ -561,10 +562,10 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
             HIP_TRY(hipMalloc(&g->d_tables, inflate_table_bytes() * cap));
             g->blocks_cap = cap;
         }
-        if (c->len + 64 > g->comp_cap) {
+        if (c->len + INFLATE_PAD > g->comp_cap) {
             g->comp_cap = 0;
-            if (int rc = regrow(st, g->d_comp, c->len + 64)) return rc;
-            g->comp_cap = c->len + 64;
+            if (int rc = regrow(st, g->d_comp, c->len + INFLATE_PAD)) return rc;
+            g->comp_cap = c->len + INFLATE_PAD;
         }
         const double t_alloc = now_s();
         HIP_TRY(hipEventRecord(g->ev0, st));
@@ -578,6 +579,9 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
                 at += c->isize[(size_t)i];
             }
             HIP_TRY(hipMemcpyAsync(g->d_comp, c->comp, c->len, hipMemcpyHostToDevice, st));
+            // zeros behind the chunk: a damaged last member that reads on finds an invalid stored-block header there, not the
+            // stale bytes of the chunk before (the kernel stops a lane a few bytes past its stream's end anyway)
+            HIP_TRY(hipMemsetAsync(g->d_comp + c->len, 0, INFLATE_PAD, st));
             HIP_TRY(hipMemcpyAsync(g->d_in_off, c->in_off.data(), sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(g->d_out_off, g->out_off.data(), sizeof(uint64_t) * nb, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(g->d_in_len, c->in_len.data(), sizeof(uint32_t) * nb, hipMemcpyHostToDevice, st));

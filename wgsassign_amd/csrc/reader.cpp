@@ -1453,6 +1453,14 @@ bool load_part(const char *path_in, PartData &p, uint64_t file_size, uint64_t mt
     bool ok = fread(magic, 1, 8, f) == 8 && memcmp(magic, kPartMagic, 8) == 0 && get(f, fs) && get(f, mt) && get(f, p.first) && get(f, p.next) &&
               get(f, nb) && get(f, hl) && fs == file_size && mt == mtime && hl < (1u << 30) && nb < (1ull << 40);
     if (ok) {
+        // the counts must fit the part file itself BEFORE anything is sized by them: a damaged part file would otherwise ask for
+        // terabytes (std::bad_alloc through an extern "C" entry point)
+        struct stat sb;
+        const uint64_t fixed = 8 + 6 * sizeof(uint64_t);
+        ok = fstat(fileno(f), &sb) == 0 && (uint64_t)sb.st_size >= fixed && hl <= (uint64_t)sb.st_size - fixed &&
+             nb <= ((uint64_t)sb.st_size - fixed - hl) / (sizeof(BgzfBlock) + sizeof(BlockLines));
+    }
+    if (ok) {
         p.header.resize((size_t)hl);
         ok = fread(&p.header[0], 1, (size_t)hl, f) == (size_t)hl || hl == 0;
         p.blocks.resize((size_t)nb);
@@ -1507,6 +1515,12 @@ int wgs_reader_index_merge(const char *path, const char *index_path, const char 
         wgs_set_error("cannot open Beagle file %s", path);
         return 2;
     }
+    // the part files are this call's to remove, however it ends (the caller falls back to the one-rank pass on rc 3)
+    struct PartFiles {
+        std::string prefix;
+        int n;
+        ~PartFiles() { for (int k = 0; k < n; ++k) unlink((prefix + "." + std::to_string(k)).c_str()); }
+    } cleanup{std::string(parts_prefix), nparts};
     std::vector<PartData> parts((size_t)nparts);
     for (int k = 0; k < nparts; ++k) {
         const std::string pp = std::string(parts_prefix) + "." + std::to_string(k);
@@ -1536,7 +1550,6 @@ int wgs_reader_index_merge(const char *path, const char *index_path, const char 
         return 1;
     }
     *sites = idx.sites;
-    for (int k = 0; k < nparts; ++k) unlink((std::string(parts_prefix) + "." + std::to_string(k)).c_str());
     return 0;
 }
 
