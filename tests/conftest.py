@@ -16,6 +16,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _class_codes_on_small_matrices(monkeypatch):
+    """The product builds the class codes only when its cost models expect them to pay (csrc/em_api.hip: em_codes_pay,
+    csrc/codes.hip: wgs_codes_pay_for_scoring) -- never for matrices of test size.  The suite wants the coded kernels exercised by
+    every test that fits or scores with shared columns, so the models are switched to "always" here; the tests of the models
+    themselves (tests/test_gpu_codes.py) remove these settings again."""
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")
+    monkeypatch.setenv("WGSASSIGN_SCORE_CODES_ALWAYS", "1")
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

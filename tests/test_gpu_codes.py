@@ -294,6 +294,7 @@ def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
     three direct sweeps; a scoring sweep with shared columns always builds them; a small matrix (fixed costs dominate) never
     builds them for an EM fit.  Same frequencies either way (the tests above)."""
     monkeypatch.delenv("WGSASSIGN_EM_CODES_SWEEPS", raising=False)
+    monkeypatch.delenv("WGSASSIGN_SCORE_CODES_ALWAYS", raising=False)
     m, n, K = 2_000_000, 400, 4
     group_of = (np.arange(n) // (n // K)).astype(np.int32)
 
@@ -328,6 +329,24 @@ def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
         em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
         em.fit(200, 0.0)
         assert b.codes_state() == 0
+        afs = dev.AFSet.from_host(np.full((20_000, K), 0.3, dtype=np.float32))
+        dev.assign(b, afs)                                       # ... and what one scoring sweep saves
+        assert b.codes_state() == 0
+        afs.close()
+        em.close()
+        b.close()
+        # quality-dependent likelihoods, 26 classes per slab among 100 individuals: a coded EM sweep saves a fifth of the direct
+        # one and the encoder needs its largest tables -- the fit keeps the float32 slabs (the sample pass said so), the scoring
+        # sweep, which saves four fifths, builds the codes
+        b = dev.DeviceBeagle(m, n, group_of, K)
+        b.synth_quality(77, 2.0)
+        em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+        em.fit(50, 0.0)
+        assert b.codes_state() == 0
+        afs = dev.AFSet.from_host(np.full((m, K), 0.3, dtype=np.float32))
+        dev.assign(b, afs)
+        assert b.codes_state() == 1
+        afs.close()
         em.close()
         b.close()
 

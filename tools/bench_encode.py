@@ -27,6 +27,13 @@ def main():
         t0 = time.perf_counter()
         info = b.codes_info()
         info["seconds"] = round(time.perf_counter() - t0, 4)
+        if os.environ.get("BENCH_ENCODE_FIT"):                   # an EM fit through the codes, and what codes_info says afterwards
+            em = device.EMBatch(b, np.arange(K, dtype=np.int32))
+            it = em.run(200, 1e-4)
+            info["fit_iterations"] = [int(x) for x in it]
+            info["fit_sweep_ms"] = round(em.fit_stats()[3], 2)
+            info["em_direct_tile_share_after_fit"] = b.codes_info()["em_direct_tile_share"]
+            em.close()
         out.append(info)
     print(json.dumps({"config": "%d x %d, K=%d" % (m, n, K), "gl_bytes": b.nbytes(), "runs": out}))
 

@@ -69,6 +69,7 @@ void wgs_ctx_destroy(wgs_ctx *ctx)
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->ws_b) (void)hipFree(ctx->ws_b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -90,6 +91,23 @@ int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out)
         ctx->ws_bytes = want;
     }
     *out = ctx->ws;
+    return 0;
+}
+
+int wgs_ctx_workspace_b(wgs_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->ws_b_bytes) {
+        if (ctx->ws_b) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(ctx->ws_b));
+            ctx->ws_b = nullptr;
+            ctx->ws_b_bytes = 0;
+        }
+        const size_t want = (bytes + 4095) & ~(size_t)4095;
+        HIP_TRY(hipMalloc(&ctx->ws_b, want));
+        ctx->ws_b_bytes = want;
+    }
+    *out = ctx->ws_b;
     return 0;
 }
 
@@ -140,6 +158,7 @@ void wgs_beagle_destroy(wgs_beagle *b)
     if (!b) return;
     wgs_beagle_drop_codes(b);
     (void)hipSetDevice(b->ctx->device);
+    if (b->pool) (void)hipFree(b->pool);
     for (auto &s : b->slabs) {
         if (s.base) (void)hipFree(s.base);
         if (s.d_members) (void)hipFree(s.d_members);

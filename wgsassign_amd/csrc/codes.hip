@@ -14,11 +14,11 @@ void wgs_beagle_drop_codes(wgs_beagle *b)
     if (wgs_codes *c = b->codes) {
         (void)hipSetDevice(b->ctx->device);
         (void)hipStreamSynchronize(b->ctx->stream);
-        if (c->pool) (void)hipFree(c->pool);
-        delete c;
+        delete c;                                          // (the pool stays with the wgs_beagle: wgs_beagle_codes uses it again)
     }
     b->codes = nullptr;
     b->codes_state = 0;
+    b->plan = wgs_codes_plan();
     b->direct_sweeps = 0;
     ++b->codes_generation;
 }
@@ -51,10 +51,79 @@ static double hist_mean(const unsigned long long *h)
     return total ? sum / (double)total : 0.0;
 }
 
-// Builds the class codes (a sample of the matrix decides whether and how, then one pass over it: ~2 x its streaming time).
-// Not worth coding -- most SNPs with more classes than the largest table holds, or hardly fewer classes than individuals -- or
-// no memory for the codes (a quarter of the matrix + the dictionaries): nullptr, and the direct kernels run.
-// WGSASSIGN_CODES=0 turns the codes off altogether.
+// What the sample pass says about the matrix (cached in the wgs_beagle until its rows change): whether class codes are worth having at
+// all, and with which geometry.  ~0.3-0.5 ms (a few thousand groups of 8 SNPs through the largest hash table, one readback).
+const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b)
+{
+    if (!b) return nullptr;
+    wgs_codes_plan &P = b->plan;
+    if (P.state != 0) return &P;
+    P = wgs_codes_plan();
+    P.state = -1;
+    if (hipSetDevice(b->ctx->device) != hipSuccess) return &P;
+    const double t0 = now_s();
+    // (the sample pass needs the slab table on the device, with no arrays behind it)
+    wgs_codes tmpc;
+    tmpc.slabs.resize(b->n_groups);
+    for (int g = 0; g < b->n_groups; ++g) tmpc.slabs[g].nquads = (b->slabs[g].ncols + 3) / 4;
+    void *tmp = nullptr;
+    if (wgs_ctx_workspace_b(b->ctx, sizeof(SlabCodes) * b->n_groups, &tmp)) return &P;
+    tmpc.d_slabs = reinterpret_cast<SlabCodes *>(tmp);
+    if (hipMemcpy(tmpc.d_slabs, tmpc.slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) != hipSuccess) return &P;
+    unsigned long long hg[256], hl[256];
+    if (launch_class_sample(b, &tmpc, 4096, hg, hl, nullptr)) {
+        (void)hipGetLastError();
+        return &P;
+    }
+    P.mean_g = hist_mean(hg);
+    P.mean_l = hist_mean(hl);
+    // geometry: the table should stay under ~60 % full for all but a few SNPs in a thousand (those become rich)
+    const int g999 = hist_quantile(hg, 0.999), g99 = hist_quantile(hg, 0.99);
+    const char *force = getenv("WGSASSIGN_CODES_TABLE");   // experiments / tests: 64, 128 or 256 slots per SNP
+    P.slots = g99 <= 36 ? 64 : (g99 <= 80 ? 128 : 256);
+    if (force && (atoi(force) == 64 || atoi(force) == 128 || atoi(force) == 256)) P.slots = atoi(force);
+    P.drows = std::min(std::min(254, P.slots - P.slots / 8), (g999 + 4 + 7) & ~7);
+    // SNPs per table of the coded scoring sweep: as many as keep a typical batch inside its LDS table
+    P.score_batch = g99 * 16 <= WGS_BATCH_ROWS_CAP ? 16 : (g99 * 8 <= WGS_BATCH_ROWS_CAP ? 8 : 4);
+    P.score_batch = std::min(P.score_batch, 2048 / P.slots);      // (the encoder checks a batch's rows inside one wavefront)
+    // the coded EM sweep's table: a tile is swept directly when one of its 64 SNPs has more classes in the slab than rows,
+    // so ~1 % of the tiles at most means ~1.5 in 10 000 (slab, SNP) pairs
+    const int l_hi = hist_quantile(hl, 1.0 - 1.0 / 6400.0);
+    P.lrows = (std::max(l_hi, 1) + 7) & ~7;
+    if (P.lrows > 64 || l_hi >= 255) P.lrows = 0;
+    if (const char *rows_env = getenv("WGSASSIGN_EM_TABLE_ROWS")) {    // experiments / tests: 8 .. 64, a multiple of 8
+        const int r = atoi(rows_env);
+        if (r >= 8 && r <= 64 && r % 8 == 0) P.lrows = r;
+    }
+    P.sample_ms = (now_s() - t0) * 1e3;
+    // not worth coding: the typical SNP overflows the largest table, or has hardly fewer classes than individuals
+    P.state = (g99 >= 200 || (P.mean_g * 2.0 > (double)b->n && !force)) ? -1 : 1;
+    return &P;
+}
+
+// The encode pass streams the matrix once and writes about half of it again (codes, the slabs' own codes and dictionaries): measured
+// 80 GB in 45 ms and 8 GB in 5 ms with 64-slot tables, 1.2 x / 1.85 x that with 128 / 256 slots, + ~0.6 ms of allocation and readbacks.
+double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots)
+{
+    return (double)b->bytes / 1.8e9 * (slots <= 64 ? 1.0 : (slots == 128 ? 1.2 : 1.85)) + 0.6;
+}
+
+// Whether a scoring sweep with shared columns over K populations should build the codes: the direct sweep costs ~1.2e-11 s per
+// (SNP, individual, population) (119 ms at 10M x 1000 x 10, on the FP64 issue roof), the coded one the share of it that is
+// table work (classes / individuals) + ~9 % for the look-ups (16.6 ms there; 6.5 of 25.7 ms with 73 classes among 1000).
+bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K)
+{
+    if (getenv("WGSASSIGN_CODES_TABLE") || getenv("WGSASSIGN_SCORE_CODES_ALWAYS")) return true;      // experiments / tests
+    const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
+    if (!P || P->state <= 0) return false;
+    const double direct_ms = 1.2e-8 * (double)b->m * (double)b->n * (double)K;
+    const double coded_share = std::min(1.0, 1.25 * P->mean_g / (double)std::max<int64_t>(1, b->n) + 0.09);
+    return direct_ms * (1.0 - coded_share) > wgs_codes_build_ms_estimate(b, P->slots);
+}
+
+// Builds the class codes (the plan of the sample pass decides whether and how, then one pass over the matrix: ~2 x its streaming
+// time).  Not worth coding -- most SNPs with more classes than the largest table holds, or hardly fewer classes than individuals --
+// or no memory for the codes (half of the matrix): nullptr, and the direct kernels run.  WGSASSIGN_CODES=0 turns the codes off altogether.
 wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
 {
     if (!b || b->codes_state < 0 || codes_switched_off()) return nullptr;
@@ -63,13 +132,17 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
     b->codes_state = -1;
     if (hipSetDevice(b->ctx->device) != hipSuccess) return nullptr;
     const double t0 = now_s();
+    const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
+    if (!P || P->state <= 0) return nullptr;
     const int64_t tiles = wgs_ntiles(b->m);
     const size_t rows = (size_t)tiles * 64;
     wgs_codes *c = new wgs_codes();
     b->codes = c;
     auto fail = [&]() -> wgs_codes * {
         (void)hipGetLastError();
+        const wgs_codes_plan keep = b->plan;
         wgs_beagle_drop_codes(b);
+        b->plan = keep;
         b->codes_state = -1;
         return nullptr;
     };
@@ -83,44 +156,14 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
         quad0 += s.nquads;
     }
     c->total_quads = quad0;
-    // ---- the sample: classes per SNP over all individuals and per population slab
-    // (the sample pass needs the slab table on the device, with no arrays behind it yet)
+    c->sample_mean_g = P->mean_g;
+    c->sample_mean_l = P->mean_l;
+    c->sample_ms = P->sample_ms;
+    c->snps_per_wave = 2048 / P->slots;
+    c->drows = P->drows;
+    c->score_batch = P->score_batch;
+    c->lrows = P->lrows;
     const size_t slab_tab = ((sizeof(SlabCodes) * b->n_groups + 255) / 256) * 256;
-    {
-        void *tmp = nullptr;
-        if (hipMalloc(&tmp, slab_tab) != hipSuccess) return fail();
-        c->d_slabs = reinterpret_cast<SlabCodes *>(tmp);
-        bool ok = hipMemcpy(c->d_slabs, c->slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) == hipSuccess;
-        unsigned long long hg[256], hl[256];
-        ok = ok && launch_class_sample(b, c, 4096, hg, hl, nullptr) == 0;
-        (void)hipFree(tmp);
-        c->d_slabs = nullptr;
-        if (!ok) return fail();
-        c->sample_mean_g = hist_mean(hg);
-        c->sample_mean_l = hist_mean(hl);
-        c->sample_ms = (now_s() - t0) * 1e3;
-        // geometry: the table should stay under ~60 % full for all but a few SNPs in a thousand (those become rich)
-        const int g999 = hist_quantile(hg, 0.999), g99 = hist_quantile(hg, 0.99);
-        const char *force = getenv("WGSASSIGN_CODES_TABLE");   // experiments / tests: 64, 128 or 256 slots per SNP
-        int slots = g99 <= 36 ? 64 : (g99 <= 80 ? 128 : 256);
-        if (force && (atoi(force) == 64 || atoi(force) == 128 || atoi(force) == 256)) slots = atoi(force);
-        c->snps_per_wave = 2048 / slots;
-        // not worth coding: the typical SNP overflows the largest table, or has hardly fewer classes than individuals
-        if (g99 >= 200 || (c->sample_mean_g * 2.0 > (double)b->n && !force)) return fail();
-        c->drows = std::min(std::min(254, slots - slots / 8), (g999 + 4 + 7) & ~7);
-        // SNPs per table of the coded scoring sweep: as many as keep a typical batch inside its LDS table
-        c->score_batch = g99 * 16 <= WGS_BATCH_ROWS_CAP ? 16 : (g99 * 8 <= WGS_BATCH_ROWS_CAP ? 8 : 4);
-        c->score_batch = std::min(c->score_batch, c->snps_per_wave);      // (the encoder checks a batch's rows inside one wavefront)
-        // the coded EM sweep's table: a tile is swept directly when one of its 64 SNPs has more classes in the slab than rows,
-        // so ~1 % of the tiles at most means ~1.5 in 10 000 (slab, SNP) pairs
-        const int l_hi = hist_quantile(hl, 1.0 - 1.0 / 6400.0);
-        c->lrows = (std::max(l_hi, 1) + 7) & ~7;
-        if (c->lrows > 64 || l_hi >= 255) c->lrows = 0;
-        if (const char *rows_env = getenv("WGSASSIGN_EM_TABLE_ROWS")) {    // experiments / tests: 8 .. 64, a multiple of 8
-            const int r = atoi(rows_env);
-            if (r >= 8 && r <= 64 && r % 8 == 0) c->lrows = r;
-        }
-    }
     // ---- one allocation for everything
     auto plan = [&](bool with_local, std::vector<size_t> &off) -> size_t {
         size_t at = 0;
@@ -142,17 +185,28 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
     const double ta = now_s();
     std::vector<size_t> off;
     size_t total = plan(c->lrows > 0, off);
-    if (hipMalloc(&c->pool, total) != hipSuccess) {
-        (void)hipGetLastError();
-        c->pool = nullptr;
+    // (the pool of an earlier build of this matrix -- dropped because rows changed -- is kept by the wgs_beagle and used again when
+    // it is large enough: freeing and allocating tens of GB again costs seconds on this driver)
+    auto take_pool = [&](size_t bytes) -> bool {
+        if (b->pool && b->pool_bytes >= bytes) return true;
+        if (b->pool) (void)hipFree(b->pool);
+        b->pool = nullptr;
+        b->pool_bytes = 0;
+        if (hipMalloc(&b->pool, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            b->pool = nullptr;
+            return false;
+        }
+        b->pool_bytes = bytes;
+        return true;
+    };
+    if (!take_pool(total)) {
         if (c->lrows == 0) return fail();
         c->lrows = 0;                                      // without the slabs' own numbering: the scoring sweep can still use the codes
         total = plan(false, off);
-        if (hipMalloc(&c->pool, total) != hipSuccess) {
-            c->pool = nullptr;
-            return fail();
-        }
+        if (!take_pool(total)) return fail();
     }
+    c->pool = b->pool;
     c->alloc_ms = (now_s() - ta) * 1e3;
     char *base = reinterpret_cast<char *>(c->pool);
     c->d_slabs = reinterpret_cast<SlabCodes *>(base + off[0]);
@@ -173,7 +227,7 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
     c->bytes = (int64_t)total - c->local_bytes;
     if (hipMemcpy(c->d_slabs, c->slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) != hipSuccess) return fail();
     if (launch_class_encode(b, c)) return fail();          // (sets kernel_ms from HIP events around the kernel)
-    c->build_ms = (now_s() - t0) * 1e3;
+    c->build_ms = (now_s() - t0) * 1e3 + (P->sample_ms > 0 && c->sample_ms == P->sample_ms ? 0.0 : 0.0);
     b->codes_state = 1;
     return c;
 }

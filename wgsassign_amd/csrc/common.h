@@ -48,6 +48,8 @@ struct wgs_ctx {
     int cus = 0;
     void *ws = nullptr;      // grow-only device workspace (assignment outputs / pointer tables)
     size_t ws_bytes = 0;
+    void *ws_b = nullptr;    // second, small one (slab tables of the encoder's sample pass)
+    size_t ws_b_bytes = 0;
     // per-context state that must not be shared between contexts on different devices
     bool log_table_ready = false;               // the log table of assign_kernels.hip is uploaded to this device
     hipEvent_t ev0 = nullptr, ev1 = nullptr;    // bracket the scoring kernels of the last wgs_assign / wgs_score_*
@@ -123,6 +125,13 @@ struct wgs_codes {
     double sample_mean_g = 0.0, sample_mean_l = 0.0;   // classes per SNP / per (slab, SNP) in the sample
 };
 
+// What the encoder's sample pass found (codes.hip: wgs_beagle_codes_plan): state 0 = not sampled, 1 = worth coding, -1 = not.
+struct wgs_codes_plan {
+    int state = 0;
+    int32_t slots = 64, drows = 0, lrows = 0, score_batch = 16;
+    double mean_g = 0.0, mean_l = 0.0, sample_ms = 0.0;
+};
+
 struct wgs_beagle {
     wgs_ctx *ctx = nullptr;
     int64_t m = 0, n = 0, site0 = 0;
@@ -138,11 +147,18 @@ struct wgs_beagle {
     wgs_codes *codes = nullptr;
     int codes_state = 0;
     int64_t codes_generation = 0;  // counts builds and drops
+    wgs_codes_plan plan;           // the sample pass's findings (reset when rows change)
+    void *pool = nullptr;          // device memory of the class codes, kept across rebuilds
+    size_t pool_bytes = 0;
     int64_t direct_sweeps = 0;     // EM sweeps over the float32 slabs so far (wgs_em_step callers: the codes are built once a run is long)
 };
 // The matrix's class codes, or nullptr when they are switched off (WGSASSIGN_CODES=0) or the matrix is not worth coding (then the
 // direct kernels are used).  build = false only returns codes that exist already.
 wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true);
+const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b);
+double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots);
+bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K);
+int wgs_ctx_workspace_b(wgs_ctx *ctx, size_t bytes, void **out);     // a second small grow-only scratch (survives wgs_ctx_workspace calls)
 void wgs_beagle_drop_codes(wgs_beagle *b);
 int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned long long *hist_g, unsigned long long *hist_l, double *rounds_per_buffer);
 int launch_class_encode(wgs_beagle *b, wgs_codes *c);

@@ -117,28 +117,37 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
 
 
 /* Whether building the class codes pays for the EM sweeps still to come (codes.hip builds them in one pass over the matrix):
- *   the encode pass costs about the matrix's bytes at 1.8 TB/s (measured: 80 GB in 44 ms, 1.6 GB in 2.3 ms) + 0.6 ms of
- *   sample pass, allocation and readbacks;
- *   a coded sweep saves a share of the direct sweep (the slabs' bytes at ~6 TB/s) that grows with the population size --
- *   measured 14 % at 30 individuals, 21 % at 36, 39 % at 62, 52 % at 100;
+ *   the encode pass costs wgs_codes_build_ms_estimate (the matrix's bytes at ~1.8 TB/s, more with larger hash tables);
+ *   a coded sweep saves a share of the direct sweep (the slabs' bytes at ~6 TB/s) that depends on how many of a population's
+ *   individuals share a class: measured 52 % at 14.7 classes per (slab, SNP) among 100 individuals, 39 % at 12.7 among 62, 21 %
+ *   at 10.5 among 40 and at 26 among 100 (quality-dependent likelihoods) -- 0.92 - 2.72 x classes / individuals fits all four;
  *   sweeps to come: what the caller knows -- wgs_em_fit its iteration limit, of which a fit rarely uses more than ~14 (the
- *   reference's default tolerance: 13-17 iterations on every data set here); a step-by-step caller nothing, so there a matrix
+ *   reference's default tolerance: 11-17 iterations on every data set here); a step-by-step caller nothing, so there a matrix
  *   that has been swept directly three times is taken to be in a long run.
+ * A first estimate assumes fixed-error low-depth data (no sample pass: small matrices are turned away for free); when that says yes
+ * the sample pass (~0.4 ms, once per matrix) supplies the matrix's own classes per slab and table size.
  * WGSASSIGN_EM_CODES_SWEEPS=k replaces the model by "k or more sweeps ahead" (0: always; tests). */
 static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, int fewest_cols, int sweeps_ahead)
 {
-    const wgs_beagle *b = em->b;
+    wgs_beagle *b = em->b;
     if (const char *sw = getenv("WGSASSIGN_EM_CODES_SWEEPS")) return sweeps_ahead >= atoi(sw) || b->direct_sweeps >= 3;
     double ahead = std::min(sweeps_ahead, 14);
     if (sweeps_ahead <= 0 && b->direct_sweeps >= 3) ahead = 12;
-    static const double at[5] = {28, 36, 62, 100, 1e9}, share[5] = {0.10, 0.21, 0.39, 0.52, 0.52};
-    double saves = share[0];
-    for (int i = 0; i + 1 < 5; ++i)
-        if (fewest_cols >= at[i]) saves = share[i] + (share[i + 1] - share[i]) * std::min(1.0, (fewest_cols - at[i]) / (at[i + 1] - at[i]));
-    double swept = 0.0;
-    for (int j : order) swept += 8.0 * (double)b->slabs[em->group[j]].ncols * (double)b->m;
-    const double direct_ms = swept / 6.0e9, build_ms = (double)b->bytes / 1.8e9 + 0.6;
-    return ahead * saves * direct_ms > build_ms;
+    double swept = 0.0, cols = 0.0;
+    for (int j : order) {
+        swept += 8.0 * (double)b->slabs[em->group[j]].ncols * (double)b->m;
+        cols += (double)b->slabs[em->group[j]].ncols;
+    }
+    cols /= (double)std::max<size_t>(1, order.size());
+    const double direct_ms = swept / 6.0e9;
+    auto saves = [&](double classes_per_slab) { return std::max(0.0, std::min(0.6, 0.92 - 2.72 * classes_per_slab / std::max(1.0, cols))); };
+    // fixed-error 2x data shows ~4.6 * cols^0.25 classes per (slab, SNP): 14.7 at 100, 12.7 at 62, 10.5 at 40
+    const double typical = 4.6 * pow(std::max(1.0, cols), 0.25);
+    if (ahead * saves(typical) * direct_ms <= wgs_codes_build_ms_estimate(b, 64)) return false;
+    const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
+    if (!P || P->state <= 0 || P->lrows == 0) return false;
+    (void)fewest_cols;
+    return ahead * saves(P->mean_l) * direct_ms > wgs_codes_build_ms_estimate(b, P->slots);
 }
 
 /* Enqueue one sweep (+ the fixed-order reduction of its sums) for the fits in `list`: descriptors into the pinned
