@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "libwgsassign_hip.so")
 SOURCES = ["api.hip", "em_api.hip", "score_api.hip", "codes.hip", "codes_kernels.hip", "em_kernels.hip", "assign_kernels.hip", "beagle_kernels.hip", "ingest.hip", "inflate.hip", "rccl_comm.hip", "reader.cpp"]
 # -ffp-contract=off: the exact-mode kernels restate the reference's rounding sequence operation by
 # operation; hipcc's default (fast) contraction would fuse a*b+c and change results.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"] + os.environ.get("WGSASSIGN_BUILD_DEFINES", "").split()
 
 
 def hipcc():

@@ -80,12 +80,12 @@ const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b)
     // geometry: the table should stay under ~60 % full for all but a few SNPs in a thousand (those become rich)
     const int g999 = hist_quantile(hg, 0.999), g99 = hist_quantile(hg, 0.99);
     const char *force = getenv("WGSASSIGN_CODES_TABLE");   // experiments / tests: 64, 128 or 256 slots per SNP
-    P.slots = g99 <= 36 ? 64 : (g99 <= 80 ? 128 : 256);
+    P.slots = g99 <= 44 ? 64 : (g99 <= 88 ? 128 : 256);       // (a larger table costs 1.4 x / 2.4 x the encode time of the 64-slot one)
     if (force && (atoi(force) == 64 || atoi(force) == 128 || atoi(force) == 256)) P.slots = atoi(force);
     P.drows = std::min(std::min(254, P.slots - P.slots / 8), (g999 + 4 + 7) & ~7);
     // SNPs per table of the coded scoring sweep: as many as keep a typical batch inside its LDS table
     P.score_batch = g99 * 16 <= WGS_BATCH_ROWS_CAP ? 16 : (g99 * 8 <= WGS_BATCH_ROWS_CAP ? 8 : 4);
-    P.score_batch = std::min(P.score_batch, 2048 / P.slots);      // (the encoder checks a batch's rows inside one wavefront)
+    P.score_batch = std::min(P.score_batch, WGS_ENC_SLOTS / P.slots);      // (the encoder checks a batch's rows inside one wavefront)
     // the coded EM sweep's table: a tile is swept directly when one of its 64 SNPs has more classes in the slab than rows,
     // so ~1 % of the tiles at most means ~1.5 in 10 000 (slab, SNP) pairs
     const int l_hi = hist_quantile(hl, 1.0 - 1.0 / 6400.0);
@@ -102,10 +102,11 @@ const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b)
 }
 
 // The encode pass streams the matrix once and writes about half of it again (codes, the slabs' own codes and dictionaries): measured
-// 80 GB in 45 ms and 8 GB in 5 ms with 64-slot tables, 1.2 x / 1.85 x that with 128 / 256 slots, + ~0.6 ms of allocation and readbacks.
+// 80 GB in 33 ms, 8 GB in 3.8 ms, 1.6 GB in 1.1 ms with 64-slot tables, ~1.4 x / 2.4 x that with 128 / 256 slots, + ~0.5 ms of sample
+// pass, allocation and readbacks.
 double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots)
 {
-    return (double)b->bytes / 1.8e9 * (slots <= 64 ? 1.0 : (slots == 128 ? 1.2 : 1.85)) + 0.6;
+    return (double)b->bytes / 2.3e9 * (slots <= 64 ? 1.0 : (slots == 128 ? 1.4 : 2.4)) + 0.5;
 }
 
 // Whether a scoring sweep with shared columns over K populations should build the codes: the direct sweep costs ~1.2e-11 s per
@@ -159,7 +160,7 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
     c->sample_mean_g = P->mean_g;
     c->sample_mean_l = P->mean_l;
     c->sample_ms = P->sample_ms;
-    c->snps_per_wave = 2048 / P->slots;
+    c->snps_per_wave = WGS_ENC_SLOTS / P->slots;
     c->drows = P->drows;
     c->score_batch = P->score_batch;
     c->lrows = P->lrows;
@@ -176,7 +177,7 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
         for (int g = 0; g < b->n_groups; ++g) {
             const size_t words = (size_t)tiles * c->slabs[g].nquads * 64;
             off.push_back(take(words * sizeof(uint32_t)));                      // codes
-            off.push_back(take(8 * (size_t)tiles));                             // tile_rows
+            off.push_back(take(WGS_TILE_ROWS_BYTES * (size_t)tiles));           // tile_rows
             off.push_back(take(with_local ? words * sizeof(uint32_t) : 0));     // lcodes
             off.push_back(take(with_local ? (size_t)tiles * c->lrows * 64 * sizeof(float2) : 0));   // ldict
         }
@@ -253,7 +254,7 @@ int wgs_beagle_codes_info(wgs_beagle *b, double *info)
     info[7] = (double)c->local_bytes;
     info[8] = c->lrows;
     info[9] = c->local_direct_share;
-    info[10] = 2048 / c->snps_per_wave;
+    info[10] = WGS_ENC_SLOTS / c->snps_per_wave;
     info[11] = b->m > 0 ? (double)c->rich_snps / (double)b->m : 0.0;
     info[12] = c->drows;
     info[13] = c->probe_rounds;

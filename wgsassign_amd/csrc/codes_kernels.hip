@@ -1,22 +1,23 @@
 // The class encoder (common.h: wgs_codes): ONE pass over the float32 slabs that leaves everything both coded sweeps need --
 // the per-SNP dictionary and class ids of every individual (scoring), and per population slab its own numbering of the
 // classes with its own dictionary rows (EM).  Round 3 did this in two kernels (77 + 14 ms at 10M x 1000) whose walk was a
-// chain of dependent LDS probes, one wavefront per tile; here the probes are LDS compare-and-swaps issued sixteen at a
-// time, so the walk is bound by issue slots and HBM instead of LDS latency.
+// chain of dependent LDS probes, one wavefront per tile; here the probes are LDS compare-and-swaps issued eight at a
+// time by four wavefronts per SIMD, and nothing is added to a shared counter.
 //
 //   hash table   per SNP, T slots of 8 bytes (the (g0, g1) bit pattern) in LDS, open addressing, linear probing, insert-only.
 //                A lookup-or-insert at slot h is ONE ds_cmpst_rtn_b64 (expect EMPTY, store the key): it returns EMPTY (inserted),
 //                the key (found) or another key (probe h + 1).  An insert-only table gives every key the same slot whatever the
-//                order of the operations, and LDS operations of a wavefront execute in issue order, so the sixteen lookups of a
+//                order of the operations, and LDS operations of a wavefront execute in issue order, so the lookups of a
 //                buffer are issued back to back without waiting for each other -- also when two of them insert the same new key.
-//   geometry     a wavefront owns 2048 slots (20 KiB of LDS with the marks: two wavefronts per SIMD, the second hides the first's
-//                waits): SNPS SNPs x T slots, (32, 64), (16, 128) or (8, 256), chosen per matrix from a sample (low-depth data
-//                with fixed error has ~27 classes per SNP among 1000 individuals, likelihoods from binned base qualities
-//                80-100).  The 64 / SNPS lanes of a SNP share its table (real atomics) and take alternate quads of individuals.
+//   geometry     a wavefront owns 1024 slots (10 KiB of LDS with the marks, <= 128 VGPRs: FOUR wavefronts per SIMD -- the walk is a
+//                chain of LDS round trips, and only other wavefronts hide them: 2048 slots at two per SIMD took 45 ms where this
+//                takes 33, 4096 at one 77): SNPS SNPs x T slots, (16, 64), (8, 128) or (4, 256), chosen per matrix from a sample
+//                (low-depth data with fixed error has ~27 classes per SNP among 1000 individuals, likelihoods from binned base
+//                qualities 70-100).  The 64 / SNPS lanes of a SNP share its table (real atomics) and take alternate quads.
 //   walk         per slab: the lane's quads, two 16-byte loads each (the slab's native layout, lane <-> SNP), 4 lookups per
 //                quad, the four SLOT numbers written as the quad's code word, a byte per (slot, SNP) in LDS marked "seen in
 //                this slab".
-//   slab end     the seen slots of each SNP are ranked in slot order (32 slots per lane, prefix over the lanes of the SNP):
+//   slab end     the seen slots of each SNP are ranked in slot order (16 slots per lane, prefix over the lanes of the SNP):
 //                that rank is the slab's OWN class number; the slab's dictionary rows are written coalesced (ldict), its
 //                code words re-read (they were written moments ago) and written as local ranks (lcodes), the most local
 //                classes of the tile's SNPs goes to tile_rows (what the coded EM sweep sizes its table by).
@@ -38,10 +39,10 @@ typedef unsigned long long __attribute__((address_space(1))) *gu64_ptr;
 typedef uint8_t __attribute__((address_space(1))) *gu8_ptr;
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;            // (g0, g1) = two NaNs with all payload bits set: no parser makes it
-constexpr int ENC_SLOTS = 2048;                            // hash slots per wavefront (16 KiB of keys + 4 KiB of marks: 8 wavefronts per CU)
+constexpr int ENC_SLOTS = WGS_ENC_SLOTS;                            // hash slots per wavefront (16 KiB of keys + 4 KiB of marks: 8 wavefronts per CU)
 constexpr int ENC_RMAX = 24;                               // probe rounds per buffer before the SNP is given up as rich
-constexpr int ENC_PD = 2;                                  // buffers requested ahead of the one being hashed
-constexpr int ENC_UQ = 4;                                  // quads per lane and buffer: 8 loads of 16 bytes, 16 lookups in flight
+constexpr int ENC_PD = ENC_SLOTS >= 2048 ? 2 : 1;                                  // buffers requested ahead of the one being hashed
+constexpr int ENC_UQ = ENC_SLOTS >= 2048 ? 4 : 2;                                 // quads per lane and buffer: 8 loads of 16 bytes, 16 lookups in flight
 
 __device__ __forceinline__ unsigned hash32(unsigned g0, unsigned g1)
 {
@@ -81,8 +82,8 @@ enum EncStat {
     ST_COUNT = 8
 };
 
-template <int SNPS, bool SAMPLE, int VARIANT = 0>
-__global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
+template <int SNPS, bool SAMPLE>
+__global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_kernel(EncodeArgs A)
 {
     constexpr int COLS = 64 / SNPS, T = ENC_SLOTS / SNPS, SCAN = ENC_SLOTS / 64;    // SCAN slots per lane when a table is ranked
     constexpr unsigned TMASK = T - 1, HSHIFT = T == 64 ? 26 : (T == 128 ? 25 : 24);
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
     auto clear_flags = [&]() {
 #pragma unroll
         for (int i = 0; i < ENC_SLOTS / 1024; ++i) reinterpret_cast<uint4 *>(flag)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        static_assert(ENC_SLOTS % 1024 == 0, "the marks are cleared sixteen bytes per lane at a time");
     };
 #pragma unroll
     for (int i = 0; i < ENC_SLOTS / 64; ++i) keys[i * 64 + lane] = KEY_EMPTY;
@@ -200,7 +202,6 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
                     pend[i] = old[i] != KEY_EMPTY && old[i] != key[i];
-                    if (VARIANT == 1) rich = rich || key[i] == KEY_EMPTY;
                 }
             } else {
 #pragma unroll
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
             const int f = flag[(col * SCAN + k) * SNPS + s];
             cnt += f;
             // a slot marked seen that holds no key: the one bit pattern used as EMPTY was looked up -- that SNP cannot be coded
-            if (VARIANT == 0 && f && keys[(col * SCAN + k) * SNPS + s] == KEY_EMPTY) rich = true;
+            if (f && keys[(col * SCAN + k) * SNPS + s] == KEY_EMPTY) rich = true;
         }
         rich = snp_or(rich);
         int pre, nloc;
@@ -281,8 +282,8 @@ __global__ __launch_bounds__(64, 2) void class_encode_kernel(EncodeArgs A)
             if (col == 0) A.sample[((int64_t)blockIdx.x * (A.n_slabs + 1) + g) * SNPS + s] = (uint8_t)(snp < A.m ? (rich ? 255 : min(nloc, 254)) : 0);
         } else {
             const int wmax = wave_max(rich ? 255 : nloc);
-            // one byte per group of 8 SNPs of the tile (this wave's SNPS / 8 of them): plain stores, the EM sweep takes the largest
-            if (lane < SNPS / 8) ((gu8_ptr)sc.tile_rows)[tile * 8 + sub * (SNPS / 8) + lane] = (uint8_t)wmax;
+            // one byte per group of WGS_ENC_MIN_SNPS SNPs of the tile (this wave's share of them): plain stores, the EM sweep takes the largest
+            if (lane < SNPS / WGS_ENC_MIN_SNPS) ((gu8_ptr)sc.tile_rows)[tile * WGS_TILE_ROWS_BYTES + sub * (SNPS / WGS_ENC_MIN_SNPS) + lane] = (uint8_t)wmax;
             if (A.lrows > 0 && wmax <= A.lrows && !(A.dbg & 8)) {          // wave-uniform: this wave's SNPs fit the EM sweep's table
                 int r = pre;
 #pragma unroll 8
@@ -436,10 +437,13 @@ __global__ __launch_bounds__(256) void encode_stats_kernel(const uint4 *wave_sta
         if (slabs[g].nquads == 0) continue;
         const unsigned long long *tr = reinterpret_cast<const unsigned long long *>(slabs[g].tile_rows);
         for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < tiles; t += step) {
-            const unsigned long long w = tr[t];
             unsigned mx = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) mx = max(mx, (unsigned)((w >> (8 * k)) & 255u));
+            for (int x = 0; x < WGS_TILE_ROWS_BYTES / 8; ++x) {
+                const unsigned long long w = tr[t * (WGS_TILE_ROWS_BYTES / 8) + x];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) mx = max(mx, (unsigned)((w >> (8 * k)) & 255u));
+            }
             direct += mx > lrows ? 1u : 0u;
         }
     }
@@ -508,17 +512,17 @@ int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned lon
 {
     int32_t *d_ncols = nullptr;
     unsigned long long *d_stats = nullptr;
-    const int64_t units = wgs_ntiles(b->m) * 8;
+    const int64_t units = wgs_ntiles(b->m) * WGS_TILE_ROWS_BYTES;
     const int64_t stride = std::max<int64_t>(1, units / std::max(1, max_units));
     const int64_t grid = (units + stride - 1) / stride;
-    const size_t sample_bytes = (size_t)grid * (b->n_groups + 1) * 8;
+    const size_t sample_bytes = (size_t)grid * (b->n_groups + 1) * WGS_ENC_MIN_SNPS;
     if (encode_scratch(b, &d_ncols, &d_stats, sample_bytes)) return 1;
     EncodeArgs A = encode_args(b, c, d_ncols, d_stats);
     A.drows = 254;
     A.lrows = 0;
     A.unit_stride = stride;
     A.sample = reinterpret_cast<uint8_t *>(d_ncols + b->n_groups + 64);
-    hipLaunchKernelGGL((class_encode_kernel<8, true>), dim3((unsigned)grid), dim3(64), 0, b->ctx->stream, A);
+    hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_MIN_SNPS, true>), dim3((unsigned)grid), dim3(64), 0, b->ctx->stream, A);
     HIP_TRY(hipGetLastError());
     std::vector<uint8_t> h(sample_bytes);
     unsigned long long st[ST_COUNT];
@@ -528,12 +532,13 @@ int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned lon
     for (int i = 0; i < 256; ++i) hist_g[i] = hist_l[i] = 0;
     const int G = b->n_groups;
     for (int64_t u = 0; u < grid; ++u) {
-        const uint8_t *row = h.data() + (size_t)u * (G + 1) * 8;
-        for (int x = 0; x < 8; ++x) {
-            if (row[(size_t)G * 8 + x] == 0) continue;     // beyond the last SNP
-            ++hist_g[row[(size_t)G * 8 + x]];
+        constexpr int W = WGS_ENC_MIN_SNPS;
+        const uint8_t *row = h.data() + (size_t)u * (G + 1) * W;
+        for (int x = 0; x < W; ++x) {
+            if (row[(size_t)G * W + x] == 0) continue;     // beyond the last SNP
+            ++hist_g[row[(size_t)G * W + x]];
             for (int g = 0; g < G; ++g)
-                if (b->slabs[g].ncols) ++hist_l[row[(size_t)g * 8 + x]];
+                if (b->slabs[g].ncols) ++hist_l[row[(size_t)g * W + x]];
         }
     }
     (void)st;
@@ -553,14 +558,9 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
     A.wave_stats = c->wave_stats;
     WGS_REQUIRE(units < (1ll << 31), "class encoder: %lld work units exceed one launch", (long long)units);
     HIP_TRY(hipEventRecord(b->ctx->ev0, b->ctx->stream));
-    switch (c->snps_per_wave) {
-        case 32:
-            if (A.dbg & 4) hipLaunchKernelGGL((class_encode_kernel<32, false, 1>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
-            else hipLaunchKernelGGL((class_encode_kernel<32, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
-            break;
-        case 16: hipLaunchKernelGGL((class_encode_kernel<16, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
-        default: hipLaunchKernelGGL((class_encode_kernel<8, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A); break;
-    }
+    if (c->snps_per_wave == WGS_ENC_SLOTS / 64) hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_SLOTS / 64, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
+    else if (c->snps_per_wave == WGS_ENC_SLOTS / 128) hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_SLOTS / 128, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
+    else hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_SLOTS / 256, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(b->ctx->ev1, b->ctx->stream));
     {

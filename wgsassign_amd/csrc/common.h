@@ -92,18 +92,24 @@ static inline int64_t wgs_ntiles(int64_t m) { return (m + 63) / 64; }
 //   tile_rows [tile * 8 + k]  most classes present in the slab at one of SNPs 8 k .. 8 k + 7 of the tile (as the encoder's wavefronts,
 //          which own 8, 16 or 32 SNPs, saw it); 255 when one of them is rich.  A tile whose largest entry exceeds lrows is swept
 //          directly from the float32 slab by the coded EM sweep.
+#ifndef WGS_ENC_SLOTS
+#define WGS_ENC_SLOTS 1024         // hash slots per wavefront of the class encoder (codes_kernels.hip): SNPs x slots per SNP.  1024 = 10 KiB of LDS
+                                   // and <= 128 VGPRs: four wavefronts per SIMD (2048: two; measured 45 ms against 33 at 10M x 1000)
+#endif
+constexpr int WGS_ENC_MIN_SNPS = WGS_ENC_SLOTS / 256;      // SNPs per wavefront with the largest tables (256 slots per SNP)
+constexpr int WGS_TILE_ROWS_BYTES = 64 / WGS_ENC_MIN_SNPS;  // tile_rows entries per tile: one per WGS_ENC_MIN_SNPS SNPs
 constexpr int WGS_BATCH_ROWS_CAP = 672;  // classes the SNPs of one batch of the coded scoring sweep may sum to: 672 rows of 80 bytes + the log table fit 64 KiB of LDS
 struct SlabCodes {
     uint32_t *codes = nullptr;
     uint32_t *lcodes = nullptr;
     float2 *ldict = nullptr;
-    uint8_t *tile_rows = nullptr;  // [tile * 8 + k]: for SNPs 8 k .. 8 k + 7 of the tile
+    uint8_t *tile_rows = nullptr;  // [tile * WGS_TILE_ROWS_BYTES + k]: for SNPs WGS_ENC_MIN_SNPS k ... of the tile
     int32_t nquads = 0;
     int32_t quad0 = 0;             // first matrix-wide quad index of this slab
 };
 struct wgs_codes {
     void *pool = nullptr;          // one allocation behind every array below
-    int32_t snps_per_wave = 32;    // encoder geometry: 32 / 16 / 8 SNPs per wavefront = hash tables of 64 / 128 / 256 slots
+    int32_t snps_per_wave = 16;    // encoder geometry: 16 / 8 / 4 SNPs per wavefront = hash tables of 64 / 128 / 256 slots
     int32_t drows = 0;             // dictionary rows per tile
     int32_t lrows = 0;             // rows of a slab's own dictionary per tile = rows of the coded EM sweep's table; 0: no local numbering
     int32_t cmax = 0;              // most classes of a coded SNP

@@ -385,10 +385,13 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
     // rows of this tile: the most classes one of its 64 SNPs has in this slab (255: a SNP the encoder gave up on)
     int nrows;
     {
-        const unsigned long long w = *reinterpret_cast<const unsigned long long *>(fd.tile_rows + tile * 8);   // one byte per 8 SNPs
-        unsigned mx = 0;
+        unsigned mx = 0;                                       // one byte per WGS_ENC_MIN_SNPS SNPs of the tile
 #pragma unroll
-        for (int k = 0; k < 8; ++k) mx = max(mx, (unsigned)((w >> (8 * k)) & 255u));
+        for (int x = 0; x < WGS_TILE_ROWS_BYTES / 8; ++x) {
+            const unsigned long long w = reinterpret_cast<const unsigned long long *>(fd.tile_rows + tile * WGS_TILE_ROWS_BYTES)[x];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mx = max(mx, (unsigned)((w >> (8 * k)) & 255u));
+        }
         nrows = (int)__builtin_amdgcn_readfirstlane((int)mx);
     }
     if (nrows > ROWS || nrows > fd.lrows) {
