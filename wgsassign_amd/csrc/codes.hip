@@ -95,6 +95,17 @@ const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b)
         const int r = atoi(rows_env);
         if (r >= 8 && r <= 64 && r % 8 == 0) P.lrows = r;
     }
+    // the slabs' own numbering is for the coded EM sweep only: when even a long fit could not repay the encode pass (many classes per
+    // slab: the sweep would save too little -- em_api.hip: em_codes_pay has the model), the pass leaves it out and is a third cheaper
+    {
+        int groups = 0;
+        for (int g = 0; g < b->n_groups; ++g) groups += b->slabs[g].ncols > 0;
+        const double cols = (double)b->n / std::max(1, groups);
+        const double saves = std::max(0.0, std::min(0.6, 0.92 - 2.72 * P.mean_l / std::max(1.0, cols)));
+        if (!getenv("WGSASSIGN_EM_TABLE_ROWS") && !getenv("WGSASSIGN_EM_CODES_SWEEPS") &&
+            14.0 * saves * ((double)b->bytes / 6.0e9) <= wgs_codes_build_ms_estimate(b, P.slots))
+            P.lrows = 0;
+    }
     P.sample_ms = (now_s() - t0) * 1e3;
     // not worth coding: the typical SNP overflows the largest table, or has hardly fewer classes than individuals
     P.state = (g99 >= 200 || (P.mean_g * 2.0 > (double)b->n && !force)) ? -1 : 1;
