@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-assign", action="store_true", help="skip the assignment sweep leg")
     ap.add_argument("--no-paths", action="store_true", help="skip extra.paths (whole-path timings of the other configurations)")
+    ap.add_argument("--no-coded", action="store_true", help="skip extra.coded and the coded scoring sweep (profiles of the float32 kernels alone: every launch of a kernel then does the same work)")
     ap.add_argument("--cpu-snps", type=int, default=200_000, help="SNP sample for the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum CPU-baseline EM timing window")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)     # one rank, started by the launcher below
@@ -314,7 +315,7 @@ def main():
         os.environ.pop("WGSASSIGN_CODES")
     else:
         os.environ["WGSASSIGN_CODES"] = user_codes
-    codes_on = args.mode == "exact" and os.environ.get("WGSASSIGN_CODES", "1") != "0"
+    codes_on = args.mode == "exact" and os.environ.get("WGSASSIGN_CODES", "1") != "0" and not args.no_coded
     codes = {"available": False}
     if codes_on and not use_dist:
         extra["coded"], codes = coded_em_leg(ctx, device, beagle, em, K, per, n, m, mode, args)

@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include "wgsassign_hip.h"
+#include "wgsassign_hip_debug.h"
 
 static char g_err[1024];
 void wgs_set_error(const char *fmt, ...)

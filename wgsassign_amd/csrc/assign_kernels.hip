@@ -443,7 +443,7 @@ constexpr int CODED_LOG_REP = 4;   // LDS copies of the log table here (phase 1 
 //     (-> 14.2 ms); TV = float where the float rows need no padding to 16 bytes (KB = 4, 8; 7 pads one): half the LDS
 //     traffic wins there.  WGS_SCORE_CODED_TABLE=float|double forces one (experiments).
 struct CodedPrep {
-    int rowoff[20];                // [j] = rows before SNP j of the batch, [batch size] = rows of the batch, [17] = an uncoded SNP in the batch
+    int rowoff[20];                // [j] = rows before SNP j of the batch, [batch size] = rows of the batch, [17] = bit j: SNP j of the batch is uncoded
     float aval[CODED_BATCH_MAX][10];   // allele frequencies [SNP of the batch][population of this pass]
 };
 
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
                     if (j == CODED_BATCH - 1) P.rowoff[CODED_BATCH] = incl;
                 }
                 const unsigned long long uncoded = __ballot(tid < CODED_BATCH && s0 + j < s_end && n == 0);
-                if (tid == 0) P.rowoff[17] = uncoded != 0;     // the batch holds a SNP the encoder left uncoded
+                if (tid == 0) P.rowoff[17] = (int)(uncoded & 0xFFFFu);     // bit j: SNP j of the batch was left uncoded by the encoder
             } else if (tid - 64 < CODED_BATCH * KB) {
                 const int e = tid - 64, j = e / KB, k = e - j * KB;
                 const int kk = kb + k < A.K ? kb + k : A.K - 1;
@@ -571,9 +571,10 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
             __syncthreads();
             // phase 2: look up and add
             const unsigned *cwv = reinterpret_cast<const unsigned *>(cw);
+            const unsigned uncoded_snps = (unsigned)__builtin_amdgcn_readfirstlane(P.rowoff[17]);
 #pragma unroll
             for (int j = 0; j < CODED_BATCH; ++j) {
-                if (j < nj && P.rowoff[j + 1] != P.rowoff[j]) {
+                if (j < nj && !((uncoded_snps >> j) & 1u)) {
                     const unsigned w = cwv[j];
                     const TV *rows_j = vtab + P.rowoff[j] * KBP;
 #pragma unroll
@@ -603,8 +604,8 @@ __global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
             // SNPs the encoder left uncoded (more classes than its tables hold; ncls = 0): their terms straight from the float32
             // slab with the direct sweep's arithmetic -- the same float32 per-site values, added to the same float64 sums
 #pragma unroll 1
-            for (int j = 0; j < (P.rowoff[17] ? nj : 0); ++j) {
-                if (P.rowoff[j + 1] == P.rowoff[j]) {
+            for (int j = 0; j < (uncoded_snps ? nj : 0); ++j) {
+                if ((uncoded_snps >> j) & 1u) {
                     if (have) {
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) {

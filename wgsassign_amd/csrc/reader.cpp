@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../include/wgsassign_hip.h"
+#include "../../include/wgsassign_hip_debug.h"
 #include "reader_text.h"
 
 void wgs_set_error(const char *fmt, ...);
