@@ -176,7 +176,7 @@ def main():
 
     use_dist = world > 1 or os.environ.get("WGS_FORCE_DIST") == "1"   # WGS_FORCE_DIST: rehearse the collective path on 1 GPU
     kind = os.environ.get("WGSASSIGN_COMM", "torch" if os.environ.get("WGSASSIGN_BACKEND") == "gloo" else "rccl")
-    device_index = int(os.environ.get("WGSASSIGN_DEVICE", local_rank))
+    device_index = int(os.environ.get("WGSASSIGN_DEVICE", local_rank))     # (narrowed below to the devices this process can see)
     dist = torch = None
     # a rank that cannot build its communicator in time leaves with status 75: the launcher retries over TCP
     watchdog = threading.Timer(INIT_WATCHDOG_S, lambda: os._exit(COMM_INIT_FAILED))
@@ -198,6 +198,8 @@ def main():
     from wgsassign_amd import comm as wcomm
     from wgsassign_amd import device
     from wgsassign_amd._lib import MODE_EXACT, MODE_FAST
+    if not (use_dist and kind == "torch"):
+        device_index = device.default_device_index()       # LOCAL_RANK modulo the visible devices (WGSASSIGN_DEVICE wins)
     mode = MODE_EXACT if args.mode == "exact" else MODE_FAST
     ctx = device.Context(device_index)
     comm_note = None

@@ -129,3 +129,68 @@ def test_native_communicator_handle_in_the_c_loops(wg, golden):
     afs.close()
     b.close()
     c.close()
+
+
+@pytest.mark.parametrize("guard", [0.0, 1e9, "band"])
+@pytest.mark.parametrize("max_iter", [200, 7, 8, 1, 2])
+def test_two_iterations_per_sweep_equal_one(wg, oracle, monkeypatch, guard, max_iter):
+    """The coded sweep runs two EM iterations per pass over the codes (csrc/em_kernels.hip: fused iterations; the update of a SNP
+    needs only that SNP's frequency, the convergence test only the sums).  Against one iteration per sweep
+    (WGSASSIGN_EM_FUSE=1), the Python step-by-step protocol and the oracle: the same iteration counts and bits -- when fits stop
+    at the first or the second iteration of a sweep (populations of different size converge at different counts), with every
+    decision parked for the exact chain (guard = 1e9: both iterations of every sweep go through park / resolve), with a band
+    wide enough to park only the last iterations, with an iteration limit that is odd, even, 1 and 2 (exhaustion: iters = 0)."""
+    dev = wg.device
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")
+    m, K = 40_000, 6
+    labels = np.repeat(np.arange(K), [9, 31, 40, 57, 23, 64])
+    L, IDs = synth.make_beagle_for_labels(m, labels, K, seed=33)
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    b = dev.DeviceBeagle.from_host(L, group_of, K)
+    assert b.codes_info()["available"]
+    monkeypatch.setattr(dev.EMBatch, "GUARD", 0.5 if guard == "band" else guard)
+    res = {}
+    for label, env in (("fused", {"WGSASSIGN_EM_FUSE": "2"}), ("single", {"WGSASSIGN_EM_FUSE": "1"}), ("python", {"WGSASSIGN_EM_LOOP": "python"})):
+        for k in ("WGSASSIGN_EM_FUSE", "WGSASSIGN_EM_LOOP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+        iters = em.run(max_iter, 1e-4)
+        res[label] = (iters.copy(), np.stack([em.get_f(j) for j in range(K)]), np.stack([em.get_f_range(j, 0, m, previous=True) for j in range(K)]),
+                      em.fit_stats()[0])
+        em.close()
+    for other in ("single", "python"):
+        assert np.array_equal(res["fused"][0], res[other][0]), (res["fused"][0], res[other][0])
+        assert same(res["fused"][1], res[other][1])
+    # the vector BEFORE the last update is the right one too (what the exact chain and a later wgs_em_rmse_chain read)
+    assert same(res["fused"][2], res["single"][2])
+    if max_iter >= 8 and guard == 0.0:
+        assert res["fused"][3] < res["single"][3]            # fewer sweeps were enqueued
+    if max_iter == 200:
+        assert len(set(res["fused"][0].tolist())) > 1 and res["fused"][0].min() > 0
+        with quiet_ctx():
+            _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+        assert list(res["fused"][0]) == [int(x) for x in it_o]
+        em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+        em.run(200, 1e-4)
+        counts = np.bincount(group_of, minlength=K)
+        cols = []
+        for k in range(K):
+            em.clamp(k, int(counts[k]))
+            cols.append(em.get_f(k))
+        em.close()
+        assert same(np.stack(cols, axis=1), af_o)
+    b.close()
+
+
+class quiet_ctx:
+    def __enter__(self):
+        import contextlib
+        import io
+        self.cm = contextlib.redirect_stdout(io.StringIO())
+        self.cm.__enter__()
+
+    def __exit__(self, *exc):
+        return self.cm.__exit__(*exc)

@@ -184,6 +184,11 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     float *f_new;
     double *ssq;       // = sum over SNPs of (f_new - f_old)^2 (written by the reduce kernel)
     double *ssq_part;  // per-tile partial sums of this fit [ntiles]
+    // fused iterations (em_coded_kernel): fuse = 2 runs a second update from f_new into f_new2, its sums in ssq2 / ssq_part2
+    float *f_new2;
+    double *ssq2;
+    double *ssq_part2;
+    int32_t fuse;
     int32_t npairs, ncols;
     int32_t skip;      // local column left out (LOO) or -1
     int32_t n_eff;     // ncols - (skip >= 0)
@@ -194,7 +199,8 @@ struct FitDesc {       // one EM fit as the sweep kernel sees it
     const uint8_t *tile_rows;
     int32_t nquads, lrows;
 };
-enum { EM_ACTIVE = 0, EM_CONVERGED = 1, EM_UNDECIDED = 2 };
+// (_A: of the two iterations of a fused sweep the FIRST converged / is undecided; the plain values then speak of the second)
+enum { EM_ACTIVE = 0, EM_CONVERGED = 1, EM_UNDECIDED = 2, EM_CONVERGED_A = 3, EM_UNDECIDED_A = 4 };
 // One exact convergence chain (emMAF_cy.pyx:30-31 over this shard): float32 running sum of (a-b)^2 from carry_in.
 struct ChainJob {
     const float *a, *b;
@@ -220,7 +226,7 @@ int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
 int ssq_reduce_chunks(void);
-int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2);
+int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2, int second = 0);
 // state[fit] of every listed fit that swept: ssq < lo -> EM_CONVERGED, ssq >= hi (or NaN) -> EM_ACTIVE, else EM_UNDECIDED
 int launch_em_decide(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, double lo, double hi);
 int launch_rcp_error(wgs_ctx *ctx, int exponent, unsigned long long *d_max_bits);

@@ -23,8 +23,11 @@ void wgs_em_destroy(wgs_em *em)
 {
     if (!em) return;
     (void)hipSetDevice(em->b->ctx->device);
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 3; ++i)
         if (em->fbuf[i]) (void)hipFree(em->fbuf[i]);
+    if (em->d_part_b) (void)hipFree(em->d_part_b);
+    for (int i = 0; i < 2; ++i)
+        if (em->h_ssq[i]) (void)hipHostFree(em->h_ssq[i]);
     if (em->d_descs) (void)hipFree(em->d_descs);
     if (em->h_descs) (void)hipHostFree(em->h_descs);
     if (em->d_groups) (void)hipFree(em->d_groups);
@@ -70,6 +73,10 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     em->skip_local.resize(n_fits);
     em->n_eff.resize(n_fits);
     em->cur.assign(n_fits, 0);
+    em->prev.assign(n_fits, 1);
+    em->fuse_used.assign(n_fits, 1);
+    em->pend_cur.assign(n_fits, 0);
+    em->pend_prev.assign(n_fits, 1);
     em->active.assign(n_fits, 1);
     for (int j = 0; j < n_fits; ++j) {
         const int g = fit_group[j];
@@ -156,7 +163,8 @@ static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, in
  * em_fits_per_group() per wavefront (group table Hg -> Dg), which share the tile's loads and conversions.
  * ssq_base[j] receives fit j's sum; state_base (device, may be NULL) holds the fit states a sweep honours. */
 static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDesc *H, FitDesc *D, int32_t *Hg, int32_t *Dg,
-                            double *ssq_base, int32_t *state_base, hipEvent_t ev0, hipEvent_t ev1, int sweeps_ahead)
+                            double *ssq_base, int32_t *state_base, hipEvent_t ev0, hipEvent_t ev1, int sweeps_ahead,
+                            const std::vector<int32_t> *may_fuse = nullptr, double *ssq_base_b = nullptr)
 {
     wgs_ctx *ctx = em->b->ctx;
     const int64_t ntiles = wgs_ntiles(em->b->m);
@@ -185,6 +193,23 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     wgs_codes *codes = worth ? wgs_beagle_codes(em->b, build) : nullptr;
     if (codes && codes->lrows == 0) codes = nullptr;
     if (worth && !codes) ++em->b->direct_sweeps;          // (a sweep the codes could have served)
+    // two iterations per sweep (em_kernels.hip: fused iterations): the coded sweep only, for the fits the caller allows (iterations
+    // left, a place for the second sums); needs a third frequency buffer and a second set of partial sums, allocated on first use
+    const bool fuse_on = !(getenv("WGSASSIGN_EM_FUSE") && atoi(getenv("WGSASSIGN_EM_FUSE")) < 2);   // (read at every sweep: tests compare both)
+    bool fusing = false;
+    if (codes && may_fuse && ssq_base_b && fuse_on) {
+        for (int j : order) fusing = fusing || (*may_fuse)[j] >= 2;
+        if (fusing && !em->fbuf[2]) {
+            const size_t fbytes = (size_t)em->n_fits * em->b->m * sizeof(float);
+            if (hipMalloc(&em->fbuf[2], fbytes) != hipSuccess || hipMalloc(&em->d_part_b, sizeof(double) * (size_t)em->n_fits * ntiles) != hipSuccess) {
+                (void)hipGetLastError();
+                if (em->fbuf[2]) (void)hipFree(em->fbuf[2]);
+                em->fbuf[2] = nullptr;
+                fusing = false;                            // no memory for it: one iteration per sweep
+            }
+        }
+    }
+    const int nb = em->fbuf[2] ? 3 : 2;
     int coded_rows_max = 0;
     for (size_t i = 0; i < order.size(); ++i) {
         const int j = order[i];
@@ -197,10 +222,19 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
         d.nquads = codes ? codes->slabs[em->group[j]].nquads : 0;
         coded_rows_max = std::max(coded_rows_max, (int)d.lrows);
         d.slab = s.base;
-        d.f_old = em_f(em, j, em->cur[j]);
-        d.f_new = em_f(em, j, em->cur[j] ^ 1);
+        const int c = em->cur[j], n1 = (c + 1) % nb, n2 = (c + 2) % nb;
+        const int fuse = fusing && (*may_fuse)[j] >= 2 ? 2 : 1;
+        d.f_old = em_f(em, j, c);
+        d.f_new = em_f(em, j, n1);
+        d.f_new2 = fuse == 2 ? em_f(em, j, n2) : d.f_new;
+        d.fuse = fuse;
         d.ssq = ssq_base + j;
+        d.ssq2 = ssq_base_b ? ssq_base_b + j : d.ssq;
         d.ssq_part = em->d_part + (size_t)j * ntiles;
+        d.ssq_part2 = fuse == 2 ? em->d_part_b + (size_t)j * ntiles : d.ssq_part;
+        em->fuse_used[j] = (uint8_t)fuse;
+        em->pend_cur[j] = (uint8_t)(fuse == 2 ? n2 : n1);
+        em->pend_prev[j] = (uint8_t)(fuse == 2 ? n1 : c);
         d.npairs = s.npairs;
         d.ncols = s.ncols;
         d.skip = em->skip_local[j];
@@ -247,6 +281,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     for (size_t off = 0; off < order.size(); off += 65535) {
         const int cnt = (int)std::min<size_t>(65535, order.size() - off);
         if (launch_ssq_reduce(ctx, D + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks())) return 1;
+        if (fusing && launch_ssq_reduce(ctx, D + off, cnt, em->b->m, em->d_part2 + off * ssq_reduce_chunks(), 1)) return 1;
     }
     return 0;
 }
@@ -264,7 +299,10 @@ int wgs_em_step_dev(wgs_em *em, double *ssq_dev)
     // h_descs / h_groups (pinned) stay untouched until the next step, which the caller only starts after
     // consuming this step's sums
     if (em_enqueue_sweep(em, em->last, em->h_descs, em->d_descs, em->h_groups, em->d_groups, ssq_dev, nullptr, em->ev0, em->ev1, 0)) return 1;
-    for (int j : em->last) em->cur[j] ^= 1;   // the new frequencies are now current; 1-cur holds f_prev
+    for (int j : em->last) {                  // the new frequencies are now current; prev holds the ones before
+        em->cur[j] = em->pend_cur[j];
+        em->prev[j] = em->pend_prev[j];
+    }
     return 0;
 }
 
@@ -286,7 +324,7 @@ int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out)
     WGS_REQUIRE(fit >= 0 && fit < em->n_fits, "fit index out of range");
     wgs_ctx *ctx = em->b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (launch_rmse_chain(ctx, em_f(em, fit, em->cur[fit]), em_f(em, fit, em->cur[fit] ^ 1), em->b->m, carry_in, em->d_carry,
+    if (launch_rmse_chain(ctx, em_f(em, fit, em->cur[fit]), em_f(em, fit, em->prev[fit]), em->b->m, carry_in, em->d_carry,
                           em->d_chain_work, reinterpret_cast<int *>(em->d_carry + 1)))
         return 1;
     float host[2];
@@ -314,8 +352,8 @@ static int em_fit_alloc(wgs_em *em)
     if (em->d_state) return 0;
     const size_t n = (size_t)em->n_fits;
     HIP_TRY(hipMalloc(&em->d_state, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&em->d_ssq2, sizeof(double) * n));
-    HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * n));
+    HIP_TRY(hipMalloc(&em->d_ssq2, sizeof(double) * 2 * n));
+    HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * 2 * n));
     HIP_TRY(hipMalloc(&em->d_jobs, sizeof(ChainJob) * n));
     HIP_TRY(hipMalloc(&em->d_chain_out, sizeof(float) * 2 * n));
     // workspace of the exact chains for all fits at once (60 bytes per fit and block of 4096 SNPs): no allocation
@@ -331,6 +369,7 @@ static int em_fit_alloc(wgs_em *em)
         HIP_TRY(hipMalloc(&em->d_groups2[i], sizeof(int32_t) * 2 * n));
         HIP_TRY(hipHostMalloc(&em->h_groups2[i], sizeof(int32_t) * 2 * n, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&em->h_ssq[i], sizeof(double) * 2 * n, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&em->ev_it[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreate(&em->ev_sw0[i]));
         HIP_TRY(hipEventCreate(&em->ev_sw1[i]));
@@ -352,7 +391,7 @@ static int em_resolve_chains(wgs_em *em, const std::vector<int32_t> &fits, doubl
     // running values it received and broadcasts the result (`world` broadcasts of nj float32, one readback at the end).
     for (int i = 0; i < nj; ++i) {
         const int j = fits[i];
-        em->h_jobs[i] = ChainJob{em_f(em, j, em->cur[j]), em_f(em, j, em->cur[j] ^ 1), 0.0f};
+        em->h_jobs[i] = ChainJob{em_f(em, j, em->cur[j]), em_f(em, j, em->prev[j]), 0.0f};
     }
     HIP_TRY(hipMemcpyAsync(em->d_jobs, em->h_jobs, sizeof(ChainJob) * nj, hipMemcpyHostToDevice, ctx->stream));
     for (int r = 0; r < world; ++r) {
@@ -392,7 +431,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         hi = thresh * (1.0 + g);
     }
     std::vector<char> fin(n, 0), skipped(n, 0);
-    std::vector<int32_t> sweeps(n, 0), init(n), ran, parked, lists[2];
+    std::vector<int32_t> sweeps(n, 0), init(n), may_fuse(n, 1), ran, parked, parked_a, lists[2];
     for (int j = 0; j < n; ++j) {
         iters_out[j] = 0;
         fin[j] = !em->active[j];
@@ -403,6 +442,19 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     em->fit_iterations = em->fit_chain_batches = 0;
     em->fit_sweep_ms = 0.0;
     const auto t_begin = std::chrono::steady_clock::now();
+    // the reference's `diff < tole` from a float64 sum, as em_decide_kernel classifies it
+    auto classify = [&](double v) { return (v != v || v >= hi) ? EM_ACTIVE : (v < lo ? EM_CONVERGED : EM_UNDECIDED); };
+    // the fit ends with the frequencies in `cur`, `it` iterations after its start
+    auto finish = [&](int j, int it) {
+        fin[j] = 1;
+        iters_out[j] = it;
+    };
+    // stream-ordered behind the iteration in flight (whose sweep must see the fit parked throughout)
+    auto set_state = [&](int j, int32_t st) -> int {
+        em->h_setstate[j] = st;
+        HIP_TRY(hipMemcpyAsync(em->d_state + j, em->h_setstate + j, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+        return 0;
+    };
     bool launched_prev = false;
     for (int t = 1;; ++t) {
         const int slot = t & 1;
@@ -411,25 +463,29 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         ran.clear();
         for (int j : lists[slot ^ 1]) {
             if (skipped[j]) continue;
-            ++sweeps[j];
-            em->cur[j] ^= 1;                                 // the new frequencies are current; 1-cur holds f_prev
+            sweeps[j] += em->fuse_used[j];                   // one EM iteration, or the two of a fused sweep
+            em->cur[j] = em->pend_cur[j];                    // the new frequencies are current; prev holds the ones before
+            em->prev[j] = em->pend_prev[j];
             ran.push_back(j);
         }
         std::fill(skipped.begin(), skipped.end(), 0);
         // ---- enqueue iteration t (fits that turn out to have converged at t-1 return at once)
         std::vector<int32_t> &L = lists[slot];
         L.clear();
-        for (int j = 0; j < n; ++j)
+        for (int j = 0; j < n; ++j) {
             if (!fin[j] && sweeps[j] < max_iter) L.push_back(j);
+            may_fuse[j] = max_iter - sweeps[j] >= 2 ? 2 : 1;
+        }
         if (!L.empty()) {
             if (em_enqueue_sweep(em, L, em->h_descs2[slot], em->d_descs2[slot], em->h_groups2[slot], em->d_groups2[slot], em->d_ssq2,
-                                 em->d_state, em->ev_sw0[slot], em->ev_sw1[slot], max_iter - t + 1))
+                                 em->d_state, em->ev_sw0[slot], em->ev_sw1[slot], max_iter - t + 1, &may_fuse, em->d_ssq2 + n))
                 return 1;
             // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
             // in the same way on every rank (all ranks take the same decisions).
-            if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, n)) return 1;
+            if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, 2 * n)) return 1;
             if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
             HIP_TRY(hipMemcpyAsync(em->h_state[slot], em->d_state, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(em->h_ssq[slot], em->d_ssq2, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(em->ev_it[slot], ctx->stream));
             ++em->fit_iterations;
         }
@@ -440,17 +496,66 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
             float sweep_ms = 0.0f;
             if (hipEventElapsedTime(&sweep_ms, em->ev_sw0[ps], em->ev_sw1[ps]) == hipSuccess) em->fit_sweep_ms += sweep_ms;
             parked.clear();
+            parked_a.clear();
             for (int j : ran) {
                 const int st = em->h_state[ps][j];
                 if (st == EM_CONVERGED) {
-                    fin[j] = 1;
                     skipped[j] = 1;                          // its sweep t (if enqueued) returned at once
-                    iters_out[j] = sweeps[j];
+                    finish(j, sweeps[j]);
+                } else if (st == EM_CONVERGED_A) {
+                    // the FIRST of the sweep's two iterations converged: its frequencies are the result, the second is dropped
+                    skipped[j] = 1;
+                    const int third = 3 - em->cur[j] - em->prev[j];
+                    em->cur[j] = em->prev[j];
+                    em->prev[j] = (uint8_t)third;
+                    sweeps[j] -= 1;
+                    finish(j, sweeps[j]);
                 } else if (st == EM_UNDECIDED) {
                     parked.push_back(j);
                     skipped[j] = 1;
+                } else if (st == EM_UNDECIDED_A) {
+                    parked_a.push_back(j);
+                    skipped[j] = 1;
                 } else if (sweeps[j] >= max_iter) {
                     fin[j] = 1;                              // exhausted: the reference prints nothing, iters stays 0
+                }
+            }
+            // parked after the first of two iterations: the exact chain speaks about (f_a, f_in) -- looked at through cur / prev
+            // for the call; when it says "not converged" the second iteration counts and its sum is classified here as the
+            // device would have (the same thresholds on the same all-reduced float64), possibly parking the fit again
+            if (!parked_a.empty()) {
+                std::vector<uint8_t> fb(parked_a.size()), fa(parked_a.size());
+                for (size_t i = 0; i < parked_a.size(); ++i) {
+                    const int j = parked_a[i];
+                    fb[i] = em->cur[j];
+                    fa[i] = em->prev[j];
+                    em->cur[j] = fa[i];
+                    em->prev[j] = (uint8_t)(3 - fa[i] - fb[i]);
+                }
+                std::vector<char> conv;
+                if (em_resolve_chains(em, parked_a, tole, m_total, comm, conv)) return 1;
+                for (size_t i = 0; i < parked_a.size(); ++i) {
+                    const int j = parked_a[i];
+                    if (conv[i]) {
+                        sweeps[j] -= 1;
+                        finish(j, sweeps[j]);
+                        if (set_state(j, EM_CONVERGED)) return 1;
+                        continue;
+                    }
+                    em->cur[j] = fb[i];                      // the first iteration goes on: the second one's result stands
+                    em->prev[j] = fa[i];
+                    const int cls = classify(em->h_ssq[ps][n + j]);
+                    if (cls == EM_CONVERGED) {
+                        finish(j, sweeps[j]);
+                        if (set_state(j, EM_CONVERGED)) return 1;
+                    } else if (cls == EM_UNDECIDED) {
+                        parked.push_back(j);
+                    } else if (sweeps[j] >= max_iter) {
+                        fin[j] = 1;
+                        if (set_state(j, EM_CONVERGED)) return 1;
+                    } else if (set_state(j, EM_ACTIVE)) {
+                        return 1;
+                    }
                 }
             }
             if (!parked.empty()) {
@@ -458,15 +563,9 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
                 if (em_resolve_chains(em, parked, tole, m_total, comm, conv)) return 1;
                 for (size_t i = 0; i < parked.size(); ++i) {
                     const int j = parked[i];
-                    if (conv[i]) {
-                        fin[j] = 1;
-                        iters_out[j] = sweeps[j];
-                    } else if (sweeps[j] >= max_iter) {
-                        fin[j] = 1;
-                    }
-                    // stream-ordered behind iteration t (whose sweep must see the fit parked throughout)
-                    em->h_setstate[j] = conv[i] ? EM_CONVERGED : EM_ACTIVE;
-                    HIP_TRY(hipMemcpyAsync(em->d_state + j, em->h_setstate + j, sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+                    if (conv[i]) finish(j, sweeps[j]);
+                    else if (sweeps[j] >= max_iter) fin[j] = 1;
+                    if (set_state(j, conv[i] ? EM_CONVERGED : EM_ACTIVE)) return 1;
                 }
             }
         }
@@ -540,7 +639,7 @@ int wgs_em_get_f_range(wgs_em *em, int32_t fit, int previous, int64_t row0, int6
                 (long long)(row0 + nrows), (long long)em->b->m);
     if (nrows == 0) return 0;
     HIP_TRY(hipSetDevice(em->b->ctx->device));
-    const float *src = em_f(em, fit, previous ? em->cur[fit] ^ 1 : em->cur[fit]) + row0;
+    const float *src = em_f(em, fit, previous ? em->prev[fit] : em->cur[fit]) + row0;
     HIP_TRY(hipMemcpyAsync(f_host, src, sizeof(float) * nrows, hipMemcpyDeviceToHost, em->b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(em->b->ctx->stream));
     return 0;

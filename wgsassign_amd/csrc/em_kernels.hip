@@ -353,6 +353,12 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDes
 // padded LDS: 24.3 / 13.2 / 9.4 / 7.5 ms at 2 / 4 / 6 / 8 wavefronts per CU for the 10M x 1000 x K=10 sweep).  The rows
 // (wgs_codes::lrows) are chosen per matrix so that ~1 % of the tiles at most have a richer SNP; those take the direct path.
 
+// FUSED ITERATIONS (round 4).  The EM update of a SNP depends on that SNP's frequency and data only (emMAF_cy.pyx:16-23); what
+// couples the SNPs is the convergence test between iterations, and that needs only the sums.  So a sweep may run iteration t + 2
+// right behind t + 1 while the tile's dictionary rows are still in registers: fd.fuse = 2 writes both frequency vectors (f_new,
+// f_new2) and both per-tile partial sums (ssq_part, ssq_part2); the decision kernel looks at the first sum, then at the second
+// (em_decide_kernel), and the host takes the vector that belongs to the iteration that stopped (wgs_em_fit).  The dictionary --
+// two thirds of the sweep's traffic -- is read once per two iterations; the arithmetic of each iteration is unchanged.
 template <int U, int ILP, int ROWS>
 __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m)
 {
@@ -369,19 +375,28 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
 
     const int64_t my_row = row0 + lane;
     const int64_t my_row_c = my_row < m ? my_row : m - 1;
-    const float f_old = ((gf32_ptr)fd.f_old)[my_row_c];
-    SnpState st;
-    st.fd = (double)f_old;
-    st.omf = 1.0 - st.fd;
-    st.fd2 = 2.0 * st.fd;
+    float f_old = ((gf32_ptr)fd.f_old)[my_row_c];
+    const int n_iter = fd.fuse == 2 ? 2 : 1;
+
+    // one iteration's result: the new frequencies and this tile's share of sum (f_new - f_old)^2
+    auto finish = [&](float tmp, int it) -> float {
+        const float f_new = tmp / (float)fd.n_eff;           // emMAF_cy.pyx:23 (float32 divide)
+        double sq = 0.0;
+        if (my_row < m) {
+            ((gf32_wptr)(it ? fd.f_new2 : fd.f_new))[my_row] = f_new;
+            const float d = f_new - f_old;                    // emMAF_cy.pyx:31, float32
+            sq = (double)(d * d);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if (lane == 0) (it ? fd.ssq_part2 : fd.ssq_part)[tile] = sq;
+        return f_new;
+    };
 
     // the first code words: in flight during phase 1
     const int nquads = fd.nquads;
     const uint32_t *src = fd.lcodes + tile * nquads * 64 + lane;
     const int last = nquads - 1;
-    uint32_t cur[U], nxt[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
     // rows of this tile: the most classes one of its 64 SNPs has in this slab (255: a SNP the encoder gave up on)
     int nrows;
     {
@@ -399,102 +414,103 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
         // the tile is swept from the float32 slab, term by term as em_sweep_kernel does
         const int npairs = fd.npairs;
         gf4_ptr gl = (gf4_ptr)fd.slab + tile * npairs * 64 + lane;
-        float tmp = 0.0f;
-        bool ok = true;
-        for (int p = 0; p < npairs; ++p) {
-            const f4 v = gl[(int64_t)p * 64];
-            if (2 * p < fd.ncols && 2 * p != fd.skip) term_exact<true>(v.x, v.y, st, tmp, ok);
-            if (2 * p + 1 < fd.ncols && 2 * p + 1 != fd.skip) term_exact<true>(v.z, v.w, st, tmp, ok);
+        for (int it = 0; it < n_iter; ++it) {
+            SnpState st;
+            st.fd = (double)f_old;
+            st.omf = 1.0 - st.fd;
+            st.fd2 = 2.0 * st.fd;
+            float tmp = 0.0f;
+            bool ok = true;
+            for (int p = 0; p < npairs; ++p) {
+                const f4 v = gl[(int64_t)p * 64];
+                if (2 * p < fd.ncols && 2 * p != fd.skip) term_exact<true>(v.x, v.y, st, tmp, ok);
+                if (2 * p + 1 < fd.ncols && 2 * p + 1 != fd.skip) term_exact<true>(v.z, v.w, st, tmp, ok);
+            }
+            f_old = finish(tmp, it);
         }
-        const float f_new = tmp / (float)fd.n_eff;
-        double sq = 0.0;
-        if (my_row < m) {
-            ((gf32_wptr)fd.f_new)[my_row] = f_new;
-            const float d = f_new - f_old;
-            sq = (double)(d * d);
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-        if (lane == 0) fd.ssq_part[tile] = sq;
         return;
     }
+    // the tile's rows of the slab's dictionary: requested once, kept in registers for every iteration of this sweep
+    double r[ROWS];
     {
         const double *drow = reinterpret_cast<const double *>(fd.ldict) + tile * fd.lrows * 64 + lane;
-        double r[ROWS];
 #pragma unroll
-        for (int g8 = 0; g8 < ROWS / 8; ++g8) {
-            if (8 * g8 < nrows) {                            // wave-uniform
+        for (int g4 = 0; g4 < ROWS / 4; ++g4) {              // (four rows at a time: a tile's richest SNP has ~19 classes in its slab,
+            if (4 * g4 < nrows) {                            //  so eight at a time read a fifth more dictionary than needed; wave-uniform)
 #pragma unroll
-                for (int u = 0; u < 8; ++u) r[8 * g8 + u] = drow[(int64_t)(8 * g8 + u) * 64];
-            }
-        }
-        auto quotient = [&](double raw) {
-            const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
-                        g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
-            const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
-            const float p0 = (float)((g0d * st.omf) * st.omf);
-            const float p1 = (float)((g1d * st.fd2) * st.omf);
-            const float p2 = (float)((g2d * st.fd) * st.fd);
-            const float ssum = (p0 + p1) + p2;
-            const double num = __builtin_fma(2.0, (double)p2, (double)p1);
-            return div_exact<true>(num, (double)ssum);
-        };
-        // (lanes whose SNP has fewer classes compute on the zero rows the encoder wrote there: never looked up)
-#pragma unroll
-        for (int r0 = 0; r0 < ROWS; r0 += ILP) {
-            if (r0 < nrows) {                                // wave-uniform
-                double qv[ILP];
-#pragma unroll
-                for (int x = 0; x < ILP; ++x) qv[x] = quotient(r[r0 + x]);
-#pragma unroll
-                for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
+                for (int u = 0; u < 4; ++u) r[4 * g4 + u] = drow[(int64_t)(4 * g4 + u) * 64];
             }
         }
     }
-    // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
-    // table before the chain of that buffer starts
-    float tmp = 0.0f;
-    for (int q0 = 0; q0 < nquads; q0 += U) {
-        if (q0 + U < nquads) {
+    for (int it = 0; it < n_iter; ++it) {
+        SnpState st;
+        st.fd = (double)f_old;
+        st.omf = 1.0 - st.fd;
+        st.fd2 = 2.0 * st.fd;
+        uint32_t cur[U], nxt[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int qq = q0 + U + u;
-                nxt[u] = src[(qq < last ? qq : last) * 64];
-            }
-        }
-        double qv[U][4];
+        for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];     // (the second iteration finds them in cache)
+        {
+            auto quotient = [&](double raw) {
+                const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
+                            g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
+                const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
+                const float p0 = (float)((g0d * st.omf) * st.omf);
+                const float p1 = (float)((g1d * st.fd2) * st.omf);
+                const float p2 = (float)((g2d * st.fd) * st.fd);
+                const float ssum = (p0 + p1) + p2;
+                const double num = __builtin_fma(2.0, (double)p2, (double)p1);
+                return div_exact<true>(num, (double)ssum);
+            };
+            // (lanes whose SNP has fewer classes compute on whatever the unwritten rows hold: never looked up)
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int r0 = 0; r0 < ROWS; r0 += ILP) {
+                if (r0 < nrows) {                                // wave-uniform
+                    double qv[ILP];
 #pragma unroll
-            for (int h = 0; h < 4; ++h) qv[u][h] = q[((cur[u] >> (8 * h)) & 255u) * 64];
-        const bool plain = 4 * (q0 + U) <= fd.ncols && (fd.skip < 4 * q0 || fd.skip >= 4 * (q0 + U));
-        if (plain) {
+                    for (int x = 0; x < ILP; ++x) qv[x] = quotient(r[r0 + x]);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int h = 0; h < 4; ++h) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    const int col = 4 * (q0 + u) + h;
-                    if (col < fd.ncols && col != fd.skip) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
+                    for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
                 }
+            }
         }
+        // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
+        // table before the chain of that buffer starts
+        float tmp = 0.0f;
+        for (int q0 = 0; q0 < nquads; q0 += U) {
+            if (q0 + U < nquads) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-    }
-    const float f_new = tmp / (float)fd.n_eff;           // emMAF_cy.pyx:23 (float32 divide)
-    double sq = 0.0;
-    if (my_row < m) {
-        ((gf32_wptr)fd.f_new)[my_row] = f_new;
-        const float d = f_new - f_old;                    // emMAF_cy.pyx:31, float32
-        sq = (double)(d * d);
-    }
+                for (int u = 0; u < U; ++u) {
+                    const int qq = q0 + U + u;
+                    nxt[u] = src[(qq < last ? qq : last) * 64];
+                }
+            }
+            double qv[U][4];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
-    if (lane == 0) fd.ssq_part[tile] = sq;
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) qv[u][h] = q[((cur[u] >> (8 * h)) & 255u) * 64];
+            const bool plain = 4 * (q0 + U) <= fd.ncols && (fd.skip < 4 * q0 || fd.skip >= 4 * (q0 + U));
+            if (plain) {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
+            } else {
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const int col = 4 * (q0 + u) + h;
+                        if (col < fd.ncols && col != fd.skip) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
+                    }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+        f_old = finish(tmp, it);
+        // (the table of the next iteration is written by the same lanes that read this one's: program order suffices)
+    }
 }
 
 // ssq[fit] = sum over tiles of the per-tile partials, in a fixed summation order (reproducible):
@@ -502,7 +518,7 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
 // part2[fit][chunk]; stage 2, one wavefront per fit adds the RED_CHUNKS slice sums.
 constexpr int RED_CHUNKS = 64;
 
-__global__ __launch_bounds__(256) void ssq_reduce1_kernel(const FitDesc *__restrict__ fits, int64_t ntiles, double *__restrict__ part2)
+__global__ __launch_bounds__(256) void ssq_reduce1_kernel(const FitDesc *__restrict__ fits, int64_t ntiles, double *__restrict__ part2, int second)
 {
     __shared__ double red[256];
     const int fit = blockIdx.x / RED_CHUNKS, chunk = blockIdx.x % RED_CHUNKS;
@@ -512,7 +528,8 @@ __global__ __launch_bounds__(256) void ssq_reduce1_kernel(const FitDesc *__restr
     int64_t t1 = t0 + per;
     if (t1 > ntiles) t1 = ntiles;
     double acc = 0.0;
-    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) acc += fd.ssq_part[t];
+    const double *part = second ? fd.ssq_part2 : fd.ssq_part;
+    for (int64_t t = t0 + threadIdx.x; t < t1; t += 256) acc += part[t];
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
@@ -522,12 +539,12 @@ __global__ __launch_bounds__(256) void ssq_reduce1_kernel(const FitDesc *__restr
     if (threadIdx.x == 0) part2[blockIdx.x] = red[0];
 }
 
-__global__ __launch_bounds__(64) void ssq_reduce2_kernel(const FitDesc *__restrict__ fits, const double *__restrict__ part2)
+__global__ __launch_bounds__(64) void ssq_reduce2_kernel(const FitDesc *__restrict__ fits, const double *__restrict__ part2, int second)
 {
     double v = part2[blockIdx.x * RED_CHUNKS + threadIdx.x];       // RED_CHUNKS == 64 lanes
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (threadIdx.x == 0) *fits[blockIdx.x].ssq = v;
+    if (threadIdx.x == 0) *(second ? fits[blockIdx.x].ssq2 : fits[blockIdx.x].ssq) = v;
 }
 
 // emMAF.py:22-23 on the device for the clear cases: the float64 sum S decides `diff < tole` unless it lies in
@@ -541,8 +558,16 @@ __global__ void em_decide_kernel(const FitDesc *__restrict__ fits, int n_fits, d
     const FitDesc fd = fits[j];
     int32_t *st = const_cast<int32_t *>(fd.state);
     if (!st || *st != EM_ACTIVE) return;
-    const double s = *fd.ssq;
-    *st = (s != s || s >= hi) ? EM_ACTIVE : (s < lo ? EM_CONVERGED : EM_UNDECIDED);
+    auto classify = [&](double s) { return (s != s || s >= hi) ? EM_ACTIVE : (s < lo ? EM_CONVERGED : EM_UNDECIDED); };
+    const int a = classify(*fd.ssq);
+    if (fd.fuse != 2) {
+        *st = a;
+        return;
+    }
+    // two iterations ran: the first decides first; only when it goes on does the second count
+    if (a == EM_CONVERGED) *st = EM_CONVERGED_A;
+    else if (a == EM_UNDECIDED) *st = EM_UNDECIDED_A;
+    else *st = classify(*fd.ssq2);
 }
 
 __global__ void fill_kernel(float *p, int64_t count, float v)
@@ -1092,11 +1117,11 @@ int launch_pairwise_mean(wgs_ctx *ctx, const float *d_rows, int count, int64_t m
     return 0;
 }
 
-int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2)
+int launch_ssq_reduce(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, double *part2, int second)
 {
     if (n_fits <= 0 || m <= 0) return 0;
-    hipLaunchKernelGGL(ssq_reduce1_kernel, dim3((unsigned)n_fits * RED_CHUNKS), dim3(256), 0, ctx->stream, d_descs, wgs_ntiles(m), part2);
-    hipLaunchKernelGGL(ssq_reduce2_kernel, dim3((unsigned)n_fits), dim3(64), 0, ctx->stream, d_descs, part2);
+    hipLaunchKernelGGL(ssq_reduce1_kernel, dim3((unsigned)n_fits * RED_CHUNKS), dim3(256), 0, ctx->stream, d_descs, wgs_ntiles(m), part2, second);
+    hipLaunchKernelGGL(ssq_reduce2_kernel, dim3((unsigned)n_fits), dim3(64), 0, ctx->stream, d_descs, part2, second);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -8,8 +8,11 @@ struct wgs_em {
     int32_t n_fits = 0;
     int mode = WGS_MODE_EXACT;
     std::vector<int32_t> group, skip_local, n_eff;
-    std::vector<uint8_t> cur, active;
-    float *fbuf[2] = {nullptr, nullptr};  // 2 x n_fits x m
+    std::vector<uint8_t> cur, prev, active;   // per fit: the buffer holding the current / the previous frequencies
+    float *fbuf[3] = {nullptr, nullptr, nullptr};  // n_fits x m each; the third only once a sweep runs two iterations at a time (em_api.hip)
+    // per fit, of the sweep last enqueued for it: iterations it runs (1 or 2) and where cur / prev point once it has run
+    std::vector<uint8_t> fuse_used, pend_cur, pend_prev;
+    double *d_part_b = nullptr;           // n_fits x ntiles partial sums of a fused sweep's second iteration
     FitDesc *d_descs = nullptr;
     FitDesc *h_descs = nullptr;           // pinned
     int32_t *d_groups = nullptr, *h_groups = nullptr;         // (first, count) pairs of the fit-group sweep, step path
@@ -26,7 +29,8 @@ struct wgs_em {
     int32_t *d_state = nullptr;           // [n_fits] EM_ACTIVE / EM_CONVERGED / EM_UNDECIDED
     FitDesc *d_descs2[2] = {nullptr, nullptr}, *h_descs2[2] = {nullptr, nullptr};
     int32_t *h_state[2] = {nullptr, nullptr}, *h_setstate = nullptr;
-    double *d_ssq2 = nullptr;             // [n_fits] sums of the iteration in flight
+    double *d_ssq2 = nullptr;             // [2 n_fits] sums of the iteration(s) in flight: first | second of a fused sweep
+    double *h_ssq[2] = {nullptr, nullptr};  // pinned read-backs of them, one per slot
     hipEvent_t ev_it[2] = {nullptr, nullptr};
     hipEvent_t ev_sw0[2] = {nullptr, nullptr}, ev_sw1[2] = {nullptr, nullptr};   // bracket the sweep kernel(s) of a slot
     double fit_sweep_ms = 0.0;            // summed sweep-kernel time of the last wgs_em_fit (HIP events)

@@ -60,13 +60,26 @@ def _as_f32c(a, name):
     return a
 
 
+def default_device_index():
+    """The GPU of this process: WGSASSIGN_DEVICE if set, else LOCAL_RANK -- taken modulo the devices this process can see, so that
+    a launcher that narrows every rank's view to one GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) and still sets
+    LOCAL_RANK = 0 .. N-1 lands every rank on its own device 0 instead of failing in hipSetDevice."""
+    if "WGSASSIGN_DEVICE" in os.environ:
+        return int(os.environ["WGSASSIGN_DEVICE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = ctypes.c_int(0)
+    if _lib.load().wgs_device_count(ctypes.byref(n)) == 0 and n.value > 0:
+        return local_rank % n.value
+    return local_rank
+
+
 class Context:
     """One HIP device + stream (wgs_ctx)."""
 
     def __init__(self, device=None):
         lib = _lib.load()
         if device is None:
-            device = int(os.environ.get("WGSASSIGN_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            device = default_device_index()
         h = ctypes.c_void_p()
         check(lib.wgs_ctx_create(int(device), ctypes.byref(h)))
         self._h = h
