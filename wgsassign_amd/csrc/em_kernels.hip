@@ -468,7 +468,13 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
                 if (r0 < nrows) {                                // wave-uniform
                     double qv[ILP];
 #pragma unroll
-                    for (int x = 0; x < ILP; ++x) qv[x] = quotient(r[r0 + x]);
+                    for (int x = 0; x < ILP; ++x) {
+                        // (opaque to the compiler: else it hoists the three float -> double forms of every row out of the iteration
+                        // loop -- six registers per row instead of two, 202 VGPRs and two wavefronts per SIMD instead of four)
+                        double raw = r[r0 + x];
+                        asm volatile("" : "+v"(raw));
+                        qv[x] = quotient(raw);
+                    }
 #pragma unroll
                     for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
                 }
