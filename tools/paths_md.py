@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Renders the whole-path section of a bench.py line (extra.coded, extra.paths) as a markdown table:
+   python tools/paths_md.py profiles/r04_bench_final.json > profiles/r04_whole_paths.md"""
+import json
+import sys
+
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+ex = d["extra"]
+rows = []
+
+
+def ms(x):
+    return "%.1f ms" % (x * 1e3) if x < 0.1 else "%.3f s" % x
+
+
+c = ex.get("coded")
+if c:
+    rows.append(("10M x 1000 x K=10 `--get_reference_af` (%d iterations)" % c["fit_cold"]["iterations"][0], ms(c["fit_cold"]["seconds"]),
+                 ms(c["fit_warm"]["seconds"]), ms(c["fit_direct"]["seconds"]), "built inside the fit: %s (%.1f ms)" % (c["fit_cold"]["codes_built_inside_the_fit"], c["fit_cold"].get("of_which_codes_build_ms", 0))))
+    if "pop_like_cold" in c:
+        a = ex["assign"]
+        rows.append(("... `--get_pop_like` alone", ms(c["pop_like_cold"]["seconds"]), "%.1f ms (kernel)" % a["coded"]["kernel_ms"], ms(a["seconds"]), "build %.1f ms" % c["pop_like_cold"]["of_which_codes_build_ms"]))
+for name, v in (ex.get("paths") or {}).items():
+    if not isinstance(v, dict):
+        continue
+    fit = v if "seconds_cold" in v else v.get("get_reference_af")
+    if fit:
+        cc = fit.get("class_codes") or {}
+        rows.append((name + " fit", ms(fit["seconds_cold"]), ms(fit["seconds_warm"]), ms(fit["seconds_float32"]),
+                     "codes built inside the cold fit: %s%s; iterations %s; identical %s" % (fit["codes_built_inside_the_cold_fit"], (" (%.1f ms)" % cc["build_ms"]) if cc.get("available") else "",
+                                                                                         fit["iterations"][0], fit["identical_frequencies"])))
+    pl = v.get("get_pop_like")
+    if pl:
+        cc = pl.get("class_codes_cold") or {}
+        rows.append(("... `--get_pop_like` alone", ms(pl["seconds_cold"]), "%.1f ms (kernel)" % pl["kernel_ms_warm"], ms(pl["seconds_float32"]),
+                     "cold build %s; after the fit %s; identical %s" % (("%.1f ms" % cc["build_ms"]) if cc.get("available") else "none", ms(pl["seconds_after_the_fit"]), pl["identical_sums"])))
+    for k in ("loo", "loo_partition_sites_3"):
+        if k in v:
+            rows.append(("... `--%s`" % k.replace("_partition_sites_3", " --partition_sites 3"), ms(v[k]["seconds"]), "", "", "EM phase %s (float32 slabs, %d re-fits)" % (ms(v[k]["em_seconds"]), v[k]["re_fits"])))
+print("# Whole paths on one MI355X (`bench.py`, %s)\n" % d["config"]["workload"])
+print("Headline: %.4g %s, %.2f ms per iteration over the float32 matrix, %.4f of the HBM peak (`%s`).\n" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel"]))
+print("cold = nothing built for the matrix before the call (the class codes, where the cost models want them, are built inside it); warm = codes present; float32 = `WGSASSIGN_CODES=0`.\n")
+print("| path | cold | warm | float32 slabs | notes |\n|---|---|---|---|---|")
+for r in rows:
+    print("| " + " | ".join(str(x) for x in r) + " |")
+rg = (ex.get("paths") or {}).get("realistic_gl_2Mx1000_K10")
+if rg:
+    print("\nQuality-dependent likelihoods (%s): classes per SNP mean / max %s, %s hash slots per SNP, %s SNPs per scoring table, uncoded SNPs %.4f %%, EM table rows %s." %
+          (rg["generator"], rg["classes_per_snp_mean_max"], rg["hash_slots_per_snp"], rg["snps_per_scoring_table"], 100 * (rg["uncoded_snp_share"] or 0), rg["em_table_rows"]))

@@ -31,7 +31,7 @@ out = ["# Device-resident BGZF ingest: kernel trace (`tools/prof_ingest.sh %d %d
        "| kernel | calls | total ms | avg ms | % |", "|---|---|---|---|---|"]
 tok_ms = None
 for r in rows:
-    name = r["Name"].split("(")[0].replace("void (anonymous namespace)::", "")
+    name = r["Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0]
     tot = float(r["TotalDurationNs"]) / 1e6
     if "tokenise_kernel" in name:
         tok_ms = tot

@@ -448,7 +448,7 @@ struct CodedPrep {
 };
 
 template <int KB, int MODE, typename TV, int CODED_BATCH>
-__global__ __launch_bounds__(256) void score_coded_kernel(CodedScoreArgs A)
+__global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
 {
     static_assert(CODED_BATCH == 16 || CODED_BATCH == 8 || CODED_BATCH == 4, "SNPs per table");
     constexpr int KBP = sizeof(TV) == 8 ? ((KB + 1) & ~1) : ((KB + 3) & ~3);      // table rows padded to 16 bytes
