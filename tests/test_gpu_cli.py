@@ -154,3 +154,30 @@ def test_random_cases_through_the_command_line(ranks, cases):
                        text=True, timeout=1200, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "%d cases, 0 mismatches" % cases in r.stdout
+
+
+def test_cli_on_quality_dependent_likelihoods(tmp_path, oracle, monkeypatch):
+    """A BGZF Beagle file whose likelihoods come from per-read base qualities (tests/synth.py: make_beagle_quality: ~45 classes per
+    SNP among 160 individuals -- 128-slot hash tables in the class encoder, 8 SNPs per table of the coded scoring sweep) through
+    the command line: `--get_reference_af` then `--get_pop_like` give the oracle pipeline's `.pop_af.npy` bytes and `%.7f` text."""
+    import sys
+    import synth
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_cli
+    monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path))
+    m, n, K = 2500, 160, 2
+    L, IDs = synth.make_beagle_quality(m, n, K, seed=11)
+    assert synth.classes_per_snp(L).mean() > 36
+    path, ids = str(tmp_path / "q.beagle.gz"), str(tmp_path / "ids.txt")
+    bench_cli.write_beagle(path, L, ids, IDs, "bgzf")
+    out = str(tmp_path / "q")
+    run_cli(["--beagle", path, "--pop_af_IDs", ids, "--get_reference_af", "--out", out, "--threads", "2"])
+    pops, af, _, _ = oracle.fit_reference_af(L, IDs, t=4)
+    assert np.load(out + ".pop_af.npy").tobytes() == af.tobytes()
+    run_cli(["--beagle", path, "--pop_af_file", out + ".pop_af.npy", "--get_pop_like", "--out", out, "--threads", "2"])
+    with np.errstate(all="ignore"):
+        ll = oracle.assignLL(L, af.copy(), 4)
+    want = io.StringIO()
+    np.savetxt(want, ll, fmt="%.7f")                          # WGSassign.py:306
+    assert open(out + ".pop_like.txt").read() == want.getvalue()
