@@ -15,7 +15,8 @@ def ms(x):
 
 c = ex.get("coded")
 if c:
-    rows.append(("10M x 1000 x K=10 `--get_reference_af` (%d iterations)" % c["fit_cold"]["iterations"][0], ms(c["fit_cold"]["seconds"]),
+    rows.append(("10M x 1000 x K=10 `--get_reference_af` (%d iterations)" % c["fit_cold"]["iterations"][0],
+                 ms(c["fit_cold"]["seconds"]) + (" (%s without the pool's hipMalloc)" % ms(c["fit_cold"]["seconds_without_hipMalloc"]) if c["fit_cold"].get("of_which_hipMalloc_ms", 0) > 5 else ""),
                  ms(c["fit_warm"]["seconds"]), ms(c["fit_direct"]["seconds"]), "built inside the fit: %s (%.1f ms)" % (c["fit_cold"]["codes_built_inside_the_fit"], c["fit_cold"].get("of_which_codes_build_ms", 0))))
     if "pop_like_cold" in c:
         a = ex["assign"]
@@ -26,7 +27,10 @@ for name, v in (ex.get("paths") or {}).items():
     fit = v if "seconds_cold" in v else v.get("get_reference_af")
     if fit:
         cc = fit.get("class_codes") or {}
-        rows.append((name + " fit", ms(fit["seconds_cold"]), ms(fit["seconds_warm"]), ms(fit["seconds_float32"]),
+        cold = ms(fit["seconds_cold"])
+        if fit.get("seconds_cold_without_hipMalloc") is not None and fit["seconds_cold"] - fit["seconds_cold_without_hipMalloc"] > 0.005:
+            cold += " (%s without the pool's hipMalloc)" % ms(fit["seconds_cold_without_hipMalloc"])
+        rows.append((name + " fit", cold, ms(fit["seconds_warm"]), ms(fit["seconds_float32"]),
                      "codes built inside the cold fit: %s%s; iterations %s; identical %s" % (fit["codes_built_inside_the_cold_fit"], (" (%.1f ms)" % cc["build_ms"]) if cc.get("available") else "",
                                                                                          fit["iterations"][0], fit["identical_frequencies"])))
     pl = v.get("get_pop_like")
