@@ -464,6 +464,17 @@ def coded_em_leg(ctx, device, beagle, em_direct, K, per, n, m, mode, args):
     built_by_fit = beagle.codes_state() == 1
     res["fit_cold"]["codes_built_inside_the_fit"] = built_by_fit
     info = beagle.codes_info() if built_by_fit else None
+    if not built_by_fit and beagle.codes_state() == 0:
+        # the model wanted the codes (or never asked): when their memory was not there in time -- hipMalloc on the helper thread,
+        # seconds for VRAM an earlier process used -- the fit ran over the float32 slabs instead of waiting; build them now for the
+        # warm measurements and say what the allocation took
+        late = beagle.codes_info()
+        if late["available"]:
+            res["fit_cold"]["note"] = ("the codes were not built inside this fit: either the cost model kept the float32 slabs, or their memory was "
+                                       "not there in time (its hipMalloc took %.1f ms on the helper thread) and the fit did not wait" % late["alloc_ms"])
+            res["fit_cold"]["pool_hipMalloc_ms"] = round(late["alloc_ms"], 1)
+            info = late
+            built_by_fit = None
     e_warm, res["fit_warm"] = fit("warm")
     os.environ["WGSASSIGN_CODES"] = "0"
     e_dir, res["fit_direct"] = fit("direct")
@@ -475,11 +486,11 @@ def coded_em_leg(ctx, device, beagle, em_direct, K, per, n, m, mode, args):
     if info is None:
         res["note"] = "the cost model (csrc/api.hip: em_codes_pay) kept the float32 slabs for this fit"
         return res, {"available": False}
-    res["fit_cold"]["of_which_codes_build_ms"] = round(info["build_ms"], 1)
-    # the first hipMalloc of the codes' memory costs between nothing and ~70 ms per GB on this pool (0.3 ms ... 3.5 s for these 42 GB
-    # on different boxes -- the driver clears fresh VRAM; the matrix's own allocation pays the same): part of the cold call, and shown
-    res["fit_cold"]["of_which_hipMalloc_ms"] = round(info["alloc_ms"], 1)
-    res["fit_cold"]["seconds_without_hipMalloc"] = round(res["fit_cold"]["seconds"] - info["alloc_ms"] * 1e-3, 4)
+    if built_by_fit:
+        res["fit_cold"]["of_which_codes_build_ms"] = round(info["build_ms"], 1)
+        # (the hipMalloc of the codes' memory runs on a helper thread -- 0.3 ms ... seconds for these 42 GB, by what earlier processes
+        # left in VRAM -- and the fit waits 3 ms for it at most)
+        res["fit_cold"]["waited_for_the_codes_memory_ms"] = round(info["alloc_wait_ms"], 2)
     # steady state: exactly `steps` coded sweeps
     e = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
     e.fit(max(1, args.warmup), 0.0)
@@ -567,8 +578,8 @@ def whole_paths(ctx, device, mode_name):
         alg = float(np.sum([(8.0 * counts[k] + 8.0) * b.m * iters[k] for k in range(K)]))
         res = {"seconds_cold": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
                "codes_built_inside_the_cold_fit": built, "cold_sweep_kernels_ms": round(st[3], 3), "class_codes": codes_note(b)}
-        if built:       # (the first hipMalloc of the codes' memory: nothing to seconds, by the box -- coded_em_leg's note)
-            res["seconds_cold_without_hipMalloc"] = round(dt - res["class_codes"]["alloc_ms"] * 1e-3, 4)
+        if not built and b.codes_state() == 0 and b.codes_info()["available"]:     # (wanted or not, they were not built inside the fit: build them now, waiting)
+            res["class_codes_after_the_cold_fit"] = codes_note(b)
         em2, dt2, it2, st2 = one_fit(b, K)
         res["seconds_warm"] = round(dt2, 4)
         res["warm_sweep_kernel"] = "em_coded_kernel" if built else "em_sweep_kernel<exact>"

@@ -119,7 +119,8 @@ int64_t wgs_beagle_bytes(const wgs_beagle *b);
  * numbering, rows of the coded EM sweep's quotient table, share of (slab, tile) pairs with more classes than rows (swept
  * directly), hash slots per SNP of the encoder (64 / 128 / 256), share of SNPs left uncoded, dictionary rows per tile, hash
  * probe rounds beyond the first per 16 lookups, milliseconds of the allocation, rows of the coded scoring sweep's table, mean classes
- * per SNP and per (population slab, SNP) in the sample pass, SNPs per table of the coded scoring sweep, [19] reserved. */
+ * per SNP and per (population slab, SNP) in the sample pass, SNPs per table of the coded scoring sweep, milliseconds the building call
+ * waited for the codes' memory ([14] is what its hipMalloc took on the helper thread). */
 int wgs_beagle_codes_info(wgs_beagle *b, double *info);
 /* 1: the codes exist, 0: nothing has asked for them yet, -1: the matrix was found not worth coding (or no memory).  Builds nothing. */
 int wgs_beagle_codes_state(wgs_beagle *b);

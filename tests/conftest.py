@@ -24,6 +24,7 @@ def _class_codes_on_small_matrices(monkeypatch):
     themselves (tests/test_gpu_codes.py) remove these settings again."""
     monkeypatch.setenv("WGSASSIGN_EM_CODES_SWEEPS", "0")
     monkeypatch.setenv("WGSASSIGN_SCORE_CODES_ALWAYS", "1")
+    monkeypatch.setenv("WGSASSIGN_CODES_ALLOC_WAIT_MS", "-1")     # ... and wait for the codes' memory however long its hipMalloc takes
 
 
 @pytest.fixture(scope="session")

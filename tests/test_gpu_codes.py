@@ -287,6 +287,38 @@ def test_small_quotient_table_sends_many_tiles_to_the_direct_path(dev, oracle, s
     b.close()
 
 
+@pytest.mark.parametrize("wait_ms", ["0", "0.05"])
+def test_sweeps_do_not_wait_for_the_codes_memory(dev, oracle, wait_ms, monkeypatch):
+    """The codes' device memory comes from a helper thread (hipMalloc of VRAM an earlier process used takes seconds); a sweep that
+    wants the codes waits WGSASSIGN_CODES_ALLOC_WAIT_MS for it (3 by default; 0 here) and otherwise runs over the float32 slabs --
+    the fit then switches to the coded sweep (two iterations per pass) in the middle, or never: same iterations and frequencies as
+    the direct kernels and the oracle either way, and the codes are there once somebody waits for them."""
+    monkeypatch.setenv("WGSASSIGN_CODES_ALLOC_WAIT_MS", wait_ms)
+    monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", "1")
+    m, n, K = 60_000, 150, 3
+    L, IDs = synth.make_beagle(m, n, K, seed=44)
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    with codes(False):
+        b0 = dev.DeviceBeagle.from_host(L, group_of, K)
+        it0, af0, out0 = fit_and_score(dev, b0, K, counts)
+        b0.close()
+    with codes(True):
+        b = dev.DeviceBeagle.from_host(L, group_of, K)
+        assert b.codes_state() == 0
+        it1, af1, out1 = fit_and_score(dev, b, K, counts)
+        assert b.codes_state() in (0, 1)                        # (built in the middle of the fit, by the scoring sweep, or not yet)
+        info = b.codes_info()                                    # waits for the memory and builds
+        assert info["available"] and b.codes_state() == 1
+        it2, af2, out2 = fit_and_score(dev, b, K, counts)
+        b.close()
+    assert it1 == it0 == it2 and same(af1, af0) and same(af2, af0) and same_nan(out1, out0) and same_nan(out2, out0)
+    with quiet():
+        _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+    assert it1 == [int(x) for x in it_o] and same(af1, af_o)
+
+
 def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
     """The cost model of csrc/api.hip: em_codes_pay (a 6.4 GB device-generated matrix, 100 individuals per population: the
     encode pass costs about four direct sweeps, a coded sweep saves half of one) -- a fit with three iterations ahead sweeps the

@@ -16,8 +16,9 @@ def ms(x):
 c = ex.get("coded")
 if c:
     rows.append(("10M x 1000 x K=10 `--get_reference_af` (%d iterations)" % c["fit_cold"]["iterations"][0],
-                 ms(c["fit_cold"]["seconds"]) + (" (%s without the pool's hipMalloc)" % ms(c["fit_cold"]["seconds_without_hipMalloc"]) if c["fit_cold"].get("of_which_hipMalloc_ms", 0) > 5 else ""),
-                 ms(c["fit_warm"]["seconds"]), ms(c["fit_direct"]["seconds"]), "built inside the fit: %s (%.1f ms)" % (c["fit_cold"]["codes_built_inside_the_fit"], c["fit_cold"].get("of_which_codes_build_ms", 0))))
+                 ms(c["fit_cold"]["seconds"]),
+                 ms(c["fit_warm"]["seconds"]), ms(c["fit_direct"]["seconds"]), "built inside the fit: %s (%.1f ms)%s" % (c["fit_cold"]["codes_built_inside_the_fit"], c["fit_cold"].get("of_which_codes_build_ms", 0),
+                                                            ("; the codes' hipMalloc took %.0f ms on the helper thread, the fit did not wait" % c["fit_cold"]["pool_hipMalloc_ms"]) if "pool_hipMalloc_ms" in c["fit_cold"] else "")))
     if "pop_like_cold" in c:
         a = ex["assign"]
         rows.append(("... `--get_pop_like` alone", ms(c["pop_like_cold"]["seconds"]), "%.1f ms (kernel)" % a["coded"]["kernel_ms"], ms(a["seconds"]), "build %.1f ms" % c["pop_like_cold"]["of_which_codes_build_ms"]))
@@ -28,8 +29,6 @@ for name, v in (ex.get("paths") or {}).items():
     if fit:
         cc = fit.get("class_codes") or {}
         cold = ms(fit["seconds_cold"])
-        if fit.get("seconds_cold_without_hipMalloc") is not None and fit["seconds_cold"] - fit["seconds_cold_without_hipMalloc"] > 0.005:
-            cold += " (%s without the pool's hipMalloc)" % ms(fit["seconds_cold_without_hipMalloc"])
         rows.append((name + " fit", cold, ms(fit["seconds_warm"]), ms(fit["seconds_float32"]),
                      "codes built inside the cold fit: %s%s; iterations %s; identical %s" % (fit["codes_built_inside_the_cold_fit"], (" (%.1f ms)" % cc["build_ms"]) if cc.get("available") else "",
                                                                                          fit["iterations"][0], fit["identical_frequencies"])))

@@ -158,7 +158,7 @@ void wgs_beagle_destroy(wgs_beagle *b)
     if (!b) return;
     wgs_beagle_drop_codes(b);
     (void)hipSetDevice(b->ctx->device);
-    if (b->pool) (void)hipFree(b->pool);
+    wgs_beagle_release_pool(b);
     for (auto &s : b->slabs) {
         if (s.base) (void)hipFree(s.base);
         if (s.d_members) (void)hipFree(s.d_members);

@@ -8,6 +8,79 @@
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// The codes' device memory comes from a helper thread: hipMalloc of VRAM that an earlier PROCESS used is cleared by the driver when
+// it is handed out again (profiles/r04_alloc_ubench.txt: 0.3 ms ... 6 s for 42 GB, by what the box did before), and kernels of this
+// thread are not held up by it (762 launches during a 1.3 s hipMalloc, none slower than usual).  A sweep that wants the codes waits
+// a few milliseconds for the memory -- long enough for the fast case -- and otherwise goes over the float32 slabs; a later sweep
+// finds the pool ready and builds the codes then.
+static void pool_join(wgs_beagle *b)
+{
+    if (b->pool_thread) {
+        b->pool_thread->join();
+        delete b->pool_thread;
+        b->pool_thread = nullptr;
+    }
+}
+
+// 1: b->pool holds at least `want` (or, failing that, `want_small`) bytes; 0: not yet; -1: no memory
+static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double grace_ms)
+{
+    if (b->pool && b->pool_bytes >= want) return 1;
+    if (b->pool_state.load() == 0) {
+        pool_join(b);
+        b->pool_want = want;
+        b->pool_want_small = want_small;
+        b->pool_request_s = now_s();
+        b->pool_state.store(1);
+        const int dev = b->ctx->device;
+        b->pool_thread = new std::thread([b, dev] {
+            const double t0 = now_s();
+            void *p = nullptr;
+            size_t got = 0;
+            if (hipSetDevice(dev) == hipSuccess) {
+                if (hipMalloc(&p, b->pool_want) == hipSuccess) got = b->pool_want;
+                else if (b->pool_want_small && b->pool_want_small < b->pool_want && hipMalloc(&p, b->pool_want_small) == hipSuccess) got = b->pool_want_small;
+                else p = nullptr;
+                (void)hipGetLastError();
+            }
+            b->pool_new = p;
+            b->pool_new_bytes = got;
+            b->pool_alloc_ms = (now_s() - t0) * 1e3;
+            b->pool_state.store(p ? 2 : -1);
+        });
+    }
+    const double t0 = now_s();
+    while (b->pool_state.load() == 1 && (grace_ms < 0 || (now_s() - t0) * 1e3 < grace_ms)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    const int st = b->pool_state.load();
+    if (st == 1) return 0;
+    pool_join(b);
+    b->pool_state.store(0);
+    if (st < 0) return -1;
+    if (b->pool) (void)hipFree(b->pool);                    // (a smaller one of an earlier build)
+    b->pool = b->pool_new;
+    b->pool_bytes = b->pool_new_bytes;
+    b->pool_new = nullptr;
+    if (b->pool_bytes >= want || (want_small && b->pool_bytes >= want_small)) return 1;
+    // (the request in flight was for an earlier, smaller content of the matrix: ask again)
+    (void)hipFree(b->pool);
+    b->pool = nullptr;
+    b->pool_bytes = 0;
+    return pool_request(b, want, want_small, grace_ms);
+}
+
+/* Ends the helper thread and releases the codes' memory (wgs_beagle_destroy). */
+void wgs_beagle_release_pool(wgs_beagle *b)
+{
+    if (!b) return;
+    pool_join(b);
+    if (b->pool_new) (void)hipFree(b->pool_new);
+    b->pool_new = nullptr;
+    b->pool_state.store(0);
+    if (b->pool) (void)hipFree(b->pool);
+    b->pool = nullptr;
+    b->pool_bytes = 0;
+}
+
 void wgs_beagle_drop_codes(wgs_beagle *b)
 {
     if (!b) return;
@@ -136,7 +209,7 @@ bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K)
 // Builds the class codes (the plan of the sample pass decides whether and how, then one pass over the matrix: ~2 x its streaming
 // time).  Not worth coding -- most SNPs with more classes than the largest table holds, or hardly fewer classes than individuals --
 // or no memory for the codes (half of the matrix): nullptr, and the direct kernels run.  WGSASSIGN_CODES=0 turns the codes off altogether.
-wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
+wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build, bool wait)
 {
     if (!b || b->codes_state < 0 || codes_switched_off()) return nullptr;
     if (b->codes_state > 0) return b->codes;
@@ -197,29 +270,31 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build)
     const double ta = now_s();
     std::vector<size_t> off;
     size_t total = plan(c->lrows > 0, off);
-    // (the pool of an earlier build of this matrix -- dropped because rows changed -- is kept by the wgs_beagle and used again when
-    // it is large enough: freeing and allocating tens of GB again costs seconds on this driver)
-    auto take_pool = [&](size_t bytes) -> bool {
-        if (b->pool && b->pool_bytes >= bytes) return true;
-        if (b->pool) (void)hipFree(b->pool);
-        b->pool = nullptr;
-        b->pool_bytes = 0;
-        if (hipMalloc(&b->pool, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            b->pool = nullptr;
-            return false;
+    {
+        // the pool of an earlier build of this matrix (dropped because rows changed) is used again when it is large enough; else the
+        // helper thread fetches one: at least without the slabs' own numbering when the full size is not to be had
+        std::vector<size_t> off_small;
+        const size_t small = c->lrows > 0 ? plan(false, off_small) : 0;
+        const char *grace_env = getenv("WGSASSIGN_CODES_ALLOC_WAIT_MS");    // (< 0: wait however long it takes; the test suite does)
+        const int got = pool_request(b, total, small, wait ? -1.0 : (grace_env ? atof(grace_env) : 3.0));
+        if (got == 0) {
+            // not there yet: nothing is decided -- this call goes without codes, the next one asks again
+            delete c;
+            b->codes = nullptr;
+            b->codes_state = 0;
+            --b->codes_generation;
+            return nullptr;
         }
-        b->pool_bytes = bytes;
-        return true;
-    };
-    if (!take_pool(total)) {
-        if (c->lrows == 0) return fail();
-        c->lrows = 0;                                      // without the slabs' own numbering: the scoring sweep can still use the codes
-        total = plan(false, off);
-        if (!take_pool(total)) return fail();
+        if (got < 0) return fail();
+        if (b->pool_bytes < total) {
+            c->lrows = 0;                                  // without the slabs' own numbering: the scoring sweep can still use the codes
+            total = plan(false, off);
+        }
     }
     c->pool = b->pool;
-    c->alloc_ms = (now_s() - ta) * 1e3;
+    c->alloc_ms = b->pool_alloc_ms;                        // the helper thread's hipMalloc (0 when an earlier pool was used again)
+    c->alloc_wait_ms = (now_s() - ta) * 1e3;               // what this call waited for it
+    b->pool_alloc_ms = 0.0;
     char *base = reinterpret_cast<char *>(c->pool);
     c->d_slabs = reinterpret_cast<SlabCodes *>(base + off[0]);
     c->ncls = reinterpret_cast<uint8_t *>(base + off[1]);
@@ -274,6 +349,7 @@ int wgs_beagle_codes_info(wgs_beagle *b, double *info)
     info[16] = c->sample_mean_g;
     info[17] = c->sample_mean_l;
     info[18] = c->score_batch;
+    info[19] = c->alloc_wait_ms;
     return 0;
 }
 

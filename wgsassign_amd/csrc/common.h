@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../../include/wgsassign_hip.h"
@@ -123,7 +125,7 @@ struct wgs_codes {
     uint4 *wave_stats = nullptr;   // the encoder's per-wavefront records (two per work unit)
     int64_t bytes = 0, local_bytes = 0;
     int64_t generation = 0;        // distinguishes this build from any earlier one of the same matrix (caches of derived tables)
-    double build_ms = 0.0, kernel_ms = 0.0, sample_ms = 0.0, alloc_ms = 0.0;
+    double build_ms = 0.0, kernel_ms = 0.0, sample_ms = 0.0, alloc_ms = 0.0, alloc_wait_ms = 0.0;
     double sum_ncls = 0.0;         // over the coded SNPs
     int64_t rich_snps = 0;
     double local_direct_share = 0.0;   // share of the (slab, tile) pairs the coded EM sweep takes from the float32 slab
@@ -156,16 +158,26 @@ struct wgs_beagle {
     wgs_codes_plan plan;           // the sample pass's findings (reset when rows change)
     void *pool = nullptr;          // device memory of the class codes, kept across rebuilds
     size_t pool_bytes = 0;
+    // ... and how it is come by: hipMalloc on a helper thread (codes.hip: pool_request) -- VRAM that an earlier process used is cleared
+    // by the driver when it is handed out again, seconds for tens of GB, and sweeps over the float32 slabs can run meanwhile
+    std::thread *pool_thread = nullptr;
+    std::atomic<int> pool_state{0};   // 0: nothing requested, 1: in flight, 2: pool_new is ready, -1: no memory
+    void *pool_new = nullptr;
+    size_t pool_new_bytes = 0, pool_want = 0, pool_want_small = 0;
+    double pool_request_s = 0.0, pool_alloc_ms = 0.0;
     int64_t direct_sweeps = 0;     // EM sweeps over the float32 slabs so far (wgs_em_step callers: the codes are built once a run is long)
 };
 // The matrix's class codes, or nullptr when they are switched off (WGSASSIGN_CODES=0) or the matrix is not worth coding (then the
 // direct kernels are used).  build = false only returns codes that exist already.
-wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true);
+// wait = false: when the codes' memory is not there yet the call returns nullptr for now (the caller sweeps the float32 slabs)
+// and a later call finishes the build.
+wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true, bool wait = true);
 const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b);
 double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots);
 bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K);
 int wgs_ctx_workspace_b(wgs_ctx *ctx, size_t bytes, void **out);     // a second small grow-only scratch (survives wgs_ctx_workspace calls)
 void wgs_beagle_drop_codes(wgs_beagle *b);
+void wgs_beagle_release_pool(wgs_beagle *b);
 int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned long long *hist_g, unsigned long long *hist_l, double *rounds_per_buffer);
 int launch_class_encode(wgs_beagle *b, wgs_codes *c);
 

@@ -190,7 +190,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     for (int j : order) fewest = std::min(fewest, (int)em->b->slabs[em->group[j]].ncols);
     worth = worth && fewest >= min_cols;
     const bool build = worth && em_codes_pay(em, order, fewest, sweeps_ahead);
-    wgs_codes *codes = worth ? wgs_beagle_codes(em->b, build) : nullptr;
+    wgs_codes *codes = worth ? wgs_beagle_codes(em->b, build, false) : nullptr;     // (memory not there yet: this sweep goes direct)
     if (codes && codes->lrows == 0) codes = nullptr;
     if (worth && !codes) ++em->b->direct_sweeps;          // (a sweep the codes could have served)
     // two iterations per sweep (em_kernels.hip: fused iterations): the coded sweep only, for the fits the caller allows (iterations

@@ -205,7 +205,8 @@ class DeviceBeagle:
                 "encode_kernel_ms": info[5], "mean_classes": info[4], "sample_ms": info[6], "slab_numbering_bytes": int(info[7]),
                 "em_table_rows": int(info[8]), "em_direct_tile_share": info[9], "hash_slots": int(info[10]), "rich_snp_share": info[11],
                 "dict_rows": int(info[12]), "probe_rounds_per_buffer": info[13], "alloc_ms": info[14], "score_table_rows": int(info[15]),
-                "sample_mean_classes": info[16], "sample_mean_classes_per_slab": info[17], "score_batch_snps": int(info[18])}
+                "sample_mean_classes": info[16], "sample_mean_classes_per_slab": info[17], "score_batch_snps": int(info[18]),
+                "alloc_wait_ms": info[19]}
 
     def close(self):
         if self._h:
