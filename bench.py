@@ -456,26 +456,25 @@ def coded_em_leg(ctx, device, beagle, em_direct, K, per, n, m, mode, args):
         iters = e.run(200, 1e-4)
         ctx.sync()
         dt = time.perf_counter() - t0
+        late_ms = beagle.codes_wait()                        # (kernel times are not readable while the codes' hipMalloc is in flight)
         st = e.fit_stats()
-        return e, {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "sweep_kernels_ms": round(st[3], 2)}
+        r = {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "sweep_kernels_ms": round(st[3], 2)}
+        if late_ms > 0:
+            r["codes_memory_arrived_after_the_fit_hipMalloc_ms"] = round(late_ms, 1)
+        return e, r
 
     res = {}
     e_cold, res["fit_cold"] = fit("cold")                    # nothing built yet: the cost model decides inside wgs_em_fit
     built_by_fit = beagle.codes_state() == 1
     res["fit_cold"]["codes_built_inside_the_fit"] = built_by_fit
-    info = beagle.codes_info() if built_by_fit else None
-    if not built_by_fit and beagle.codes_state() == 0:
-        # the model wanted the codes (or never asked): when their memory was not there in time -- hipMalloc on the helper thread,
-        # seconds for VRAM an earlier process used -- the fit ran over the float32 slabs instead of waiting; build them now for the
-        # warm measurements and say what the allocation took
-        late = beagle.codes_info()
-        if late["available"]:
-            res["fit_cold"]["note"] = ("the codes were not built inside this fit: either the cost model kept the float32 slabs, or their memory was "
-                                       "not there in time (its hipMalloc took %.1f ms on the helper thread) and the fit did not wait" % late["alloc_ms"])
-            res["fit_cold"]["pool_hipMalloc_ms"] = round(late["alloc_ms"], 1)
-            info = late
-            built_by_fit = None
+    if not built_by_fit and "codes_memory_arrived_after_the_fit_hipMalloc_ms" in res["fit_cold"]:
+        # the model wanted the codes, their memory was not there within 3 ms -- the hipMalloc (on the library's helper thread) of VRAM
+        # an earlier process used takes seconds on this driver -- and the fit ran over the float32 slabs instead of waiting
+        res["fit_cold"]["note"] = "the codes' memory was not there in time: the fit did not wait and ran over the float32 slabs; the next fit builds them"
+        e2, res["fit_second_builds_the_codes"] = fit("second")
+        e2.close()
     e_warm, res["fit_warm"] = fit("warm")
+    info = beagle.codes_info() if beagle.codes_state() == 1 else None
     os.environ["WGSASSIGN_CODES"] = "0"
     e_dir, res["fit_direct"] = fit("direct")
     os.environ.pop("WGSASSIGN_CODES")
@@ -569,7 +568,9 @@ def whole_paths(ctx, device, mode_name):
         em = device.EMBatch(b, np.arange(K, dtype=np.int32))
         iters = em.run(200, 1e-4)
         ctx.sync()
-        return em, time.perf_counter() - t0, iters, em.fit_stats()
+        dt = time.perf_counter() - t0
+        late_ms = b.codes_wait()                 # (kernel times are not readable while the codes' hipMalloc is in flight on the helper thread)
+        return em, dt, iters, em.fit_stats() + (late_ms,)
 
     def fit(b, K, counts):
         """--get_reference_af: cold, warm, float32"""
@@ -578,11 +579,14 @@ def whole_paths(ctx, device, mode_name):
         alg = float(np.sum([(8.0 * counts[k] + 8.0) * b.m * iters[k] for k in range(K)]))
         res = {"seconds_cold": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
                "codes_built_inside_the_cold_fit": built, "cold_sweep_kernels_ms": round(st[3], 3), "class_codes": codes_note(b)}
-        if not built and b.codes_state() == 0 and b.codes_info()["available"]:     # (wanted or not, they were not built inside the fit: build them now, waiting)
-            res["class_codes_after_the_cold_fit"] = codes_note(b)
+        if st[-1] > 0 and not built:             # wanted, but the memory came too late for this fit (it did not wait): the next fit builds them
+            res["codes_memory_arrived_after_the_cold_fit_hipMalloc_ms"] = round(st[-1], 1)
+            em_b, dt_b, it_b, st_b = one_fit(b, K)
+            res["seconds_second_fit_building_the_codes"] = round(dt_b, 4)
+            em_b.close()
         em2, dt2, it2, st2 = one_fit(b, K)
         res["seconds_warm"] = round(dt2, 4)
-        res["warm_sweep_kernel"] = "em_coded_kernel" if built else "em_sweep_kernel<exact>"
+        res["warm_sweep_kernel"] = "em_coded_kernel" if b.codes_state() == 1 else "em_sweep_kernel<exact>"
         res["warm_sweep_kernels_ms"] = round(st2[3], 3)
         em2.close()
         with codes_off():
@@ -608,10 +612,15 @@ def whole_paths(ctx, device, mode_name):
         t0 = time.perf_counter()
         o, _ = device.assign(b, afs)
         dt = time.perf_counter() - t0
+        late_ms = b.codes_wait()
         terms = float(b.m) * b.n * K
+        if late_ms > 0 and b.codes_state() != 1:
+            device.assign(b, afs)                # (the memory came too late for that call, which did not wait: this one builds the codes)
         coded = b.codes_state() == 1
         kern = "score_coded_kernel<exact>" if coded else "score_sweep_kernel<exact>"
         res = {"seconds_after_the_fit": round(dt, 4), "codes_present_before_the_call": had, "kernel": kern}
+        if late_ms > 0:
+            res["codes_memory_arrived_after_the_call_hipMalloc_ms"] = round(late_ms, 1)
         o, _ = device.assign(b, afs)
         ms = device.assign.last_ms
         res.update({"kernel_ms_warm": round(ms, 3), "snps_per_s_warm": b.m / (ms * 1e-3), "bound": "valu_issue (+ LDS table reads)" if coded else "valu_fp64_issue",
@@ -627,6 +636,7 @@ def whole_paths(ctx, device, mode_name):
         t0 = time.perf_counter()
         oc, _ = device.assign(b, afs)
         res["seconds_cold"] = round(time.perf_counter() - t0, 4)
+        b.codes_wait()
         res["class_codes_cold"] = codes_note(b)
         res["identical_sums"] = bool(od.tobytes() == o.tobytes() == oc.tobytes())
         af = afs.to_host()

@@ -124,6 +124,11 @@ int64_t wgs_beagle_bytes(const wgs_beagle *b);
 int wgs_beagle_codes_info(wgs_beagle *b, double *info);
 /* 1: the codes exist, 0: nothing has asked for them yet, -1: the matrix was found not worth coding (or no memory).  Builds nothing. */
 int wgs_beagle_codes_state(wgs_beagle *b);
+/* The codes' device memory is allocated on a helper thread (hipMalloc of VRAM an earlier process used takes seconds on this driver);
+ * a sweep that wants the codes waits WGSASSIGN_CODES_ALLOC_WAIT_MS (3) for it and otherwise runs over the float32 slabs.  This call
+ * waits for an allocation in flight, builds nothing; *alloc_ms = what that hipMalloc took (0: none was in flight).  While one is in
+ * flight wgs_em_fit_stats and wgs_assign_last_ms report -1 for kernel times (hipEventElapsedTime would wait for it). */
+int wgs_beagle_codes_wait(wgs_beagle *b, double *alloc_ms);
 /* Builds the codes now rather than at the first sweep that asks.  (`em` is ignored since version 2: one pass builds all.) */
 int wgs_beagle_codes_prepare(wgs_beagle *b, int em);
 

@@ -309,7 +309,8 @@ def test_sweeps_do_not_wait_for_the_codes_memory(dev, oracle, wait_ms, monkeypat
         assert b.codes_state() == 0
         it1, af1, out1 = fit_and_score(dev, b, K, counts)
         assert b.codes_state() in (0, 1)                        # (built in the middle of the fit, by the scoring sweep, or not yet)
-        info = b.codes_info()                                    # waits for the memory and builds
+        assert b.codes_wait() >= 0.0 and b.codes_wait() == 0.0  # (waits for an allocation in flight; none is afterwards)
+        info = b.codes_info()                                    # builds, if nothing has yet
         assert info["available"] and b.codes_state() == 1
         it2, af2, out2 = fit_and_score(dev, b, K, counts)
         b.close()

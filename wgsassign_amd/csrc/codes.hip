@@ -10,7 +10,8 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 // The codes' device memory comes from a helper thread: hipMalloc of VRAM that an earlier PROCESS used is cleared by the driver when
 // it is handed out again (profiles/r04_alloc_ubench.txt: 0.3 ms ... 6 s for 42 GB, by what the box did before), and kernels of this
-// thread are not held up by it (762 launches during a 1.3 s hipMalloc, none slower than usual).  A sweep that wants the codes waits
+// thread are not held up by it (762 launches during a 1.3 s hipMalloc, none slower than usual; nor are copies and synchronisation --
+// hipEventElapsedTime is, which is why the library reads elapsed times lazily: ctx->allocs_in_flight).  A sweep that wants the codes waits
 // a few milliseconds for the memory -- long enough for the fast case -- and otherwise goes over the float32 slabs; a later sweep
 // finds the pool ready and builds the codes then.
 static void pool_join(wgs_beagle *b)
@@ -20,6 +21,22 @@ static void pool_join(wgs_beagle *b)
         delete b->pool_thread;
         b->pool_thread = nullptr;
     }
+}
+
+// What the helper thread came back with becomes b->pool.  1: done; 0: still allocating; -1: no memory
+static int pool_adopt(wgs_beagle *b)
+{
+    const int st = b->pool_state.load();
+    if (st == 0) return b->pool ? 1 : -1;
+    if (st == 1) return 0;
+    pool_join(b);
+    b->pool_state.store(0);
+    if (st < 0) return -1;
+    if (b->pool) (void)hipFree(b->pool);                    // (a smaller one of an earlier build)
+    b->pool = b->pool_new;
+    b->pool_bytes = b->pool_new_bytes;
+    b->pool_new = nullptr;
+    return 1;
 }
 
 // 1: b->pool holds at least `want` (or, failing that, `want_small`) bytes; 0: not yet; -1: no memory
@@ -33,7 +50,9 @@ static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double gr
         b->pool_request_s = now_s();
         b->pool_state.store(1);
         const int dev = b->ctx->device;
-        b->pool_thread = new std::thread([b, dev] {
+        wgs_ctx *ctx = b->ctx;
+        ++ctx->allocs_in_flight;
+        b->pool_thread = new std::thread([b, dev, ctx] {
             const double t0 = now_s();
             void *p = nullptr;
             size_t got = 0;
@@ -46,26 +65,32 @@ static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double gr
             b->pool_new = p;
             b->pool_new_bytes = got;
             b->pool_alloc_ms = (now_s() - t0) * 1e3;
+            --ctx->allocs_in_flight;
             b->pool_state.store(p ? 2 : -1);
         });
     }
     const double t0 = now_s();
     while (b->pool_state.load() == 1 && (grace_ms < 0 || (now_s() - t0) * 1e3 < grace_ms)) std::this_thread::sleep_for(std::chrono::microseconds(50));
-    const int st = b->pool_state.load();
-    if (st == 1) return 0;
-    pool_join(b);
-    b->pool_state.store(0);
-    if (st < 0) return -1;
-    if (b->pool) (void)hipFree(b->pool);                    // (a smaller one of an earlier build)
-    b->pool = b->pool_new;
-    b->pool_bytes = b->pool_new_bytes;
-    b->pool_new = nullptr;
+    const int st = pool_adopt(b);
+    if (st <= 0) return st;
     if (b->pool_bytes >= want || (want_small && b->pool_bytes >= want_small)) return 1;
     // (the request in flight was for an earlier, smaller content of the matrix: ask again)
     (void)hipFree(b->pool);
     b->pool = nullptr;
     b->pool_bytes = 0;
     return pool_request(b, want, want_small, grace_ms);
+}
+
+extern "C" int wgs_beagle_codes_wait(wgs_beagle *b, double *alloc_ms)
+{
+    WGS_REQUIRE(b, "null argument");
+    if (alloc_ms) *alloc_ms = 0.0;
+    if (b->pool_state.load() == 0) return 0;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    while (b->pool_state.load() == 1) std::this_thread::sleep_for(std::chrono::microseconds(100));
+    (void)pool_adopt(b);
+    if (alloc_ms) *alloc_ms = b->pool_alloc_ms;
+    return 0;
 }
 
 /* Ends the helper thread and releases the codes' memory (wgs_beagle_destroy). */

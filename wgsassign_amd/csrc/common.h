@@ -12,9 +12,33 @@
 
 void wgs_set_error(const char *fmt, ...);
 
+// (-DWGS_TRACE_STALLS=ms: runtime calls that took longer are named on stderr -- how the wait behind a slow hipMalloc was found)
+#ifdef WGS_TRACE_STALLS
+#include <chrono>
+#include <cstdio>
+struct wgs_stall_probe {
+    const char *what, *file;
+    int line;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    ~wgs_stall_probe() {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms >= WGS_TRACE_STALLS) fprintf(stderr, "[stall] %.1f ms in %s (%s:%d)\n", ms, what, file, line);
+    }
+};
+#define WGS_STALL_PROBE(expr) wgs_stall_probe probe_{#expr, __FILE__, __LINE__}
+#define WGS_STALL_SCOPE(name) wgs_stall_probe scope_probe_{name, __FILE__, __LINE__}
+#else
+#define WGS_STALL_PROBE(expr)
+#define WGS_STALL_SCOPE(name)
+#endif
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
-        hipError_t e_ = (expr);                                                               \
+        hipError_t e_;                                                                        \
+        {                                                                                     \
+            WGS_STALL_PROBE(expr);                                                            \
+            e_ = (expr);                                                                      \
+        }                                                                                     \
         if (e_ != hipSuccess) {                                                               \
             wgs_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
             return 1;                                                                         \
@@ -56,6 +80,10 @@ struct wgs_ctx {
     bool log_table_ready = false;               // the log table of assign_kernels.hip is uploaded to this device
     hipEvent_t ev0 = nullptr, ev1 = nullptr;    // bracket the scoring kernels of the last wgs_assign / wgs_score_*
     float last_assign_ms = 0.0f;
+    bool assign_ms_pending = false;             // ev0 .. ev1 not read yet: hipEventElapsedTime WAITS for a hipMalloc in flight on another thread
+                                                // (tools/ubench_alloc3.hip; kernel launches, copies and synchronisation do not), so elapsed times
+                                                // are read when somebody asks and no allocation of this library is in flight (wgs_assign_last_ms)
+    std::atomic<int> allocs_in_flight{0};       // helper-thread hipMallocs under way (codes.hip)
 };
 // Device workspace of at least `bytes` (256-byte aligned); contents are not preserved across calls.
 int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out);

@@ -43,13 +43,12 @@ void wgs_em_destroy(wgs_em *em)
     if (em->d_chain_work) (void)hipFree(em->d_chain_work);
     if (em->ev0) (void)hipEventDestroy(em->ev0);
     if (em->ev1) (void)hipEventDestroy(em->ev1);
+    for (hipEvent_t e : em->ev_sw) (void)hipEventDestroy(e);
     for (int i = 0; i < 2; ++i) {
         if (em->d_descs2[i]) (void)hipFree(em->d_descs2[i]);
         if (em->h_descs2[i]) (void)hipHostFree(em->h_descs2[i]);
         if (em->h_state[i]) (void)hipHostFree(em->h_state[i]);
         if (em->ev_it[i]) (void)hipEventDestroy(em->ev_it[i]);
-        if (em->ev_sw0[i]) (void)hipEventDestroy(em->ev_sw0[i]);
-        if (em->ev_sw1[i]) (void)hipEventDestroy(em->ev_sw1[i]);
     }
     for (void *p : {(void *)em->d_state, (void *)em->d_ssq2, (void *)em->d_jobs, (void *)em->d_chain_out, em->d_chain_batch})
         if (p) (void)hipFree(p);
@@ -190,7 +189,12 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     for (int j : order) fewest = std::min(fewest, (int)em->b->slabs[em->group[j]].ncols);
     worth = worth && fewest >= min_cols;
     const bool build = worth && em_codes_pay(em, order, fewest, sweeps_ahead);
-    wgs_codes *codes = worth ? wgs_beagle_codes(em->b, build, false) : nullptr;     // (memory not there yet: this sweep goes direct)
+    wgs_codes *codes = nullptr;
+    {
+        WGS_STALL_SCOPE("wgs_beagle_codes from the sweep");
+        codes = worth ? wgs_beagle_codes(em->b, build, false) : nullptr;     // (memory not there yet: this sweep goes direct)
+    }
+    WGS_STALL_SCOPE("the sweep's launches");
     if (codes && codes->lrows == 0) codes = nullptr;
     if (worth && !codes) ++em->b->direct_sweeps;          // (a sweep the codes could have served)
     // two iterations per sweep (em_kernels.hip: fused iterations): the coded sweep only, for the fits the caller allows (iterations
@@ -371,8 +375,6 @@ static int em_fit_alloc(wgs_em *em)
         HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&em->h_ssq[i], sizeof(double) * 2 * n, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&em->ev_it[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreate(&em->ev_sw0[i]));
-        HIP_TRY(hipEventCreate(&em->ev_sw1[i]));
     }
     return 0;
 }
@@ -441,6 +443,8 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     em->fit_iterations = em->fit_chain_batches = 0;
     em->fit_sweep_ms = 0.0;
+    em->fit_timed = 0;
+    em->fit_sweep_pending = false;
     const auto t_begin = std::chrono::steady_clock::now();
     // the reference's `diff < tole` from a float64 sum, as em_decide_kernel classifies it
     auto classify = [&](double v) { return (v != v || v >= hi) ? EM_ACTIVE : (v < lo ? EM_CONVERGED : EM_UNDECIDED); };
@@ -457,6 +461,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     };
     bool launched_prev = false;
     for (int t = 1;; ++t) {
+        WGS_STALL_SCOPE("one trip of the fit loop");
         const int slot = t & 1;
         // Who ran at t-1 is known now: its list minus the fits found finished or parked when the decisions
         // of t-2 were read (those sweeps returned at once).
@@ -477,13 +482,28 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
             may_fuse[j] = max_iter - sweeps[j] >= 2 ? 2 : 1;
         }
         if (!L.empty()) {
+            hipEvent_t sw0 = nullptr, sw1 = nullptr;         // this iteration's pair (the first EM_TIMED_SWEEPS iterations of a fit are timed)
+            if (em->fit_timed < EM_TIMED_SWEEPS) {
+                while ((int)em->ev_sw.size() < 2 * em->fit_timed + 2) {
+                    hipEvent_t e = nullptr;
+                    HIP_TRY(hipEventCreate(&e));
+                    em->ev_sw.push_back(e);
+                }
+                sw0 = em->ev_sw[2 * em->fit_timed];
+                sw1 = em->ev_sw[2 * em->fit_timed + 1];
+                ++em->fit_timed;
+                em->fit_sweep_pending = true;
+            }
             if (em_enqueue_sweep(em, L, em->h_descs2[slot], em->d_descs2[slot], em->h_groups2[slot], em->d_groups2[slot], em->d_ssq2,
-                                 em->d_state, em->ev_sw0[slot], em->ev_sw1[slot], max_iter - t + 1, &may_fuse, em->d_ssq2 + n))
+                                 em->d_state, sw0, sw1, max_iter - t + 1, &may_fuse, em->d_ssq2 + n))
                 return 1;
             // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
             // in the same way on every rank (all ranks take the same decisions).
             if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, 2 * n)) return 1;
-            if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
+            {
+                WGS_STALL_SCOPE("launch_em_decide");
+                if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
+            }
             HIP_TRY(hipMemcpyAsync(em->h_state[slot], em->d_state, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipMemcpyAsync(em->h_ssq[slot], em->d_ssq2, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(em->ev_it[slot], ctx->stream));
@@ -493,8 +513,6 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         if (launched_prev) {
             const int ps = slot ^ 1;
             HIP_TRY(hipEventSynchronize(em->ev_it[ps]));     // also: the pinned descriptors of t-1 have been consumed
-            float sweep_ms = 0.0f;
-            if (hipEventElapsedTime(&sweep_ms, em->ev_sw0[ps], em->ev_sw1[ps]) == hipSuccess) em->fit_sweep_ms += sweep_ms;
             parked.clear();
             parked_a.clear();
             for (int j : ran) {
@@ -580,14 +598,31 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
 }
 
 /* Diagnostics of the last wgs_em_fit: iterations enqueued, batched exact-chain resolutions, wall seconds, and the
- * summed duration of its sweep kernels (HIP events on the context's stream around each iteration's sweep). */
+ * summed duration of its sweep kernels (HIP events on the context's stream around each iteration's sweep; read here, not
+ * inside the fit; -1 while the codes' memory is being allocated on the helper thread -- the query would wait for it). */
 int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds, double *sweep_ms)
 {
     WGS_REQUIRE(em, "null argument");
     if (iterations) *iterations = em->fit_iterations;
     if (chain_batches) *chain_batches = em->fit_chain_batches;
     if (seconds) *seconds = em->fit_seconds;
-    if (sweep_ms) *sweep_ms = em->fit_sweep_ms;
+    if (sweep_ms) {
+        if (em->fit_sweep_pending && em->b->ctx->allocs_in_flight.load() > 0) {
+            *sweep_ms = -1.0;
+            return 0;
+        }
+        if (em->fit_sweep_pending) {
+            HIP_TRY(hipSetDevice(em->b->ctx->device));
+            em->fit_sweep_ms = 0.0;
+            for (int i = 0; i < em->fit_timed; ++i) {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, em->ev_sw[2 * i], em->ev_sw[2 * i + 1]) == hipSuccess) em->fit_sweep_ms += ms;
+            }
+            (void)hipGetLastError();
+            em->fit_sweep_pending = false;
+        }
+        *sweep_ms = em->fit_sweep_ms;
+    }
     return 0;
 }
 

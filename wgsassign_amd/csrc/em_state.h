@@ -3,6 +3,8 @@
 #pragma once
 #include "common.h"
 
+constexpr int EM_TIMED_SWEEPS = 4096;     // iterations of one wgs_em_fit whose sweeps are bracketed by HIP events
+
 struct wgs_em {
     wgs_beagle *b = nullptr;
     int32_t n_fits = 0;
@@ -32,7 +34,9 @@ struct wgs_em {
     double *d_ssq2 = nullptr;             // [2 n_fits] sums of the iteration(s) in flight: first | second of a fused sweep
     double *h_ssq[2] = {nullptr, nullptr};  // pinned read-backs of them, one per slot
     hipEvent_t ev_it[2] = {nullptr, nullptr};
-    hipEvent_t ev_sw0[2] = {nullptr, nullptr}, ev_sw1[2] = {nullptr, nullptr};   // bracket the sweep kernel(s) of a slot
+    std::vector<hipEvent_t> ev_sw;        // pairs bracketing the sweep kernel(s) of the iterations of the last wgs_em_fit (grown as needed, EM_TIMED_SWEEPS at most);
+    int fit_timed = 0;                    //   read when wgs_em_fit_stats is asked (hipEventElapsedTime waits for a hipMalloc in flight: common.h)
+    bool fit_sweep_pending = false;
     double fit_sweep_ms = 0.0;            // summed sweep-kernel time of the last wgs_em_fit (HIP events)
     ChainJob *d_jobs = nullptr, *h_jobs = nullptr;
     float *d_chain_out = nullptr, *h_chain_out = nullptr;     // [n_fits] carries | [n_fits] serial-block counts

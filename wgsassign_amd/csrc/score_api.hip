@@ -16,6 +16,16 @@ extern "C" {
 int wgs_assign_last_ms(wgs_ctx *ctx, float *ms)
 {
     WGS_REQUIRE(ctx && ms, "null argument");
+    if (ctx->assign_ms_pending) {
+        if (ctx->allocs_in_flight.load() > 0) {              // the query would wait for that hipMalloc: not known yet (ask again later)
+            *ms = -1.0f;
+            return 0;
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1) != hipSuccess) ctx->last_assign_ms = 0.0f;
+        (void)hipGetLastError();
+        ctx->assign_ms_pending = false;
+    }
     *ms = ctx->last_assign_ms;
     return 0;
 }
@@ -217,7 +227,7 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipMemcpyAsync(out, sc->d_out, sizeof(double) * sc->cells, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    ctx->assign_ms_pending = true;
     sc->have_prefix = (mode == WGS_MODE_EXACT);
     return 0;
 }
@@ -319,7 +329,7 @@ int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start)
     if (launch_chain_cand(ctx, A)) return 1;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));       // `start` (host) has been consumed
-    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    ctx->assign_ms_pending = true;
     return 0;
 }
 
@@ -369,7 +379,7 @@ int wgs_score_chains_walk(wgs_score *sc, const float *carry_in, float *parts_out
     HIP_TRY(hipMemcpyAsync(parts_out, sc->d_parts, sizeof(float) * chains, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(&sc->last_serial_blocks, sc->d_nserial, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    ctx->assign_ms_pending = true;
     return 0;
 }
 
@@ -395,7 +405,7 @@ int wgs_score_chains_walk_all(wgs_score *sc, wgs_comm *comm, float *parts_out)
     }
     HIP_TRY(hipMemcpyAsync(parts_out, sc->d_parts, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    ctx->assign_ms_pending = true;
     return 0;
 }
 
@@ -416,6 +426,7 @@ int wgs_assign(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int mode
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t cells = (size_t)b->n * a->K;
     ctx->last_assign_ms = 0.0f;
+    ctx->assign_ms_pending = false;
     std::vector<double> h(cells);
     // one launch over all population slabs, reproducible sums (wgs_score_sums)
     wgs_score *sc = nullptr;
@@ -442,6 +453,7 @@ int wgs_debug_assign_parts_f64(wgs_beagle *b, wgs_afset *a, const float *const *
     const int64_t n = b->n;
     const size_t cells = (size_t)n * P * K;
     ctx->last_assign_ms = 0.0f;
+    ctx->assign_ms_pending = false;
     std::vector<double> h(cells);
     // one grow-only workspace: [cells doubles | K shared pointers | n*K per-individual pointers]
     const size_t off_acol = (sizeof(double) * cells + 255) & ~(size_t)255;
@@ -480,7 +492,7 @@ int wgs_debug_assign_parts_f64(wgs_beagle *b, wgs_afset *a, const float *const *
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipMemcpyAsync(h.data(), d_out, sizeof(double) * cells, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    (void)hipEventElapsedTime(&ctx->last_assign_ms, ctx->ev0, ctx->ev1);
+    ctx->assign_ms_pending = true;
     for (size_t c = 0; c < cells; ++c) parts[c] += h[c];
     for (int64_t i = 0; i < n; ++i)
         for (int k = 0; k < K; ++k) {
@@ -570,6 +582,7 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
             int32_t it = 0, cb = 0;
             double sec = 0.0, sweep_ms = 0.0;
             wgs_em_fit_stats(em, &it, &cb, &sec, &sweep_ms);
+            if (sweep_ms < 0) sweep_ms = 0.0;                // (not known while the codes' memory is being allocated)
             g_loo_stats[0] += wall_s() - t_phase;
             g_loo_stats[3] += sweep_ms;
             g_loo_stats[4] += 1.0;

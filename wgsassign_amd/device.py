@@ -194,6 +194,13 @@ class DeviceBeagle:
         """1: the class codes exist, 0: nothing has asked for them yet, -1: not worth coding.  Builds nothing."""
         return int(_lib.load().wgs_beagle_codes_state(self._h))
 
+    def codes_wait(self):
+        """Wait for the codes' device memory if its allocation is under way on the library's helper thread (sweeps do not wait for it:
+        they run over the float32 slabs meanwhile).  Returns the milliseconds that hipMalloc took (0.0: none was in flight)."""
+        ms = ctypes.c_double()
+        check(_lib.load().wgs_beagle_codes_wait(self._h, ctypes.byref(ms)))
+        return ms.value
+
     def codes_info(self):
         """Class codes of the matrix (built on first use; csrc/common.h: wgs_codes, csrc/codes.hip): what they hold and what
         they cost.  `build_ms` is the whole build (sample pass, one allocation, the encode pass); `rich_snp_share` the SNPs
