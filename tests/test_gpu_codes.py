@@ -386,7 +386,7 @@ def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
 
 def test_row_ranges_and_leave_one_out_are_unchanged(dev, oracle):
     """A scoring object restricted to a range of individuals goes through the codes too; leave-one-out (per-individual
-    columns, several fits per slab) keeps the direct kernels -- both give the bits they gave without codes."""
+    columns, several fits per slab: populations of 15 stay with the float32 group kernel) -- both give the bits they gave without codes."""
     from wgsassign_amd import glassy
     m, n, K = 30_000, 45, 3
     L, IDs = synth.make_beagle(m, n, K, seed=6)
@@ -409,6 +409,43 @@ def test_row_ranges_and_leave_one_out_are_unchanged(dev, oracle):
     assert same_nan(res[True, "loo"][0], res[False, "loo"][0]) and same(res[True, "loo"][1], res[False, "loo"][1])
     afs.close()
     b.close()
+
+
+@pytest.mark.parametrize("rows,min_cols,n,P", [(None, None, 120, 2), ("8", None, 120, 1), (None, "1", 36, 3), (None, None, 200, 1)])
+def test_leave_one_out_through_the_codes(dev, oracle, rows, min_cols, n, P, monkeypatch):
+    """Leave-one-out re-fits (glassy.py:65-85: every individual's population without it) through the class codes: em_coded_group_kernel
+    walks the fits of a slab one after the other over a tile whose dictionary rows stay in registers.  Same iterations, log-likelihoods
+    and partition sums as the float32 group kernel (WGSASSIGN_LOO_CODES=0) and as the oracle; with an 8-row table most tiles take the
+    kernel's term-by-term path; with the population limit lowered, populations of 12."""
+    from wgsassign_amd import glassy
+    if rows:
+        monkeypatch.setenv("WGSASSIGN_EM_TABLE_ROWS", rows)
+    if min_cols:
+        monkeypatch.setenv("WGSASSIGN_EM_CODES_MIN", min_cols)
+    m, K = 12_000, 3
+    L, IDs = synth.make_beagle(m, n, K, seed=31 + n)
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    with quiet():
+        _, af, _, _ = oracle.fit_reference_af(L, IDs, t=4)
+    res = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("WGSASSIGN_LOO_CODES", on)
+        b = dev.DeviceBeagle.from_host(L, group_of, K)
+        tm = {}
+        a = af.copy()
+        with quiet():
+            ll, parts = glassy.loo_device(b, b, a, group_of, 200, 1e-4, P, verbose=False, timings=tm, need_parts=True)
+        res[on] = (ll, parts, tm["iters"].copy(), a)
+        assert b.codes_state() == (1 if on == "1" else 0)          # (only the re-fits' sweeps ask for codes here: per-individual columns are scored directly)
+        if on == "1" and rows:
+            assert b.codes_info()["em_direct_tile_share"] > 0.5
+        b.close()
+    assert same_nan(res["1"][0], res["0"][0]) and same(res["1"][1], res["0"][1]) and list(res["1"][2]) == list(res["0"][2]) and same(res["1"][3], res["0"][3])
+    if n <= 120:
+        with quiet():
+            ll_o, parts_o = oracle.loo(L, af.copy(), IDs, 4, 200, 1e-4, None, P)
+        assert same_nan(res["1"][0].astype(np.float32), ll_o) and same(res["1"][1], parts_o)
 
 
 def test_tiles_richer_than_the_quotient_table_are_swept_directly(dev, oracle, monkeypatch):

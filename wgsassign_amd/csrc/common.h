@@ -263,6 +263,7 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 // the same sweep through the class codes (exact mode; every fit's descriptor carries its slab's local codes; rows = the
 // largest SlabLocal::rows among the fits)
 int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int rows);
+int launch_em_coded_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int rows);
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);
 int ssq_reduce_chunks(void);

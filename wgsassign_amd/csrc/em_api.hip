@@ -133,7 +133,18 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
  * A first estimate assumes fixed-error low-depth data (no sample pass: small matrices are turned away for free); when that says yes
  * the sample pass (~0.4 ms, once per matrix) supplies the matrix's own classes per slab and table size.
  * WGSASSIGN_EM_CODES_SWEEPS=k replaces the model by "k or more sweeps ahead" (0: always; tests). */
-static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, int fewest_cols, int sweeps_ahead)
+// Share of a leave-one-out sweep's time the codes save (<= 0: none).  Such batches (many fits per slab) are bound by instruction
+// issue, not by memory: em_sweep_group_kernel spends 25.9 vector instructions per (fit, SNP, individual) term; through the codes
+// (em_coded_group_kernel) a (fit, SNP) costs one quotient (29 instructions) per table row of its tile -- the richest SNP of the
+// tile, ~1.7 x the mean classes per (slab, SNP) -- 5.5 per individual and ~190 around them (measured at 2M x 500, K=8, 62
+// individuals per slab and 12.7 classes: 469 ms of sweeps against 645).
+static double loo_codes_saving(const wgs_codes_plan *P, double cols)
+{
+    if (!P || P->state <= 0 || P->lrows == 0) return 0.0;
+    return 1.0 - (1.7 * P->mean_l * 29.0 + 5.5 * cols + 190.0) / (25.9 * std::max(1.0, cols));
+}
+
+static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, int fewest_cols, int sweeps_ahead, bool shared)
 {
     wgs_beagle *b = em->b;
     if (const char *sw = getenv("WGSASSIGN_EM_CODES_SWEEPS")) return sweeps_ahead >= atoi(sw) || b->direct_sweeps >= 3;
@@ -145,6 +156,14 @@ static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, in
         cols += (double)b->slabs[em->group[j]].ncols;
     }
     cols /= (double)std::max<size_t>(1, order.size());
+    if (shared) {
+        constexpr double LOO_MS_PER_TERM = 7.6e-10;          // em_sweep_group_kernel, per (fit, SNP, individual)
+        const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
+        if (!P || P->state <= 0 || P->lrows == 0) return false;
+        const double direct_ms = swept / 8.0 * LOO_MS_PER_TERM;
+        const double saves_loo = std::max(0.0, loo_codes_saving(P, cols));
+        return ahead * saves_loo * direct_ms > wgs_codes_build_ms_estimate(b, P->slots);
+    }
     const double direct_ms = swept / 6.0e9;
     auto saves = [&](double classes_per_slab) { return std::max(0.0, std::min(0.6, 0.92 - 2.72 * classes_per_slab / std::max(1.0, cols))); };
     // fixed-error 2x data shows ~4.6 * cols^0.25 classes per (slab, SNP): 14.7 at 100, 12.7 at 62, 10.5 at 40
@@ -176,19 +195,25 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     }
     if (shared) std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return em->group[x] < em->group[y]; });
     // exact mode on a coded matrix: the sweep through the class codes (same frequencies, bit for bit)
-    // -- for fits of different slabs; leave-one-out batches (several fits per slab) stay with em_sweep_group_kernel,
-    // whose shared loads and conversions serve them better than a quotient table per fit
+    // -- leave-one-out batches (several fits per slab) where the table saves instructions (loo_codes_saving), else they stay with
+    // em_sweep_group_kernel and its shared loads and conversions
     // -- and small populations stay with em_sweep_kernel too: below ~28 individuals the table costs more than it saves
     // (measured: 20 individuals 0.98x, 30 1.16x, 36 1.26x, 62 1.64x, 100 2.1x)
     // -- and the codes are BUILT for it only when the sweeps still to come repay the encode pass (em_codes_pay below).
     // Codes that exist already (a scoring sweep built them, or wgs_beagle_codes_prepare) are used at once.
-    bool worth = em->mode == WGS_MODE_EXACT && !shared;
+    const bool loo_codes = !(getenv("WGSASSIGN_LOO_CODES") && atoi(getenv("WGSASSIGN_LOO_CODES")) == 0);
+    bool worth = em->mode == WGS_MODE_EXACT && (!shared || loo_codes);
     const char *min_env = getenv("WGSASSIGN_EM_CODES_MIN");    // tests lower it to run small populations through the codes
     const int min_cols = min_env ? atoi(min_env) : 28;
     int fewest = INT32_MAX;
     for (int j : order) fewest = std::min(fewest, (int)em->b->slabs[em->group[j]].ncols);
     worth = worth && fewest >= min_cols;
-    const bool build = worth && em_codes_pay(em, order, fewest, sweeps_ahead);
+    if (worth && shared && !getenv("WGSASSIGN_EM_CODES_SWEEPS")) {      // (also when the codes exist already: a scoring sweep may have built them)
+        double cols = 0.0;
+        for (int j : order) cols += (double)em->b->slabs[em->group[j]].ncols;
+        worth = loo_codes_saving(wgs_beagle_codes_plan(em->b), cols / (double)order.size()) > 0.03;
+    }
+    const bool build = worth && em_codes_pay(em, order, fewest, sweeps_ahead, shared);
     wgs_codes *codes = nullptr;
     {
         WGS_STALL_SCOPE("wgs_beagle_codes from the sweep");
@@ -201,7 +226,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     // left, a place for the second sums); needs a third frequency buffer and a second set of partial sums, allocated on first use
     const bool fuse_on = !(getenv("WGSASSIGN_EM_FUSE") && atoi(getenv("WGSASSIGN_EM_FUSE")) < 2);   // (read at every sweep: tests compare both)
     bool fusing = false;
-    if (codes && may_fuse && ssq_base_b && fuse_on) {
+    if (codes && may_fuse && ssq_base_b && fuse_on && !shared) {    // (leave-one-out batches are bound by arithmetic: a second iteration that turns out unneeded is not free there)
         for (int j : order) fusing = fusing || (*may_fuse)[j] >= 2;
         if (fusing && !em->fbuf[2]) {
             const size_t fbytes = (size_t)em->n_fits * em->b->m * sizeof(float);
@@ -248,8 +273,10 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     // H (pinned) stays untouched until the caller has waited for this sweep
     HIP_TRY(hipMemcpyAsync(D, H, sizeof(FitDesc) * order.size(), hipMemcpyHostToDevice, ctx->stream));
     int32_t n_groups = 0;
-    if (shared && !codes) {
-        const int fg = em_fits_per_group();
+    if (shared) {
+        // groups of fits of one slab: four per wavefront for the float32 kernel (shared loads and conversions); through the codes a
+        // wavefront walks up to 16 fits one after the other (the dictionary rows stay in registers)
+        const int fg = codes ? 16 : em_fits_per_group();
         for (size_t i = 0; i < order.size();) {
             size_t k = i + 1;
             while (k < order.size() && (int)(k - i) < fg && em->group[order[k]] == em->group[order[i]]) ++k;
@@ -263,7 +290,14 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     if (ev0) HIP_TRY(hipEventRecord(ev0, ctx->stream));
     const int64_t per_unit = ((ntiles + 3) / 4 + 7) / 8 * 8 + 8;       // workgroups per fit / per group: slices stay below 2^31
     const size_t max_units = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_unit);
-    if (codes) {
+    if (codes && shared) {
+        const int64_t per_group = (ntiles + 7) / 8 * 8 + 8;
+        const size_t max_groups = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_group);
+        for (size_t off = 0; off < (size_t)n_groups; off += max_groups) {
+            const int cnt = (int)std::min<size_t>(max_groups, (size_t)n_groups - off);
+            if (launch_em_coded_groups(ctx, D, Dg + 2 * off, cnt, em->b->m, coded_rows_max)) return 1;
+        }
+    } else if (codes) {
         const int64_t per_fit = (ntiles + 7) / 8 * 8 + 8;            // at least one tile per workgroup
         const size_t max_fits = (size_t)std::max<int64_t>(1, ((1ll << 31) - 1) / per_fit);
         for (size_t off = 0; off < order.size(); off += max_fits) {

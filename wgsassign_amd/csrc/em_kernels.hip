@@ -359,6 +359,87 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDes
 // f_new2) and both per-tile partial sums (ssq_part, ssq_part2); the decision kernel looks at the first sum, then at the second
 // (em_decide_kernel), and the host takes the vector that belongs to the iteration that stopped (wgs_em_fit).  The dictionary --
 // two thirds of the sweep's traffic -- is read once per two iterations; the arithmetic of each iteration is unchanged.
+// One EM iteration of one (fit, tile) through the slab's class table: r = the tile's dictionary rows (registers), q = this wavefront's
+// quotient table in LDS (slot of rank k: q[k * 64]), src = the tile's code words.  Returns the serial float32 sum over the slab's
+// individuals (all but `skip`), emMAF_cy.pyx:19-22.
+template <int U, int ILP, int ROWS>
+__device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], double *q, int nrows, const uint32_t *src, int nquads, int ncols, int skip, float f_old)
+{
+    const int last = nquads - 1;
+    SnpState st;
+    st.fd = (double)f_old;
+    st.omf = 1.0 - st.fd;
+    st.fd2 = 2.0 * st.fd;
+    uint32_t cur[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
+    {
+        auto quotient = [&](double raw) {
+            const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
+                        g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
+            const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
+            const float p0 = (float)((g0d * st.omf) * st.omf);
+            const float p1 = (float)((g1d * st.fd2) * st.omf);
+            const float p2 = (float)((g2d * st.fd) * st.fd);
+            const float ssum = (p0 + p1) + p2;
+            const double num = __builtin_fma(2.0, (double)p2, (double)p1);
+            return div_exact<true>(num, (double)ssum);
+        };
+        // (lanes whose SNP has fewer classes compute on whatever the unwritten rows hold: never looked up)
+#pragma unroll
+        for (int r0 = 0; r0 < ROWS; r0 += ILP) {
+            if (r0 < nrows) {                                // wave-uniform
+                double qv[ILP];
+#pragma unroll
+                for (int x = 0; x < ILP; ++x) {
+                    // (opaque to the compiler: else it hoists the three float -> double forms of every row out of the iteration
+                    // loop -- six registers per row instead of two, 202 VGPRs and two wavefronts per SIMD instead of four)
+                    double raw = r[r0 + x];
+                    asm volatile("" : "+v"(raw));
+                    qv[x] = quotient(raw);
+                }
+#pragma unroll
+                for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
+            }
+        }
+    }
+    // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
+    // table before the chain of that buffer starts
+    float tmp = 0.0f;
+    for (int q0 = 0; q0 < nquads; q0 += U) {
+        if (q0 + U < nquads) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int qq = q0 + U + u;
+                nxt[u] = src[(qq < last ? qq : last) * 64];
+            }
+        }
+        double qv[U][4];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int h = 0; h < 4; ++h) qv[u][h] = q[((cur[u] >> (8 * h)) & 255u) * 64];
+        const bool plain = 4 * (q0 + U) <= ncols && (skip < 4 * q0 || skip >= 4 * (q0 + U));
+        if (plain) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const int col = 4 * (q0 + u) + h;
+                    if (col < ncols && col != skip) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    }
+    return tmp;
+}
+
 template <int U, int ILP, int ROWS>
 __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict__ fits, int n_fits, int64_t m)
 {
@@ -396,7 +477,6 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
     // the first code words: in flight during phase 1
     const int nquads = fd.nquads;
     const uint32_t *src = fd.lcodes + tile * nquads * 64 + lane;
-    const int last = nquads - 1;
     // rows of this tile: the most classes one of its 64 SNPs has in this slab (255: a SNP the encoder gave up on)
     int nrows;
     {
@@ -443,79 +523,104 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
         }
     }
     for (int it = 0; it < n_iter; ++it) {
-        SnpState st;
-        st.fd = (double)f_old;
-        st.omf = 1.0 - st.fd;
-        st.fd2 = 2.0 * st.fd;
-        uint32_t cur[U], nxt[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];     // (the second iteration finds them in cache)
-        {
-            auto quotient = [&](double raw) {
-                const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
-                            g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
-                const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
-                const float p0 = (float)((g0d * st.omf) * st.omf);
-                const float p1 = (float)((g1d * st.fd2) * st.omf);
-                const float p2 = (float)((g2d * st.fd) * st.fd);
-                const float ssum = (p0 + p1) + p2;
-                const double num = __builtin_fma(2.0, (double)p2, (double)p1);
-                return div_exact<true>(num, (double)ssum);
-            };
-            // (lanes whose SNP has fewer classes compute on whatever the unwritten rows hold: never looked up)
-#pragma unroll
-            for (int r0 = 0; r0 < ROWS; r0 += ILP) {
-                if (r0 < nrows) {                                // wave-uniform
-                    double qv[ILP];
-#pragma unroll
-                    for (int x = 0; x < ILP; ++x) {
-                        // (opaque to the compiler: else it hoists the three float -> double forms of every row out of the iteration
-                        // loop -- six registers per row instead of two, 202 VGPRs and two wavefronts per SIMD instead of four)
-                        double raw = r[r0 + x];
-                        asm volatile("" : "+v"(raw));
-                        qv[x] = quotient(raw);
-                    }
-#pragma unroll
-                    for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
-                }
-            }
-        }
-        // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
-        // table before the chain of that buffer starts
-        float tmp = 0.0f;
-        for (int q0 = 0; q0 < nquads; q0 += U) {
-            if (q0 + U < nquads) {
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int qq = q0 + U + u;
-                    nxt[u] = src[(qq < last ? qq : last) * 64];
-                }
-            }
-            double qv[U][4];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int h = 0; h < 4; ++h) qv[u][h] = q[((cur[u] >> (8 * h)) & 255u) * 64];
-            const bool plain = 4 * (q0 + U) <= fd.ncols && (fd.skip < 4 * q0 || fd.skip >= 4 * (q0 + U));
-            if (plain) {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
-            } else {
-#pragma unroll
-                for (int u = 0; u < U; ++u)
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const int col = 4 * (q0 + u) + h;
-                        if (col < fd.ncols && col != fd.skip) tmp = (float)__builtin_fma(0.5, qv[u][h], (double)tmp);
-                    }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        }
+        const float tmp = coded_iteration<U, ILP, ROWS>(r, q, nrows, src, nquads, fd.ncols, fd.skip, f_old);     // (the second iteration finds the code words in cache)
         f_old = finish(tmp, it);
         // (the table of the next iteration is written by the same lanes that read this one's: program order suffices)
+    }
+}
+
+// Leave-one-out batches through the codes: groups[g] = (first descriptor, count) into `fits`, all of one slab (as for
+// em_sweep_group_kernel).  One wavefront takes a tile and walks the group's fits one after the other: the tile's dictionary rows
+// are read once and stay in registers, the code words come from cache, and the chain of dependent requests a (fit, tile) pair
+// starts with (descriptor -> state, table rows, frequencies, dictionary) is paid once per group instead of once per fit -- the
+// re-fits are bound by instruction issue, and with one pair per wavefront (em_coded_kernel) a quarter of the time went to those
+// waits (measured at 2M x 500, K=8: 526 ms of sweeps against 657 ms for the float32 group kernel; this kernel: see DESIGN 7).
+// The next fit's frequencies are requested before the current fit's work.  One iteration per sweep (no fused second iteration: an
+// iteration that turns out unneeded costs its full arithmetic here).
+template <int U, int ILP, int ROWS>
+__global__ __launch_bounds__(64) void em_coded_group_kernel(const FitDesc *__restrict__ fits, const int2 *__restrict__ groups, int n_groups, int64_t m)
+{
+    extern __shared__ __align__(16) double qtab_all[];
+    const unsigned xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const int grp = (int)(j % (unsigned)n_groups);
+    const int64_t tile = (int64_t)(j / (unsigned)n_groups) * 8 + xcd;
+    const int lane = threadIdx.x;
+    const int64_t row0 = tile * 64;
+    if (row0 >= m) return;                       // wave-uniform; no barriers below
+    const int2 gd = groups[grp];
+    const FitDesc *gf = fits + gd.x;
+    double *q = qtab_all + lane;
+    const int64_t my_row = row0 + lane;
+    const int64_t my_row_c = my_row < m ? my_row : m - 1;
+    // what the fits of a group share: the slab
+    const int nquads = gf[0].nquads, ncols = gf[0].ncols, lrows = gf[0].lrows;
+    const uint32_t *src = gf[0].lcodes + tile * nquads * 64 + lane;
+    int nrows;
+    {
+        unsigned mx = 0;
+#pragma unroll
+        for (int x = 0; x < WGS_TILE_ROWS_BYTES / 8; ++x) {
+            const unsigned long long w = reinterpret_cast<const unsigned long long *>(gf[0].tile_rows + tile * WGS_TILE_ROWS_BYTES)[x];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) mx = max(mx, (unsigned)((w >> (8 * k)) & 255u));
+        }
+        nrows = (int)__builtin_amdgcn_readfirstlane((int)mx);
+    }
+    auto finish = [&](const FitDesc *fd, float tmp, float f_old) {
+        const float f_new = tmp / (float)fd->n_eff;          // emMAF_cy.pyx:23 (float32 divide)
+        double sq = 0.0;
+        if (my_row < m) {
+            ((gf32_wptr)fd->f_new)[my_row] = f_new;
+            const float d = f_new - f_old;                    // emMAF_cy.pyx:31, float32
+            sq = (double)(d * d);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sq += __shfl_down(sq, off, 64);
+        if (lane == 0) fd->ssq_part[tile] = sq;
+    };
+    if (nrows > ROWS || nrows > lrows) {
+        // a tile richer than the table: every fit of the group from the float32 slab, term by term
+        const int npairs = gf[0].npairs;
+        gf4_ptr gl = (gf4_ptr)gf[0].slab + tile * npairs * 64 + lane;
+        for (int f = 0; f < gd.y; ++f) {
+            const FitDesc *fd = gf + f;
+            if (fd->state && *fd->state != EM_ACTIVE) continue;
+            const float f_old = ((gf32_ptr)fd->f_old)[my_row_c];
+            const int skip = fd->skip;
+            SnpState st;
+            st.fd = (double)f_old;
+            st.omf = 1.0 - st.fd;
+            st.fd2 = 2.0 * st.fd;
+            float tmp = 0.0f;
+            bool ok = true;
+            for (int p = 0; p < npairs; ++p) {
+                const f4 v = gl[(int64_t)p * 64];
+                if (2 * p < ncols && 2 * p != skip) term_exact<true>(v.x, v.y, st, tmp, ok);
+                if (2 * p + 1 < ncols && 2 * p + 1 != skip) term_exact<true>(v.z, v.w, st, tmp, ok);
+            }
+            finish(fd, tmp, f_old);
+        }
+        return;
+    }
+    double r[ROWS];
+    {
+        const double *drow = reinterpret_cast<const double *>(gf[0].ldict) + tile * lrows * 64 + lane;
+#pragma unroll
+        for (int g4 = 0; g4 < ROWS / 4; ++g4) {
+            if (4 * g4 < nrows) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) r[4 * g4 + u] = drow[(int64_t)(4 * g4 + u) * 64];
+            }
+        }
+    }
+    float f_next = ((gf32_ptr)gf[0].f_old)[my_row_c];
+    for (int f = 0; f < gd.y; ++f) {
+        const FitDesc *fd = gf + f;
+        const float f_old = f_next;
+        if (f + 1 < gd.y) f_next = ((gf32_ptr)fd[1].f_old)[my_row_c];       // in flight during this fit's arithmetic
+        if (fd->state && *fd->state != EM_ACTIVE) continue;                  // decided on the device: skip (wave-uniform)
+        const float tmp = coded_iteration<U, ILP, ROWS>(r, q, nrows, src, nquads, ncols, fd->skip, f_old);
+        finish(fd, tmp, f_old);
     }
 }
 
@@ -1056,6 +1161,33 @@ int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
         default: WGS_EMC(64); break;
     }
 #undef WGS_EMC
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// d_groups: n_groups (first, count) pairs into d_descs, every group's fits on one slab (leave-one-out batches), through the codes
+int launch_em_coded_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int rows)
+{
+    if (n_groups <= 0 || m <= 0) return 0;
+    WGS_REQUIRE(rows >= 8 && rows <= 64 && rows % 8 == 0, "em sweep: %d table rows", rows);
+    const int64_t tiles = (m + 63) / 64;
+    const int64_t tgroups = (tiles + 7) / 8 * 8;
+    const int64_t blocks = tgroups * n_groups;
+    WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
+    const int2 *g = reinterpret_cast<const int2 *>(d_groups);
+    const size_t lds = (size_t)rows * 512;
+#define WGS_EMG(RW) hipLaunchKernelGGL((em_coded_group_kernel<4, 2, RW>), dim3((unsigned)blocks), dim3(64), lds, ctx->stream, d_descs, g, n_groups, m)
+    switch (rows) {
+        case 8: WGS_EMG(8); break;
+        case 16: WGS_EMG(16); break;
+        case 24: WGS_EMG(24); break;
+        case 32: WGS_EMG(32); break;
+        case 40: WGS_EMG(40); break;
+        case 48: WGS_EMG(48); break;
+        case 56: WGS_EMG(56); break;
+        default: WGS_EMG(64); break;
+    }
+#undef WGS_EMG
     HIP_TRY(hipGetLastError());
     return 0;
 }
