@@ -26,7 +26,10 @@ def main():
     af = np.stack([(em.clamp(k, int(counts[k])), em.get_f(k))[1] for k in range(K)], axis=1)
     em.close()
     res, outs = {}, {}
-    for leg, env in (("float32", "0"), ("coded_cold", "1"), ("coded_warm", "1"), ("float32_again", "0")):
+    legs = (("float32", "0"), ("coded_cold", "1"), ("coded_warm", "1"), ("float32_again", "0"))
+    if os.environ.get("PROBE_LOO_LEGS"):                     # (profiling: e.g. PROBE_LOO_LEGS=coded_warm,float32_again)
+        legs = tuple(x for x in legs if x[0] in os.environ["PROBE_LOO_LEGS"].split(","))
+    for leg, env in legs:
         os.environ["WGSASSIGN_LOO_CODES"] = env
         tm = {}
         t0 = time.perf_counter()
@@ -36,7 +39,7 @@ def main():
         res[leg] = {"seconds": round(dt, 4), "em_seconds": round(tm.get("em_seconds", 0.0), 4), "em_sweep_kernels_ms": round(tm.get("em_sweep_kernel_ms", 0.0), 2),
                     "score_seconds": round(tm.get("score_seconds", 0.0), 4), "iterations_min_max": [int(it.min()), int(it.max())], "codes_state": b.codes_state()}
         outs[leg] = (ll.tobytes(), None if parts is None else parts.tobytes(), it.tobytes())
-    res["identical"] = bool(outs["float32"] == outs["coded_cold"] == outs["coded_warm"] == outs["float32_again"])
+    res["identical"] = bool(len(set(outs.values())) == 1)
     if b.codes_state() == 1:
         info = b.codes_info()
         res["codes"] = {k: info[k] for k in ("build_ms", "em_table_rows", "em_direct_tile_share", "sample_mean_classes_per_slab", "mean_classes")}

@@ -63,7 +63,6 @@ struct EncodeArgs {
     int32_t batch, batch_cap;      // the coded scoring sweep tables `batch` (16, 8 or 4) consecutive SNPs at a time: most classes such an
                                    // aligned group may sum to (its LDS table)
     int64_t unit_stride;           // sample pass: work unit = blockIdx.x * unit_stride
-    int32_t dbg;                   // experiments (WGS_ENC_DBG)
     uint8_t *sample;               // sample pass: [unit][slab, then all][SNP of the unit] classes found (0: beyond the last SNP, 255: overflow)
     unsigned long long *stats;     // see EncStat
     uint4 *wave_stats;             // full pass: two records per work unit (sum of ncls, rich SNPs, most classes, most rows of a batch | rounds, buffers)
@@ -186,13 +185,6 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
                     slot[4 * u + h] = hash32(g0, g1) >> HSHIFT;
                 }
             }
-            if (A.dbg & 32) {                              // (experiment: the loads alone)
-                unsigned acc = 0;
-#pragma unroll
-                for (int i = 0; i < NL; ++i) acc ^= slot[i];
-                if (acc == 0x7fffffffu) flag[0] = 1;
-                continue;
-            }
             bool pend[NL];                                 // lane masks in scalar registers
             // a buffer whose 4 x ENC_UQ x COLS individuals all exist, in a wavefront without a rich SNP: no per-lookup predicates
             const bool plain = 4 * (qb + COLS * ENC_UQ) <= nc && !__any(rich);
@@ -284,7 +276,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
             const int wmax = wave_max(rich ? 255 : nloc);
             // one byte per group of WGS_ENC_MIN_SNPS SNPs of the tile (this wave's share of them): plain stores, the EM sweep takes the largest
             if (lane < SNPS / WGS_ENC_MIN_SNPS) ((gu8_ptr)sc.tile_rows)[tile * WGS_TILE_ROWS_BYTES + sub * (SNPS / WGS_ENC_MIN_SNPS) + lane] = (uint8_t)wmax;
-            if (A.lrows > 0 && wmax <= A.lrows && !(A.dbg & 8)) {          // wave-uniform: this wave's SNPs fit the EM sweep's table
+            if (A.lrows > 0 && wmax <= A.lrows) {          // wave-uniform: this wave's SNPs fit the EM sweep's table
                 int r = pre;
 #pragma unroll 8
                 for (int k = 0; k < SCAN; ++k) {
@@ -298,7 +290,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // dictionary rows: as many as the richest of this wave's SNPs has (the EM sweep requests rows eight at a time and never
                 // looks at a row beyond a SNP's own classes: what it finds in the unwritten ones does not matter)
-                const int rows_w = (A.dbg & 2) ? min(A.lrows, (wmax + 7) & ~7) : wmax;
+                const int rows_w = wmax;
                 gu64_ptr ld = (gu64_ptr)sc.ldict + (tile * A.lrows) * 64 + ls;
                 for (int r0 = col; r0 < rows_w; r0 += COLS) {
                     unsigned long long e = 0;
@@ -400,7 +392,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
     for (int r0 = col; r0 < wmax; r0 += COLS)
         if (r0 < eff) dd[(int64_t)r0 * 64] = keys[(unsigned)order[r0 * SNPS + s] * SNPS + s];
     // every slab's code words: slot numbers -> class ids, in place
-    for (int g = 0; g < ((A.dbg & 16) ? 0 : A.n_slabs); ++g) {
+    for (int g = 0; g < A.n_slabs; ++g) {
         const SlabCodes sc = A.slabs[g];
         const int nquads = sc.nquads;
         gu32_ptr cw = (gu32_ptr)sc.codes + tile * nquads * 64 + ls;
@@ -484,7 +476,6 @@ static EncodeArgs encode_args(wgs_beagle *b, wgs_codes *c, const int32_t *d_ncol
     A.batch_cap = WGS_BATCH_ROWS_CAP;
     A.unit_stride = 1;
     A.sample = nullptr;
-    A.dbg = getenv("WGS_ENC_DBG") ? atoi(getenv("WGS_ENC_DBG")) : 0;
     A.stats = d_stats;
     A.wave_stats = nullptr;
     return A;
