@@ -174,7 +174,8 @@ typedef struct wgs_comm wgs_comm;
 int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_comm *comm, double guard_floor,
                int32_t *iters_out);
 /* Iterations enqueued / batched exact-chain resolutions / wall seconds of the last wgs_em_fit, and the summed
- * duration in ms of its sweep kernels (HIP events recorded on the context's stream around every sweep). */
+ * duration in ms of its sweep kernels (HIP events recorded on the context's stream around every sweep; read by this
+ * call, not inside the fit).  *sweep_ms = -1 while the class codes' memory is being allocated (wgs_beagle_codes_wait). */
 int wgs_em_fit_stats(wgs_em *em, int32_t *iterations, int32_t *chain_batches, double *seconds, double *sweep_ms);
 /* Clamp fit j's frequencies to [lo, hi] the way WGSassign.py:236-240 does (float32 compares,
  * NaN untouched). */
@@ -382,7 +383,8 @@ int wgs_ingest_stats(wgs_ingest *g, double *stats);
 /* Blocks of 4096 elements that fell back to the serial loop in the last wgs_em_rmse_chain of an EM batch (diagnostics). */
 int wgs_em_last_chain_serial_blocks(wgs_em *em);
 
-/* Kernel time (HIP events on the context's stream) of the context's last wgs_assign / wgs_score_* call. */
+/* Kernel time (HIP events on the context's stream) of the context's last wgs_assign / wgs_score_* call; -1 while the class
+ * codes' memory is being allocated (wgs_beagle_codes_wait): ask again afterwards. */
 int wgs_assign_last_ms(wgs_ctx *ctx, float *ms);
 
 #ifdef __cplusplus

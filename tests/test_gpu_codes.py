@@ -320,6 +320,52 @@ def test_sweeps_do_not_wait_for_the_codes_memory(dev, oracle, wait_ms, monkeypat
     assert it1 == [int(x) for x in it_o] and same(af1, af_o)
 
 
+def test_a_slow_allocation_is_not_waited_for(dev, oracle, monkeypatch):
+    """WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS makes the helper thread's hipMalloc take 400 ms (the driver takes seconds for VRAM an earlier
+    process used).  With no waiting allowed the fit and the scoring call run over the float32 slabs and return long before the memory;
+    kernel times read -1 meanwhile (hipEventElapsedTime would wait for the allocation) and are there after codes_wait(); the next fit
+    builds the codes.  Same results throughout."""
+    import time
+    monkeypatch.setenv("WGSASSIGN_CODES_ALLOC_WAIT_MS", "0")
+    monkeypatch.setenv("WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS", "400")
+    m, n, K = 50_000, 120, 3
+    L, IDs = synth.make_beagle(m, n, K, seed=45)
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    with quiet():
+        _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+    b = dev.DeviceBeagle.from_host(L, group_of, K)
+    em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+    t0 = time.perf_counter()
+    it1 = em.run(200, 1e-4)
+    dt = time.perf_counter() - t0
+    assert dt < 0.3 and b.codes_state() == 0                 # did not wait; nothing built
+    assert em.fit_stats()[3] == -1.0                         # sweep kernel time: not readable yet
+    afs = dev.AFSet(b.m, K, ctx=b.ctx)
+    for k in range(K):
+        em.clamp(k, int(counts[k]))
+        afs.set_column_from_em(k, em, k)
+    out1, _ = dev.assign(b, afs)
+    assert dev.assign.last_ms == -1.0 and b.codes_state() == 0
+    waited = b.codes_wait()
+    assert waited >= 350.0 and em.fit_stats()[3] > 0.0 and dev.last_assign_ms(b.ctx) > 0.0
+    af1 = np.stack([em.get_f(k) for k in range(K)], axis=1)
+    em.close()
+    em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
+    it2 = em.run(200, 1e-4)
+    assert b.codes_state() == 1 and em.fit_stats()[3] > 0.0  # the memory is there: built by the first sweep
+    for k in range(K):
+        em.clamp(k, int(counts[k]))
+    af2 = np.stack([em.get_f(k) for k in range(K)], axis=1)
+    out2, _ = dev.assign(b, afs)
+    assert dev.assign.last_ms > 0.0
+    em.close()
+    afs.close()
+    b.close()
+    assert list(it1) == list(it2) == [int(x) for x in it_o] and same(af1, af_o) and same(af2, af_o) and same_nan(out1, out2)
+
+
 def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
     """The cost model of csrc/api.hip: em_codes_pay (a 6.4 GB device-generated matrix, 100 individuals per population: the
     encode pass costs about four direct sweeps, a coded sweep saves half of one) -- a fit with three iterations ahead sweeps the

@@ -60,6 +60,10 @@ def build(force=False, verbose=False):
     if not os.path.exists(id_header) or open(id_header).read() != text:
         with open(id_header, "w") as fh:
             fh.write(text)
+    # objects built with other flags (WGSASSIGN_BUILD_DEFINES) are stale whatever their time stamps say
+    stamp = os.path.join(CSRC, ".build_flags")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(FLAGS):
+        force = True
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -85,6 +89,8 @@ def build(force=False, verbose=False):
                 print(warn)
     if force or jobs or _stale(LIB, objs):
         run([cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread", "-ldl"])
+    with open(stamp, "w") as fh:
+        fh.write(" ".join(FLAGS))
     return LIB
 
 

@@ -52,8 +52,11 @@ static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double gr
         const int dev = b->ctx->device;
         wgs_ctx *ctx = b->ctx;
         ++ctx->allocs_in_flight;
-        b->pool_thread = new std::thread([b, dev, ctx] {
+        const char *delay_env = getenv("WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS");      // tests: a slow hipMalloc on demand
+        const int delay_ms = delay_env ? atoi(delay_env) : 0;
+        auto work = [b, dev, ctx, delay_ms] {
             const double t0 = now_s();
+            if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
             void *p = nullptr;
             size_t got = 0;
             if (hipSetDevice(dev) == hipSuccess) {
@@ -67,7 +70,13 @@ static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double gr
             b->pool_alloc_ms = (now_s() - t0) * 1e3;
             --ctx->allocs_in_flight;
             b->pool_state.store(p ? 2 : -1);
-        });
+        };
+        try {
+            b->pool_thread = new std::thread(work);
+        } catch (...) {                                      // no thread to be had: allocate here
+            b->pool_thread = nullptr;
+            work();
+        }
     }
     const double t0 = now_s();
     while (b->pool_state.load() == 1 && (grace_ms < 0 || (now_s() - t0) * 1e3 < grace_ms)) std::this_thread::sleep_for(std::chrono::microseconds(50));

@@ -515,16 +515,21 @@ int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned lon
     A.sample = reinterpret_cast<uint8_t *>(d_ncols + b->n_groups + 64);
     hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_MIN_SNPS, true>), dim3((unsigned)grid), dim3(64), 0, b->ctx->stream, A);
     HIP_TRY(hipGetLastError());
-    std::vector<uint8_t> h(sample_bytes);
-    unsigned long long st[ST_COUNT];
-    HIP_TRY(hipMemcpyAsync(h.data(), A.sample, sample_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
-    HIP_TRY(hipMemcpyAsync(st, d_stats, sizeof(st), hipMemcpyDeviceToHost, b->ctx->stream));
+    // into the context's pinned scratch when it fits (a pageable destination of this size cost 8 ms the first time in a process: the
+    // runtime's staging buffer)
+    std::vector<uint8_t> pageable;
+    uint8_t *hdata = reinterpret_cast<uint8_t *>(b->ctx->pinned);
+    if (sample_bytes > b->ctx->pinned_bytes) {
+        pageable.resize(sample_bytes);
+        hdata = pageable.data();
+    }
+    HIP_TRY(hipMemcpyAsync(hdata, A.sample, sample_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     for (int i = 0; i < 256; ++i) hist_g[i] = hist_l[i] = 0;
     const int G = b->n_groups;
     for (int64_t u = 0; u < grid; ++u) {
         constexpr int W = WGS_ENC_MIN_SNPS;
-        const uint8_t *row = h.data() + (size_t)u * (G + 1) * W;
+        const uint8_t *row = hdata + (size_t)u * (G + 1) * W;
         for (int x = 0; x < W; ++x) {
             if (row[(size_t)G * W + x] == 0) continue;     // beyond the last SNP
             ++hist_g[row[(size_t)G * W + x]];
@@ -532,7 +537,6 @@ int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned lon
                 if (b->slabs[g].ncols) ++hist_l[row[(size_t)g * W + x]];
         }
     }
-    (void)st;
     if (rounds_per_buffer) *rounds_per_buffer = 0.0;
     return 0;
 }
@@ -560,8 +564,8 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
                            (unsigned)(c->lrows > 0 ? c->lrows : 255), d_stats);
         HIP_TRY(hipGetLastError());
     }
-    unsigned long long h[8];
-    HIP_TRY(hipMemcpyAsync(h, d_stats, sizeof(h), hipMemcpyDeviceToHost, b->ctx->stream));
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(b->ctx->pinned);
+    HIP_TRY(hipMemcpyAsync(h, d_stats, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     float ev_ms = 0.0f;
     if (hipEventElapsedTime(&ev_ms, b->ctx->ev0, b->ctx->ev1) == hipSuccess) c->kernel_ms = ev_ms;     // the encode kernel alone (HIP events)
