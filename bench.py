@@ -452,13 +452,17 @@ def coded_em_leg(ctx, device, beagle, em_direct, K, per, n, m, mode, args):
     the same fit over the float32 slabs and the warm fit; the steady-state sweep with ITS algorithmic bytes."""
     def fit(label):
         e = device.EMBatch(beagle, np.arange(K, dtype=np.int32), mode=mode)
+        mal0 = device.malloc_seconds()
         t0 = time.perf_counter()
         iters = e.run(200, 1e-4)
         ctx.sync()
         dt = time.perf_counter() - t0
+        mal = device.malloc_seconds() - mal0
         late_ms = beagle.codes_wait()                        # (kernel times are not readable while the codes' hipMalloc is in flight)
         st = e.fit_stats()
         r = {"seconds": round(dt, 4), "iterations": [int(x) for x in iters], "sweep_kernels_ms": round(st[3], 2)}
+        if mal > 1e-3:                                       # (buffers of the fused sweep, allocated at first use: what the driver took for them)
+            r["of_which_hipMalloc_seconds"] = round(mal, 4)
         if late_ms > 0:
             r["codes_memory_arrived_after_the_fit_hipMalloc_ms"] = round(late_ms, 1)
         return e, r
@@ -520,8 +524,9 @@ FP64_ISSUE_CLOCK_GHZ = 2.4      # MI355X peak engine clock: issue fractions belo
 WAVE_ISSUE_PER_S = 1024 * FP64_ISSUE_CLOCK_GHZ * 1e9 / 4.0       # 1024 SIMDs, 4 cycles per wave-wide FP64-rate instruction
 # VALU wave-instructions per (SNP, individual[, population]) term of the FP64-issue-bound kernels, from the committed PMC
 # passes (profiles/r02_e_loo_final: em_sweep_group_kernel 2.49e10 per sweep of 6.15e10 terms; r02_g_final: score sweep;
-# r03_b_final: coded score sweep 4.26e9 per 1e11 terms)
-INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "score_sweep_kernel<exact>": 41.6, "score_coded_kernel<exact>": 2.7}
+# r03_b_final: coded score sweep 4.26e9 per 1e11 terms; r04_loo: em_coded_group_kernel 1.465e10 per sweep of 6.15e10 terms at 62
+# individuals and 12.7 classes per slab -- a figure of that shape, not a constant of the kernel)
+INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "em_coded_group_kernel": 15.2, "score_sweep_kernel<exact>": 41.6, "score_coded_kernel<exact>": 2.7}
 
 
 def whole_paths(ctx, device, mode_name):
@@ -564,11 +569,13 @@ def whole_paths(ctx, device, mode_name):
                 "em_direct_tile_share": round(info["em_direct_tile_share"], 5), "uncoded_snp_share": info["rich_snp_share"], "hash_slots_per_snp": info["hash_slots"]}
 
     def one_fit(b, K):
+        mal0 = device.malloc_seconds()
         t0 = time.perf_counter()
         em = device.EMBatch(b, np.arange(K, dtype=np.int32))
         iters = em.run(200, 1e-4)
         ctx.sync()
         dt = time.perf_counter() - t0
+        one_fit.malloc_s = device.malloc_seconds() - mal0    # (hipMalloc of VRAM an earlier process used: up to ~100 ms per GB on this driver)
         late_ms = b.codes_wait()                 # (kernel times are not readable while the codes' hipMalloc is in flight on the helper thread)
         return em, dt, iters, em.fit_stats() + (late_ms,)
 
@@ -577,6 +584,7 @@ def whole_paths(ctx, device, mode_name):
         em, dt, iters, st = one_fit(b, K)
         built = b.codes_state() == 1
         alg = float(np.sum([(8.0 * counts[k] + 8.0) * b.m * iters[k] for k in range(K)]))
+        mal_cold = one_fit.malloc_s
         res = {"seconds_cold": round(dt, 4), "iterations": [int(x) for x in iters], "exact_chain_batches": int(st[1]),
                "codes_built_inside_the_cold_fit": built, "cold_sweep_kernels_ms": round(st[3], 3), "class_codes": codes_note(b)}
         if st[-1] > 0 and not built:             # wanted, but the memory came too late for this fit (it did not wait): the next fit builds them
@@ -586,6 +594,7 @@ def whole_paths(ctx, device, mode_name):
             em_b.close()
         em2, dt2, it2, st2 = one_fit(b, K)
         res["seconds_warm"] = round(dt2, 4)
+        slow = {"cold": mal_cold, "warm": one_fit.malloc_s}
         res["warm_sweep_kernel"] = "em_coded_kernel" if b.codes_state() == 1 else "em_sweep_kernel<exact>"
         res["warm_sweep_kernels_ms"] = round(st2[3], 3)
         em2.close()
@@ -593,6 +602,9 @@ def whole_paths(ctx, device, mode_name):
             em3, dt3, it3, st3 = one_fit(b, K)
         res["seconds_float32"] = round(dt3, 4)
         res["float32_sweep_kernels_ms"] = round(st3[3], 3)
+        slow["float32"] = one_fit.malloc_s
+        if max(slow.values()) > 2e-3:            # (each figure above includes the allocation of its fit's buffers)
+            res["of_which_hipMalloc_seconds"] = {k: round(v, 4) for k, v in slow.items()}
         res["bound"] = "hbm"
         res["hbm_frac_of_float32_sweeps"] = round(alg / (st3[3] * 1e-3) / HBM_PEAK, 4) if st3[3] > 0 else None
         res["identical_frequencies"] = bool(list(it3) == list(iters) and em3.get_f(0).tobytes() == em.get_f(0).tobytes())
@@ -645,18 +657,23 @@ def whole_paths(ctx, device, mode_name):
 
     def loo(b, group_of, counts, af, P):
         tm = {}
+        mal0 = device.malloc_seconds()
         t0 = time.perf_counter()
         ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, P, verbose=False, timings=tm, need_parts=P > 1)
         dt = time.perf_counter() - t0
+        mal = device.malloc_seconds() - mal0
         it = tm["iters"]
         terms = float(np.sum([float(it[i]) * (counts[group_of[i]] - 1) for i in range(b.n)])) * b.m
         kms = tm.get("em_sweep_kernel_ms", 0.0)
-        return {"seconds": round(dt, 4), "re_fits": int(b.n), "partitions": P, "one_call_wgs_loo": bool(tm.get("one_call")),
+        return {"seconds": round(dt, 4), "of_which_hipMalloc_seconds": round(mal, 4), "re_fits": int(b.n), "partitions": P, "one_call_wgs_loo": bool(tm.get("one_call")),
                 "em_seconds": round(tm.get("em_seconds", 0.0), 4), "scoring_seconds": round(tm.get("score_seconds", 0.0), 4),
                 "partition_chain_seconds": round(tm.get("chain_seconds", 0.0), 4), "em_sweep_kernels_ms": round(kms, 2),
                 "em_batches": tm.get("em_batches"), "iterations_min_max": [int(it.min()), int(it.max())], "bound": "valu_fp64_issue",
-                "fp64_issue_frac_of_em_sweeps": round(terms * INSTS_PER_TERM["em_sweep_group_kernel<exact>"] / 64.0 / WAVE_ISSUE_PER_S / (kms * 1e-3), 4) if kms > 0 else None,
-                "note": "leave-one-out re-fits share slabs and score through per-individual columns: the float32 slabs, no class codes",
+                "fp64_issue_frac_of_em_sweeps": round(terms * INSTS_PER_TERM["em_coded_group_kernel" if b.codes_state() == 1 else "em_sweep_group_kernel<exact>"]
+                                                      / 64.0 / WAVE_ISSUE_PER_S / (kms * 1e-3), 4) if kms > 0 else None,
+                "em_sweep_kernel": "em_coded_group_kernel (the slab's class table per fit)" if b.codes_state() == 1 else "em_sweep_group_kernel<exact> (float32 slabs)",
+                "note": "the re-fits' buffers (8 bytes per SNP and fit) are allocated inside the call: of_which_hipMalloc_seconds is what the driver took for that "
+                        "(VRAM an earlier process used is cleared when handed out again); scoring goes through per-individual columns over the float32 slabs",
                 "self_assignment_accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of)),
                 "checksum": float(np.sum(ll.astype(np.float64))), "partitions_checksum": float(np.sum(parts.astype(np.float64))) if P > 1 else None}
 

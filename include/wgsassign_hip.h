@@ -129,6 +129,11 @@ int wgs_beagle_codes_state(wgs_beagle *b);
  * waits for an allocation in flight, builds nothing; *alloc_ms = what that hipMalloc took (0: none was in flight).  While one is in
  * flight wgs_em_fit_stats and wgs_assign_last_ms report -1 for kernel times (hipEventElapsedTime would wait for it). */
 int wgs_beagle_codes_wait(wgs_beagle *b, double *alloc_ms);
+/* Seconds the calling threads of this process have spent inside hipMalloc through the library so far (a running total; the
+ * helper thread's allocation of the class codes' memory is not in it).  The driver clears VRAM an earlier process used when
+ * it hands it out again, so the same allocation costs 0.3 ms or seconds by what the box did before; callers that time whole
+ * paths (bench.py) report the share. */
+double wgs_malloc_seconds(void);
 /* Builds the codes now rather than at the first sweep that asks.  (`em` is ignored since version 2: one pass builds all.) */
 int wgs_beagle_codes_prepare(wgs_beagle *b, int em);
 

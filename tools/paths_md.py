@@ -18,7 +18,9 @@ if c:
     rows.append(("10M x 1000 x K=10 `--get_reference_af` (%d iterations)" % c["fit_cold"]["iterations"][0],
                  ms(c["fit_cold"]["seconds"]),
                  ms(c["fit_warm"]["seconds"]), ms(c["fit_direct"]["seconds"]), "built inside the fit: %s (%.1f ms)%s" % (c["fit_cold"]["codes_built_inside_the_fit"], c["fit_cold"].get("of_which_codes_build_ms", 0),
-                                                            ("; the codes' hipMalloc took %.0f ms on the helper thread, the fit did not wait" % c["fit_cold"]["pool_hipMalloc_ms"]) if "pool_hipMalloc_ms" in c["fit_cold"] else "")))
+                                                            ("; the codes' hipMalloc took %.0f ms on the helper thread, the fit did not wait: the second fit builds them in %s" %
+                                                             (c["fit_cold"]["codes_memory_arrived_after_the_fit_hipMalloc_ms"], ms(c["fit_second_builds_the_codes"]["seconds"])))
+                                                            if "codes_memory_arrived_after_the_fit_hipMalloc_ms" in c["fit_cold"] else "")))
     if "pop_like_cold" in c:
         a = ex["assign"]
         rows.append(("... `--get_pop_like` alone", ms(c["pop_like_cold"]["seconds"]), "%.1f ms (kernel)" % a["coded"]["kernel_ms"], ms(a["seconds"]), "build %.1f ms" % c["pop_like_cold"]["of_which_codes_build_ms"]))
@@ -29,9 +31,14 @@ for name, v in (ex.get("paths") or {}).items():
     if fit:
         cc = fit.get("class_codes") or {}
         cold = ms(fit["seconds_cold"])
-        rows.append((name + " fit", cold, ms(fit["seconds_warm"]), ms(fit["seconds_float32"]),
-                     "codes built inside the cold fit: %s%s; iterations %s; identical %s" % (fit["codes_built_inside_the_cold_fit"], (" (%.1f ms)" % cc["build_ms"]) if cc.get("available") else "",
-                                                                                         fit["iterations"][0], fit["identical_frequencies"])))
+        note = "codes built inside the cold fit: %s%s; iterations %s; identical %s" % (fit["codes_built_inside_the_cold_fit"], (" (%.1f ms)" % cc["build_ms"]) if cc.get("available") else "",
+                                                                                         fit["iterations"][0], fit["identical_frequencies"])
+        if "codes_memory_arrived_after_the_cold_fit_hipMalloc_ms" in fit:
+            note += "; the codes' hipMalloc took %.0f ms (helper thread), the cold fit did not wait; the second fit, building them: %s" % (
+                fit["codes_memory_arrived_after_the_cold_fit_hipMalloc_ms"], ms(fit["seconds_second_fit_building_the_codes"]))
+        if "of_which_hipMalloc_seconds" in fit:
+            note += "; hipMalloc of the fits' buffers: " + ", ".join("%s %s" % (k, ms(x)) for k, x in fit["of_which_hipMalloc_seconds"].items())
+        rows.append((name + " fit", cold, ms(fit["seconds_warm"]), ms(fit["seconds_float32"]), note))
     pl = v.get("get_pop_like")
     if pl:
         cc = pl.get("class_codes_cold") or {}
@@ -39,7 +46,8 @@ for name, v in (ex.get("paths") or {}).items():
                      "cold build %s; after the fit %s; identical %s" % (("%.1f ms" % cc["build_ms"]) if cc.get("available") else "none", ms(pl["seconds_after_the_fit"]), pl["identical_sums"])))
     for k in ("loo", "loo_partition_sites_3"):
         if k in v:
-            rows.append(("... `--%s`" % k.replace("_partition_sites_3", " --partition_sites 3"), ms(v[k]["seconds"]), "", "", "EM phase %s (float32 slabs, %d re-fits)" % (ms(v[k]["em_seconds"]), v[k]["re_fits"])))
+            rows.append(("... `--%s`" % k.replace("_partition_sites_3", " --partition_sites 3"), ms(v[k]["seconds"]), "", "", "EM phase %s (%d re-fits, %s)%s" % (ms(v[k]["em_seconds"]), v[k]["re_fits"], v[k].get("em_sweep_kernel", "em_sweep_group_kernel<exact>"),
+                                                                            ("; of which hipMalloc of the re-fits' buffers %s" % ms(v[k]["of_which_hipMalloc_seconds"])) if v[k].get("of_which_hipMalloc_seconds", 0) > 2e-3 else "")))
 print("# Whole paths on one MI355X (`bench.py`, %s)\n" % d["config"]["workload"])
 print("Headline: %.4g %s, %.2f ms per iteration over the float32 matrix, %.4f of the HBM peak (`%s`).\n" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel"]))
 print("cold = nothing built for the matrix before the call (the class codes, where the cost models want them, are built inside it); warm = codes present; float32 = `WGSASSIGN_CODES=0`.\n")

@@ -2,9 +2,15 @@
 """Per kernel: dispatches, summed duration and summed counters of rocprofv3 --pmc passes: python tools/sum_counters.py <dir> [<dir> ...]"""
 import csv
 import glob
+import os
 import re
 import sys
 from collections import defaultdict
+
+
+def newest(pattern):
+    """gpurun merges every call's files into the same directories: only the most recent run counts"""
+    return sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)[-1:]
 
 
 def short(name):
@@ -15,13 +21,13 @@ def short(name):
 for d in sys.argv[1:]:
     sums = defaultdict(lambda: defaultdict(float))
     seen = defaultdict(set)
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for f in newest(d + "/**/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             sums[k][r["Counter_Name"]] += float(r["Counter_Value"])
             seen[k].add(r["Dispatch_Id"])
     dur = defaultdict(float)
-    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    for f in newest(d + "/**/*kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
             dur[short(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
     print("==", d)

@@ -3,8 +3,14 @@
 import collections
 import csv
 import glob
+import os
 import json
 import sys
+
+
+def newest(pattern):
+    """gpurun merges every call's files into the same directories: only the most recent run counts"""
+    return sorted(glob.glob(pattern), key=os.path.getmtime)[-1:]
 
 
 
@@ -15,10 +21,10 @@ def name(k):
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 for d in ("enc_sq", "enc_sq2", "enc_fetch", "enc_write"):
-    for f in glob.glob("%s/%s/*/*counter_collection.csv" % (root, d)):
+    for f in newest("%s/%s/*/*counter_collection.csv" % (root, d)):
         for r in csv.DictReader(open(f)):
             agg[name(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
-    for f in glob.glob("%s/%s/*/*kernel_trace.csv" % (root, d)):
+    for f in newest("%s/%s/*/*kernel_trace.csv" % (root, d)):
         for r in csv.DictReader(open(f)):
             k = name(r["Kernel_Name"])
             agg[k]["ms_" + d] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6

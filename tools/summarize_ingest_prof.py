@@ -12,7 +12,7 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 ids = json.load(open(os.path.join(src, "ing_ids.json")))
-stats = glob.glob(os.path.join(src, "ing_kt", "*", "*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "ing_kt", "*", "*kernel_stats.csv")), key=os.path.getmtime)[-1:]      # (the most recent run only)
 assert stats, "no kernel_stats.csv under %s/ing_kt" % src
 shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
 json.dump(ids, open(os.path.join(dst, "ids.json"), "w"), indent=1)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "wgs_beagle_codes_prepare": (c_int, [c_vp, c_int]),
     "wgs_beagle_codes_state": (c_int, [c_vp]),
     "wgs_beagle_codes_wait": (c_int, [c_vp, c_f64p]),
+    "wgs_malloc_seconds": (ctypes.c_double, []),
     "wgs_em_create": (c_int, [c_vp, c_i32, c_i32p, c_i32p, c_int, ctypes.POINTER(c_vp)]),
     "wgs_em_destroy": (None, [c_vp]),
     "wgs_em_step": (c_int, [c_vp, c_f64p]),

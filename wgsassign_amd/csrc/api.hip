@@ -25,7 +25,10 @@ void wgs_set_error(const char *fmt, ...)
     g_err = buf;
 }
 
+std::atomic<long long> g_wgs_malloc_ns{0};
+
 extern "C" {
+double wgs_malloc_seconds(void) { return (double)g_wgs_malloc_ns.load() * 1e-9; }
 
 const char *wgs_last_error(void) { return g_err.c_str(); }
 int wgs_version(void) { return WGS_ABI_VERSION; }
@@ -87,7 +90,7 @@ int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out)
             ctx->ws_bytes = 0;
         }
         const size_t want = (bytes + (1u << 20)) & ~((size_t)(1u << 20) - 1);
-        HIP_TRY(hipMalloc(&ctx->ws, want));
+        HIP_TRY(wgs_malloc(&ctx->ws, want));
         ctx->ws_bytes = want;
     }
     *out = ctx->ws;
@@ -104,7 +107,7 @@ int wgs_ctx_workspace_b(wgs_ctx *ctx, size_t bytes, void **out)
             ctx->ws_b_bytes = 0;
         }
         const size_t want = (bytes + 4095) & ~(size_t)4095;
-        HIP_TRY(hipMalloc(&ctx->ws_b, want));
+        HIP_TRY(wgs_malloc(&ctx->ws_b, want));
         ctx->ws_b_bytes = want;
     }
     *out = ctx->ws_b;
@@ -207,7 +210,7 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
         s.npairs = (s.ncols + 1) / 2;
         if (s.ncols == 0) continue;
         const size_t bytes = (size_t)wgs_ntiles(m) * s.npairs * 64 * sizeof(float4);
-        if (hipMalloc(&s.base, bytes) != hipSuccess) {
+        if (wgs_malloc(&s.base, bytes) != hipSuccess) {
             wgs_set_error("hipMalloc of %zu bytes for population slab %d failed", bytes, g);
             return 1;
         }
@@ -215,16 +218,16 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
         b->bytes += (int64_t)bytes;
         bases[g] = s.base;
         nps[g] = s.npairs;
-        if (hipMalloc(&s.d_members, sizeof(int32_t) * s.ncols) != hipSuccess ||
+        if (wgs_malloc(&s.d_members, sizeof(int32_t) * s.ncols) != hipSuccess ||
             hipMemcpy(s.d_members, s.members.data(), sizeof(int32_t) * s.ncols, hipMemcpyHostToDevice) != hipSuccess) {
             wgs_set_error("could not upload the member table of slab %d", g);
             return 1;
         }
     }
-    HIP_TRY(hipMalloc(&b->d_group_of, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&b->d_col_of, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&b->d_npairs, sizeof(int32_t) * n_groups));
-    HIP_TRY(hipMalloc(&b->d_base, sizeof(float4 *) * n_groups));
+    HIP_TRY(wgs_malloc(&b->d_group_of, sizeof(int32_t) * n));
+    HIP_TRY(wgs_malloc(&b->d_col_of, sizeof(int32_t) * n));
+    HIP_TRY(wgs_malloc(&b->d_npairs, sizeof(int32_t) * n_groups));
+    HIP_TRY(wgs_malloc(&b->d_base, sizeof(float4 *) * n_groups));
     HIP_TRY(hipMemcpy(b->d_group_of, b->group_of.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_col_of, b->col_of.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->d_npairs, nps.data(), sizeof(int32_t) * n_groups, hipMemcpyHostToDevice));
@@ -326,7 +329,7 @@ int wgs_afset_create(wgs_ctx *ctx, int64_t m, int32_t K, wgs_afset **out)
     a->ctx = ctx;
     a->m = m;
     a->K = K;
-    if (hipMalloc(&a->buf, sizeof(float) * (size_t)m * K) != hipSuccess) {
+    if (wgs_malloc(&a->buf, sizeof(float) * (size_t)m * K) != hipSuccess) {
         wgs_set_error("hipMalloc for allele frequencies failed");
         delete a;
         return 1;
@@ -349,7 +352,7 @@ int wgs_afset_upload(wgs_afset *a, const float *A_mK)
     HIP_TRY(hipSetDevice(a->ctx->device));
     float *tmp = nullptr;
     const size_t bytes = sizeof(float) * (size_t)a->m * a->K;
-    HIP_TRY(hipMalloc(&tmp, bytes));
+    HIP_TRY(wgs_malloc(&tmp, bytes));
     int rc = 0;
     if (hipMemcpyAsync(tmp, A_mK, bytes, hipMemcpyHostToDevice, a->ctx->stream) != hipSuccess) rc = 1;
     if (!rc) rc = launch_transpose_mK_to_Km(a->ctx, tmp, a->buf, a->m, a->K);
@@ -365,7 +368,7 @@ int wgs_afset_download(wgs_afset *a, float *A_mK)
     HIP_TRY(hipSetDevice(a->ctx->device));
     float *tmp = nullptr;
     const size_t bytes = sizeof(float) * (size_t)a->m * a->K;
-    HIP_TRY(hipMalloc(&tmp, bytes));
+    HIP_TRY(wgs_malloc(&tmp, bytes));
     int rc = launch_transpose_Km_to_mK(a->ctx, a->buf, tmp, a->m, a->K);
     if (!rc && hipMemcpyAsync(A_mK, tmp, bytes, hipMemcpyDeviceToHost, a->ctx->stream) != hipSuccess) rc = 1;
     if (hipStreamSynchronize(a->ctx->stream) != hipSuccess) rc = 1;
@@ -595,8 +598,8 @@ int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *cou
     HIP_TRY(hipSetDevice(ctx->device));
     unsigned long long *d_count = nullptr;
     unsigned int *d_first = nullptr;
-    HIP_TRY(hipMalloc(&d_count, sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&d_first, sizeof(unsigned int)));
+    HIP_TRY(wgs_malloc(&d_count, sizeof(unsigned long long)));
+    HIP_TRY(wgs_malloc(&d_first, sizeof(unsigned int)));
     HIP_TRY(hipMemsetAsync(d_count, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipMemsetAsync(d_first, 0xFF, sizeof(unsigned int), ctx->stream));
     int rc = launch_log_mismatch(ctx, b0, b1, d_count, d_first);
@@ -621,7 +624,7 @@ int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, in
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(ctx->device));
     float *d = nullptr;
-    HIP_TRY(hipMalloc(&d, sizeof(float) * 2 * (size_t)n));
+    HIP_TRY(wgs_malloc(&d, sizeof(float) * 2 * (size_t)n));
     int rc = 0;
     if (hipMemcpyAsync(d, x, sizeof(float) * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = 1;
     if (!rc) rc = launch_log_values(ctx, d, d + n, n, use_libm);
@@ -682,8 +685,8 @@ static int rmse1d_impl(wgs_ctx *ctx, const float *v1, const float *v2, int64_t m
     }
     float *d = nullptr;
     void *work = nullptr;
-    HIP_TRY(hipMalloc(&d, sizeof(float) * (2 * (size_t)m + 2)));
-    HIP_TRY(hipMalloc(&work, rmse_chain_workspace_bytes(m)));
+    HIP_TRY(wgs_malloc(&d, sizeof(float) * (2 * (size_t)m + 2)));
+    HIP_TRY(wgs_malloc(&work, rmse_chain_workspace_bytes(m)));
     int rc = 0;
     float res = 0.0f;
     int nser = 0;
@@ -717,7 +720,7 @@ int wgs_loglike(wgs_ctx *ctx, const float *L, int64_t m, int64_t n, const float 
     if (m == 0) return 0;
     HIP_TRY(hipSetDevice(ctx->device));
     float *d = nullptr;   // [2m g | m a | m vec]
-    HIP_TRY(hipMalloc(&d, sizeof(float) * 4 * (size_t)m));
+    HIP_TRY(wgs_malloc(&d, sizeof(float) * 4 * (size_t)m));
     int rc = 0;
     // strided host columns -> compact device vectors
     if (hipMemcpy2DAsync(d, 2 * sizeof(float), L + 2 * i, sizeof(float) * 2 * n, 2 * sizeof(float), m, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||

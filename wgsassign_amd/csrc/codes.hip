@@ -43,7 +43,9 @@ static int pool_adopt(wgs_beagle *b)
 static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double grace_ms)
 {
     if (b->pool && b->pool_bytes >= want) return 1;
+    bool started = false;
     if (b->pool_state.load() == 0) {
+        started = true;
         pool_join(b);
         b->pool_want = want;
         b->pool_want_small = want_small;
@@ -78,8 +80,10 @@ static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double gr
             work();
         }
     }
+    // the call that starts the allocation gives it `grace_ms` (the fast case takes 0.3 ms); later calls only look (a fit of short
+    // sweeps would otherwise wait at every one of them)
     const double t0 = now_s();
-    while (b->pool_state.load() == 1 && (grace_ms < 0 || (now_s() - t0) * 1e3 < grace_ms)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    while (b->pool_state.load() == 1 && (grace_ms < 0 || (started && (now_s() - t0) * 1e3 < grace_ms))) std::this_thread::sleep_for(std::chrono::microseconds(50));
     const int st = pool_adopt(b);
     if (st <= 0) return st;
     if (b->pool_bytes >= want || (want_small && b->pool_bytes >= want_small)) return 1;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -44,6 +45,19 @@ struct wgs_stall_probe {
             return 1;                                                                         \
         }                                                                                     \
     } while (0)
+
+// hipMalloc with the time it took added to a process-wide total (wgs_malloc_seconds): on this driver an allocation of VRAM that an
+// earlier process used is cleared when it is handed out again -- up to ~100 ms per GB, for the same call that takes 0.3 ms on
+// untouched memory (profiles/r04_alloc_ubench.txt) -- and a caller timing whole paths wants to know what share that was.
+extern std::atomic<long long> g_wgs_malloc_ns;
+template <typename T>
+static inline hipError_t wgs_malloc(T **p, size_t bytes)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipMalloc(p, bytes);
+    g_wgs_malloc_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    return e;
+}
 
 #define WGS_REQUIRE(cond, ...)          \
     do {                                \

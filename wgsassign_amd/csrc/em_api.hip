@@ -98,21 +98,21 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     }
     const size_t fbytes = (size_t)n_fits * b->m * sizeof(float);
     for (int i = 0; i < 2; ++i) {
-        if (hipMalloc(&em->fbuf[i], fbytes) != hipSuccess) {
+        if (wgs_malloc(&em->fbuf[i], fbytes) != hipSuccess) {
             wgs_set_error("hipMalloc of %zu bytes for EM frequencies failed", fbytes);
             return 1;
         }
     }
-    HIP_TRY(hipMalloc(&em->d_descs, sizeof(FitDesc) * n_fits));
-    HIP_TRY(hipMalloc(&em->d_ssq, sizeof(double) * n_fits));
-    HIP_TRY(hipMalloc(&em->d_part, sizeof(double) * (size_t)n_fits * wgs_ntiles(b->m)));
-    HIP_TRY(hipMalloc(&em->d_part2, sizeof(double) * (size_t)n_fits * ssq_reduce_chunks()));
-    HIP_TRY(hipMalloc(&em->d_carry, 2 * sizeof(float)));
-    HIP_TRY(hipMalloc(&em->d_chain_work, rmse_chain_workspace_bytes(b->m)));
+    HIP_TRY(wgs_malloc(&em->d_descs, sizeof(FitDesc) * n_fits));
+    HIP_TRY(wgs_malloc(&em->d_ssq, sizeof(double) * n_fits));
+    HIP_TRY(wgs_malloc(&em->d_part, sizeof(double) * (size_t)n_fits * wgs_ntiles(b->m)));
+    HIP_TRY(wgs_malloc(&em->d_part2, sizeof(double) * (size_t)n_fits * ssq_reduce_chunks()));
+    HIP_TRY(wgs_malloc(&em->d_carry, 2 * sizeof(float)));
+    HIP_TRY(wgs_malloc(&em->d_chain_work, rmse_chain_workspace_bytes(b->m)));
     HIP_TRY(hipEventCreate(&em->ev0));
     HIP_TRY(hipEventCreate(&em->ev1));
     HIP_TRY(hipHostMalloc(&em->h_descs, sizeof(FitDesc) * n_fits, hipHostMallocDefault));
-    HIP_TRY(hipMalloc(&em->d_groups, sizeof(int32_t) * 2 * n_fits));
+    HIP_TRY(wgs_malloc(&em->d_groups, sizeof(int32_t) * 2 * n_fits));
     HIP_TRY(hipHostMalloc(&em->h_groups, sizeof(int32_t) * 2 * n_fits, hipHostMallocDefault));
     if (launch_fill(b->ctx, em->fbuf[0], (int64_t)n_fits * b->m, 0.25f)) return 1;   // emMAF.py:17-18
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -230,7 +230,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
         for (int j : order) fusing = fusing || (*may_fuse)[j] >= 2;
         if (fusing && !em->fbuf[2]) {
             const size_t fbytes = (size_t)em->n_fits * em->b->m * sizeof(float);
-            if (hipMalloc(&em->fbuf[2], fbytes) != hipSuccess || hipMalloc(&em->d_part_b, sizeof(double) * (size_t)em->n_fits * ntiles) != hipSuccess) {
+            if (wgs_malloc(&em->fbuf[2], fbytes) != hipSuccess || wgs_malloc(&em->d_part_b, sizeof(double) * (size_t)em->n_fits * ntiles) != hipSuccess) {
                 (void)hipGetLastError();
                 if (em->fbuf[2]) (void)hipFree(em->fbuf[2]);
                 em->fbuf[2] = nullptr;
@@ -389,22 +389,22 @@ static int em_fit_alloc(wgs_em *em)
 {
     if (em->d_state) return 0;
     const size_t n = (size_t)em->n_fits;
-    HIP_TRY(hipMalloc(&em->d_state, sizeof(int32_t) * n));
-    HIP_TRY(hipMalloc(&em->d_ssq2, sizeof(double) * 2 * n));
+    HIP_TRY(wgs_malloc(&em->d_state, sizeof(int32_t) * n));
+    HIP_TRY(wgs_malloc(&em->d_ssq2, sizeof(double) * 2 * n));
     HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * 2 * n));
-    HIP_TRY(hipMalloc(&em->d_jobs, sizeof(ChainJob) * n));
-    HIP_TRY(hipMalloc(&em->d_chain_out, sizeof(float) * 2 * n));
+    HIP_TRY(wgs_malloc(&em->d_jobs, sizeof(ChainJob) * n));
+    HIP_TRY(wgs_malloc(&em->d_chain_out, sizeof(float) * 2 * n));
     // workspace of the exact chains for all fits at once (60 bytes per fit and block of 4096 SNPs): no allocation
     // inside the convergence loop
-    HIP_TRY(hipMalloc(&em->d_chain_batch, rmse_chain_workspace_bytes(em->b->m) * n));
+    HIP_TRY(wgs_malloc(&em->d_chain_batch, rmse_chain_workspace_bytes(em->b->m) * n));
     em->chain_batch_jobs = n;
     HIP_TRY(hipHostMalloc(&em->h_jobs, sizeof(ChainJob) * n, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&em->h_chain_out, sizeof(float) * 2 * n, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc(&em->h_setstate, sizeof(int32_t) * n, hipHostMallocDefault));
     for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipMalloc(&em->d_descs2[i], sizeof(FitDesc) * n));
+        HIP_TRY(wgs_malloc(&em->d_descs2[i], sizeof(FitDesc) * n));
         HIP_TRY(hipHostMalloc(&em->h_descs2[i], sizeof(FitDesc) * n, hipHostMallocDefault));
-        HIP_TRY(hipMalloc(&em->d_groups2[i], sizeof(int32_t) * 2 * n));
+        HIP_TRY(wgs_malloc(&em->d_groups2[i], sizeof(int32_t) * 2 * n));
         HIP_TRY(hipHostMalloc(&em->h_groups2[i], sizeof(int32_t) * 2 * n, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&em->h_ssq[i], sizeof(double) * 2 * n, hipHostMallocDefault));

@@ -408,15 +408,15 @@ int wgs_debug_inflate(wgs_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, con
         for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_status, (void *)d_io, (void *)d_oo, (void *)d_il, (void *)d_is, d_tab})
             if (p) (void)hipFree(p);
     });
-    HIP_TRY(hipMalloc(&d_comp, (size_t)comp_bytes + 128));
+    HIP_TRY(wgs_malloc(&d_comp, (size_t)comp_bytes + 128));
     HIP_TRY(hipMemset(d_comp + comp_bytes, 0, 128));
-    HIP_TRY(hipMalloc(&d_out, (size_t)std::max<int64_t>(out_bytes, 1)));
-    HIP_TRY(hipMalloc(&d_status, (size_t)nblocks));
-    HIP_TRY(hipMalloc(&d_io, sizeof(uint64_t) * nblocks));
-    HIP_TRY(hipMalloc(&d_oo, sizeof(uint64_t) * nblocks));
-    HIP_TRY(hipMalloc(&d_il, sizeof(uint32_t) * nblocks));
-    HIP_TRY(hipMalloc(&d_is, sizeof(uint32_t) * nblocks));
-    HIP_TRY(hipMalloc(&d_tab, inflate_table_bytes() * (size_t)nblocks));
+    HIP_TRY(wgs_malloc(&d_out, (size_t)std::max<int64_t>(out_bytes, 1)));
+    HIP_TRY(wgs_malloc(&d_status, (size_t)nblocks));
+    HIP_TRY(wgs_malloc(&d_io, sizeof(uint64_t) * nblocks));
+    HIP_TRY(wgs_malloc(&d_oo, sizeof(uint64_t) * nblocks));
+    HIP_TRY(wgs_malloc(&d_il, sizeof(uint32_t) * nblocks));
+    HIP_TRY(wgs_malloc(&d_is, sizeof(uint32_t) * nblocks));
+    HIP_TRY(wgs_malloc(&d_tab, inflate_table_bytes() * (size_t)nblocks));
     HIP_TRY(hipMemcpy(d_comp, comp, (size_t)comp_bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_io, in_off, sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_oo, out_off, sizeof(uint64_t) * nblocks, hipMemcpyHostToDevice));

@@ -427,7 +427,7 @@ int regrow(hipStream_t st, T *&p, size_t count)
     HIP_TRY(hipStreamSynchronize(st));
     if (p) HIP_TRY(hipFree(p));
     p = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
+    HIP_TRY(wgs_malloc(reinterpret_cast<void **>(&p), count * sizeof(T)));
     return 0;
 }
 
@@ -541,7 +541,7 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
             HIP_TRY(hipStreamSynchronize(st));
             void *q = nullptr;
             const size_t cap = need + need / 8;
-            HIP_TRY(hipMalloc(&q, cap));
+            HIP_TRY(wgs_malloc(&q, cap));
             if (g->carry) HIP_TRY(hipMemcpy(q, g->d_text, g->carry, hipMemcpyDeviceToDevice));
             if (g->d_text) HIP_TRY(hipFree(g->d_text));
             g->d_text = q;
@@ -559,7 +559,7 @@ int ingest_next_resident(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64
             HIP_TRY(hipStreamSynchronize(st));
             if (g->d_tables) HIP_TRY(hipFree(g->d_tables));
             g->d_tables = nullptr;
-            HIP_TRY(hipMalloc(&g->d_tables, inflate_table_bytes() * cap));
+            HIP_TRY(wgs_malloc(&g->d_tables, inflate_table_bytes() * cap));
             g->blocks_cap = cap;
         }
         if (c->len + INFLATE_PAD > g->comp_cap) {
@@ -822,7 +822,7 @@ int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t 
     if (resident) {
         HIP_TRY(hipEventCreate(&g->iev0));
         HIP_TRY(hipEventCreate(&g->iev1));
-        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&g->d_totals), T_COUNT * sizeof(uint32_t)));
+        HIP_TRY(wgs_malloc(reinterpret_cast<void **>(&g->d_totals), T_COUNT * sizeof(uint32_t)));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g->h_totals), T_COUNT * sizeof(uint32_t), hipHostMallocDefault));
         g->chunk_text = (size_t)std::max<int64_t>(chunk_bytes, 1 << 20);
         g->resident = true;
@@ -897,7 +897,7 @@ int wgs_ingest_next(wgs_ingest *g, int64_t row0, const uint8_t *keep, int64_t ke
         g->d_text = nullptr;
         g->text_cap = 0;
         const size_t cap = std::max(text_bytes, c->cap);
-        HIP_TRY(hipMalloc(&g->d_text, cap));
+        HIP_TRY(wgs_malloc(&g->d_text, cap));
         g->text_cap = cap;
     }
     if (int rc = ensure_line_arrays(g, st, nl, false)) return rc;

@@ -327,7 +327,7 @@ double *wgs_comm_buffer(wgs_comm *c, int64_t n)
         c->buf = nullptr;
         c->buf_elems = 0;
         const size_t want = (size_t)n < 1024 ? 1024 : (size_t)n;
-        if (hipMalloc(&c->buf, sizeof(double) * want) != hipSuccess) {
+        if (wgs_malloc(&c->buf, sizeof(double) * want) != hipSuccess) {
             wgs_set_error("hipMalloc of the communicator bounce buffer failed");
             return nullptr;
         }

@@ -90,7 +90,7 @@ static int build_slab_table(wgs_score *sc, int np, int which)
     sc->n_slabs[which] = (int)tab.size();
     sc->total_pg[which] = pg;
     if (tab.empty()) return 0;
-    HIP_TRY(hipMalloc(&sc->d_slabs[which], sizeof(ScoreSlab) * tab.size()));
+    HIP_TRY(wgs_malloc(&sc->d_slabs[which], sizeof(ScoreSlab) * tab.size()));
     HIP_TRY(hipMemcpy(sc->d_slabs[which], tab.data(), sizeof(ScoreSlab) * tab.size(), hipMemcpyHostToDevice));
     return 0;
 }
@@ -116,10 +116,10 @@ int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, in
     sc->nblocks = (int32_t)((wgs_ntiles(b->m) + WGS_BLOCK_TILES - 1) / WGS_BLOCK_TILES);
     std::vector<const float *> acol(a->K);
     for (int k = 0; k < a->K; ++k) acol[k] = a->buf + (size_t)k * a->m;
-    HIP_TRY(hipMalloc(&sc->d_acol, sizeof(float *) * a->K));
+    HIP_TRY(wgs_malloc(&sc->d_acol, sizeof(float *) * a->K));
     HIP_TRY(hipMemcpy(sc->d_acol, acol.data(), sizeof(float *) * a->K, hipMemcpyHostToDevice));
     if (colptr) {
-        HIP_TRY(hipMalloc(&sc->d_colptr, sizeof(float *) * sc->cells));
+        HIP_TRY(wgs_malloc(&sc->d_colptr, sizeof(float *) * sc->cells));
         HIP_TRY(hipMemcpy(sc->d_colptr, colptr, sizeof(float *) * sc->cells, hipMemcpyHostToDevice));
     }
     const int np_sweep = score_pairs_per_wave(a->K, sc->per_ind), np_chain = chain_pairs_per_wave(a->K, sc->per_ind);
@@ -131,11 +131,11 @@ int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, in
     } else if (build_slab_table(sc, np_chain, 1)) {
         return 1;
     }
-    if (hipMalloc(&sc->d_S, sizeof(double) * (size_t)sc->nblocks * sc->cells) != hipSuccess) {
+    if (wgs_malloc(&sc->d_S, sizeof(double) * (size_t)sc->nblocks * sc->cells) != hipSuccess) {
         wgs_set_error("hipMalloc of %zu bytes for the block sums failed", sizeof(double) * (size_t)sc->nblocks * sc->cells);
         return 1;
     }
-    HIP_TRY(hipMalloc(&sc->d_out, sizeof(double) * sc->cells));
+    HIP_TRY(wgs_malloc(&sc->d_out, sizeof(double) * sc->cells));
     guard.dismiss();
     *out = sc;
     return 0;
@@ -204,7 +204,7 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
         sc->n_coded = (int)tab.size();
         sc->coded_quads = quad0;
         if (!tab.empty()) {
-            HIP_TRY(hipMalloc(&sc->d_coded, sizeof(CodedSlabHost) * tab.size()));
+            HIP_TRY(wgs_malloc(&sc->d_coded, sizeof(CodedSlabHost) * tab.size()));
             HIP_TRY(hipMemcpy(sc->d_coded, tab.data(), sizeof(CodedSlabHost) * tab.size(), hipMemcpyHostToDevice));
         }
         sc->coded_generation = codes->generation;
@@ -219,7 +219,7 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     } else if (launch_score_sweep(ctx, score_args(sc, 0), mode)) {
         return 1;
     }
-    if (!sc->d_chunks && hipMalloc(&sc->d_chunks, sizeof(double) * (size_t)((sc->nblocks + 1) / 2) * sc->cells) != hipSuccess) {
+    if (!sc->d_chunks && wgs_malloc(&sc->d_chunks, sizeof(double) * (size_t)((sc->nblocks + 1) / 2) * sc->cells) != hipSuccess) {
         wgs_set_error("hipMalloc of the chunk sums failed");
         return 1;
     }
@@ -242,7 +242,7 @@ int wgs_score_total_from(wgs_score *sc, const double *carry_in, double *out)
     WGS_REQUIRE(sc->d_chunks, "wgs_score_total_from needs wgs_score_sums first");
     wgs_ctx *ctx = sc->b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!sc->d_start) HIP_TRY(hipMalloc(&sc->d_start, sizeof(double) * sc->cells));
+    if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, sizeof(double) * sc->cells));
     if (carry_in) HIP_TRY(hipMemcpyAsync(sc->d_start, carry_in, sizeof(double) * sc->cells, hipMemcpyHostToDevice, ctx->stream));
     if (launch_chunk_total(ctx, sc->d_chunks, (sc->nblocks + 1) / 2, sc->cells, carry_in ? sc->d_start : nullptr, sc->d_out)) return 1;
     HIP_TRY(hipMemcpyAsync(out, sc->d_out, sizeof(double) * sc->cells, hipMemcpyDeviceToHost, ctx->stream));
@@ -265,8 +265,8 @@ int wgs_score_totals_all(wgs_score *sc, wgs_comm *comm, double *totals_out, doub
     int world = 1, rank = 0;
     if (comm) wgs_comm_rank(comm, &rank, &world);
     const size_t bytes = sizeof(double) * sc->cells;
-    if (!sc->d_start) HIP_TRY(hipMalloc(&sc->d_start, bytes));
-    if (!sc->d_run) HIP_TRY(hipMalloc(&sc->d_run, bytes));
+    if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, bytes));
+    if (!sc->d_run) HIP_TRY(wgs_malloc(&sc->d_run, bytes));
     HIP_TRY(hipMemsetAsync(sc->d_start, 0, bytes, ctx->stream));
     for (int r = 0; r < world; ++r) {
         if (r == rank) {
@@ -302,14 +302,14 @@ int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start)
         sc->d_cand = nullptr;
         sc->d_carry = sc->d_parts = nullptr;
         sc->P = 0;
-        if (hipMalloc(&sc->d_cand, sizeof(uint32_t) * chains * sc->nblocks) != hipSuccess) {
+        if (wgs_malloc(&sc->d_cand, sizeof(uint32_t) * chains * sc->nblocks) != hipSuccess) {
             wgs_set_error("hipMalloc of %zu bytes for the partition-chain block functions failed", sizeof(uint32_t) * chains * sc->nblocks);
             return 1;
         }
-        HIP_TRY(hipMalloc(&sc->d_carry, sizeof(float) * chains));
-        HIP_TRY(hipMalloc(&sc->d_parts, sizeof(float) * chains));
-        if (!sc->d_nserial) HIP_TRY(hipMalloc(&sc->d_nserial, sizeof(int32_t)));
-        if (!sc->d_start) HIP_TRY(hipMalloc(&sc->d_start, sizeof(double) * sc->cells));
+        HIP_TRY(wgs_malloc(&sc->d_carry, sizeof(float) * chains));
+        HIP_TRY(wgs_malloc(&sc->d_parts, sizeof(float) * chains));
+        if (!sc->d_nserial) HIP_TRY(wgs_malloc(&sc->d_nserial, sizeof(int32_t)));
+        if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, sizeof(double) * sc->cells));
         sc->P = P;
     }
     HIP_TRY(hipMemsetAsync(sc->d_cand, 0, sizeof(uint32_t) * chains * sc->nblocks, ctx->stream));

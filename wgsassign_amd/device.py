@@ -524,6 +524,11 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
     return out, parts
 
 
+def malloc_seconds():
+    """Seconds this process has spent inside hipMalloc through the library so far (include/wgsassign_hip.h: wgs_malloc_seconds)."""
+    return float(_lib.load().wgs_malloc_seconds())
+
+
 def last_assign_ms(ctx):
     """Kernel time of the context's last scoring call (HIP events on its stream)."""
     ms = ctypes.c_float()
