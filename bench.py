@@ -662,6 +662,8 @@ def whole_paths(ctx, device, mode_name):
         ll, parts = glassy.loo_device(b, b, af, group_of, 200, 1e-4, P, verbose=False, timings=tm, need_parts=P > 1)
         dt = time.perf_counter() - t0
         mal = device.malloc_seconds() - mal0
+        # (the shared columns of the scoring step may have built codes without the slabs' own numbering: only codes WITH it serve the re-fits)
+        coded_refits = b.codes_state() == 1 and b.codes_info()["em_table_rows"] > 0
         it = tm["iters"]
         terms = float(np.sum([float(it[i]) * (counts[group_of[i]] - 1) for i in range(b.n)])) * b.m
         kms = tm.get("em_sweep_kernel_ms", 0.0)
@@ -669,9 +671,9 @@ def whole_paths(ctx, device, mode_name):
                 "em_seconds": round(tm.get("em_seconds", 0.0), 4), "scoring_seconds": round(tm.get("score_seconds", 0.0), 4),
                 "partition_chain_seconds": round(tm.get("chain_seconds", 0.0), 4), "em_sweep_kernels_ms": round(kms, 2),
                 "em_batches": tm.get("em_batches"), "iterations_min_max": [int(it.min()), int(it.max())], "bound": "valu_fp64_issue",
-                "fp64_issue_frac_of_em_sweeps": round(terms * INSTS_PER_TERM["em_coded_group_kernel" if b.codes_state() == 1 else "em_sweep_group_kernel<exact>"]
+                "fp64_issue_frac_of_em_sweeps": round(terms * INSTS_PER_TERM["em_coded_group_kernel" if coded_refits else "em_sweep_group_kernel<exact>"]
                                                       / 64.0 / WAVE_ISSUE_PER_S / (kms * 1e-3), 4) if kms > 0 else None,
-                "em_sweep_kernel": "em_coded_group_kernel (the slab's class table per fit)" if b.codes_state() == 1 else "em_sweep_group_kernel<exact> (float32 slabs)",
+                "em_sweep_kernel": "em_coded_group_kernel (the slab's class table per fit)" if coded_refits else "em_sweep_group_kernel<exact> (float32 slabs)",
                 "note": "the re-fits' buffers (8 bytes per SNP and fit) are allocated inside the call: of_which_hipMalloc_seconds is what the driver took for that "
                         "(VRAM an earlier process used is cleared when handed out again); scoring goes through per-individual columns over the float32 slabs",
                 "self_assignment_accuracy": float(np.mean(np.argmax(ll, axis=1) == group_of)),

@@ -320,6 +320,35 @@ def test_sweeps_do_not_wait_for_the_codes_memory(dev, oracle, wait_ms, monkeypat
     assert it1 == [int(x) for x in it_o] and same(af1, af_o)
 
 
+def test_a_scoring_sweep_builds_the_codes_without_the_slab_numbering(dev, oracle):
+    """--get_pop_like alone never fits: a build that a scoring sweep asks for leaves out the slabs' own numbering (the coded EM sweep's
+    tables: a third of the encode pass, two thirds of the memory).  An EM fit on the same matrix afterwards rebuilds in full; same
+    results as the direct kernels in every order."""
+    m, n, K = 40_000, 150, 3
+    L, IDs = synth.make_beagle(m, n, K, seed=46)
+    pops = np.unique(IDs[:, 1])
+    group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+    counts = np.bincount(group_of, minlength=K)
+    with quiet():
+        _, af_o, _, it_o = oracle.fit_reference_af(L, IDs, t=4)
+    afs = dev.AFSet.from_host(af_o)
+    with codes(False):
+        b0 = dev.DeviceBeagle.from_host(L, group_of, K)
+        out0, _ = dev.assign(b0, afs)
+        b0.close()
+    with codes(True):
+        b = dev.DeviceBeagle.from_host(L, group_of, K)
+        out1, _ = dev.assign(b, afs)
+        first = b.codes_info()
+        assert b.codes_state() == 1 and first["em_table_rows"] == 0 and first["slab_numbering_bytes"] == 0
+        it, af, out2 = fit_and_score(dev, b, K, counts)
+        second = b.codes_info()
+        assert second["em_table_rows"] > 0 and second["slab_numbering_bytes"] > 0 and second["bytes"] > first["bytes"]
+        b.close()
+    afs.close()
+    assert same_nan(out1, out0) and it == [int(x) for x in it_o] and same(af, af_o)
+
+
 def test_a_slow_allocation_is_not_waited_for(dev, oracle, monkeypatch):
     """WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS makes the helper thread's hipMalloc take 400 ms (the driver takes seconds for VRAM an earlier
     process used).  With no waiting allowed the fit and the scoring call run over the float32 slabs and return long before the memory;

@@ -225,10 +225,10 @@ const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b)
 
 // The encode pass streams the matrix once and writes about half of it again (codes, the slabs' own codes and dictionaries): measured
 // 80 GB in 33 ms, 8 GB in 3.8 ms, 1.6 GB in 1.1 ms with 64-slot tables, ~1.4 x / 2.4 x that with 128 / 256 slots, + ~0.5 ms of sample
-// pass, allocation and readbacks.
-double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots)
+// pass, allocation and readbacks.  Without the slabs' own numbering (a build for a scoring sweep) 0.78 x that: 27 ms, 3.1 ms.
+double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots, bool with_slab_numbering)
 {
-    return (double)b->bytes / 2.3e9 * (slots <= 64 ? 1.0 : (slots == 128 ? 1.4 : 2.4)) + 0.5;
+    return (double)b->bytes / 2.3e9 * (slots <= 64 ? 1.0 : (slots == 128 ? 1.4 : 2.4)) * (with_slab_numbering ? 1.0 : 0.78) + 0.5;
 }
 
 // Whether a scoring sweep with shared columns over K populations should build the codes: the direct sweep costs ~1.2e-11 s per
@@ -241,13 +241,13 @@ bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K)
     if (!P || P->state <= 0) return false;
     const double direct_ms = 1.2e-8 * (double)b->m * (double)b->n * (double)K;
     const double coded_share = std::min(1.0, 1.25 * P->mean_g / (double)std::max<int64_t>(1, b->n) + 0.09);
-    return direct_ms * (1.0 - coded_share) > wgs_codes_build_ms_estimate(b, P->slots);
+    return direct_ms * (1.0 - coded_share) > wgs_codes_build_ms_estimate(b, P->slots, false);
 }
 
 // Builds the class codes (the plan of the sample pass decides whether and how, then one pass over the matrix: ~2 x its streaming
 // time).  Not worth coding -- most SNPs with more classes than the largest table holds, or hardly fewer classes than individuals --
 // or no memory for the codes (half of the matrix): nullptr, and the direct kernels run.  WGSASSIGN_CODES=0 turns the codes off altogether.
-wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build, bool wait)
+wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build, bool wait, bool for_scoring_only)
 {
     if (!b || b->codes_state < 0 || codes_switched_off()) return nullptr;
     if (b->codes_state > 0) return b->codes;
@@ -285,7 +285,10 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build, bool wait)
     c->snps_per_wave = WGS_ENC_SLOTS / P->slots;
     c->drows = P->drows;
     c->score_batch = P->score_batch;
-    c->lrows = P->lrows;
+    // a scoring sweep needs the class codes and the dictionary only: the slabs' own numbering (the coded EM sweep's) is left out of a
+    // build it asks for -- a third of the pass and two thirds of the memory
+    c->lrows = for_scoring_only ? 0 : P->lrows;
+    c->local_skipped = for_scoring_only && P->lrows > 0;
     const size_t slab_tab = ((sizeof(SlabCodes) * b->n_groups + 255) / 256) * 256;
     // ---- one allocation for everything
     auto plan = [&](bool with_local, std::vector<size_t> &off) -> size_t {

@@ -171,6 +171,8 @@ struct wgs_codes {
     double sum_ncls = 0.0;         // over the coded SNPs
     int64_t rich_snps = 0;
     double local_direct_share = 0.0;   // share of the (slab, tile) pairs the coded EM sweep takes from the float32 slab
+    bool local_skipped = false;        // built for a scoring sweep: without the slabs' own numbering although the matrix could have one (an EM fit that
+                                       // wants it rebuilds: em_api.hip)
     double probe_rounds = 0.0;     // hash probe rounds beyond the first per buffer of 16 lookups (encoder diagnostics)
     double sample_mean_g = 0.0, sample_mean_l = 0.0;   // classes per SNP / per (slab, SNP) in the sample
 };
@@ -213,9 +215,9 @@ struct wgs_beagle {
 // direct kernels are used).  build = false only returns codes that exist already.
 // wait = false: when the codes' memory is not there yet the call returns nullptr for now (the caller sweeps the float32 slabs)
 // and a later call finishes the build.
-wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true, bool wait = true);
+wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true, bool wait = true, bool for_scoring_only = false);
 const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b);
-double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots);
+double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots, bool with_slab_numbering = true);
 bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K);
 int wgs_ctx_workspace_b(wgs_ctx *ctx, size_t bytes, void **out);     // a second small grow-only scratch (survives wgs_ctx_workspace calls)
 void wgs_beagle_drop_codes(wgs_beagle *b);

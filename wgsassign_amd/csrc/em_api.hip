@@ -218,6 +218,13 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     {
         WGS_STALL_SCOPE("wgs_beagle_codes from the sweep");
         codes = worth ? wgs_beagle_codes(em->b, build, false) : nullptr;     // (memory not there yet: this sweep goes direct)
+        if (codes && codes->lrows == 0 && codes->local_skipped && build) {
+            // built by a scoring sweep, without the slabs' own numbering: this fit repays a full build
+            const wgs_codes_plan keep = em->b->plan;
+            wgs_beagle_drop_codes(em->b);
+            em->b->plan = keep;
+            codes = wgs_beagle_codes(em->b, true, false);
+        }
     }
     WGS_STALL_SCOPE("the sweep's launches");
     if (codes && codes->lrows == 0) codes = nullptr;

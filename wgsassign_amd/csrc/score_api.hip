@@ -175,7 +175,7 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     // shared columns + a codable matrix: the sweep through the class codes (same S, bit for bit)
     // (built for this sweep only when what it saves exceeds the encode pass: codes.hip: wgs_codes_pay_for_scoring)
     wgs_codes *codes = sc->per_ind ? nullptr : wgs_beagle_codes(sc->b, false);
-    if (!codes && !sc->per_ind && wgs_codes_pay_for_scoring(sc->b, sc->K)) codes = wgs_beagle_codes(sc->b, true, false);
+    if (!codes && !sc->per_ind && wgs_codes_pay_for_scoring(sc->b, sc->K)) codes = wgs_beagle_codes(sc->b, true, false, true);
     if (codes && score_coded_lds_bytes(codes->rows_batch, score_kb(sc->K), codes->score_batch) > 64 * 1024) codes = nullptr;
     if (codes && sc->coded_generation != codes->generation) {     // (keyed on the build, not on the object's address: a rebuilt wgs_codes may reuse it)
         std::vector<CodedSlabHost> tab;
