@@ -359,52 +359,58 @@ __global__ __launch_bounds__(WAVES * 64) void em_sweep_group_kernel(const FitDes
 // f_new2) and both per-tile partial sums (ssq_part, ssq_part2); the decision kernel looks at the first sum, then at the second
 // (em_decide_kernel), and the host takes the vector that belongs to the iteration that stopped (wgs_em_fit).  The dictionary --
 // two thirds of the sweep's traffic -- is read once per two iterations; the arithmetic of each iteration is unchanged.
-// One EM iteration of one (fit, tile) through the slab's class table: r = the tile's dictionary rows (registers), q = this wavefront's
-// quotient table in LDS (slot of rank k: q[k * 64]), src = the tile's code words.  Returns the serial float32 sum over the slab's
-// individuals (all but `skip`), emMAF_cy.pyx:19-22.
-template <int U, int ILP, int ROWS>
-__device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], double *q, int nrows, const uint32_t *src, int nquads, int ncols, int skip, float f_old)
+// The pieces of one EM iteration of one (fit, tile) through the slab's class table.  q = this wavefront's quotient table in LDS (slot of
+// rank k of the SNP of lane l: q[k * 64 + l], `q` already offset by the lane), src = the tile's code words (offset by the lane).
+
+// The quotient (p1 + 2 p2) / ((p0 + p1) + p2) of the class whose (g0, g1) bit patterns are the halves of `raw`: term_exact_shared's
+// rounding sequence up to the divide (emMAF_cy.pyx:19-22).
+__device__ __forceinline__ double class_quotient(double raw, const SnpState &st)
 {
-    const int last = nquads - 1;
+    const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
+                g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
+    const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
+    const float p0 = (float)((g0d * st.omf) * st.omf);
+    const float p1 = (float)((g1d * st.fd2) * st.omf);
+    const float p2 = (float)((g2d * st.fd) * st.fd);
+    const float ssum = (p0 + p1) + p2;
+    const double num = __builtin_fma(2.0, (double)p2, (double)p1);
+    return div_exact<true>(num, (double)ssum);
+}
+
+// phase 1, lane <-> SNP: r = the tile's dictionary rows (registers); every lane fills the rows of its own SNP, ILP at a time
+template <int ILP, int ROWS>
+__device__ __forceinline__ void coded_phase1_lane(const double (&r)[ROWS], double *q, int nrows, float f_old)
+{
     SnpState st;
     st.fd = (double)f_old;
     st.omf = 1.0 - st.fd;
     st.fd2 = 2.0 * st.fd;
-    uint32_t cur[U], nxt[U];
+    // (lanes whose SNP has fewer classes compute on whatever the unwritten rows hold: never looked up)
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];
-    {
-        auto quotient = [&](double raw) {
-            const float g0 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw))),
-                        g1 = __uint_as_float((uint32_t)((unsigned long long)__double_as_longlong(raw) >> 32));
-            const double g0d = (double)g0, g1d = (double)g1, g2d = (1.0 - g0d) - g1d;
-            const float p0 = (float)((g0d * st.omf) * st.omf);
-            const float p1 = (float)((g1d * st.fd2) * st.omf);
-            const float p2 = (float)((g2d * st.fd) * st.fd);
-            const float ssum = (p0 + p1) + p2;
-            const double num = __builtin_fma(2.0, (double)p2, (double)p1);
-            return div_exact<true>(num, (double)ssum);
-        };
-        // (lanes whose SNP has fewer classes compute on whatever the unwritten rows hold: never looked up)
+    for (int r0 = 0; r0 < ROWS; r0 += ILP) {
+        if (r0 < nrows) {                                // wave-uniform
+            double qv[ILP];
 #pragma unroll
-        for (int r0 = 0; r0 < ROWS; r0 += ILP) {
-            if (r0 < nrows) {                                // wave-uniform
-                double qv[ILP];
-#pragma unroll
-                for (int x = 0; x < ILP; ++x) {
-                    // (opaque to the compiler: else it hoists the three float -> double forms of every row out of the iteration
-                    // loop -- six registers per row instead of two, 202 VGPRs and two wavefronts per SIMD instead of four)
-                    double raw = r[r0 + x];
-                    asm volatile("" : "+v"(raw));
-                    qv[x] = quotient(raw);
-                }
-#pragma unroll
-                for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
+            for (int x = 0; x < ILP; ++x) {
+                // (opaque to the compiler: else it hoists the three float -> double forms of every row out of the iteration
+                // loop -- six registers per row instead of two, 202 VGPRs and two wavefronts per SIMD instead of four)
+                double raw = r[r0 + x];
+                asm volatile("" : "+v"(raw));
+                qv[x] = class_quotient(raw, st);
             }
+#pragma unroll
+            for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
         }
     }
-    // phase 2: the serial accumulation over the slab's individuals; the quotients of a buffer of U quads are read from the
-    // table before the chain of that buffer starts
+}
+
+// phase 2: the serial float32 sum over the slab's individuals (all but `skip`), emMAF_cy.pyx:19-22; the quotients of a buffer of U
+// quads are read from the table before the chain of that buffer starts.  cur = the first U code words (requested before phase 1).
+template <int U>
+__device__ __forceinline__ float coded_phase2(const double *q, const uint32_t *src, int nquads, int ncols, int skip, uint32_t (&cur)[U])
+{
+    const int last = nquads - 1;
+    uint32_t nxt[U];
     float tmp = 0.0f;
     for (int q0 = 0; q0 < nquads; q0 += U) {
         if (q0 + U < nquads) {
@@ -438,6 +444,17 @@ __device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], double
         for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
     return tmp;
+}
+
+template <int U, int ILP, int ROWS>
+__device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], double *q, int nrows, const uint32_t *src, int nquads, int ncols, int skip, float f_old)
+{
+    const int last = nquads - 1;
+    uint32_t cur[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];      // in flight during phase 1
+    coded_phase1_lane<ILP, ROWS>(r, q, nrows, f_old);
+    return coded_phase2<U>(q, src, nquads, ncols, skip, cur);
 }
 
 template <int U, int ILP, int ROWS>
@@ -603,6 +620,10 @@ __global__ __launch_bounds__(64) void em_coded_group_kernel(const FitDesc *__res
         }
         return;
     }
+    // the tile's rows of the slab's dictionary: requested once for all fits of the group
+    // (Tried: dealing the tile's (SNP, class) pairs evenly over the lanes instead of every lane evaluating the tile's richest SNP's row
+    // count -- 14 quotients per lane instead of 20 at 62 individuals per slab.  10 % fewer vector instructions, 2 % less time: fetching
+    // the pair's frequency through LDS and 162 registers took back what the rows saved.  Not kept.)
     double r[ROWS];
     {
         const double *drow = reinterpret_cast<const double *>(gf[0].ldict) + tile * lrows * 64 + lane;
