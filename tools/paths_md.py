@@ -50,7 +50,7 @@ for name, v in (ex.get("paths") or {}).items():
                                                                             ("; of which hipMalloc of the re-fits' buffers %s" % ms(v[k]["of_which_hipMalloc_seconds"])) if v[k].get("of_which_hipMalloc_seconds", 0) > 2e-3 else "")))
 print("# Whole paths on one MI355X (`bench.py`, %s)\n" % d["config"]["workload"])
 print("Headline: %.4g %s, %.2f ms per iteration over the float32 matrix, %.4f of the HBM peak (`%s`).\n" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel"]))
-print("cold = nothing built for the matrix before the call (the class codes, where the cost models want them, are built inside it); warm = codes present; float32 = `WGSASSIGN_CODES=0`.\n")
+print("cold = nothing built for the matrix before the call (the class codes, where the cost models want them, are built inside it -- unless the driver takes longer than 3 ms to hand out their memory: then the call runs over the float32 slabs and the NEXT call builds them, see the notes); warm = codes present; float32 = `WGSASSIGN_CODES=0`.\n")
 print("| path | cold | warm | float32 slabs | notes |\n|---|---|---|---|---|")
 for r in rows:
     print("| " + " | ".join(str(x) for x in r) + " |")
