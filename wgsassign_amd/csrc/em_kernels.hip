@@ -25,6 +25,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));   // plain vector type: st
 typedef const f4 __attribute__((address_space(1))) *gf4_ptr;
 typedef const float __attribute__((address_space(1))) *gf32_ptr;
 typedef float __attribute__((address_space(1))) *gf32_wptr;
+typedef const uint32_t __attribute__((address_space(1))) *gu32_ptr;
 
 template <bool NT>
 __device__ __forceinline__ f4 ldg(gf4_ptr p)
@@ -377,9 +378,45 @@ __device__ __forceinline__ double class_quotient(double raw, const SnpState &st)
     return div_exact<true>(num, (double)ssum);
 }
 
+// The quotient table of a wavefront in LDS, ROWS x 64 doubles, kept as two planes of 32-bit halves: low words of rank k at dword
+// k * 64 + lane, high words ROWS * 64 dwords further.  A look-up's address is then (rank << 8) | (lane << 2) -- ONE v_perm_b32 takes
+// the code byte out of the code word and puts it above the lane's byte (a double-wide table needs a bit-field extract and a shifted
+// add per look-up: 5.5 instead of 4 vector instructions per individual) -- and both halves come back from one ds_read2st64_b32.
+// The table is the kernel's only LDS (the dynamic allocation of a kernel without static LDS starts at address 0: checked once per
+// wavefront, a trap otherwise), so the permuted word IS the address.
+typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+struct QTable {
+    uint32_t lane4;      // lane * 4: one byte
+};
+__device__ __forceinline__ QTable qtable_of(double *lds, int lane)
+{
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)lds != 0u) __builtin_trap();
+    QTable t;
+    t.lane4 = (uint32_t)lane * 4u;
+    return t;
+}
+template <int ROWS>
+__device__ __forceinline__ void qtable_store(const QTable &t, int rank, double v)
+{
+    lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)t.lane4;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    p[rank * 64] = (uint32_t)bits;
+    p[(ROWS + rank) * 64] = (uint32_t)(bits >> 32);
+}
+// the quotient of the class in byte H of code word w
+template <int ROWS, int H>
+__device__ __forceinline__ double qtable_lookup(const QTable &t, uint32_t w)
+{
+    // result bytes, low to high: lane4's byte 0, w's byte H, zero, zero   (selector values 0-3: second operand, 4-7: first, 0x0c: zero)
+    const uint32_t a = __builtin_amdgcn_perm(w, t.lane4, 0x0c0c0000u | ((4u + H) << 8));
+    lds_u32_ptr p = (lds_u32_ptr)(uintptr_t)a;
+    const uint32_t lo = p[0], hi = p[ROWS * 64];
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // phase 1, lane <-> SNP: r = the tile's dictionary rows (registers); every lane fills the rows of its own SNP, ILP at a time
 template <int ILP, int ROWS>
-__device__ __forceinline__ void coded_phase1_lane(const double (&r)[ROWS], double *q, int nrows, float f_old)
+__device__ __forceinline__ void coded_phase1_lane(const double (&r)[ROWS], const QTable &q, int nrows, float f_old)
 {
     SnpState st;
     st.fd = (double)f_old;
@@ -399,15 +436,15 @@ __device__ __forceinline__ void coded_phase1_lane(const double (&r)[ROWS], doubl
                 qv[x] = class_quotient(raw, st);
             }
 #pragma unroll
-            for (int x = 0; x < ILP; ++x) q[(r0 + x) * 64] = qv[x];
+            for (int x = 0; x < ILP; ++x) qtable_store<ROWS>(q, r0 + x, qv[x]);
         }
     }
 }
 
 // phase 2: the serial float32 sum over the slab's individuals (all but `skip`), emMAF_cy.pyx:19-22; the quotients of a buffer of U
 // quads are read from the table before the chain of that buffer starts.  cur = the first U code words (requested before phase 1).
-template <int U>
-__device__ __forceinline__ float coded_phase2(const double *q, const uint32_t *src, int nquads, int ncols, int skip, uint32_t (&cur)[U])
+template <int U, int ROWS>
+__device__ __forceinline__ float coded_phase2(const QTable &q, gu32_ptr src, int nquads, int ncols, int skip, uint32_t (&cur)[U])
 {
     const int last = nquads - 1;
     uint32_t nxt[U];
@@ -422,9 +459,12 @@ __device__ __forceinline__ float coded_phase2(const double *q, const uint32_t *s
         }
         double qv[U][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int h = 0; h < 4; ++h) qv[u][h] = q[((cur[u] >> (8 * h)) & 255u) * 64];
+        for (int u = 0; u < U; ++u) {
+            qv[u][0] = qtable_lookup<ROWS, 0>(q, cur[u]);
+            qv[u][1] = qtable_lookup<ROWS, 1>(q, cur[u]);
+            qv[u][2] = qtable_lookup<ROWS, 2>(q, cur[u]);
+            qv[u][3] = qtable_lookup<ROWS, 3>(q, cur[u]);
+        }
         const bool plain = 4 * (q0 + U) <= ncols && (skip < 4 * q0 || skip >= 4 * (q0 + U));
         if (plain) {
 #pragma unroll
@@ -447,14 +487,14 @@ __device__ __forceinline__ float coded_phase2(const double *q, const uint32_t *s
 }
 
 template <int U, int ILP, int ROWS>
-__device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], double *q, int nrows, const uint32_t *src, int nquads, int ncols, int skip, float f_old)
+__device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], const QTable &q, int nrows, gu32_ptr src, int nquads, int ncols, int skip, float f_old)
 {
     const int last = nquads - 1;
     uint32_t cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];      // in flight during phase 1
     coded_phase1_lane<ILP, ROWS>(r, q, nrows, f_old);
-    return coded_phase2<U>(q, src, nquads, ncols, skip, cur);
+    return coded_phase2<U, ROWS>(q, src, nquads, ncols, skip, cur);
 }
 
 template <int U, int ILP, int ROWS>
@@ -469,7 +509,7 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
     const int lane = threadIdx.x;
     const int64_t row0 = tile * 64;
     if (row0 >= m) return;                       // wave-uniform; no barriers below
-    double *q = qtab_all + lane;                 // slot of rank r: q[r * 64]
+    const QTable q = qtable_of(qtab_all, lane);
 
     const int64_t my_row = row0 + lane;
     const int64_t my_row_c = my_row < m ? my_row : m - 1;
@@ -493,7 +533,7 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
 
     // the first code words: in flight during phase 1
     const int nquads = fd.nquads;
-    const uint32_t *src = fd.lcodes + tile * nquads * 64 + lane;
+    gu32_ptr src = (gu32_ptr)fd.lcodes + tile * nquads * 64 + lane;      // (device-global by construction: global_load, not flat_load)
     // rows of this tile: the most classes one of its 64 SNPs has in this slab (255: a SNP the encoder gave up on)
     int nrows;
     {
@@ -567,12 +607,12 @@ __global__ __launch_bounds__(64) void em_coded_group_kernel(const FitDesc *__res
     if (row0 >= m) return;                       // wave-uniform; no barriers below
     const int2 gd = groups[grp];
     const FitDesc *gf = fits + gd.x;
-    double *q = qtab_all + lane;
+    const QTable q = qtable_of(qtab_all, lane);
     const int64_t my_row = row0 + lane;
     const int64_t my_row_c = my_row < m ? my_row : m - 1;
     // what the fits of a group share: the slab
     const int nquads = gf[0].nquads, ncols = gf[0].ncols, lrows = gf[0].lrows;
-    const uint32_t *src = gf[0].lcodes + tile * nquads * 64 + lane;
+    gu32_ptr src = (gu32_ptr)gf[0].lcodes + tile * nquads * 64 + lane;
     int nrows;
     {
         unsigned mx = 0;
