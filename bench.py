@@ -527,9 +527,9 @@ FP64_ISSUE_CLOCK_GHZ = 2.4      # MI355X peak engine clock: issue fractions belo
 WAVE_ISSUE_PER_S = 1024 * FP64_ISSUE_CLOCK_GHZ * 1e9 / 4.0       # 1024 SIMDs, 4 cycles per wave-wide FP64-rate instruction
 # VALU wave-instructions per (SNP, individual[, population]) term of the FP64-issue-bound kernels, from the committed PMC
 # passes (profiles/r02_e_loo_final: em_sweep_group_kernel 2.49e10 per sweep of 6.15e10 terms; r02_g_final: score sweep;
-# r03_b_final: coded score sweep 4.26e9 per 1e11 terms; r04_loo: em_coded_group_kernel 1.465e10 per sweep of 6.15e10 terms at 62
+# r03_b_final: coded score sweep 4.26e9 per 1e11 terms; r04_loo: em_coded_group_kernel 1.32e10 per sweep of 6.15e10 terms at 62
 # individuals and 12.7 classes per slab -- a figure of that shape, not a constant of the kernel)
-INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "em_coded_group_kernel": 15.2, "score_sweep_kernel<exact>": 41.6, "score_coded_kernel<exact>": 2.7}
+INSTS_PER_TERM = {"em_sweep_group_kernel<exact>": 25.9, "em_coded_group_kernel": 13.7, "score_sweep_kernel<exact>": 41.6, "score_coded_kernel<exact>": 2.7}
 
 
 def whole_paths(ctx, device, mode_name):

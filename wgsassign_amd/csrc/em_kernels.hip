@@ -26,6 +26,7 @@ typedef const f4 __attribute__((address_space(1))) *gf4_ptr;
 typedef const float __attribute__((address_space(1))) *gf32_ptr;
 typedef float __attribute__((address_space(1))) *gf32_wptr;
 typedef const uint32_t __attribute__((address_space(1))) *gu32_ptr;
+typedef const double __attribute__((address_space(1))) *gf64_ptr;
 
 template <bool NT>
 __device__ __forceinline__ f4 ldg(gf4_ptr p)
@@ -570,7 +571,7 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
     // the tile's rows of the slab's dictionary: requested once, kept in registers for every iteration of this sweep
     double r[ROWS];
     {
-        const double *drow = reinterpret_cast<const double *>(fd.ldict) + tile * fd.lrows * 64 + lane;
+        gf64_ptr drow = (gf64_ptr) reinterpret_cast<const double *>(fd.ldict) + tile * fd.lrows * 64 + lane;
 #pragma unroll
         for (int g4 = 0; g4 < ROWS / 4; ++g4) {              // (four rows at a time: a tile's richest SNP has ~19 classes in its slab,
             if (4 * g4 < nrows) {                            //  so eight at a time read a fifth more dictionary than needed; wave-uniform)
@@ -666,7 +667,7 @@ __global__ __launch_bounds__(64) void em_coded_group_kernel(const FitDesc *__res
     // the pair's frequency through LDS and 162 registers took back what the rows saved.  Not kept.)
     double r[ROWS];
     {
-        const double *drow = reinterpret_cast<const double *>(gf[0].ldict) + tile * lrows * 64 + lane;
+        gf64_ptr drow = (gf64_ptr) reinterpret_cast<const double *>(gf[0].ldict) + tile * lrows * 64 + lane;
 #pragma unroll
         for (int g4 = 0; g4 < ROWS / 4; ++g4) {
             if (4 * g4 < nrows) {
