@@ -414,6 +414,29 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
     }
 }
 
+// After the sample pass: hist[c] = sampled SNPs with c classes, hist[256 + c] = sampled (slab, SNP) pairs with c classes in the slab
+// (slabs with individuals only).  One workgroup; the host reads back 4 KiB instead of the sample (the first device-to-host copy of
+// more than a few KiB in a process costs ~7 ms, whatever its destination).
+__global__ __launch_bounds__(256) void sample_hist_kernel(const uint8_t *sample, int64_t units, int n_slabs, const int32_t *ncols, unsigned long long *hist)
+{
+    __shared__ unsigned int hg[256], hl[256];
+    hg[threadIdx.x] = hl[threadIdx.x] = 0;
+    __syncthreads();
+    constexpr int W = WGS_ENC_MIN_SNPS;
+    for (int64_t i = threadIdx.x; i < units * W; i += 256) {
+        const uint8_t *row = sample + (i / W) * (n_slabs + 1) * W;
+        const int x = (int)(i % W);
+        const unsigned g = row[n_slabs * W + x];
+        if (g == 0) continue;                                // beyond the last SNP
+        atomicAdd(&hg[g], 1u);
+        for (int sl = 0; sl < n_slabs; ++sl)
+            if (ncols[sl]) atomicAdd(&hl[row[sl * W + x]], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x] = hg[threadIdx.x];
+    hist[256 + threadIdx.x] = hl[threadIdx.x];
+}
+
 // After the encode pass: the wavefronts' records added up, and the (slab, tile) pairs whose SNPs do not fit the EM sweep's table counted.
 __global__ __launch_bounds__(256) void encode_stats_kernel(const uint4 *wave_stats, int64_t units, const SlabCodes *slabs, int n_slabs, int64_t tiles,
                                                            unsigned lrows, unsigned long long *out)
@@ -506,36 +529,24 @@ int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned lon
     const int64_t units = wgs_ntiles(b->m) * WGS_TILE_ROWS_BYTES;
     const int64_t stride = std::max<int64_t>(1, units / std::max(1, max_units));
     const int64_t grid = (units + stride - 1) / stride;
-    const size_t sample_bytes = (size_t)grid * (b->n_groups + 1) * WGS_ENC_MIN_SNPS;
-    if (encode_scratch(b, &d_ncols, &d_stats, sample_bytes)) return 1;
+    const size_t sample_bytes = ((size_t)grid * (b->n_groups + 1) * WGS_ENC_MIN_SNPS + 7) / 8 * 8, hist_bytes = 512 * sizeof(unsigned long long);
+    if (encode_scratch(b, &d_ncols, &d_stats, sample_bytes + hist_bytes + 8)) return 1;
     EncodeArgs A = encode_args(b, c, d_ncols, d_stats);
     A.drows = 254;
     A.lrows = 0;
     A.unit_stride = stride;
     A.sample = reinterpret_cast<uint8_t *>(d_ncols + b->n_groups + 64);
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(A.sample + sample_bytes) + 7) & ~(uintptr_t)7);
     hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_MIN_SNPS, true>), dim3((unsigned)grid), dim3(64), 0, b->ctx->stream, A);
     HIP_TRY(hipGetLastError());
-    // into the context's pinned scratch when it fits (a pageable destination of this size cost 8 ms the first time in a process: the
-    // runtime's staging buffer)
-    std::vector<uint8_t> pageable;
-    uint8_t *hdata = reinterpret_cast<uint8_t *>(b->ctx->pinned);
-    if (sample_bytes > b->ctx->pinned_bytes) {
-        pageable.resize(sample_bytes);
-        hdata = pageable.data();
-    }
-    HIP_TRY(hipMemcpyAsync(hdata, A.sample, sample_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
+    hipLaunchKernelGGL(sample_hist_kernel, dim3(1), dim3(256), 0, b->ctx->stream, A.sample, grid, (int)b->n_groups, d_ncols, d_hist);
+    HIP_TRY(hipGetLastError());
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(b->ctx->pinned);
+    HIP_TRY(hipMemcpyAsync(h, d_hist, hist_bytes, hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
-    for (int i = 0; i < 256; ++i) hist_g[i] = hist_l[i] = 0;
-    const int G = b->n_groups;
-    for (int64_t u = 0; u < grid; ++u) {
-        constexpr int W = WGS_ENC_MIN_SNPS;
-        const uint8_t *row = hdata + (size_t)u * (G + 1) * W;
-        for (int x = 0; x < W; ++x) {
-            if (row[(size_t)G * W + x] == 0) continue;     // beyond the last SNP
-            ++hist_g[row[(size_t)G * W + x]];
-            for (int g = 0; g < G; ++g)
-                if (b->slabs[g].ncols) ++hist_l[row[(size_t)g * W + x]];
-        }
+    for (int i = 0; i < 256; ++i) {
+        hist_g[i] = h[i];
+        hist_l[i] = h[256 + i];
     }
     if (rounds_per_buffer) *rounds_per_buffer = 0.0;
     return 0;
