@@ -148,7 +148,9 @@ static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, in
 {
     wgs_beagle *b = em->b;
     if (const char *sw = getenv("WGSASSIGN_EM_CODES_SWEEPS")) return sweeps_ahead >= atoi(sw) || b->direct_sweeps >= 3;
-    double ahead = std::min(sweeps_ahead, 14);
+    // a fit uses ~14 iterations: what this one has done already (the codes' memory may arrive in the middle of it) no longer counts --
+    // but a fit that has gone past 14 is taken to need a few more
+    double ahead = std::min<double>(sweeps_ahead, std::max(3, 14 - em->fit_iterations));
     if (sweeps_ahead <= 0 && b->direct_sweeps >= 3) ahead = 12;
     double swept = 0.0, cols = 0.0;
     for (int j : order) {
