@@ -36,9 +36,13 @@ for name, v in (ex.get("paths") or {}).items():
         if "codes_memory_arrived_after_the_cold_fit_hipMalloc_ms" in fit:
             note += "; the codes' hipMalloc took %.0f ms (helper thread), the cold fit did not wait; the second fit, building them: %s" % (
                 fit["codes_memory_arrived_after_the_cold_fit_hipMalloc_ms"], ms(fit["seconds_second_fit_building_the_codes"]))
-        if "of_which_hipMalloc_seconds" in fit:
-            note += "; hipMalloc of the fits' buffers: " + ", ".join("%s %s" % (k, ms(x)) for k, x in fit["of_which_hipMalloc_seconds"].items())
-        rows.append((name + " fit", cold, ms(fit["seconds_warm"]), ms(fit["seconds_float32"]), note))
+        mal = fit.get("of_which_hipMalloc_seconds", {})
+
+        def cell(seconds, key):
+            """a figure with the driver's share of it taken out where that share is more than 5 ms (VRAM an earlier process used)"""
+            m = mal.get(key, 0.0)
+            return ms(seconds) if m < 5e-3 else "%s + %s of hipMalloc" % (ms(seconds - m), ms(m))
+        rows.append((name + " fit", cell(fit["seconds_cold"], "cold"), cell(fit["seconds_warm"], "warm"), cell(fit["seconds_float32"], "float32"), note))
     pl = v.get("get_pop_like")
     if pl:
         cc = pl.get("class_codes_cold") or {}
