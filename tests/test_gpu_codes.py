@@ -320,6 +320,20 @@ def test_sweeps_do_not_wait_for_the_codes_memory(dev, oracle, wait_ms, monkeypat
     assert it1 == [int(x) for x in it_o] and same(af1, af_o)
 
 
+def test_allocation_time_is_accounted(dev):
+    """wgs_malloc_seconds: a running total of what hipMalloc took through the library (the driver clears VRAM an earlier process
+    used, so the same call costs 0.3 ms or seconds; bench.py reports the share of every whole path)."""
+    before = dev.malloc_seconds()
+    L, IDs = synth.make_beagle(5_000, 12, 2, seed=3)
+    group_of = np.searchsorted(np.unique(IDs[:, 1]), IDs[:, 1]).astype(np.int32)
+    b = dev.DeviceBeagle.from_host(L, group_of, 2)
+    em = dev.EMBatch(b, np.arange(2, dtype=np.int32))
+    after = dev.malloc_seconds()
+    em.close()
+    b.close()
+    assert 0.0 <= before < after < before + 60.0 and dev.malloc_seconds() >= after
+
+
 def test_a_scoring_sweep_builds_the_codes_without_the_slab_numbering(dev, oracle):
     """--get_pop_like alone never fits: a build that a scoring sweep asks for leaves out the slabs' own numbering (the coded EM sweep's
     tables: a third of the encode pass, two thirds of the memory).  An EM fit on the same matrix afterwards rebuilds in full; same
