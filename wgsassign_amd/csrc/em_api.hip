@@ -136,12 +136,12 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
 // Share of a leave-one-out sweep's time the codes save (<= 0: none).  Such batches (many fits per slab) are bound by instruction
 // issue, not by memory: em_sweep_group_kernel spends 25.9 vector instructions per (fit, SNP, individual) term; through the codes
 // (em_coded_group_kernel) a (fit, SNP) costs one quotient (29 instructions) per table row of its tile -- the richest SNP of the
-// tile, ~1.7 x the mean classes per (slab, SNP) -- 5.5 per individual and ~190 around them (measured at 2M x 500, K=8, 62
-// individuals per slab and 12.7 classes: 469 ms of sweeps against 645).
+// tile, ~1.7 x the mean classes per (slab, SNP) -- 4 per individual, and the equivalent of ~250 more in issue slots it leaves open
+// (measured at 2M x 500, K=8, 62 individuals per slab and 12.7 classes: 458 ms of sweeps against 655).
 static double loo_codes_saving(const wgs_codes_plan *P, double cols)
 {
     if (!P || P->state <= 0 || P->lrows == 0) return 0.0;
-    return 1.0 - (1.7 * P->mean_l * 29.0 + 5.5 * cols + 190.0) / (25.9 * std::max(1.0, cols));
+    return 1.0 - (1.7 * P->mean_l * 29.0 + 4.0 * cols + 250.0) / (25.9 * std::max(1.0, cols));
 }
 
 static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, int fewest_cols, int sweeps_ahead, bool shared)
