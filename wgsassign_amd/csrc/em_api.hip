@@ -204,7 +204,8 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     // -- and the codes are BUILT for it only when the sweeps still to come repay the encode pass (em_codes_pay below).
     // Codes that exist already (a scoring sweep built them, or wgs_beagle_codes_prepare) are used at once.
     const bool loo_codes = !(getenv("WGSASSIGN_LOO_CODES") && atoi(getenv("WGSASSIGN_LOO_CODES")) == 0);
-    bool worth = em->mode == WGS_MODE_EXACT && (!shared || loo_codes);
+    const char *codes_env = getenv("WGSASSIGN_CODES");      // ("0": no codes at all -- and no sample pass to decide about them; codes.hip reads it the same way)
+    bool worth = em->mode == WGS_MODE_EXACT && (!shared || loo_codes) && !(codes_env && codes_env[0] == '0');
     const char *min_env = getenv("WGSASSIGN_EM_CODES_MIN");    // tests lower it to run small populations through the codes
     const int min_cols = min_env ? atoi(min_env) : 28;
     int fewest = INT32_MAX;
