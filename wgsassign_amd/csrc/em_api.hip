@@ -505,7 +505,6 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     };
     bool launched_prev = false;
     for (int t = 1;; ++t) {
-        WGS_STALL_SCOPE("one trip of the fit loop");
         const int slot = t & 1;
         // Who ran at t-1 is known now: its list minus the fits found finished or parked when the decisions
         // of t-2 were read (those sweeps returned at once).
@@ -544,10 +543,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
             // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
             // in the same way on every rank (all ranks take the same decisions).
             if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, 2 * n)) return 1;
-            {
-                WGS_STALL_SCOPE("launch_em_decide");
-                if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
-            }
+            if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
             HIP_TRY(hipMemcpyAsync(em->h_state[slot], em->d_state, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipMemcpyAsync(em->h_ssq[slot], em->d_ssq2, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
             HIP_TRY(hipEventRecord(em->ev_it[slot], ctx->stream));
