@@ -397,3 +397,56 @@ def test_cli_three_ranks_on_a_bgzf_file_equal_one_process(tmp_path, oracle):
     loo_o, parts_o = oracle.loo(L, af_o.copy(), IDs, 8, 200, 1e-4, None, 2)
     rows = [l.split("\t") for l in gzip.open(tmp_path / "one.pop_like_LOO_partitions_2.tsv.gz", "rt").read().strip().split("\n")][1:]
     assert [["%.6f" % v for v in row] for row in parts_o] == [r[3:] for r in rows]
+
+
+_MIXED_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+rank, world, variant = int(sys.argv[1]), 2, sys.argv[2]
+if variant == "one_rank_without_codes" and rank == 1:
+    os.environ["WGSASSIGN_CODES"] = "0"                       # this rank sweeps the float32 slabs throughout
+if variant == "memory_late_on_one_rank" and rank == 1:
+    os.environ["WGSASSIGN_CODES_ALLOC_WAIT_MS"] = "0"          # ... this one until its codes' memory arrives, in the middle of the fit
+    os.environ["WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS"] = "4"
+import synth
+from oracle import oracle
+from wgsassign_amd import device, emMAF
+from wgsassign_amd.comm import SocketComm, shard_range
+import io, contextlib
+comm = SocketComm(rank, world, "127.0.0.1", {port})
+m, n, K = 150_000, 96, 3
+L, IDs = synth.make_beagle(m, n, K, seed=21)
+with contextlib.redirect_stdout(io.StringIO()):
+    pops, af, _, iters = oracle.fit_reference_af(L, IDs, t=4)
+group_of = np.searchsorted(pops, IDs[:, 1]).astype(np.int32)
+lo, hi = shard_range(m, rank, world)
+ctx = device.Context(0)
+comm.attach(ctx)
+b = device.DeviceBeagle.from_host(np.ascontiguousarray(L[lo:hi]), group_of, K, site0=lo, ctx=ctx)
+ok = True
+for fit in range(3):          # cold (codes built inside where allowed), then with whatever each rank has by then
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, af_c, it_c = emMAF.emMAF_populations(None, IDs, 200, 1e-4, beagle=b, comm=comm)
+    ok &= af_c.tobytes() == np.ascontiguousarray(af[lo:hi]).tobytes() and list(it_c) == [int(x) for x in iters]
+print("RANK", rank, "OK" if ok else "FAIL", "codes_state", b.codes_state(), flush=True)
+comm.close()
+sys.exit(0 if ok else 1)
+'''
+
+
+@pytest.mark.parametrize("variant", ["both_with_codes", "one_rank_without_codes", "memory_late_on_one_rank"])
+def test_ranks_that_disagree_about_the_codes(tmp_path, variant):
+    """SNP shards on two ranks whose sweeps go different ways -- one through the class codes (two iterations per sweep when it may),
+    the other over the float32 slabs, or through the codes only from the middle of the fit -- must still run the same number of
+    iterations per sweep: the sums of a sweep are all-reduced.  wgs_em_fit agrees once per fit whether EVERY rank can run two;
+    frequencies and iteration counts equal the oracle's on three fits in a row."""
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(_MIXED_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
+        assert "RANK %d OK" % r in o

@@ -177,6 +177,21 @@ static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, in
     return ahead * saves(P->mean_l) * direct_ms > wgs_codes_build_ms_estimate(b, P->slots);
 }
 
+// The buffers of two iterations per sweep: a third frequency buffer and a second set of partial sums.  false: no memory for them.
+static bool em_fuse_buffers(wgs_em *em)
+{
+    if (em->fbuf[2]) return true;
+    const size_t fbytes = (size_t)em->n_fits * em->b->m * sizeof(float);
+    const int64_t ntiles = wgs_ntiles(em->b->m);
+    if (wgs_malloc(&em->fbuf[2], fbytes) != hipSuccess || wgs_malloc(&em->d_part_b, sizeof(double) * (size_t)em->n_fits * ntiles) != hipSuccess) {
+        (void)hipGetLastError();
+        if (em->fbuf[2]) (void)hipFree(em->fbuf[2]);
+        em->fbuf[2] = nullptr;
+        return false;
+    }
+    return true;
+}
+
 /* Enqueue one sweep (+ the fixed-order reduction of its sums) for the fits in `list`: descriptors into the pinned
  * array H and from there to D.  Fits of different populations stream their slabs once (nontemporal loads); when
  * several fits share a slab (leave-one-out batches) they are ordered by slab and swept in groups of up to
@@ -238,15 +253,7 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
     bool fusing = false;
     if (codes && may_fuse && ssq_base_b && fuse_on && !shared) {    // (leave-one-out batches are bound by arithmetic: a second iteration that turns out unneeded is not free there)
         for (int j : order) fusing = fusing || (*may_fuse)[j] >= 2;
-        if (fusing && !em->fbuf[2]) {
-            const size_t fbytes = (size_t)em->n_fits * em->b->m * sizeof(float);
-            if (wgs_malloc(&em->fbuf[2], fbytes) != hipSuccess || wgs_malloc(&em->d_part_b, sizeof(double) * (size_t)em->n_fits * ntiles) != hipSuccess) {
-                (void)hipGetLastError();
-                if (em->fbuf[2]) (void)hipFree(em->fbuf[2]);
-                em->fbuf[2] = nullptr;
-                fusing = false;                            // no memory for it: one iteration per sweep
-            }
-        }
+        if (fusing && !em_fuse_buffers(em)) fusing = false;       // no memory for it: one iteration per sweep
     }
     const int nb = em->fbuf[2] ? 3 : 2;
     int coded_rows_max = 0;
@@ -476,6 +483,22 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         lo = g < 1.0 ? thresh * (1.0 - g) : -1.0;
         hi = thresh * (1.0 + g);
     }
+    // Across SNP shards every rank must run the same number of iterations per sweep (the sums of a sweep are all-reduced, and the
+    // bookkeeping below counts iterations): two per sweep only when EVERY rank can -- its codes built with the slabs' own numbering
+    // and the buffers at hand NOW; a rank whose codes arrive during the fit (or whose cost model decides otherwise) still sweeps
+    // through them, one iteration at a time like the others.  Agreed once per fit (one host all-reduce of a flag).
+    bool fuse_allowed = true;
+    {
+        int world = 1, rank = 0;
+        if (comm) wgs_comm_rank(comm, &rank, &world);
+        if (world > 1) {
+            const bool fuse_on = !(getenv("WGSASSIGN_EM_FUSE") && atoi(getenv("WGSASSIGN_EM_FUSE")) < 2);
+            wgs_codes *have = wgs_beagle_codes(em->b, false);
+            double mine = (em->mode == WGS_MODE_EXACT && fuse_on && have && have->lrows > 0 && em_fuse_buffers(em)) ? 1.0 : 0.0;
+            if (wgs_comm_allreduce_f64(comm, &mine, 1)) return 1;
+            fuse_allowed = mine == (double)world;
+        }
+    }
     std::vector<char> fin(n, 0), skipped(n, 0);
     std::vector<int32_t> sweeps(n, 0), init(n), may_fuse(n, 1), ran, parked, parked_a, lists[2];
     for (int j = 0; j < n; ++j) {
@@ -538,7 +561,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
                 em->fit_sweep_pending = true;
             }
             if (em_enqueue_sweep(em, L, em->h_descs2[slot], em->d_descs2[slot], em->h_groups2[slot], em->d_groups2[slot], em->d_ssq2,
-                                 em->d_state, sw0, sw1, max_iter - t + 1, &may_fuse, em->d_ssq2 + n))
+                                 em->d_state, sw0, sw1, max_iter - t + 1, fuse_allowed ? &may_fuse : nullptr, em->d_ssq2 + n))
                 return 1;
             // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
             // in the same way on every rank (all ranks take the same decisions).
