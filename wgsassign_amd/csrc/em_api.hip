@@ -491,7 +491,15 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
     {
         int world = 1, rank = 0;
         if (comm) wgs_comm_rank(comm, &rank, &world);
-        if (world > 1) {
+        // (leave-one-out batches -- several fits per slab, the same on every rank -- never run two iterations per sweep: nothing to agree on)
+        std::vector<char> seen_slab(em->b->n_groups, 0);
+        bool shared_slabs = false;
+        for (int j = 0; j < n; ++j) {
+            shared_slabs = shared_slabs || seen_slab[em->group[j]];
+            seen_slab[em->group[j]] = 1;
+        }
+        if (world > 1 && shared_slabs) fuse_allowed = false;
+        if (world > 1 && !shared_slabs) {
             const bool fuse_on = !(getenv("WGSASSIGN_EM_FUSE") && atoi(getenv("WGSASSIGN_EM_FUSE")) < 2);
             wgs_codes *have = wgs_beagle_codes(em->b, false);
             double mine = (em->mode == WGS_MODE_EXACT && fuse_on && have && have->lrows > 0 && em_fuse_buffers(em)) ? 1.0 : 0.0;
