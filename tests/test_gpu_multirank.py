@@ -429,7 +429,21 @@ for fit in range(3):          # cold (codes built inside where allowed), then wi
     with contextlib.redirect_stdout(io.StringIO()):
         _, af_c, it_c = emMAF.emMAF_populations(None, IDs, 200, 1e-4, beagle=b, comm=comm)
     ok &= af_c.tobytes() == np.ascontiguousarray(af[lo:hi]).tobytes() and list(it_c) == [int(x) for x in iters]
-print("RANK", rank, "OK" if ok else "FAIL", "codes_state", b.codes_state(), flush=True)
+# leave-one-out on a smaller matrix: the re-fits of one rank through the slab's class table, of the other over the float32 slabs
+from wgsassign_amd import glassy
+m2 = 12_000
+L2, IDs2 = synth.make_beagle(m2, n, K, seed=22)
+with contextlib.redirect_stdout(io.StringIO()):
+    _, af2, _, _ = oracle.fit_reference_af(L2, IDs2, t=4)
+    with np.errstate(all="ignore"):
+        loo_o, parts_o = oracle.loo(L2, af2.copy(), IDs2, 4, 200, 1e-4, None, 2)
+lo2, hi2 = shard_range(m2, rank, world)
+b2 = device.DeviceBeagle.from_host(np.ascontiguousarray(L2[lo2:hi2]), group_of, K, site0=lo2, ctx=ctx)
+a2 = np.ascontiguousarray(af2[lo2:hi2]).copy()
+with contextlib.redirect_stdout(io.StringIO()):
+    ll, parts = glassy.loo_device(b2, b2, a2, group_of, 200, 1e-4, 2, comm=comm, verbose=False)
+ok &= ll.tobytes() == loo_o.tobytes() and parts.tobytes() == parts_o.tobytes()
+print("RANK", rank, "OK" if ok else "FAIL", "codes_state", b.codes_state(), b2.codes_state(), flush=True)
 comm.close()
 sys.exit(0 if ok else 1)
 '''
