@@ -44,8 +44,9 @@ const char *wgs_last_error(void);
 /* ABI version of this header (WGS_ABI_VERSION).  2 (round 4): wgs_assign lost its `P` / `parts` arguments and
  * wgs_fisher_obs_ind was removed in round 3 while the number stayed 1 -- a caller built against the older header must
  * compare wgs_version() with the WGS_ABI_VERSION it was compiled with and refuse to run on a mismatch (the ctypes shim does:
- * wgsassign_amd/_lib.py); wgs_beagle_codes_info fills 20 entries; wgs_comm_info is new. */
-#define WGS_ABI_VERSION 2
+ * wgsassign_amd/_lib.py); wgs_beagle_codes_info fills 20 entries; wgs_comm_info is new.  3 (round 5): self-checking
+ * collectives (wgs_coll_tag, wgs_comm_check, wgs_comm_next_generation, wgs_comm_allreduce_host_tagged). */
+#define WGS_ABI_VERSION 3
 int wgs_version(void);
 /* sha256[:16] over every source of the library / over the sources of the EM and scoring kernels (em_kernels.hip,
  * assign_kernels.hip, beagle_kernels.hip, codes_kernels.hip, common.h, log_table.h), fixed at build time: profiles record them, bench.py quotes hardware
@@ -282,7 +283,31 @@ typedef int (*wgs_allreduce_fn)(double *buf, int64_t n, void *user);
 int wgs_comm_create_host(wgs_ctx *ctx, int rank, int world, wgs_allreduce_fn fn, void *user, wgs_comm **out);
 void wgs_comm_destroy(wgs_comm *c);
 int wgs_comm_rank(wgs_comm *c, int *rank, int *world);
-/* In-place sum of n float64 in device memory, enqueued on the context's stream (pairs with wgs_em_step_dev). */
+/* Self-checking collectives (ABI 3).  The ranks of the sharded path must issue the same collectives in the same order with the
+ * same meaning; every collective of a wgs_comm therefore carries -- inside the SAME transfer as its payload -- a row per rank:
+ * {sequence number on this communicator, op, generation, iteration, shape_a, shape_b, payload elements, aux}.  An all-reduce
+ * all-gathers the rows (each rank fills its own, the sum fills in the rest) and every rank compares all of them with its own; a
+ * broadcast carries the root's row and every receiver compares.  A rank that is out of step makes the NEXT wgs_comm_check -- every
+ * entry point that takes a communicator calls it wherever it synchronises -- fail with rc 1 and a wgs_last_error() that starts
+ * "collective mismatch:" and names both ranks' tuples; the communicator refuses all further collectives.  `aux` is not compared:
+ * a free word per rank that all ranks get to see (wgs_em_fit: "this rank could run two iterations per sweep").  The reference has
+ * no counterpart (its only parallelism is OpenMP inside one process, emMAF_cy.pyx:16). */
+typedef struct wgs_coll_tag {
+    int32_t op;                 /* WGS_OP_*: which exchange step of the path */
+    int32_t generation;         /* which fit / scoring call / leave-one-out batch of this communicator (wgs_comm_next_generation) */
+    int32_t iteration;          /* EM sweep number, rank hop, ... */
+    int32_t shape_a, shape_b;   /* what the payload means: fits in the sweep and EM iterations they run, cells, root of a broadcast */
+    int32_t aux;                /* not compared */
+} wgs_coll_tag;
+enum { WGS_OP_GENERIC = 0, WGS_OP_EM_SUMS = 1, WGS_OP_EM_CHAIN = 2, WGS_OP_EM_FIT_END = 3, WGS_OP_SCORE_TOTALS = 4,
+       WGS_OP_PART_CHAINS = 5, WGS_OP_LOO_BATCH = 6, WGS_OP_TIMING = 7, WGS_OP_HOST = 8 };
+int32_t wgs_comm_next_generation(wgs_comm *c);
+int wgs_comm_check(wgs_comm *c);
+/* Sum all-reduce of n host float64 with a caller-given tag; rows_out (NULL or world * 8 float64) receives every rank's row
+ * (rows_out[r * 8 + 7] = rank r's aux).  Returns after the rows have been compared. */
+int wgs_comm_allreduce_host_tagged(wgs_comm *c, double *host_buf, int64_t n, const wgs_coll_tag *tag, double *rows_out);
+/* In-place sum of n float64 in device memory, enqueued on the context's stream (pairs with wgs_em_step_dev); tagged
+ * WGS_OP_GENERIC (sequence number and size are still compared), staged through the communicator's bounce buffer. */
 int wgs_comm_allreduce_f64_dev(wgs_comm *c, double *dev_buf, int64_t n);
 /* Broadcast of `bytes` bytes (a multiple of 4) of DEVICE memory from rank `root`, enqueued on the context's stream: how
  * a running value -- np.sum's float64 total, a float32 chain carry -- passes from SNP shard to SNP shard without a host
@@ -293,7 +318,8 @@ int wgs_comm_bcast_dev(wgs_comm *c, void *dev_buf, int64_t bytes, int root);
 int wgs_comm_stats(wgs_comm *c, int64_t *stats);
 /* info[0..7]: 1 = RCCL communicator / 0 = host-backed; the number of ranks, this rank and the device as RCCL ITSELF reports
  * them for the communicator it built (ncclCommCount / ncclCommUserRank / ncclCommCuDevice; -1 where unavailable) -- wgs_comm_init
- * fails when they differ from what was asked for --; world and rank as given at creation; two reserved entries. */
+ * fails when they differ from what was asked for --; world and rank as given at creation; [6] collectives issued so far, [7] 1 once
+ * a rank was found out of step. */
 int wgs_comm_info(wgs_comm *c, int64_t *info);
 /* Mean device microseconds (HIP events on the context's stream) of `reps` sum all-reduces of n float64 and of `reps`
  * broadcasts of n float64 from rank 0: us_out[0..1].  Collective. */

@@ -13,6 +13,15 @@
 extern "C" {
 #endif
 
+/* Named process-wide switches of the test suite (the product path reads no environment variable for them; 0 = off):
+ *   codes_alloc_delay_ms              the helper thread's hipMalloc of the class codes' memory takes this much longer
+ *   codes_alloc_release_after_sweeps  ... and is handed over only once the matrix has been swept directly this many times (or after
+ *                                     2 s): which sweep of a fit finds the codes is then decided by a count, not by a race
+ *   em_fuse_without_agreement         wgs_em_fit runs two iterations per sweep whenever THIS rank can, without the ranks' agreement
+ *                                     (replays the defect of commit 807a461: the collectives' tags must catch it)
+ *   em_coded_extra_lds                bytes of LDS em_coded_kernel requests beyond its table (occupancy experiment) */
+int wgs_debug_hook(const char *name, int64_t value);
+
 /* The literal one-lane-per-chain kernel behind wgs_assign_parts_exact, whatever P. */
 int wgs_debug_parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P,
                                   const float *carry_in, float *parts_out);

@@ -254,3 +254,118 @@ def test_three_ranks_split_the_bgzf_index_pass(tmp_path):
         _lib.check(_lib.load().wgs_reader_build_index(p.encode(), alone.encode(), None, reader_cy.INDEX_SPAN_BYTES,
                                                       reader_cy.INDEX_MAX_POINTS, ctypes.byref(sites)))
         assert open(os.path.join(cache, files[0]), "rb").read() == open(alone, "rb").read()
+
+
+_OUT_OF_STEP_WORKER = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from wgsassign_amd.comm import SocketComm, CollectiveMismatch, COMM_DIVERGED
+rank, world, variant = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+comm = SocketComm(rank, world, "127.0.0.1", {port})
+x = np.arange(5, dtype=np.float64) + rank
+def step_a():
+    return comm.allreduce_sum(x)                        # one call site ...
+def step_b():
+    return comm.allreduce_sum(x)                        # ... and another: a different collective although the payloads look alike
+try:
+    for it in range(6):
+        assert step_a().tobytes() == sum(np.arange(5, dtype=np.float64) + r for r in range(world)).tobytes()
+        if variant == "other_call_site" and rank == 1 and it == 3:
+            step_b()                                    # rank 1 takes another branch of the host code: same size, other meaning
+        elif variant == "other_iteration" and it == 3:
+            comm.allreduce_sum(x, tag=(7, it + (rank == 2), 0, 0))      # rank 2 believes it is one iteration further
+        elif variant == "other_kind" and rank == 1 and it == 3:
+            comm.allgather_object(["names"])            # a gather where the others all-reduce
+        elif variant == "other_size" and rank == 2 and it == 3:
+            comm.allreduce_sum(np.zeros(9))
+        else:
+            step_a()
+    print("RANK", rank, "went through", flush=True)
+    sys.exit(0)
+except CollectiveMismatch as e:
+    print("RANK", rank, "MISMATCH:", e, flush=True)
+    os._exit(COMM_DIVERGED)
+'''
+
+
+@pytest.mark.parametrize("variant", ["other_call_site", "other_iteration", "other_kind", "other_size"])
+def test_ranks_out_of_step_stop_with_both_tuples(tmp_path, variant):
+    """Three ranks over the TCP star, one of which issues a DIFFERENT collective at its fourth step (another call site with the
+    same payload size, another iteration in its tag, another kind of collective, another size): no rank may go on -- every rank
+    ends with status 76 and a message that names what two ranks issued.  Before round 5 the first two variants summed the
+    payloads of different collectives without a word."""
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(_OUT_OF_STEP_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "3", variant], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(3)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert "went through" not in o, "rank %d did not notice:\n%s" % (r, o[-2000:])
+        assert p.returncode == 76, "rank %d: status %s\n%s" % (r, p.returncode, o[-2000:])
+        assert "collective mismatch" in o
+    text = "\n".join(outs)
+    if variant == "other_call_site":       # both call sites are named, file and line
+        import re
+        sites = set(re.findall(r"host all-reduce at (worker\.py|<other file>):(\d+)", text))
+        assert len({line for _, line in sites}) == 2, text[-2000:]
+    if variant == "other_iteration":
+        assert "generation 7, iteration 3" in text and "generation 7, iteration 4" in text
+    if variant == "other_size":
+        assert "5 payload elements" in text or "float64" in text
+
+
+def test_tag_rows_carry_a_free_word_per_rank(tmp_path):
+    """aux is not compared: ranks report different values in it and every rank sees all of them (how wgs_em_fit learns that
+    every rank can run two iterations per sweep)."""
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from wgsassign_amd.comm import SocketComm
+rank = int(sys.argv[1])
+comm = SocketComm(rank, 3, "127.0.0.1", %d)
+out = comm.allreduce_sum(np.ones(2), tag=(1, 0, 0, 10 + rank))
+assert out.tolist() == [3.0, 3.0] and comm.last_rows[:, 7].tolist() == [10.0, 11.0, 12.0], comm.last_rows
+comm.barrier(); comm.close()
+''' % (ROOT, port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    for r, p in enumerate(procs):
+        o = p.communicate(timeout=60)[0]
+        assert p.returncode == 0, "rank %d:\n%s" % (r, o[-2000:])
+
+
+def test_two_gloo_ranks_out_of_step_stop_with_both_tuples(tmp_path):
+    """The same over torch.distributed (gloo, world_size 2): rank 1 issues its fourth all-reduce from another call site; both
+    ranks see both rows in the all-gathered table and stop with the two call sites named."""
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=int(sys.argv[1]), world_size=2)
+from wgsassign_amd.comm import TorchComm, CollectiveMismatch, COMM_DIVERGED
+comm = TorchComm()
+x = np.arange(4.0) + comm.rank
+try:
+    for it in range(6):
+        if comm.rank == 1 and it == 3:
+            got = comm.allreduce_sum(x)          # another line of the host code
+        else:
+            got = comm.allreduce_sum(x)
+        assert got.tolist() == (2 * np.arange(4.0) + 1).tolist()
+    print("went through", flush=True)
+except CollectiveMismatch as e:
+    print("MISMATCH:", e, flush=True)
+    os._exit(COMM_DIVERGED)
+''' % (ROOT, port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 76 and "went through" not in o, "rank %d: status %s\n%s" % (r, p.returncode, o[-2000:])
+        assert "rank 0 issued collective #4" in o and "rank 1 issued collective #4" in o, o[-2000:]

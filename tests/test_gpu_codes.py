@@ -364,13 +364,13 @@ def test_a_scoring_sweep_builds_the_codes_without_the_slab_numbering(dev, oracle
 
 
 def test_a_slow_allocation_is_not_waited_for(dev, oracle, monkeypatch):
-    """WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS makes the helper thread's hipMalloc take 400 ms (the driver takes seconds for VRAM an earlier
+    """The test hook codes_alloc_delay_ms makes the helper thread's hipMalloc take 400 ms (the driver takes seconds for VRAM an earlier
     process used).  With no waiting allowed the fit and the scoring call run over the float32 slabs and return long before the memory;
     kernel times read -1 meanwhile (hipEventElapsedTime would wait for the allocation) and are there after codes_wait(); the next fit
     builds the codes.  Same results throughout."""
     import time
     monkeypatch.setenv("WGSASSIGN_CODES_ALLOC_WAIT_MS", "0")
-    monkeypatch.setenv("WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS", "400")
+    dev.debug_hook("codes_alloc_delay_ms", 400)
     m, n, K = 50_000, 120, 3
     L, IDs = synth.make_beagle(m, n, K, seed=45)
     pops = np.unique(IDs[:, 1])
@@ -392,6 +392,7 @@ def test_a_slow_allocation_is_not_waited_for(dev, oracle, monkeypatch):
     out1, _ = dev.assign(b, afs)
     assert dev.assign.last_ms == -1.0 and b.codes_state() == 0
     waited = b.codes_wait()
+    dev.debug_hook("codes_alloc_delay_ms", 0)
     assert waited >= 350.0 and em.fit_stats()[3] > 0.0 and dev.last_assign_ms(b.ctx) > 0.0
     af1 = np.stack([em.get_f(k) for k in range(K)], axis=1)
     em.close()

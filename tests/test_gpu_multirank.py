@@ -406,14 +406,18 @@ sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests")
 rank, world, variant = int(sys.argv[1]), 2, sys.argv[2]
 if variant == "one_rank_without_codes" and rank == 1:
     os.environ["WGSASSIGN_CODES"] = "0"                       # this rank sweeps the float32 slabs throughout
-if variant == "memory_late_on_one_rank" and rank == 1:
+late = variant in ("memory_late_on_one_rank", "memory_late_and_no_agreement") and rank == 1
+if late:
     os.environ["WGSASSIGN_CODES_ALLOC_WAIT_MS"] = "0"          # ... this one until its codes' memory arrives, in the middle of the fit
-    os.environ["WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS"] = "4"
 import synth
 from oracle import oracle
 from wgsassign_amd import device, emMAF
-from wgsassign_amd.comm import SocketComm, shard_range
+from wgsassign_amd.comm import SocketComm, shard_range, CollectiveMismatch, COMM_DIVERGED
 import io, contextlib
+if late:
+    device.debug_hook("codes_alloc_release_after_sweeps", 4)   # handed over after the fourth sweep over the float32 slabs: a count, not a race
+if variant == "memory_late_and_no_agreement":
+    device.debug_hook("em_fuse_without_agreement", 1)          # the defect of commit 807a461: each rank runs two iterations per sweep as soon as IT can
 comm = SocketComm(rank, world, "127.0.0.1", {port})
 m, n, K = 150_000, 96, 3
 L, IDs = synth.make_beagle(m, n, K, seed=21)
@@ -425,10 +429,17 @@ ctx = device.Context(0)
 comm.attach(ctx)
 b = device.DeviceBeagle.from_host(np.ascontiguousarray(L[lo:hi]), group_of, K, site0=lo, ctx=ctx)
 ok = True
-for fit in range(3):          # cold (codes built inside where allowed), then with whatever each rank has by then
-    with contextlib.redirect_stdout(io.StringIO()):
-        _, af_c, it_c = emMAF.emMAF_populations(None, IDs, 200, 1e-4, beagle=b, comm=comm)
-    ok &= af_c.tobytes() == np.ascontiguousarray(af[lo:hi]).tobytes() and list(it_c) == [int(x) for x in iters]
+fused = []
+try:
+    for fit in range(3):          # cold (codes built inside where allowed), then with whatever each rank has by then
+        with contextlib.redirect_stdout(io.StringIO()):
+            _, af_c, it_c = emMAF.emMAF_populations(None, IDs, 200, 1e-4, beagle=b, comm=comm)
+        ok &= af_c.tobytes() == np.ascontiguousarray(af[lo:hi]).tobytes() and list(it_c) == [int(x) for x in iters]
+        fused.append(emMAF.emMAF_populations.last_stats[0])         # sweeps enqueued: fewer than iterations once two run per sweep
+except CollectiveMismatch as e:
+    print("RANK", rank, "MISMATCH:", e, flush=True)
+    os._exit(COMM_DIVERGED)
+print("RANK", rank, "sweeps per fit", fused, "iterations", [int(x) for x in iters], flush=True)
 # leave-one-out on a smaller matrix: the re-fits of one rank through the slab's class table, of the other over the float32 slabs
 from wgsassign_amd import glassy
 m2 = 12_000
@@ -453,8 +464,11 @@ sys.exit(0 if ok else 1)
 def test_ranks_that_disagree_about_the_codes(tmp_path, variant):
     """SNP shards on two ranks whose sweeps go different ways -- one through the class codes (two iterations per sweep when it may),
     the other over the float32 slabs, or through the codes only from the middle of the fit -- must still run the same number of
-    iterations per sweep: the sums of a sweep are all-reduced.  wgs_em_fit agrees once per fit whether EVERY rank can run two;
-    frequencies and iteration counts equal the oracle's on three fits in a row."""
+    iterations per sweep: the sums of a sweep are all-reduced.  Every sweep's all-reduce carries each rank's "I could run two"
+    (the free word of its tag row); once all ranks have said so, all of them do -- also in the MIDDLE of a fit, which is what a
+    cold fit across shards is (the codes are built inside it).  Frequencies and iteration counts equal the oracle's on three fits
+    in a row."""
+    import re
     port = free_port()
     script = tmp_path / "worker.py"
     script.write_text(_MIXED_WORKER.format(root=ROOT, port=port))
@@ -464,3 +478,30 @@ def test_ranks_that_disagree_about_the_codes(tmp_path, variant):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o[-3000:])
         assert "RANK %d OK" % r in o
+    sweeps = [eval(re.search(r"sweeps per fit (\[.*?\])", o).group(1)) for o in outs]
+    iters = max(eval(re.search(r"iterations (\[.*?\])", outs[0]).group(1)))
+    assert sweeps[0] == sweeps[1]                                   # the ranks enqueue the same sweeps
+    if variant == "one_rank_without_codes":
+        assert all(s >= iters for s in sweeps[0])                   # one rank never can: nobody ever runs two iterations per sweep
+    else:
+        assert sweeps[0][0] < iters, sweeps                         # fusion switched on inside the cold fit, on both ranks at the same sweep
+        assert sweeps[0][2] <= sweeps[0][0]
+
+
+def test_ranks_out_of_step_in_the_fit_fail_loudly(tmp_path):
+    """The constellation of commit 807a461 replayed with the agreement switched off (test hook em_fuse_without_agreement): rank 0 has
+    its codes from the first sweep and runs two iterations per sweep at once, rank 1 -- whose codes' memory arrives after its
+    fourth sweep -- runs one.  Before the fix this paired the sums of different iterations and returned wrong frequencies without a
+    word.  Now the tag of the very first all-reduce differs (3 fits running 6 iterations against 3 running 3): both ranks stop
+    with status 76 and a message naming both tuples; nothing is retried."""
+    port = free_port()
+    script = tmp_path / "worker.py"
+    script.write_text(_MIXED_WORKER.format(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "memory_late_and_no_agreement"], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 76, "rank %d: status %s\n%s" % (r, p.returncode, o[-3000:])
+        assert "OK" not in o.replace("MISMATCH", "")
+        assert "collective mismatch" in o and "EM convergence sums" in o
+        assert "shape 3 / 6" in o and "shape 3 / 3" in o, o[-3000:]

@@ -260,7 +260,15 @@ def main(argv=None):
         return
     # One code path for one or many GPUs: the Beagle file is streamed chunk by chunk into the device
     # slabs (host memory stays at one chunk; the reference holds two full copies of the matrix).
-    return _run(args, comm)
+    from .comm import COMM_DIVERGED, CollectiveMismatch
+    try:
+        return _run(args, comm)
+    except CollectiveMismatch as e:
+        # the ranks issued different collectives: nothing computed from here on could be trusted, and nothing is retried --
+        # every rank that sees it leaves with its own message; the launcher ends the others and reports this status
+        print("wgsassign_amd: rank %d: %s" % (comm.rank, e), file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(COMM_DIVERGED)         # (not sys.exit: a peer blocked inside a collective would keep atexit handlers waiting)
 
 
 if __name__ == "__main__":

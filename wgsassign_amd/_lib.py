@@ -82,6 +82,9 @@ SIGNATURES = {
     "wgs_comm_destroy": (None, [c_vp]),
     "wgs_comm_allreduce_f64_dev": (c_int, [c_vp, c_vp, c_i64]),
     "wgs_comm_allreduce_f64": (c_int, [c_vp, c_f64p, c_i64]),
+    "wgs_comm_allreduce_host_tagged": (c_int, [c_vp, c_f64p, c_i64, c_vp, c_f64p]),
+    "wgs_comm_next_generation": (c_i32, [c_vp]),
+    "wgs_comm_check": (c_int, [c_vp]),
     "wgs_comm_bcast_dev": (c_int, [c_vp, c_vp, c_i64, c_int]),
     "wgs_comm_info": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_comm_time_collectives": (c_int, [c_vp, c_i32, c_i64, c_f64p]),
@@ -133,13 +136,14 @@ SIGNATURES = {
     "wgs_loo": (c_int, [c_vp, c_vp, c_vp, c_i32, ctypes.c_double, c_i64, c_vp, c_i32, c_i32, c_int, c_int, c_f64p, c_f32p, c_i32p]),
     "wgs_loo_stats": (c_int, [c_f64p]),
     "wgs_score_last_serial_blocks": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
+    "wgs_debug_hook": (c_int, [ctypes.c_char_p, c_i64]),
     "wgs_debug_parts_exact_literal": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_f32p, c_f32p]),
     "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_int, c_f64p]),
     "wgs_debug_assign_parts_f64": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),
 }
 
 _lib = None
-ABI_VERSION = 2      # = WGS_ABI_VERSION of include/wgsassign_hip.h
+ABI_VERSION = 3      # = WGS_ABI_VERSION of include/wgsassign_hip.h
 
 
 def load():
@@ -169,11 +173,26 @@ def last_error():
     return msg.decode() if msg else ""
 
 
+class CollTag(ctypes.Structure):
+    """wgs_coll_tag of include/wgsassign_hip.h: what a collective is, said by its caller."""
+    _fields_ = [("op", c_i32), ("generation", c_i32), ("iteration", c_i32), ("shape_a", c_i32), ("shape_b", c_i32), ("aux", c_i32)]
+
+
+callback_error = None      # an exception raised inside a Python callback the library called (comm.SocketComm's all-reduce): check() re-raises it
+
+
 def check(rc):
+    global callback_error
     if rc != 0:
         msg = last_error()
+        if callback_error is not None:
+            e, callback_error = callback_error, None
+            raise e
         if rc == 2:
             raise ValueError(msg)
+        if msg.startswith("collective mismatch"):          # the ranks are out of step (csrc/rccl_comm.hip): its own exception, never retried
+            from .comm import CollectiveMismatch, decode_sites
+            raise CollectiveMismatch(decode_sites(msg))
         # HIP_TRY reports "<file>.hip:<line>: <call> failed: <hip error>"; other failures (the reader's) carry their own text
         raise RuntimeError(("wgsassign_amd HIP call failed: " if ".hip:" in msg else "wgsassign_amd: ") + msg)
 

@@ -28,13 +28,84 @@ import time
 import numpy as np
 
 COMM_INIT_FAILED = 75        # exit status of a worker whose communicator could not initialise (EX_TEMPFAIL)
+COMM_DIVERGED = 76           # exit status of a worker that found the ranks issuing different collectives (never retried)
+
+
+class CollectiveMismatch(RuntimeError):
+    """The ranks have stopped issuing the same sequence of collectives: wrong numbers would follow, so every rank that sees it
+    stops.  The message names what this rank issued and what the other one did."""
+
+
+# ---- self-checking collectives -----------------------------------------------------------------
+# Every all-reduce carries, behind its payload, a table of one row per rank: {sequence number on this communicator, op, generation,
+# iteration, shape a, shape b, payload elements, aux}.  A rank fills its own row and zeros the rest, so the sum all-gathers the rows;
+# afterwards every rank compares all rows with its own (aux, a free word, excepted).  The C library does the same for the
+# collectives it issues itself (csrc/rccl_comm.hip); this is the host side's copy for the all-reduces Python issues -- over sockets,
+# torch.distributed or, through wgs_comm_allreduce_host_tagged, RCCL.  Host all-reduces are told apart by their CALL SITE: the tag of
+# one issued at device.py line 458 is op 8 (WGS_OP_HOST), shape a = 100000 * (index of "device.py") + 458.
+TAG_WORDS = 8
+OP_HOST = 8
+_SITE_FILES = ["device.py", "glassy.py", "fisher.py", "reader_cy.py", "WGSassign.py", "comm.py", "emMAF.py", "bench.py", "utils.py"]
+
+
+def _call_site(depth=1):
+    """100000 * (1 + index of the file) + line of the first frame outside this module's all-reduce plumbing."""
+    import sys
+    f = sys._getframe(1)
+    while f is not None and os.path.basename(f.f_code.co_filename) == "comm.py" and f.f_back is not None and \
+            f.f_code.co_name in ("allreduce_sum", "barrier", "_tagged_allreduce", "fn", "allreduce_device"):
+        f = f.f_back
+    name = os.path.basename(f.f_code.co_filename)
+    idx = _SITE_FILES.index(name) if name in _SITE_FILES else len(_SITE_FILES)
+    return 100000 * (idx + 1) + min(int(f.f_lineno), 99999)
+
+
+def site_name(code):
+    idx, line = int(code) // 100000 - 1, int(code) % 100000
+    return "%s:%d" % (_SITE_FILES[idx] if 0 <= idx < len(_SITE_FILES) else "<other file>", line)
+
+
+def describe_row(rank, w):
+    what = "host all-reduce at %s" % site_name(w[4]) if int(w[1]) == OP_HOST else "op %d, shape %d" % (int(w[1]), int(w[4]))
+    return "rank %d issued collective #%d: %s, generation %d, iteration %d, shape b %d, %d payload elements" % (
+        rank, int(w[0]), what, int(w[2]), int(w[3]), int(w[5]), int(w[6]))
+
+
+def decode_sites(msg):
+    """The library's own mismatch text with the call sites of host all-reduces (op 8: shape a) spelled out."""
+    import re
+    return re.sub(r"\(op 8\), generation (-?\d+), iteration (-?\d+), shape (\d+) /",
+                  lambda mt: "(op 8), generation %s, iteration %s, shape %s [%s] /" % (mt.group(1), mt.group(2), mt.group(3), site_name(mt.group(3))), msg)
+
+
+class _Tagged:
+    """allreduce_sum(arr, tag=None) over a subclass's _allreduce_raw(flat float64) with the rows attached and compared.
+    tag: None, or (generation, iteration, shape_b, aux) -- the call site supplies op and shape a."""
+    _seq = 0
+    last_rows = None         # the table of the last all-reduce: last_rows[r, 7] is rank r's aux
+
+    def _tagged_allreduce(self, arr, tag=None, depth=3):
+        a = np.ascontiguousarray(arr, dtype=np.float64)
+        gen, it, shape_b, aux = tag if tag is not None else (0, 0, 0, 0)
+        self._seq += 1
+        row = np.array([self._seq, OP_HOST, gen, it, _call_site(depth), shape_b, a.size, aux], dtype=np.float64)
+        table = np.zeros((self.world, TAG_WORDS))
+        table[self.rank] = row
+        out = np.asarray(self._allreduce_raw(np.concatenate([a.reshape(-1), table.reshape(-1)])), dtype=np.float64)
+        rows = out[a.size:].reshape(self.world, TAG_WORDS)
+        for r in range(self.world):
+            if not np.array_equal(rows[r, :7], row[:7]):
+                raise CollectiveMismatch("collective mismatch: the ranks have stopped issuing the same sequence of collectives -- %s; %s"
+                                         % (describe_row(self.rank, row), describe_row(r, rows[r])))
+        self.last_rows = rows
+        return out[:a.size].reshape(a.shape).copy()
 
 
 class LocalComm:
     rank = 0
     world = 1
 
-    def allreduce_sum(self, arr):
+    def allreduce_sum(self, arr, tag=None):
         return arr
 
     def gather_rows(self, arr):
@@ -58,11 +129,13 @@ class SideChannel:
     Frames are length-prefixed raw bytes; objects travel as JSON, arrays as a JSON header + raw
     buffer -- nothing is unpickled.  A connection must open with magic | rank | world | token."""
 
-    MAGIC = b"WGSCOMM2"
+    MAGIC = b"WGSCOMM3"
+    ABORT = -1               # kind of the frame with which rank 0 tells the others that the ranks are out of step
 
     def __init__(self, rank, world, addr="127.0.0.1", port=29401, token=None, timeout=120.0):
         self.rank, self.world = int(rank), int(world)
         self.peers, self.hub = {}, None
+        self._seq = 0            # collectives issued on this star: every frame says which one it belongs to, and of what kind
         if self.world == 1:
             return
         if token is None:
@@ -123,7 +196,7 @@ class SideChannel:
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             c.sendall(self.MAGIC + struct.pack("<ii", self.rank, self.world) + tok)
             c.settimeout(max(1.0, deadline - time.monotonic()))
-            if self._recv(c) != b"ok":
+            if self._recv(c)[2] != b"ok":
                 raise RuntimeError("SideChannel: rank 0 refused the connection")
             c.settimeout(None)
             self.hub = c
@@ -141,31 +214,56 @@ class SideChannel:
 
     @classmethod
     def _recv(cls, conn):
-        return cls._take(conn, struct.unpack("<q", cls._take(conn, 8))[0])
+        """(kind, sequence number, payload) of the next frame."""
+        size, kind, seq = struct.unpack("<qii", cls._take(conn, 16))
+        return kind, seq, cls._take(conn, size)
 
     @staticmethod
-    def _send(conn, data):
-        conn.sendall(struct.pack("<q", len(data)))
+    def _send(conn, data, kind=0, seq=0):
+        conn.sendall(struct.pack("<qii", len(data), kind, seq))
         conn.sendall(data)
 
-    # ---- collectives on bytes
-    def bcast(self, data):
+    def _expect(self, got, kind, sender):
+        """A frame of another kind or number than this rank's own current collective: the ranks are out of step."""
+        k, q, data = got
+        if k == self.ABORT:
+            raise CollectiveMismatch(data.decode(errors="replace"))
+        if (k, q) != (kind, self._seq):
+            msg = ("collective mismatch: the ranks have stopped issuing the same sequence of collectives -- rank %d is at host "
+                   "collective #%d of kind %d; rank %d sent a frame of collective #%d, kind %d" % (self.rank, self._seq, kind, sender, q, k))
+            self.abort(msg)
+        return data
+
+    def abort(self, msg):
+        """Raise CollectiveMismatch(msg); rank 0 first tells every other rank, whatever it is waiting for."""
+        if self.rank == 0:
+            for c in self.peers.values():
+                try:
+                    self._send(c, msg.encode(), self.ABORT, self._seq)
+                except OSError:
+                    pass
+        raise CollectiveMismatch(msg)
+
+    # ---- collectives on bytes (kind: what the caller is doing -- 1 all-reduce, 2 rows, 3 objects, 4 bootstrap)
+    def bcast(self, data, kind=0):
         """rank 0's bytes on every rank."""
         if self.world == 1:
             return data
+        self._seq += 1
         if self.rank == 0:
             for r in sorted(self.peers):
-                self._send(self.peers[r], data)
+                self._send(self.peers[r], data, kind, self._seq)
             return data
-        return self._recv(self.hub)
+        return self._expect(self._recv(self.hub), kind, 0)
 
-    def gather(self, data):
+    def gather(self, data, kind=0):
         """list of every rank's bytes (rank order) on rank 0, None elsewhere."""
         if self.world == 1:
             return [data]
+        self._seq += 1
         if self.rank == 0:
-            return [data] + [self._recv(self.peers[r]) for r in range(1, self.world)]
-        self._send(self.hub, data)
+            return [data] + [self._expect(self._recv(self.peers[r]), kind, r) for r in range(1, self.world)]
+        self._send(self.hub, data, kind, self._seq)
         return None
 
     def close(self):
@@ -192,7 +290,7 @@ def _unpack_array(blob):
     return np.frombuffer(blob, dtype=dt, offset=4 + k).reshape(head["shape"])
 
 
-class SocketComm:
+class SocketComm(_Tagged):
     """All collectives over the TCP star (host-staged; sums formed on rank 0 in rank order, so every
     rank sees identical bits).  Latency ~0.1 ms per all-reduce: fine for the few float64 this path
     exchanges, and independent of any GPU library."""
@@ -214,9 +312,10 @@ class SocketComm:
         def fn(buf, n, _user):
             try:
                 view = np.ctypeslib.as_array(buf, shape=(int(n),))
-                view[:] = SocketComm.allreduce_sum(self, view.copy())
+                view[:] = SocketComm._tagged_allreduce(self, view.copy(), None, 2)
                 return 0
-            except BaseException:
+            except BaseException as e:
+                _lib.callback_error = e              # (the library reports a failed all-reduce; _lib.check() raises this instead)
                 return 1
         self._host_fn = _lib.ALLREDUCE_FN(fn)                  # kept alive with the communicator
         h = ctypes.c_void_p()
@@ -229,36 +328,42 @@ class SocketComm:
         """wgs_comm* for the C entry points that run whole loops, or None (not attached: step-by-step Python drivers)."""
         return self._host_h
 
-    def allreduce_sum(self, arr):
-        a = np.ascontiguousarray(arr, dtype=np.float64)
+    def allreduce_sum(self, arr, tag=None):
         if self.world == 1:
-            return a
-        parts = self.ch.gather(a.tobytes())
+            return np.ascontiguousarray(arr, dtype=np.float64)
+        return self._tagged_allreduce(arr, tag)
+
+    def _allreduce_raw(self, a):
+        parts = self.ch.gather(a.tobytes(), 1)
         if self.rank == 0:
+            if any(len(p) != len(parts[0]) for p in parts):
+                self.ch.abort("collective mismatch: the ranks have stopped issuing the same sequence of collectives -- their all-reduce "
+                              "payloads (with %d float64 of tag rows each) have %s float64, by rank" % (self.world * TAG_WORDS, [len(p) // 8 for p in parts]))
             tot = np.frombuffer(parts[0], dtype=np.float64).copy()
             for p in parts[1:]:
                 tot += np.frombuffer(p, dtype=np.float64)
-            blob = self.ch.bcast(tot.tobytes())
+            blob = self.ch.bcast(tot.tobytes(), 1)
         else:
-            blob = self.ch.bcast(None)
-        return np.frombuffer(blob, dtype=np.float64).reshape(a.shape).copy()
+            blob = self.ch.bcast(None, 1)
+        return np.frombuffer(blob, dtype=np.float64)
 
     def gather_rows(self, arr):
         """Every rank's rows (SNP shards, rank order) concatenated on rank 0 -- raw buffers, rank 0 only;
         the other ranks get None (only rank 0 writes output files)."""
-        parts = self.ch.gather(_pack_array(arr))
+        parts = self.ch.gather(_pack_array(arr), 2)
         if self.rank != 0:
             return None
         return np.concatenate([_unpack_array(p) for p in parts], axis=0)
 
     def allgather_object(self, obj):
         """JSON-serialisable objects (site-name previews, counts) from every rank, on every rank."""
-        parts = self.ch.gather(json.dumps(obj).encode())
-        blob = self.ch.bcast(json.dumps([json.loads(p.decode()) for p in parts]).encode() if self.rank == 0 else None)
+        parts = self.ch.gather(json.dumps(obj).encode(), 3)
+        blob = self.ch.bcast(json.dumps([json.loads(p.decode()) for p in parts]).encode() if self.rank == 0 else None, 3)
         return json.loads(blob.decode())
 
     def barrier(self):
-        self.allreduce_sum(np.zeros(1))
+        if self.world > 1:
+            self._tagged_allreduce(np.zeros(1))
 
     def _detach(self):
         if getattr(self, "_host_h", None) is not None:
@@ -288,7 +393,7 @@ class RcclComm(SocketComm):
         ok = 1
         if self.rank == 0 and lib.wgs_comm_unique_id(ident) != 0:
             ok, self.native_error = 0, _lib.last_error()
-        blob = self.ch.bcast(bytes([ok]) + bytes(ident) if self.rank == 0 else None)
+        blob = self.ch.bcast(bytes([ok]) + bytes(ident) if self.rank == 0 else None, 4)
         if blob[0]:
             ident = (ctypes.c_uint8 * 128).from_buffer_copy(blob[1:129])
             h = ctypes.c_void_p()
@@ -311,7 +416,7 @@ class RcclComm(SocketComm):
                 self._h = h
             else:
                 ok, self.native_error = 0, _lib.last_error()
-        flags = SocketComm.allreduce_sum(self, np.array([float(ok and blob[0])]))
+        flags = SocketComm._tagged_allreduce(self, np.array([float(ok and blob[0])]), None, 2)
         self.native = int(flags[0]) == self.world
         if not self.native:
             if self._h:
@@ -320,12 +425,20 @@ class RcclComm(SocketComm):
             self.attach(ctx)                     # the library's loops still run in one call, over the TCP all-reduce
 
     # ---- the collective
-    def allreduce_sum(self, arr):
+    def allreduce_sum(self, arr, tag=None):
         if not self.native:
-            return SocketComm.allreduce_sum(self, arr)
+            return SocketComm.allreduce_sum(self, arr, tag)
         a = np.ascontiguousarray(arr, dtype=np.float64).copy()
-        self._lib.check(self._lib.load().wgs_comm_allreduce_f64(self._h, self._lib.f64p(a.reshape(-1)), a.size))
+        gen, it, shape_b, aux = tag if tag is not None else (0, 0, 0, 0)
+        ctag = self._lib.CollTag(OP_HOST, int(gen), int(it), _call_site(2), int(shape_b), int(aux))
+        rows = np.zeros((self.world, TAG_WORDS))
+        self._lib.check(self._lib.load().wgs_comm_allreduce_host_tagged(self._h, self._lib.f64p(a.reshape(-1)), a.size,
+                                                                        self._ct.byref(ctag), self._lib.f64p(rows)))
+        self.last_rows = rows
         return a
+
+    def barrier(self):
+        self.allreduce_sum(np.zeros(1))
 
     def step_reduced(self, em_handle, n_fits):
         """EM sweep into the communicator's device buffer, all-reduce behind it on the same stream,
@@ -334,7 +447,7 @@ class RcclComm(SocketComm):
         if not self.native:
             out = np.zeros(int(n_fits), dtype=np.float64)
             self._lib.check(lib.wgs_em_step(em_handle, self._lib.f64p(out)))
-            return SocketComm.allreduce_sum(self, out)
+            return SocketComm._tagged_allreduce(self, out)
         buf = lib.wgs_comm_buffer(self._h, int(n_fits))
         if not buf:
             raise RuntimeError("wgsassign_amd HIP call failed: " + self._lib.last_error())
@@ -350,7 +463,7 @@ class RcclComm(SocketComm):
         out = (self._ct.c_int64 * 8)()
         self._lib.check(self._lib.load().wgs_comm_info(h, out))
         return {"native": bool(out[0]), "rccl_ranks_seen": int(out[1]), "rccl_rank": int(out[2]), "rccl_device": int(out[3]),
-                "world": int(out[4]), "rank": int(out[5])}
+                "world": int(out[4]), "rank": int(out[5]), "collectives_issued": int(out[6]), "out_of_step": bool(out[7])}
 
     def time_collectives(self, reps=20, n=16):
         """Mean device microseconds of a sum all-reduce / a broadcast of n float64 on the context's stream (collective)."""
@@ -370,7 +483,7 @@ class RcclComm(SocketComm):
         SocketComm.close(self)
 
 
-class TorchComm:
+class TorchComm(_Tagged):
     """torch.distributed process group (backend `nccl` == RCCL on ROCm, or `gloo` on CPU).
 
     Ordering note: torch bundles its own HIP runtime; import torch and initialise the process group
@@ -391,32 +504,46 @@ class TorchComm:
     def _dev(self):
         return self._device if self._device is not None else "cuda"
 
-    def allreduce_sum(self, arr):
-        """Sum `arr` (float64) over all ranks; every rank gets identical bits."""
+    def allreduce_sum(self, arr, tag=None):
+        """Sum `arr` (float64) over all ranks; every rank gets identical bits (and has compared every rank's tag row with its own)."""
+        return self._tagged_allreduce(arr, tag)
+
+    def _allreduce_raw(self, a):
         torch, dist = self._torch, self._dist
-        a = np.ascontiguousarray(arr, dtype=np.float64)
-        t = torch.from_numpy(a.copy())
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64).copy())
         if self._cuda:
             t = t.to(self._dev())
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return t.cpu().numpy().reshape(a.shape)
+        return t.cpu().numpy()
 
     # ---- device-resident variant: the sums never visit the host before the collective
     def device_buffer(self, n):
-        """A float64 CUDA tensor of n elements (its data_ptr() is handed to wgs_em_step_dev)."""
+        """A float64 CUDA tensor of n elements (its data_ptr() is handed to wgs_em_step_dev) + room for the ranks' tag rows."""
         if not self._cuda:
             return None
-        return self._torch.zeros(int(n), dtype=self._torch.float64, device=self._dev())
+        return self._torch.zeros(int(n) + self.world * TAG_WORDS, dtype=self._torch.float64, device=self._dev())
 
-    def allreduce_device(self, t, stream_ptr):
-        """RCCL all-reduce of tensor t, ordered after the work already enqueued on the library's
-        HIP stream `stream_ptr`; returns the reduced values as a NumPy array."""
+    def allreduce_device(self, t, stream_ptr, tag=None):
+        """RCCL all-reduce of tensor t (a device_buffer), ordered after the work already enqueued on the library's
+        HIP stream `stream_ptr`, the ranks' tag rows behind the payload; returns the reduced values as a NumPy array."""
         torch, dist = self._torch, self._dist
+        n = t.numel() - self.world * TAG_WORDS
+        gen, it, shape_b, aux = tag if tag is not None else (0, 0, 0, 0)
+        self._seq += 1
+        row = np.array([self._seq, OP_HOST, gen, it, _call_site(), shape_b, n, aux], dtype=np.float64)
+        table = np.zeros((self.world, TAG_WORDS))
+        table[self.rank] = row
         ext = torch.cuda.ExternalStream(int(stream_ptr), device=t.device)
         with torch.cuda.stream(ext):
+            t[n:] = torch.from_numpy(table.reshape(-1)).to(t.device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            out = t.cpu()            # enqueued on the same stream, synchronises it
-        return out.numpy()
+            out = t.cpu().numpy()    # enqueued on the same stream, synchronises it
+        rows = out[n:].reshape(self.world, TAG_WORDS)
+        for r in range(self.world):
+            if not np.array_equal(rows[r, :7], row[:7]):
+                raise CollectiveMismatch("collective mismatch: the ranks have stopped issuing the same sequence of collectives -- %s; %s"
+                                         % (describe_row(self.rank, row), describe_row(r, rows[r])))
+        return out[:n]
 
     def gather_rows(self, arr):
         """Every rank's rows (rank order) concatenated on rank 0 (None elsewhere): row counts by one
@@ -425,7 +552,7 @@ class TorchComm:
         a = np.ascontiguousarray(arr)
         counts = np.zeros(self.world)
         counts[self.rank] = a.shape[0]
-        counts = self.allreduce_sum(counts).astype(np.int64)
+        counts = self._tagged_allreduce(counts).astype(np.int64)
         if self.world == 1:
             return a
         dev = self._dev() if self._cuda else "cpu"

@@ -17,7 +17,7 @@ static thread_local std::string g_err;
 
 void wgs_set_error(const char *fmt, ...)
 {
-    char buf[1024];
+    char buf[2048];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
@@ -26,6 +26,35 @@ void wgs_set_error(const char *fmt, ...)
 }
 
 std::atomic<long long> g_wgs_malloc_ns{0};
+
+// Test hooks: named process-wide switches that only wgs_debug_hook (include/wgsassign_hip_debug.h) sets -- the product path reads
+// no environment variable for them.  A handful of names, looked up rarely (per allocation request, per fit), so a locked list does.
+#include <mutex>
+static std::mutex g_hook_mutex;
+static std::vector<std::pair<std::string, int64_t>> g_hooks;
+int64_t wgs_hook(const char *name)
+{
+    std::lock_guard<std::mutex> lock(g_hook_mutex);
+    for (auto &h : g_hooks)
+        if (h.first == name) return h.second;
+    return 0;
+}
+extern "C" int wgs_debug_hook(const char *name, int64_t value)
+{
+    WGS_REQUIRE(name, "null argument");
+    static const char *known[] = {"codes_alloc_delay_ms", "codes_alloc_release_after_sweeps", "em_fuse_without_agreement", "em_coded_extra_lds"};
+    bool ok = false;
+    for (const char *k : known) ok = ok || strcmp(k, name) == 0;
+    WGS_REQUIRE(ok, "unknown test hook '%s'", name);
+    std::lock_guard<std::mutex> lock(g_hook_mutex);
+    for (auto &h : g_hooks)
+        if (h.first == name) {
+            h.second = value;
+            return 0;
+        }
+    g_hooks.emplace_back(name, value);
+    return 0;
+}
 
 extern "C" {
 double wgs_malloc_seconds(void) { return (double)g_wgs_malloc_ns.load() * 1e-9; }
@@ -60,6 +89,8 @@ int wgs_ctx_create(int device, wgs_ctx **out)
     c->cus = prop.multiProcessorCount;
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipEventCreate(&c->enc_ev0));
+    HIP_TRY(hipEventCreate(&c->enc_ev1));
     guard.dismiss();
     *out = c;
     return 0;
@@ -75,6 +106,8 @@ void wgs_ctx_destroy(wgs_ctx *ctx)
     if (ctx->ws_b) (void)hipFree(ctx->ws_b);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->enc_ev0) (void)hipEventDestroy(ctx->enc_ev0);
+    if (ctx->enc_ev1) (void)hipEventDestroy(ctx->enc_ev1);
     delete ctx;
 }
 

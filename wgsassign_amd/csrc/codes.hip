@@ -54,11 +54,12 @@ static int pool_request(wgs_beagle *b, size_t want, size_t want_small, double gr
         const int dev = b->ctx->device;
         wgs_ctx *ctx = b->ctx;
         ++ctx->allocs_in_flight;
-        const char *delay_env = getenv("WGSASSIGN_CODES_ALLOC_TEST_DELAY_MS");      // tests: a slow hipMalloc on demand
-        const int delay_ms = delay_env ? atoi(delay_env) : 0;
-        auto work = [b, dev, ctx, delay_ms] {
+        const int delay_ms = (int)wgs_hook("codes_alloc_delay_ms");                 // tests: a slow hipMalloc on demand ...
+        const int64_t release_at = wgs_hook("codes_alloc_release_after_sweeps");    // ... handed over after this many direct sweeps
+        auto work = [b, dev, ctx, delay_ms, release_at] {
             const double t0 = now_s();
             if (delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(delay_ms));
+            while (release_at > 0 && b->direct_sweeps.load() < release_at && now_s() - t0 < 2.0) std::this_thread::sleep_for(std::chrono::microseconds(50));
             void *p = nullptr;
             size_t got = 0;
             if (hipSetDevice(dev) == hipSuccess) {
@@ -355,7 +356,7 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build, bool wait, bool for_scori
     c->bytes = (int64_t)total - c->local_bytes;
     if (hipMemcpy(c->d_slabs, c->slabs.data(), sizeof(SlabCodes) * b->n_groups, hipMemcpyHostToDevice) != hipSuccess) return fail();
     if (launch_class_encode(b, c)) return fail();          // (sets kernel_ms from HIP events around the kernel)
-    c->build_ms = (now_s() - t0) * 1e3 + (P->sample_ms > 0 && c->sample_ms == P->sample_ms ? 0.0 : 0.0);
+    c->build_ms = (now_s() - t0) * 1e3;
     b->codes_state = 1;
     return c;
 }

@@ -563,12 +563,12 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
     const int64_t units = tiles * (64 / c->snps_per_wave);
     A.wave_stats = c->wave_stats;
     WGS_REQUIRE(units < (1ll << 31), "class encoder: %lld work units exceed one launch", (long long)units);
-    HIP_TRY(hipEventRecord(b->ctx->ev0, b->ctx->stream));
+    HIP_TRY(hipEventRecord(b->ctx->enc_ev0, b->ctx->stream));
     if (c->snps_per_wave == WGS_ENC_SLOTS / 64) hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_SLOTS / 64, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
     else if (c->snps_per_wave == WGS_ENC_SLOTS / 128) hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_SLOTS / 128, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
     else hipLaunchKernelGGL((class_encode_kernel<WGS_ENC_SLOTS / 256, false>), dim3((unsigned)units), dim3(64), 0, b->ctx->stream, A);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(b->ctx->ev1, b->ctx->stream));
+    HIP_TRY(hipEventRecord(b->ctx->enc_ev1, b->ctx->stream));
     {
         const unsigned gx = (unsigned)std::max<int64_t>(1, std::min<int64_t>(512, (units + 255) / 256));
         hipLaunchKernelGGL(encode_stats_kernel, dim3(gx), dim3(256), 0, b->ctx->stream, c->wave_stats, units, c->d_slabs, (int)b->n_groups, tiles,
@@ -579,7 +579,7 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
     HIP_TRY(hipMemcpyAsync(h, d_stats, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
     float ev_ms = 0.0f;
-    if (hipEventElapsedTime(&ev_ms, b->ctx->ev0, b->ctx->ev1) == hipSuccess) c->kernel_ms = ev_ms;     // the encode kernel alone (HIP events)
+    if (hipEventElapsedTime(&ev_ms, b->ctx->enc_ev0, b->ctx->enc_ev1) == hipSuccess) c->kernel_ms = ev_ms;     // the encode kernel alone (HIP events)
     c->sum_ncls = (double)h[ST_SUM_NCLS];
     c->rich_snps = (int64_t)h[ST_RICH];
     c->cmax = (int32_t)h[ST_CMAX];

@@ -98,6 +98,8 @@ struct wgs_ctx {
                                                 // (tools/ubench_alloc3.hip; kernel launches, copies and synchronisation do not), so elapsed times
                                                 // are read when somebody asks and no allocation of this library is in flight (wgs_assign_last_ms)
     std::atomic<int> allocs_in_flight{0};       // helper-thread hipMallocs under way (codes.hip)
+    int64_t dyn_lds_base = -1;                  // LDS address at which a kernel's dynamic allocation starts (em_coded_usable probes it once; -1: not yet)
+    hipEvent_t enc_ev0 = nullptr, enc_ev1 = nullptr;   // bracket the class encoder (its own pair: ev0 / ev1 may still hold an unread scoring time)
 };
 // Device workspace of at least `bytes` (256-byte aligned); contents are not preserved across calls.
 int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out);
@@ -209,7 +211,7 @@ struct wgs_beagle {
     void *pool_new = nullptr;
     size_t pool_new_bytes = 0, pool_want = 0, pool_want_small = 0;
     double pool_request_s = 0.0, pool_alloc_ms = 0.0;
-    int64_t direct_sweeps = 0;     // EM sweeps over the float32 slabs so far (wgs_em_step callers: the codes are built once a run is long)
+    std::atomic<int64_t> direct_sweeps{0};     // EM sweeps over the float32 slabs so far (wgs_em_step callers: the codes are built once a run is long)
 };
 // The matrix's class codes, or nullptr when they are switched off (WGSASSIGN_CODES=0) or the matrix is not worth coding (then the
 // direct kernels are used).  build = false only returns codes that exist already.
@@ -224,6 +226,25 @@ void wgs_beagle_drop_codes(wgs_beagle *b);
 void wgs_beagle_release_pool(wgs_beagle *b);
 int launch_class_sample(wgs_beagle *b, wgs_codes *c, int max_units, unsigned long long *hist_g, unsigned long long *hist_l, double *rounds_per_buffer);
 int launch_class_encode(wgs_beagle *b, wgs_codes *c);
+
+// ---- self-checking collectives (rccl_comm.hip): the row every rank attaches to every collective
+enum { WGS_TAG_SEQ = 0, WGS_TAG_OP, WGS_TAG_GEN, WGS_TAG_ITER, WGS_TAG_SHAPE_A, WGS_TAG_SHAPE_B, WGS_TAG_COUNT, WGS_TAG_AUX, WGS_TAG_WORDS };
+struct CommRow {
+    double w[WGS_TAG_WORDS];       // small integers, exact in float64: a sum all-reduce with zeros from the others all-gathers them
+};
+struct CommFault {                 // page-locked: written by comm_tag_check_kernel, read by wgs_comm_check
+    int flag, claimed, rank, other;
+    double mine[WGS_TAG_WORDS], theirs[WGS_TAG_WORDS];
+};
+constexpr int WGS_COMM_MAX_WORLD = 64;
+// float64 a buffer handed to wgs_comm_allreduce_tagged / wgs_comm_bcast_tagged must have room for behind its payload
+constexpr size_t wgs_comm_tail_doubles() { return (size_t)WGS_COMM_MAX_WORLD * WGS_TAG_WORDS + 1; }
+constexpr size_t wgs_comm_tail_bytes() { return wgs_comm_tail_doubles() * sizeof(double); }
+extern "C" int wgs_comm_allreduce_tagged(wgs_comm *c, double *dev_buf, int64_t n, const wgs_coll_tag *tag);
+extern "C" int wgs_comm_bcast_tagged(wgs_comm *c, void *dev_buf, int64_t bytes, int root, const wgs_coll_tag *tag);
+
+// ---- test hooks (include/wgsassign_hip_debug.h: wgs_debug_hook): process-wide switches only the test suite sets, by name
+int64_t wgs_hook(const char *name);        // 0 unless a test set it
 
 struct wgs_afset {
     wgs_ctx *ctx = nullptr;
@@ -279,6 +300,7 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
 // the same sweep through the class codes (exact mode; every fit's descriptor carries its slab's local codes; rows = the
 // largest SlabLocal::rows among the fits)
 int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int rows);
+bool em_coded_usable(wgs_ctx *ctx);
 int launch_em_coded_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int rows);
 int em_fits_per_group(void);
 int launch_em_sweep_groups(wgs_ctx *ctx, const FitDesc *d_descs, const int32_t *d_groups, int32_t n_groups, int64_t m, int mode);

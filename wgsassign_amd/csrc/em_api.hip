@@ -199,7 +199,8 @@ static bool em_fuse_buffers(wgs_em *em)
  * ssq_base[j] receives fit j's sum; state_base (device, may be NULL) holds the fit states a sweep honours. */
 static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDesc *H, FitDesc *D, int32_t *Hg, int32_t *Dg,
                             double *ssq_base, int32_t *state_base, hipEvent_t ev0, hipEvent_t ev1, int sweeps_ahead,
-                            const std::vector<int32_t> *may_fuse = nullptr, double *ssq_base_b = nullptr)
+                            const std::vector<int32_t> *may_fuse = nullptr, double *ssq_base_b = nullptr, bool fuse_agreed = true,
+                            int *can_fuse_out = nullptr)
 {
     wgs_ctx *ctx = em->b->ctx;
     const int64_t ntiles = wgs_ntiles(em->b->m);
@@ -245,16 +246,22 @@ static int em_enqueue_sweep(wgs_em *em, const std::vector<int32_t> &list, FitDes
         }
     }
     WGS_STALL_SCOPE("the sweep's launches");
-    if (codes && codes->lrows == 0) codes = nullptr;
+    if (codes && (codes->lrows == 0 || !em_coded_usable(ctx))) codes = nullptr;
     if (worth && !codes) ++em->b->direct_sweeps;          // (a sweep the codes could have served)
     // two iterations per sweep (em_kernels.hip: fused iterations): the coded sweep only, for the fits the caller allows (iterations
-    // left, a place for the second sums); needs a third frequency buffer and a second set of partial sums, allocated on first use
+    // left, a place for the second sums); needs a third frequency buffer and a second set of partial sums, allocated on first use.
+    // `can_fuse` is what THIS rank could do -- every input of it is rank-local (the codes' arrival, a cost model, environment
+    // switches, free memory) -- and is what the rank tells the others (wgs_em_fit puts it into the sweep's collective); what the
+    // sweep DOES additionally needs `fuse_agreed`: every rank has said it can.
     const bool fuse_on = !(getenv("WGSASSIGN_EM_FUSE") && atoi(getenv("WGSASSIGN_EM_FUSE")) < 2);   // (read at every sweep: tests compare both)
-    bool fusing = false;
+    bool fusing = false, can_fuse = false;
     if (codes && may_fuse && ssq_base_b && fuse_on && !shared) {    // (leave-one-out batches are bound by arithmetic: a second iteration that turns out unneeded is not free there)
-        for (int j : order) fusing = fusing || (*may_fuse)[j] >= 2;
-        if (fusing && !em_fuse_buffers(em)) fusing = false;       // no memory for it: one iteration per sweep
+        bool wanted = false;
+        for (int j : order) wanted = wanted || (*may_fuse)[j] >= 2;
+        can_fuse = (em->fbuf[2] || wanted) && em_fuse_buffers(em);         // (no memory for the buffers: one iteration per sweep)
+        fusing = can_fuse && wanted && (fuse_agreed || wgs_hook("em_fuse_without_agreement") != 0);
     }
+    if (can_fuse_out) *can_fuse_out = can_fuse ? 1 : 0;
     const int nb = em->fbuf[2] ? 3 : 2;
     int coded_rows_max = 0;
     for (size_t i = 0; i < order.size(); ++i) {
@@ -402,15 +409,21 @@ int wgs_em_rmse_chain(wgs_em *em, int32_t fit, float carry_in, float *carry_out)
  *     in one batched launch; across SNP shards the float32 carries travel in rank order) and either
  *     finishes them or re-activates them -- such a fit simply runs its next sweep one iteration later.
  * Decisions use only all-reduced sums, so every rank takes the same path. */
+// d_chain_out: [n_fits] float32 carries (broadcast from shard to shard, the root's tag row behind them) | room for that row |
+// [n_fits] serial-block counts
+static size_t em_chain_serial_off(size_t n) { return (n + 1) / 2 * 2 + 2 * wgs_comm_tail_doubles(); }
+static size_t em_chain_out_floats(size_t n) { return em_chain_serial_off(n) + n; }
+
 static int em_fit_alloc(wgs_em *em)
 {
     if (em->d_state) return 0;
     const size_t n = (size_t)em->n_fits;
     HIP_TRY(wgs_malloc(&em->d_state, sizeof(int32_t) * n));
-    HIP_TRY(wgs_malloc(&em->d_ssq2, sizeof(double) * 2 * n));
-    HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * 2 * n));
+    // (the sums of a sweep | its second iteration's | room for the rows the communicator attaches to their all-reduce)
+    HIP_TRY(wgs_malloc(&em->d_ssq2, sizeof(double) * (2 * n + wgs_comm_tail_doubles())));
+    HIP_TRY(hipMemset(em->d_ssq2, 0, sizeof(double) * (2 * n + wgs_comm_tail_doubles())));
     HIP_TRY(wgs_malloc(&em->d_jobs, sizeof(ChainJob) * n));
-    HIP_TRY(wgs_malloc(&em->d_chain_out, sizeof(float) * 2 * n));
+    HIP_TRY(wgs_malloc(&em->d_chain_out, sizeof(float) * em_chain_out_floats(n)));
     // workspace of the exact chains for all fits at once (60 bytes per fit and block of 4096 SNPs): no allocation
     // inside the convergence loop
     HIP_TRY(wgs_malloc(&em->d_chain_batch, rmse_chain_workspace_bytes(em->b->m) * n));
@@ -424,7 +437,7 @@ static int em_fit_alloc(wgs_em *em)
         HIP_TRY(wgs_malloc(&em->d_groups2[i], sizeof(int32_t) * 2 * n));
         HIP_TRY(hipHostMalloc(&em->h_groups2[i], sizeof(int32_t) * 2 * n, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc(&em->h_state[i], sizeof(int32_t) * n, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc(&em->h_ssq[i], sizeof(double) * 2 * n, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&em->h_ssq[i], sizeof(double) * (2 * n + wgs_comm_tail_doubles()), hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&em->ev_it[i], hipEventDisableTiming));
     }
     return 0;
@@ -432,7 +445,7 @@ static int em_fit_alloc(wgs_em *em)
 
 /* Exact chains of `fits` (all at once): converged[i] = the reference's `diff < tole` for fits[i]. */
 static int em_resolve_chains(wgs_em *em, const std::vector<int32_t> &fits, double tole, int64_t m_total, wgs_comm *comm,
-                             std::vector<char> &converged)
+                             std::vector<char> &converged, int32_t generation, int32_t iteration)
 {
     wgs_ctx *ctx = em->b->ctx;
     const int nj = (int)fits.size();
@@ -451,13 +464,15 @@ static int em_resolve_chains(wgs_em *em, const std::vector<int32_t> &fits, doubl
         if (r == rank) {
             if (r > 0 && launch_chain_set_carry(ctx, em->d_jobs, em->d_chain_out, nj)) return 1;
             if (launch_rmse_chain_batch(ctx, em->d_jobs, nj, em->b->m, em->d_chain_out, em->d_chain_batch,
-                                        reinterpret_cast<int *>(em->d_chain_out + em->n_fits)))
+                                        reinterpret_cast<int *>(em->d_chain_out + em_chain_serial_off(em->n_fits))))
                 return 1;
         }
-        if (world > 1 && wgs_comm_bcast_dev(comm, em->d_chain_out, (int64_t)sizeof(float) * nj, r)) return 1;
+        const wgs_coll_tag tag = {WGS_OP_EM_CHAIN, generation, iteration, nj, r, 0};
+        if (world > 1 && wgs_comm_bcast_tagged(comm, em->d_chain_out, (int64_t)sizeof(float) * nj, r, &tag)) return 1;
     }
     HIP_TRY(hipMemcpyAsync(em->h_chain_out, em->d_chain_out, sizeof(float) * nj, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));       // also: h_jobs has been consumed
+    if (wgs_comm_check(comm)) return 1;               // (a receiver's view of the senders' rows)
     const float *carry = em->h_chain_out;
     ++em->fit_chain_batches;
     for (int i = 0; i < nj; ++i) {
@@ -484,29 +499,17 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         hi = thresh * (1.0 + g);
     }
     // Across SNP shards every rank must run the same number of iterations per sweep (the sums of a sweep are all-reduced, and the
-    // bookkeeping below counts iterations): two per sweep only when EVERY rank can -- its codes built with the slabs' own numbering
-    // and the buffers at hand NOW; a rank whose codes arrive during the fit (or whose cost model decides otherwise) still sweeps
-    // through them, one iteration at a time like the others.  Agreed once per fit (one host all-reduce of a flag).
-    bool fuse_allowed = true;
-    {
-        int world = 1, rank = 0;
-        if (comm) wgs_comm_rank(comm, &rank, &world);
-        // (leave-one-out batches -- several fits per slab, the same on every rank -- never run two iterations per sweep: nothing to agree on)
-        std::vector<char> seen_slab(em->b->n_groups, 0);
-        bool shared_slabs = false;
-        for (int j = 0; j < n; ++j) {
-            shared_slabs = shared_slabs || seen_slab[em->group[j]];
-            seen_slab[em->group[j]] = 1;
-        }
-        if (world > 1 && shared_slabs) fuse_allowed = false;
-        if (world > 1 && !shared_slabs) {
-            const bool fuse_on = !(getenv("WGSASSIGN_EM_FUSE") && atoi(getenv("WGSASSIGN_EM_FUSE")) < 2);
-            wgs_codes *have = wgs_beagle_codes(em->b, false);
-            double mine = (em->mode == WGS_MODE_EXACT && fuse_on && have && have->lrows > 0 && em_fuse_buffers(em)) ? 1.0 : 0.0;
-            if (wgs_comm_allreduce_f64(comm, &mine, 1)) return 1;
-            fuse_allowed = mine == (double)world;
-        }
-    }
+    // bookkeeping below counts iterations): two per sweep only once EVERY rank can -- its codes built with the slabs' own numbering
+    // and the buffers at hand.  Whether a rank can is rank-local (its cost model, when its helper thread's allocation arrives, its
+    // environment), so it is never acted upon directly: each sweep's all-reduce carries every rank's "I could" (the free word of its
+    // tag row), the host reads the rows with the sweep's decisions -- one sweep behind, like everything else here -- and from then on
+    // every rank fuses, at the same sweep.  A fit whose codes arrive during it on some rank therefore starts with one iteration per
+    // sweep everywhere and switches to two everywhere.  The tag of the all-reduce also says how many fits the sweep lists and how
+    // many EM iterations it runs; a rank that got this wrong is found at that very collective (rccl_comm.hip), not by its numbers.
+    int world = 1, rank = 0;
+    if (comm) wgs_comm_rank(comm, &rank, &world);
+    const int32_t generation = comm ? wgs_comm_next_generation(comm) : 0;
+    bool fuse_agreed = comm == nullptr;                      // one shard: nothing to agree on
     std::vector<char> fin(n, 0), skipped(n, 0);
     std::vector<int32_t> sweeps(n, 0), init(n), may_fuse(n, 1), ran, parked, parked_a, lists[2];
     for (int j = 0; j < n; ++j) {
@@ -568,15 +571,22 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
                 ++em->fit_timed;
                 em->fit_sweep_pending = true;
             }
+            int can_fuse = 0;
             if (em_enqueue_sweep(em, L, em->h_descs2[slot], em->d_descs2[slot], em->h_groups2[slot], em->d_groups2[slot], em->d_ssq2,
-                                 em->d_state, sw0, sw1, max_iter - t + 1, fuse_allowed ? &may_fuse : nullptr, em->d_ssq2 + n))
+                                 em->d_state, sw0, sw1, max_iter - t + 1, &may_fuse, em->d_ssq2 + n, fuse_agreed, &can_fuse))
                 return 1;
             // Fits that skipped this sweep have stale sums; the decision kernel ignores them, and they are stale
             // in the same way on every rank (all ranks take the same decisions).
-            if (comm && wgs_comm_allreduce_f64_dev(comm, em->d_ssq2, 2 * n)) return 1;
+            if (comm) {
+                int32_t iterations_run = 0;
+                for (int j : L) iterations_run += em->fuse_used[j];
+                const wgs_coll_tag tag = {WGS_OP_EM_SUMS, generation, t, (int32_t)L.size(), iterations_run, can_fuse};
+                if (wgs_comm_allreduce_tagged(comm, em->d_ssq2, 2 * n, &tag)) return 1;
+            }
             if (launch_em_decide(ctx, em->d_descs2[slot], (int)L.size(), lo, hi)) return 1;
             HIP_TRY(hipMemcpyAsync(em->h_state[slot], em->d_state, sizeof(int32_t) * n, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipMemcpyAsync(em->h_ssq[slot], em->d_ssq2, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(em->h_ssq[slot], em->d_ssq2, sizeof(double) * (2 * n + (comm ? world * WGS_TAG_WORDS : 0)), hipMemcpyDeviceToHost,
+                                   ctx->stream));
             HIP_TRY(hipEventRecord(em->ev_it[slot], ctx->stream));
             ++em->fit_iterations;
         }
@@ -584,6 +594,12 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         if (launched_prev) {
             const int ps = slot ^ 1;
             HIP_TRY(hipEventSynchronize(em->ev_it[ps]));     // also: the pinned descriptors of t-1 have been consumed
+            if (comm) {
+                if (wgs_comm_check(comm)) return 1;          // some rank's sweep t-1 was not this rank's sweep t-1
+                bool all = true;                             // every rank's "I could run two iterations per sweep" as of sweep t-1
+                for (int r = 0; r < world; ++r) all = all && em->h_ssq[ps][2 * n + r * WGS_TAG_WORDS + WGS_TAG_AUX] == 1.0;
+                fuse_agreed = all;                           // acted upon from sweep t+1 on, by every rank alike
+            }
             parked.clear();
             parked_a.clear();
             for (int j : ran) {
@@ -622,7 +638,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
                     em->prev[j] = (uint8_t)(3 - fa[i] - fb[i]);
                 }
                 std::vector<char> conv;
-                if (em_resolve_chains(em, parked_a, tole, m_total, comm, conv)) return 1;
+                if (em_resolve_chains(em, parked_a, tole, m_total, comm, conv, generation, 2 * t)) return 1;
                 for (size_t i = 0; i < parked_a.size(); ++i) {
                     const int j = parked_a[i];
                     if (conv[i]) {
@@ -649,7 +665,7 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
             }
             if (!parked.empty()) {
                 std::vector<char> conv;
-                if (em_resolve_chains(em, parked, tole, m_total, comm, conv)) return 1;
+                if (em_resolve_chains(em, parked, tole, m_total, comm, conv, generation, 2 * t + 1)) return 1;
                 for (size_t i = 0; i < parked.size(); ++i) {
                     const int j = parked[i];
                     if (conv[i]) finish(j, sweeps[j]);
@@ -662,6 +678,17 @@ int wgs_em_fit(wgs_em *em, int32_t max_iter, double tole, int64_t m_total, wgs_c
         if (!launched_prev) break;                           // nothing in flight: every fit finished or exhausted
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (comm) {
+        // the ranks close the fit together: what each of them found (iteration counts, sweeps enqueued, chain resolutions) travels
+        // as the tag of one last collective, so ranks that ended with different results fail here instead of returning them
+        int64_t sum = 0, mix = 0;
+        for (int j = 0; j < n; ++j) {
+            sum += iters_out[j];
+            mix = (mix * 31 + iters_out[j] + 7 * (j + 1)) % 16777213;
+        }
+        const wgs_coll_tag tag = {WGS_OP_EM_FIT_END, generation, em->fit_iterations, (int32_t)(sum % 16777213), (int32_t)mix, em->fit_chain_batches};
+        if (wgs_comm_allreduce_host_tagged(comm, nullptr, 0, &tag, nullptr)) return 1;
+    }
     for (int j = 0; j < n; ++j)
         if (iters_out[j] > 0) em->active[j] = 0;             // frozen, as wgs_em_set_active(j, 0) would
     em->fit_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();

@@ -383,15 +383,17 @@ __device__ __forceinline__ double class_quotient(double raw, const SnpState &st)
 // k * 64 + lane, high words ROWS * 64 dwords further.  A look-up's address is then (rank << 8) | (lane << 2) -- ONE v_perm_b32 takes
 // the code byte out of the code word and puts it above the lane's byte (a double-wide table needs a bit-field extract and a shifted
 // add per look-up: 5.5 instead of 4 vector instructions per individual) -- and both halves come back from one ds_read2st64_b32.
-// The table is the kernel's only LDS (the dynamic allocation of a kernel without static LDS starts at address 0: checked once per
-// wavefront, a trap otherwise), so the permuted word IS the address.
+// The table is the kernel's only LDS and the dynamic allocation of a kernel without static LDS starts at address 0, so the permuted
+// word IS the address.  That assumption is checked on the HOST, once per context, by a probe kernel of the same shape
+// (em_coded_usable below): where it does not hold -- an instrumented build, a runtime that places something of its own first -- the
+// coded EM sweeps are not used and the fits run over the float32 slabs (no device-side trap).
 typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
 struct QTable {
     uint32_t lane4;      // lane * 4: one byte
 };
 __device__ __forceinline__ QTable qtable_of(double *lds, int lane)
 {
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)lds != 0u) __builtin_trap();
+    (void)lds;
     QTable t;
     t.lane4 = (uint32_t)lane * 4u;
     return t;
@@ -1202,6 +1204,34 @@ int launch_em_sweep(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     return 0;
 }
 
+// Where the dynamic LDS of a kernel without static LDS begins (the address the coded EM kernels take to be 0).
+__global__ void dyn_lds_base_probe_kernel(uint32_t *out)
+{
+    extern __shared__ __align__(16) double probe_dyn[];
+    if (threadIdx.x == 0) {
+        probe_dyn[0] = 1.0;                  // (the allocation must be real)
+        out[0] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double *)probe_dyn;
+    }
+}
+
+// true when the coded EM sweeps may run on this context: their quotient table addresses LDS from 0 (qtable_of).  Probed once.
+bool em_coded_usable(wgs_ctx *ctx)
+{
+    if (ctx->dyn_lds_base < 0) {
+        uint32_t *d = nullptr, h = 0xffffffffu;
+        if (hipMalloc(&d, sizeof(uint32_t)) == hipSuccess) {
+            hipLaunchKernelGGL(dyn_lds_base_probe_kernel, dim3(1), dim3(64), 24 * 512, ctx->stream, d);
+            if (hipMemcpyAsync(&h, d, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                h = 0xffffffffu;
+            (void)hipFree(d);
+        }
+        (void)hipGetLastError();
+        ctx->dyn_lds_base = (int64_t)h;
+    }
+    return ctx->dyn_lds_base == 0;
+}
+
 int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_t m, int rows)
 {
     if (n_fits <= 0 || m <= 0) return 0;
@@ -1210,8 +1240,7 @@ int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     const int64_t tgroups = (tiles + 7) / 8 * 8;                    // the XCD-aware order covers whole groups of 8
     const int64_t blocks = tgroups * n_fits;
     WGS_REQUIRE(blocks < (1ll << 31), "em sweep: %lld workgroups exceed one launch; split the fit batch", (long long)blocks);
-    const char *xl = getenv("WGS_EM_CODED_EXTRA_LDS");              // experiment: how the sweep depends on wavefronts per CU
-    const size_t lds = (size_t)rows * 512 + (xl ? (size_t)atoi(xl) : 0);
+    const size_t lds = (size_t)rows * 512 + (size_t)wgs_hook("em_coded_extra_lds");   // (test hook: how the sweep depends on wavefronts per CU)
 #define WGS_EMC(RW) hipLaunchKernelGGL((em_coded_kernel<4, 2, RW>), dim3((unsigned)blocks), dim3(64), lds, ctx->stream, d_descs, n_fits, m)
     switch (rows) {
         case 8: WGS_EMC(8); break;

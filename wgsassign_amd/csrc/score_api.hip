@@ -266,19 +266,21 @@ int wgs_score_totals_all(wgs_score *sc, wgs_comm *comm, double *totals_out, doub
     if (comm) wgs_comm_rank(comm, &rank, &world);
     const size_t bytes = sizeof(double) * sc->cells;
     if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, bytes));
-    if (!sc->d_run) HIP_TRY(wgs_malloc(&sc->d_run, bytes));
+    if (!sc->d_run) HIP_TRY(wgs_malloc(&sc->d_run, bytes + wgs_comm_tail_bytes()));      // (+ the sender's tag row behind the totals)
     HIP_TRY(hipMemsetAsync(sc->d_start, 0, bytes, ctx->stream));
+    const int32_t generation = comm ? wgs_comm_next_generation(comm) : 0;
     for (int r = 0; r < world; ++r) {
         if (r == rank) {
             if (r > 0) HIP_TRY(hipMemcpyAsync(sc->d_start, sc->d_run, bytes, hipMemcpyDeviceToDevice, ctx->stream));   // what precedes this shard
             if (launch_chunk_total(ctx, sc->d_chunks, (sc->nblocks + 1) / 2, sc->cells, r > 0 ? sc->d_start : nullptr, sc->d_run)) return 1;
         }
-        if (world > 1 && wgs_comm_bcast_dev(comm, sc->d_run, (int64_t)bytes, r)) return 1;
+        const wgs_coll_tag tag = {WGS_OP_SCORE_TOTALS, generation, r, (int32_t)(sc->row_hi - sc->row_lo), r, 0};
+        if (world > 1 && wgs_comm_bcast_tagged(comm, sc->d_run, (int64_t)bytes, r, &tag)) return 1;
     }
     HIP_TRY(hipMemcpyAsync(totals_out, sc->d_run, bytes, hipMemcpyDeviceToHost, ctx->stream));
     if (before_out) HIP_TRY(hipMemcpyAsync(before_out, sc->d_start, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return 0;
+    return wgs_comm_check(comm);
 }
 
 /* Block functions of the exact partition chains (utils.py:147-149) for P partitions; needs the block
@@ -307,7 +309,7 @@ int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start)
             return 1;
         }
         HIP_TRY(wgs_malloc(&sc->d_carry, sizeof(float) * chains));
-        HIP_TRY(wgs_malloc(&sc->d_parts, sizeof(float) * chains));
+        HIP_TRY(wgs_malloc(&sc->d_parts, sizeof(float) * chains + wgs_comm_tail_bytes()));   // (+ the sender's tag row behind the carries)
         if (!sc->d_nserial) HIP_TRY(wgs_malloc(&sc->d_nserial, sizeof(int32_t)));
         if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, sizeof(double) * sc->cells));
         sc->P = P;
@@ -395,18 +397,20 @@ int wgs_score_chains_walk_all(wgs_score *sc, wgs_comm *comm, float *parts_out)
     int world = 1, rank = 0;
     if (comm) wgs_comm_rank(comm, &rank, &world);
     const size_t bytes = sizeof(float) * (size_t)sc->cells * sc->P;
+    const int32_t generation = comm ? wgs_comm_next_generation(comm) : 0;
     for (int r = 0; r < world; ++r) {
         if (r == rank) {
             if (r > 0) HIP_TRY(hipMemcpyAsync(sc->d_carry, sc->d_parts, bytes, hipMemcpyDeviceToDevice, ctx->stream));
             if (chains_walk_enqueue(sc, r > 0)) return 1;
             HIP_TRY(hipMemcpyAsync(&sc->last_serial_blocks, sc->d_nserial, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         }
-        if (world > 1 && wgs_comm_bcast_dev(comm, sc->d_parts, (int64_t)bytes, r)) return 1;
+        const wgs_coll_tag tag = {WGS_OP_PART_CHAINS, generation, r, sc->P, r, 0};
+        if (world > 1 && wgs_comm_bcast_tagged(comm, sc->d_parts, (int64_t)bytes, r, &tag)) return 1;
     }
     HIP_TRY(hipMemcpyAsync(parts_out, sc->d_parts, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->assign_ms_pending = true;
-    return 0;
+    return wgs_comm_check(comm);
 }
 
 /* Test hook: blocks that took the literal serial loop in the last wgs_score_chains_walk, and the number of
@@ -556,7 +560,8 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
     if (world > 1) {       // every rank must run the same batches: the minimum over ranks
         std::vector<double> slots(world, 0.0);
         slots[rank] = (double)batch;
-        if (wgs_comm_allreduce_f64(comm, slots.data(), world)) return 1;
+        const wgs_coll_tag tag = {WGS_OP_LOO_BATCH, wgs_comm_next_generation(comm), 0, (int32_t)n, P, batch};
+        if (wgs_comm_allreduce_host_tagged(comm, slots.data(), world, &tag, nullptr)) return 1;
         batch = (int32_t)*std::min_element(slots.begin(), slots.end());
     }
     std::vector<int32_t> counts(K, 0);
@@ -631,7 +636,7 @@ int wgs_loo(wgs_beagle *b, wgs_beagle *scored, wgs_afset *a, int32_t max_iter, d
         wgs_score_destroy(sc);
         wgs_em_destroy(em);
     }
-    return 0;
+    return wgs_comm_check(comm);
 }
 
 static int parts_exact_literal(wgs_beagle *b, wgs_afset *a, const float *const *colptr, int32_t P, const float *carry_in,

@@ -61,15 +61,20 @@ def _as_f32c(a, name):
 
 
 def default_device_index():
-    """The GPU of this process: WGSASSIGN_DEVICE if set, else LOCAL_RANK -- taken modulo the devices this process can see, so that
-    a launcher that narrows every rank's view to one GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) and still sets
-    LOCAL_RANK = 0 .. N-1 lands every rank on its own device 0 instead of failing in hipSetDevice."""
+    """The GPU of this process: WGSASSIGN_DEVICE if set, else LOCAL_RANK.  When exactly ONE device is visible -- a launcher that
+    narrows every rank's view to its own GPU (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) and still sets LOCAL_RANK =
+    0 .. N-1 -- that device is it.  With several devices visible a LOCAL_RANK beyond them is an error: taken modulo the count it
+    would put two ranks on one GPU without a word."""
     if "WGSASSIGN_DEVICE" in os.environ:
         return int(os.environ["WGSASSIGN_DEVICE"])
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n = ctypes.c_int(0)
     if _lib.load().wgs_device_count(ctypes.byref(n)) == 0 and n.value > 0:
-        return local_rank % n.value
+        if n.value == 1:
+            return 0
+        if local_rank >= n.value:
+            raise RuntimeError("wgsassign_amd: LOCAL_RANK=%d but only %d GPUs are visible to this process (set WGSASSIGN_DEVICE to share "
+                               "a device deliberately)" % (local_rank, n.value))
     return local_rank
 
 
@@ -522,6 +527,11 @@ def assign(beagle, afset, colptr=None, P=1, mode=None, comm=None):
         if parts is not None:
             parts = comm.allreduce_sum(parts)
     return out, parts
+
+
+def debug_hook(name, value):
+    """A named process-wide test switch of the library (include/wgsassign_hip_debug.h: wgs_debug_hook); 0 switches it off."""
+    check(_lib.load().wgs_debug_hook(name.encode(), int(value)))
 
 
 def malloc_seconds():

@@ -48,6 +48,10 @@ def emMAF_populations(L, IDs, iter, tole, beagle=None, comm=None):
         beagle = DeviceBeagle.from_host(L, group_of, len(pops))
     em = EMBatch(beagle, np.arange(len(pops), dtype=np.int32))
     iters = em.run(iter, tole, comm=comm)
+    try:        # (sweeps enqueued, exact-chain resolutions, wall seconds, sweep-kernel ms) of the one-call fit, for whoever asks
+        emMAF_populations.last_stats = em.fit_stats()
+    except Exception:
+        emMAF_populations.last_stats = None
     af = np.empty((beagle.m, len(pops)), dtype=np.float32)
     for k in range(len(pops)):
         if iters[k] > 0:
