@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-assign", action="store_true", help="skip the assignment sweep leg")
     ap.add_argument("--no-paths", action="store_true", help="skip extra.paths (whole-path timings of the other configurations)")
+    ap.add_argument("--no-projection", action="store_true", help="skip extra.shard_projection (one-GPU timings of the per-rank shards of N = 2, 4, 8)")
     ap.add_argument("--no-coded", action="store_true", help="skip extra.coded and the coded scoring sweep (profiles of the float32 kernels alone: every launch of a kernel then does the same work)")
     ap.add_argument("--cpu-snps", type=int, default=200_000, help="SNP sample for the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="minimum CPU-baseline EM timing window")
@@ -377,10 +378,13 @@ def main():
             # through the class codes: the second call is the steady state; a cold call (codes built inside it) is
             # extra.coded.pop_like_cold on a matrix whose codes were dropped
             o1, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
+            ctx.sync()
+            t0 = time.perf_counter()
             o1, _ = device.assign(beagle, afs, mode=mode, comm=comm if use_dist else None)
+            t_warm = time.perf_counter() - t0
             info = beagle.codes_info()
             extra["assign"]["coded"] = {"available": info["available"], "kernel": "score_coded_kernel<%s> (per-class value table in LDS)" % args.mode,
-                                        "kernel_ms": round(device.assign.last_ms, 3), "snps_per_s_steady_state": m_total / (device.assign.last_ms * 1e-3) / 1.0 if device.assign.last_ms > 0 else None,
+                                        "seconds_warm": round(t_warm, 4), "kernel_ms": round(device.assign.last_ms, 3), "snps_per_s_steady_state": m_total / (device.assign.last_ms * 1e-3) / 1.0 if device.assign.last_ms > 0 else None,
                                         "identical_sums": bool(o1.tobytes() == out.tobytes()), "codes_build_ms_once_per_matrix": round(info["build_ms"], 1)}
         if args.mode == "exact":
             # the float32 scoring sweep (WGSASSIGN_MODE=fast), validated against exact on this very matrix
@@ -406,6 +410,16 @@ def main():
                                                "note": "one call on a matrix without codes: sample pass + allocation + encode pass + coded sweep"}
         afs.close()
 
+    if "assign" in extra:
+        # the other half of BASELINE's metric, where the driver's parser keeps it: the scoring sweep over the float32 matrix is bound
+        # by FP64 issue (one double log per term), so its roof is stated as the share of the issue slots its instructions fill
+        a = extra["assign"]
+        issue = m * float(n) * K * INSTS_PER_TERM["score_sweep_kernel<exact>"] / 64.0 / WAVE_ISSUE_PER_S / (a["kernel_ms"] * 1e-3) if a["kernel_ms"] > 0 and args.mode == "exact" else None
+        roofline["assign"] = {"bound": "valu_fp64_issue", "kernel": "score_sweep_kernel<%s>" % args.mode, "kernel_ms": a["kernel_ms"],
+                              "snps_per_s": a["value"], "hbm_frac": a["hbm_frac"], "valu_frac": a.get("valu_frac"),
+                              "fp64_issue_frac": round(issue, 4) if issue else None,
+                              "coded_kernel_ms": a.get("coded", {}).get("kernel_ms"), "coded_identical_sums": a.get("coded", {}).get("identical_sums")}
+
     cpu = None
     if rank == 0 and not args.no_cpu:
         # rank 0's host cores; at N > 1 a shorter window (the other ranks wait at the closing barrier)
@@ -419,14 +433,20 @@ def main():
         em = beagle = None
         paths = whole_paths(ctx, device, args.mode)
         extra["paths"] = paths
+    if rank == 0 and world == 1 and not use_dist and args.mode == "exact" and not args.no_projection:
+        if em is not None:
+            em.close()
+            beagle.close()
+            em = beagle = None
+        extra["shard_projection"] = shard_projection(ctx, device, wcomm, args, ms_per_step * 1e-3, extra)
 
     if rank == 0:
         line = {"metric": "EM SNP-updates/s (per-population update, n_call=%g)" % n_call, "value": value,
                 "unit": "SNP-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f64" if args.mode == "exact" else "f32", "data": "synthetic",
-                "config": {"workload": "synthetic Beagle %d SNPs x %d ind, K=%d, --get_reference_af EM sweep (+ --get_pop_like sweep), SNP-sharded over %d GPU(s)"
-                                       % (m_total, n, K, world), "mode": args.mode, "snps_per_gpu": m,
+                "config": {"workload": "%d GPU(s), SNP-sharded: synthetic Beagle %d SNPs x %d ind, K=%d, EM sweep (+ pop_like sweep)" % (world, m_total, n, K),
+                           "mode": args.mode, "snps_per_gpu": m,
                            "gl_bytes_per_gpu": gl_bytes, "comm": comm_note,
                            "rccl_ranks_seen": comm_info["rccl_ranks_seen"] if comm_info and comm_info["native"] else None,
                            "comm_native_rccl": bool(comm_info and comm_info["native"]),
@@ -489,6 +509,19 @@ def coded_em_leg(ctx, device, beagle, em_direct, K, per, n, m, mode, args):
     res["identical_frequencies"] = bool(same and res["fit_cold"]["iterations"] == res["fit_direct"]["iterations"])
     for e in (e_cold, e_warm, e_dir):
         e.close()
+    md = beagle.codes_model(0)                   # the cost model's own numbers beside the measurements (as in extra.paths)
+    its = float(max(res["fit_direct"]["iterations"])) or 14.0
+    f32_ms = res["fit_direct"]["seconds"] * 1e3
+    pred_warm = its * md["em_share_saved_by_a_coded_sweep"] * md["em_float32_sweep_ms"] if md["builds_for_a_fit"] else 0.0
+    pred_cold = pred_warm - md["encode_ms"] if md["builds_for_a_fit"] else 0.0
+    meas_cold = f32_ms - (res["fit_building_the_codes_seconds"] or res["fit_cold"]["seconds"]) * 1e3
+    meas_warm = f32_ms - res["fit_warm"]["seconds"] * 1e3
+    res["cost_model"] = {"builds_the_codes": md["builds_for_a_fit"], "classes_per_slab_and_snp": round(md["sample_classes_per_slab_and_snp"], 2),
+                         "float32_fit_ms": {"predicted": round(its * md["em_float32_sweep_ms"], 3), "measured": round(f32_ms, 3)},
+                         "encode_ms": {"predicted": round(md["encode_ms"], 3), "measured": round(info["build_ms"], 2) if info else None},
+                         "saving_cold_ms": {"predicted": round(pred_cold, 3), "measured": round(meas_cold, 3)},
+                         "saving_warm_ms": {"predicted": round(pred_warm, 3), "measured": round(meas_warm, 3)},
+                         "abs_error_share_of_float32_fit": {"cold": round(abs(pred_cold - meas_cold) / f32_ms, 4), "warm": round(abs(pred_warm - meas_warm) / f32_ms, 4)}}
     if info is None:
         res["note"] = "the cost model (csrc/api.hip: em_codes_pay) kept the float32 slabs for this fit"
         return res, {"available": False}
@@ -521,6 +554,151 @@ def coded_em_leg(ctx, device, beagle, em_direct, K, per, n, m, mode, args):
                           "em_direct_tile_share": round(info["em_direct_tile_share"], 5), "slab_numbering_bytes": info["slab_numbering_bytes"],
                           "probe_rounds_per_16_lookups": round(info["probe_rounds_per_buffer"], 2)}
     return res, info
+
+
+def shard_projection(ctx, device, wcomm, args, full_step_s, extra):
+    """extra.shard_projection (N = 1 runs only): no 8-GPU node was available to any round of this build, so the per-rank work of the
+    SNP-sharded path is timed here, on ONE MI355X, at the shard sizes of N = 2, 4, 8 -- the LAST rank's SNP range of the same 10M-SNP
+    matrix, so `site0 != 0` -- for every leg the path has grown since the float32 sweep: the float32 EM step, the --get_reference_af
+    fit cold (class codes built inside it) and warm, --get_pop_like cold and warm, and the --loo batch of BASELINE configs[3].  A
+    rank's wall time at N GPUs is predicted as its shard's time + the collectives the leg issues (counted by the same rules
+    tests/test_gpu_multirank.py asserts through wgs_comm_stats) x the measured device time of one tagged collective on a ONE-RANK RCCL
+    communicator -- launch, RCCL kernel, tag-row kernels; the xGMI hop itself is NOT in that figure, so `headroom_us_per_collective`
+    says how slow a collective may be before the leg falls below 6x at 8 GPUs.  speedup = seconds on the whole matrix (this same run) /
+    predicted seconds at N."""
+    from wgsassign_amd import glassy
+    m_total, n, K = args.m, args.n, args.K
+    out = {"note": "one MI355X at the per-rank shard sizes of N = 2, 4, 8 (last rank's SNP range); predicted = shard seconds + collectives x "
+                   "one-rank RCCL collective time; no N > 1 run over RCCL/xGMI has executed anywhere yet"}
+    coll = {"allreduce_us": None, "bcast_us": None}
+    try:
+        c1 = wcomm.RcclComm(ctx, 0, 1)
+        coll = c1.time_collectives(reps=50, n=2 * K)
+        c1.close()
+        coll["what"] = "wgs_comm_time_collectives on a one-rank RCCL communicator: tag rows + ncclAllReduce / ncclBroadcast + check kernel, on the stream"
+    except Exception as e:                       # no librccl: the projection still shows the shards' own times
+        coll["error"] = str(e)
+    ar, bc = (coll.get("allreduce_us") or 0.0) * 1e-6, (coll.get("bcast_us") or 0.0) * 1e-6
+    if coll.get("bcast_us") == 0.0:              # (a one-rank broadcast returns at once: take the all-reduce's time for a hop)
+        bc = ar
+    out["collectives"] = coll
+
+    def codes_env(v):
+        old = os.environ.get("WGSASSIGN_CODES")
+        if v is None:
+            os.environ.pop("WGSASSIGN_CODES", None)
+        else:
+            os.environ["WGSASSIGN_CODES"] = v
+        return old
+
+    def leg(full_s, shard_s, n_ar, n_bc, N):
+        if not full_s or not shard_s:
+            return None
+        pred = shard_s + n_ar * ar + n_bc * bc
+        r = {"shard_seconds": round(shard_s, 5), "allreduces": int(n_ar), "broadcasts": int(n_bc), "predicted_seconds": round(pred, 5),
+             "speedup": round(full_s / pred, 2), "efficiency": round(full_s / pred / N, 3)}
+        if N == 8:
+            n_coll = n_ar + n_bc
+            r["holds_6x"] = bool(full_s / pred >= 6.0)
+            r["headroom_us_per_collective"] = round((full_s / 6.0 - shard_s) / n_coll * 1e6, 1) if n_coll else None
+        return r
+
+    coded = extra.get("coded", {})
+    full = {"float32_em_step": full_step_s,
+            "fit_cold": coded.get("fit_building_the_codes_seconds") or coded.get("fit_cold", {}).get("seconds"),
+            "fit_warm": coded.get("fit_warm", {}).get("seconds"),
+            "pop_like_cold": coded.get("pop_like_cold", {}).get("seconds"),
+            "pop_like_warm": extra.get("assign", {}).get("coded", {}).get("seconds_warm")}
+    out["seconds_on_the_whole_matrix"] = {k: (round(v, 5) if v else None) for k, v in full.items()}
+    per = n // K
+    group_of = np.minimum(np.arange(n) // per, K - 1).astype(np.int32)
+    for N in (2, 4, 8):
+        lo, hi = wcomm.shard_range(m_total, N - 1, N)
+        ms = hi - lo
+        b = device.DeviceBeagle(ms, n, group_of, K, site0=lo, ctx=ctx)
+        b.synth(SEED, 2.0)
+        ctx.sync()
+        res = {"snps": ms, "site0": lo}
+        # the float32 EM step (the headline's kernel)
+        old = codes_env("0")
+        e = device.EMBatch(b, np.arange(K, dtype=np.int32))
+        e.fit(max(1, args.warmup), 0.0, None, m_total)
+        ctx.sync()
+        t0 = time.perf_counter()
+        e.fit(args.steps, 0.0, None, m_total)
+        ctx.sync()
+        step_s = (time.perf_counter() - t0) / args.steps
+        res["float32_em_step"] = leg(full["float32_em_step"], step_s, 1, 0, N)
+        res["float32_em_step"]["sweep_kernel_ms"] = round(e.fit_stats()[3] / args.steps, 4)
+        e.close()
+        codes_env(old)
+        # --get_reference_af: the cold fit (nothing built), then the warm one
+        for label in ("fit_cold", "fit_warm"):
+            e = device.EMBatch(b, np.arange(K, dtype=np.int32))
+            t0 = time.perf_counter()
+            iters = e.fit(200, 1e-4, None, m_total)
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            b.codes_wait()
+            st = e.fit_stats()
+            res[label] = leg(full[label], dt, st[0] + 1, N * st[1], N)
+            if res[label]:
+                res[label].update({"iterations": int(max(iters)), "sweeps_enqueued": int(st[0]), "codes": b.codes_state() == 1})
+            if label == "fit_warm":
+                afs = device.AFSet(ms, K, ctx=ctx)
+                for k in range(K):
+                    e.clamp(k, per)
+                    afs.set_column_from_em(k, e, k)
+            e.close()
+        # --get_pop_like: warm (codes there), then cold on the same matrix generated again
+        device.assign(b, afs)
+        ctx.sync()
+        t0 = time.perf_counter()
+        device.assign(b, afs)
+        res["pop_like_warm"] = leg(full["pop_like_warm"], time.perf_counter() - t0, 0, N, N)
+        b.synth(SEED, 2.0)
+        ctx.sync()
+        t0 = time.perf_counter()
+        device.assign(b, afs)
+        res["pop_like_cold"] = leg(full["pop_like_cold"], time.perf_counter() - t0, 0, N, N)
+        b.codes_wait()
+        afs.close()
+        b.close()
+        out["N=%d" % N] = res
+    # BASELINE configs[3]: --loo --partition_sites 3 at 2M x 500, K=8; whole matrix from extra.paths when it ran
+    loo_full = extra.get("paths", {}).get("config4_2Mx500_K8", {}).get("loo_partition_sites_3", {}).get("seconds")
+    if loo_full:
+        m4, n4, K4 = 2_000_000, 500, 8
+        g4 = np.minimum(np.arange(n4) // (n4 // K4), K4 - 1).astype(np.int32)
+        out["seconds_on_the_whole_matrix"]["config4_loo"] = loo_full
+        for N in (2, 4, 8):
+            lo, hi = wcomm.shard_range(m4, N - 1, N)
+            b = device.DeviceBeagle(hi - lo, n4, g4, K4, site0=lo, ctx=ctx)
+            b.synth(SEED, 2.0)
+            e = device.EMBatch(b, np.arange(K4, dtype=np.int32))
+            e.fit(200, 1e-4, None, m4)
+            af = np.empty((hi - lo, K4), dtype=np.float32)
+            cnt = np.bincount(g4, minlength=K4)
+            for k in range(K4):
+                e.clamp(k, int(cnt[k]))
+                af[:, k] = e.get_f(k)
+            e.close()
+            tm = {}
+            t0 = time.perf_counter()
+            glassy.loo_device(b, b, af, g4, 200, 1e-4, 3, verbose=False, timings=tm, need_parts=True)
+            dt = time.perf_counter() - t0
+            # per batch: the batch-size agreement, one all-reduce per sweep enqueued, the one that closes the fit; `world` broadcasts per
+            # chain resolution, for the totals and for the partition chains
+            r = leg(loo_full, dt, 2 * tm.get("em_batches", 1) + tm.get("em_iterations_enqueued", 0), N * (2 * tm.get("em_batches", 1) + tm.get("em_chain_resolutions", 0)), N)
+            r["snps"] = hi - lo
+            out["N=%d" % N]["config4_loo"] = r
+            b.close()
+    verdict = {}
+    for k, v in out.get("N=8", {}).items():
+        if isinstance(v, dict) and "holds_6x" in v:
+            verdict[k] = {"speedup_at_8": v["speedup"], "holds_6x": v["holds_6x"]}
+    out["at_8_gpus"] = verdict
+    return out
 
 
 FP64_ISSUE_CLOCK_GHZ = 2.4      # MI355X peak engine clock: issue fractions below are lower bounds of the busy share
@@ -615,6 +793,21 @@ def whole_paths(ctx, device, mode_name):
         res["identical_frequencies"] = bool(list(it3) == list(iters) and em3.get_f(0).tobytes() == em.get_f(0).tobytes())
         res["snp_updates_per_s_cold"] = float(b.m) * float(np.sum(iters)) / dt
         em3.close()
+        # the cost model's own numbers (csrc/em_api.hip: em_codes_model -- what em_codes_pay decided with) beside what was measured:
+        # the fit over the float32 slabs, and what the class codes saved of it cold (their build inside the fit) and warm
+        md = b.codes_model(0)
+        its = float(max(iters)) if max(iters) > 0 else 14.0
+        f32_ms = dt3 * 1e3
+        pred_warm = its * md["em_share_saved_by_a_coded_sweep"] * md["em_float32_sweep_ms"] if md["builds_for_a_fit"] else 0.0
+        pred_cold = pred_warm - md["encode_ms"] if md["builds_for_a_fit"] else 0.0
+        meas_cold, meas_warm = (dt3 - res.get("seconds_fit_building_the_codes", dt)) * 1e3, (dt3 - dt2) * 1e3
+        res["cost_model"] = {"builds_the_codes": md["builds_for_a_fit"], "from_the_sample_pass": md["from_the_sample_pass"],
+                             "classes_per_slab_and_snp": round(md["sample_classes_per_slab_and_snp"], 2),
+                             "float32_fit_ms": {"predicted": round(its * md["em_float32_sweep_ms"], 3), "measured": round(f32_ms, 3)},
+                             "encode_ms": {"predicted": round(md["encode_ms"], 3), "measured": res["class_codes"].get("build_ms")},
+                             "saving_cold_ms": {"predicted": round(pred_cold, 3), "measured": round(meas_cold, 3)},
+                             "saving_warm_ms": {"predicted": round(pred_warm, 3), "measured": round(meas_warm, 3)},
+                             "abs_error_share_of_float32_fit": {"cold": round(abs(pred_cold - meas_cold) / f32_ms, 4), "warm": round(abs(pred_warm - meas_warm) / f32_ms, 4)}}
         return em, res
 
     def pop_like(b, em, K, counts):
@@ -656,6 +849,17 @@ def whole_paths(ctx, device, mode_name):
         b.codes_wait()
         res["class_codes_cold"] = codes_note(b)
         res["identical_sums"] = bool(od.tobytes() == o.tobytes() == oc.tobytes())
+        md = b.codes_model(K)                    # csrc/codes.hip: wgs_codes_scoring_model, what wgs_codes_pay_for_scoring decided with
+        f32_ms = res["seconds_float32"] * 1e3
+        pred_warm = md["score_float32_sweep_ms"] * (1.0 - md["score_share_of_the_coded_sweep"]) if md["builds_for_scoring"] else 0.0
+        pred_cold = pred_warm - md["encode_for_scoring_ms"] if md["builds_for_scoring"] else 0.0
+        meas_cold, meas_warm = f32_ms - res["seconds_cold"] * 1e3, res["float32_kernel_ms"] - res["kernel_ms_warm"]
+        res["cost_model"] = {"builds_the_codes": md["builds_for_scoring"], "classes_per_snp": round(md["sample_classes_per_snp"], 2),
+                             "float32_sweep_ms": {"predicted": round(md["score_float32_sweep_ms"], 3), "measured": res["float32_kernel_ms"]},
+                             "encode_ms": {"predicted": round(md["encode_for_scoring_ms"], 3), "measured": res["class_codes_cold"].get("build_ms")},
+                             "saving_cold_ms": {"predicted": round(pred_cold, 3), "measured": round(meas_cold, 3)},
+                             "saving_warm_ms": {"predicted": round(pred_warm, 3), "measured": round(meas_warm, 3)},
+                             "abs_error_share_of_float32_sweep": {"cold": round(abs(pred_cold - meas_cold) / f32_ms, 4), "warm": round(abs(pred_warm - meas_warm) / f32_ms, 4)}}
         af = afs.to_host()
         afs.close()
         return af, res

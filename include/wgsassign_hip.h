@@ -135,6 +135,13 @@ int wgs_beagle_codes_wait(wgs_beagle *b, double *alloc_ms);
  * it hands it out again, so the same allocation costs 0.3 ms or seconds by what the box did before; callers that time whole
  * paths (bench.py) report the share. */
 double wgs_malloc_seconds(void);
+/* What the library's cost models predict for this matrix (csrc/em_api.hip: em_codes_model; csrc/codes.hip: wgs_codes_pay_for_scoring),
+ * so that a caller can put the prediction beside its measurement.  out[0..11]: one EM sweep of all population slabs over the float32
+ * matrix in ms | share of it a coded sweep saves | encode pass (with the slabs' own numbering) in ms | sweeps the decision counts |
+ * 1 = the model builds the codes for a fit | one scoring sweep over K_score populations over the float32 matrix in ms | share of
+ * that the coded sweep costs | encode pass for scoring alone in ms | 1 = the model builds them for scoring | 1 = from the matrix's
+ * own sample pass | classes per (slab, SNP) and per SNP in the sample.  K_score = 0: the EM entries only. */
+int wgs_codes_model(wgs_beagle *b, int32_t K_score, double *out);
 /* Builds the codes now rather than at the first sweep that asks.  (`em` is ignored since version 2: one pass builds all.) */
 int wgs_beagle_codes_prepare(wgs_beagle *b, int em);
 

@@ -245,10 +245,11 @@ a1 = np.ascontiguousarray(af[lo:hi]).copy()
 c0, tm = collectives(), {{}}
 with contextlib.redirect_stdout(io.StringIO()):
     ll, parts = glassy.loo_device(b, b, a1, group_of, 200, 1e-4, 2, comm=comm, verbose=False, timings=tm)      # one C call (wgs_loo)
-# --loo, one batch: the batch-size agreement + one all-reduce of the convergence sums per EM iteration enqueued;
-# `world` broadcasts per batched resolution of undecided fits, for the totals, and for the partition chains
+# --loo, one batch: the batch-size agreement + one all-reduce of the convergence sums per EM iteration enqueued + the one that
+# closes the fit (the ranks compare what they found); `world` broadcasts per batched resolution of undecided fits, for the
+# totals, and for the partition chains
 assert tm["one_call"] and tm["em_batches"] == 1
-assert list(collectives() - c0) == [1 + tm["em_iterations_enqueued"], world * (2 + tm["em_chain_resolutions"])], (collectives() - c0, tm)
+assert list(collectives() - c0) == [2 + tm["em_iterations_enqueued"], world * (2 + tm["em_chain_resolutions"])], (collectives() - c0, tm)
 os.environ["WGSASSIGN_LOO"] = "python"
 a2 = np.ascontiguousarray(af[lo:hi]).copy()
 with contextlib.redirect_stdout(io.StringIO()):

@@ -50,6 +50,7 @@ SIGNATURES = {
     "wgs_beagle_synth_quality": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_double, c_i32, c_f64p, c_f64p]),
     "wgs_beagle_codes_info": (c_int, [c_vp, c_f64p]),
     "wgs_beagle_codes_prepare": (c_int, [c_vp, c_int]),
+    "wgs_codes_model": (c_int, [c_vp, c_i32, c_f64p]),
     "wgs_beagle_codes_state": (c_int, [c_vp]),
     "wgs_beagle_codes_wait": (c_int, [c_vp, c_f64p]),
     "wgs_malloc_seconds": (ctypes.c_double, []),

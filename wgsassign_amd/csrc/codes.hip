@@ -235,14 +235,24 @@ double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots, bool with_sla
 // Whether a scoring sweep with shared columns over K populations should build the codes: the direct sweep costs ~1.2e-11 s per
 // (SNP, individual, population) (119 ms at 10M x 1000 x 10, on the FP64 issue roof), the coded one the share of it that is
 // table work (classes / individuals) + ~9 % for the look-ups (16.6 ms there; 6.5 of 25.7 ms with 73 classes among 1000).
+bool wgs_codes_scoring_model(wgs_beagle *b, int K, double *direct_ms, double *coded_share, double *build_ms)
+{
+    const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
+    *direct_ms = 1.2e-8 * (double)b->m * (double)b->n * (double)K;
+    *coded_share = 1.0;
+    *build_ms = 0.0;
+    if (!P || P->state <= 0) return false;
+    *coded_share = std::min(1.0, 1.25 * P->mean_g / (double)std::max<int64_t>(1, b->n) + 0.09);
+    *build_ms = wgs_codes_build_ms_estimate(b, P->slots, false);
+    return true;
+}
+
 bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K)
 {
     if (getenv("WGSASSIGN_CODES_TABLE") || getenv("WGSASSIGN_SCORE_CODES_ALWAYS")) return true;      // experiments / tests
-    const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
-    if (!P || P->state <= 0) return false;
-    const double direct_ms = 1.2e-8 * (double)b->m * (double)b->n * (double)K;
-    const double coded_share = std::min(1.0, 1.25 * P->mean_g / (double)std::max<int64_t>(1, b->n) + 0.09);
-    return direct_ms * (1.0 - coded_share) > wgs_codes_build_ms_estimate(b, P->slots, false);
+    double direct_ms, coded_share, build_ms;
+    if (!wgs_codes_scoring_model(b, K, &direct_ms, &coded_share, &build_ms)) return false;
+    return direct_ms * (1.0 - coded_share) > build_ms;
 }
 
 // Builds the class codes (the plan of the sample pass decides whether and how, then one pass over the matrix: ~2 x its streaming

@@ -221,6 +221,8 @@ wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true, bool wait = true, 
 const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b);
 double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots, bool with_slab_numbering = true);
 bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K);
+// the numbers that decision is made from: the direct sweep's time, the share of it the coded sweep costs, the encode pass (false: not worth coding)
+bool wgs_codes_scoring_model(wgs_beagle *b, int K, double *direct_ms, double *coded_share, double *build_ms);
 int wgs_ctx_workspace_b(wgs_ctx *ctx, size_t bytes, void **out);     // a second small grow-only scratch (survives wgs_ctx_workspace calls)
 void wgs_beagle_drop_codes(wgs_beagle *b);
 void wgs_beagle_release_pool(wgs_beagle *b);

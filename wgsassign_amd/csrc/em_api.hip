@@ -144,6 +144,47 @@ static double loo_codes_saving(const wgs_codes_plan *P, double cols)
     return 1.0 - (1.7 * P->mean_l * 29.0 + 4.0 * cols + 250.0) / (25.9 * std::max(1.0, cols));
 }
 
+// The model's own numbers for a batch of fits that sweep `swept` bytes of slabs with `cols` individuals per slab on average: what a
+// sweep over the float32 slabs takes, the share of it a coded sweep saves, what the encode pass costs.  em_codes_pay decides with
+// them and wgs_codes_model hands them out, so that what is reported beside a measurement is what decided.
+struct EmCodesModel {
+    double direct_ms = 0.0, saves = 0.0, build_ms = 0.0;
+    bool sampled = false;          // saves / build_ms come from the matrix's own sample pass (else from the fixed-error typical)
+    bool codable = false;          // the sample pass found the matrix worth coding, with the slabs' own numbering
+};
+static EmCodesModel em_codes_model(wgs_beagle *b, double swept, double cols, bool shared, bool sample)
+{
+    EmCodesModel M;
+    auto saves = [&](double classes_per_slab) { return std::max(0.0, std::min(0.6, 0.92 - 2.72 * classes_per_slab / std::max(1.0, cols))); };
+    if (shared) {
+        constexpr double LOO_MS_PER_TERM = 7.6e-10;          // em_sweep_group_kernel, per (fit, SNP, individual)
+        M.direct_ms = swept / 8.0 * LOO_MS_PER_TERM;
+        const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
+        M.sampled = true;
+        M.codable = P && P->state > 0 && P->lrows > 0;
+        if (!M.codable) return M;
+        M.saves = std::max(0.0, loo_codes_saving(P, cols));
+        M.build_ms = wgs_codes_build_ms_estimate(b, P->slots);
+        return M;
+    }
+    M.direct_ms = swept / 6.0e9;
+    // fixed-error 2x data shows ~4.6 * cols^0.25 classes per (slab, SNP): 14.7 at 100, 12.7 at 62, 10.5 at 40
+    M.saves = saves(4.6 * pow(std::max(1.0, cols), 0.25));
+    M.build_ms = wgs_codes_build_ms_estimate(b, 64);
+    M.codable = true;
+    if (!sample) return M;
+    const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
+    M.sampled = true;
+    M.codable = P && P->state > 0 && P->lrows > 0;
+    if (!M.codable) {
+        M.saves = 0.0;
+        return M;
+    }
+    M.saves = saves(P->mean_l);
+    M.build_ms = wgs_codes_build_ms_estimate(b, P->slots);
+    return M;
+}
+
 static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, int fewest_cols, int sweeps_ahead, bool shared)
 {
     wgs_beagle *b = em->b;
@@ -158,23 +199,54 @@ static bool em_codes_pay(const wgs_em *em, const std::vector<int32_t> &order, in
         cols += (double)b->slabs[em->group[j]].ncols;
     }
     cols /= (double)std::max<size_t>(1, order.size());
-    if (shared) {
-        constexpr double LOO_MS_PER_TERM = 7.6e-10;          // em_sweep_group_kernel, per (fit, SNP, individual)
-        const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
-        if (!P || P->state <= 0 || P->lrows == 0) return false;
-        const double direct_ms = swept / 8.0 * LOO_MS_PER_TERM;
-        const double saves_loo = std::max(0.0, loo_codes_saving(P, cols));
-        return ahead * saves_loo * direct_ms > wgs_codes_build_ms_estimate(b, P->slots);
-    }
-    const double direct_ms = swept / 6.0e9;
-    auto saves = [&](double classes_per_slab) { return std::max(0.0, std::min(0.6, 0.92 - 2.72 * classes_per_slab / std::max(1.0, cols))); };
-    // fixed-error 2x data shows ~4.6 * cols^0.25 classes per (slab, SNP): 14.7 at 100, 12.7 at 62, 10.5 at 40
-    const double typical = 4.6 * pow(std::max(1.0, cols), 0.25);
-    if (ahead * saves(typical) * direct_ms <= wgs_codes_build_ms_estimate(b, 64)) return false;
-    const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
-    if (!P || P->state <= 0 || P->lrows == 0) return false;
     (void)fewest_cols;
-    return ahead * saves(P->mean_l) * direct_ms > wgs_codes_build_ms_estimate(b, P->slots);
+    if (!shared) {      // a first estimate with the classes typical of fixed-error data turns small matrices away without a sample pass
+        const EmCodesModel T = em_codes_model(b, swept, cols, false, false);
+        if (ahead * T.saves * T.direct_ms <= T.build_ms) return false;
+    }
+    const EmCodesModel M = em_codes_model(b, swept, cols, shared, true);
+    return M.codable && ahead * M.saves * M.direct_ms > M.build_ms;
+}
+
+/* The cost models' own predictions for this matrix (so that a caller can print them beside what it measures: bench.py,
+ * tests/test_gpu_codes.py): the fits of --get_reference_af (one per population slab) and a --get_pop_like sweep over K populations.
+ * out[0..11]: EM sweep over the float32 slabs, ms | share of it a coded sweep saves | encode pass incl. the slabs' numbering, ms |
+ * sweeps the decision counts (14) | 1 = the model builds the codes for such a fit | scoring sweep over the float32 slabs, ms | share
+ * of it the coded sweep costs | encode pass for scoring alone, ms | 1 = the model builds them for scoring | 1 = predictions from the
+ * matrix's own sample pass | classes per (slab, SNP) in the sample | classes per SNP in the sample.  Runs the sample pass (~0.4 ms)
+ * unless the first estimate already turns the matrix away. */
+int wgs_codes_model(wgs_beagle *b, int32_t K_score, double *out)
+{
+    WGS_REQUIRE(b && out, "null argument");
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    double swept = 0.0, cols = 0.0;
+    int groups = 0;
+    for (int g = 0; g < b->n_groups; ++g) {
+        if (b->slabs[g].ncols == 0) continue;
+        swept += 8.0 * (double)b->slabs[g].ncols * (double)b->m;
+        cols += (double)b->slabs[g].ncols;
+        ++groups;
+    }
+    cols /= std::max(1, groups);
+    const EmCodesModel T = em_codes_model(b, swept, cols, false, false);
+    const bool first_ok = 14.0 * T.saves * T.direct_ms > T.build_ms;
+    const EmCodesModel M = first_ok ? em_codes_model(b, swept, cols, false, true) : T;
+    for (int i = 0; i < 12; ++i) out[i] = 0.0;
+    out[0] = M.direct_ms;
+    out[1] = M.saves;
+    out[2] = M.build_ms;
+    out[3] = 14.0;
+    out[4] = (first_ok && M.codable && 14.0 * M.saves * M.direct_ms > M.build_ms) ? 1.0 : 0.0;
+    out[9] = M.sampled ? 1.0 : 0.0;
+    if (K_score > 0) {
+        if (wgs_codes_scoring_model(b, K_score, &out[5], &out[6], &out[7])) out[8] = out[5] * (1.0 - out[6]) > out[7] ? 1.0 : 0.0;
+        out[9] = 1.0;
+    }
+    if (b->plan.state != 0) {
+        out[10] = b->plan.mean_l;
+        out[11] = b->plan.mean_g;
+    }
+    return 0;
 }
 
 // The buffers of two iterations per sweep: a third frequency buffer and a second set of partial sums.  false: no memory for them.

@@ -206,6 +206,15 @@ class DeviceBeagle:
         check(_lib.load().wgs_beagle_codes_wait(self._h, ctypes.byref(ms)))
         return ms.value
 
+    def codes_model(self, K_score=0):
+        """What the library's cost models predict for this matrix (wgs_codes_model): the numbers its decisions are made from."""
+        o = (ctypes.c_double * 12)()
+        check(_lib.load().wgs_codes_model(self._h, int(K_score), o))
+        return {"em_float32_sweep_ms": o[0], "em_share_saved_by_a_coded_sweep": o[1], "encode_ms": o[2], "sweeps_counted": o[3],
+                "builds_for_a_fit": bool(o[4]), "score_float32_sweep_ms": o[5], "score_share_of_the_coded_sweep": o[6],
+                "encode_for_scoring_ms": o[7], "builds_for_scoring": bool(o[8]), "from_the_sample_pass": bool(o[9]),
+                "sample_classes_per_slab_and_snp": o[10], "sample_classes_per_snp": o[11]}
+
     def codes_info(self):
         """Class codes of the matrix (built on first use; csrc/common.h: wgs_codes, csrc/codes.hip): what they hold and what
         they cost.  `build_ms` is the whole build (sample pass, one allocation, the encode pass); `rich_snp_share` the SNPs
