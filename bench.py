@@ -572,15 +572,26 @@ def shard_projection(ctx, device, wcomm, args, full_step_s, extra):
                    "one-rank RCCL collective time; no N > 1 run over RCCL/xGMI has executed anywhere yet"}
     coll = {"allreduce_us": None, "bcast_us": None}
     try:
-        c1 = wcomm.RcclComm(ctx, 0, 1)
-        coll = c1.time_collectives(reps=50, n=2 * K)
-        c1.close()
+        # (librccl prints a version banner on STDOUT when its first communicator initialises: this process's stdout carries the one JSON
+        # line and nothing else, so the descriptor points at stderr meanwhile)
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            c1 = wcomm.RcclComm(ctx, 0, 1)
+            coll = c1.time_collectives(reps=50, n=2 * K)
+            c1.close()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
         coll["what"] = "wgs_comm_time_collectives on a one-rank RCCL communicator: tag rows + ncclAllReduce / ncclBroadcast + check kernel, on the stream"
     except Exception as e:                       # no librccl: the projection still shows the shards' own times
         coll["error"] = str(e)
     ar, bc = (coll.get("allreduce_us") or 0.0) * 1e-6, (coll.get("bcast_us") or 0.0) * 1e-6
-    if coll.get("bcast_us") == 0.0:              # (a one-rank broadcast returns at once: take the all-reduce's time for a hop)
+    if (coll.get("bcast_us") or 0.0) < 1.0:      # (a one-rank broadcast returns at once: take the all-reduce's time for a hop)
         bc = ar
+        coll["bcast_us_used"] = coll.get("allreduce_us")
     out["collectives"] = coll
 
     def codes_env(v):
@@ -622,10 +633,10 @@ def shard_projection(ctx, device, wcomm, args, full_step_s, extra):
         # the float32 EM step (the headline's kernel)
         old = codes_env("0")
         e = device.EMBatch(b, np.arange(K, dtype=np.int32))
-        e.fit(max(1, args.warmup), 0.0, None, m_total)
+        e.fit(max(1, args.warmup), 0.0)
         ctx.sync()
         t0 = time.perf_counter()
-        e.fit(args.steps, 0.0, None, m_total)
+        e.fit(args.steps, 0.0)
         ctx.sync()
         step_s = (time.perf_counter() - t0) / args.steps
         res["float32_em_step"] = leg(full["float32_em_step"], step_s, 1, 0, N)
@@ -636,7 +647,7 @@ def shard_projection(ctx, device, wcomm, args, full_step_s, extra):
         for label in ("fit_cold", "fit_warm"):
             e = device.EMBatch(b, np.arange(K, dtype=np.int32))
             t0 = time.perf_counter()
-            iters = e.fit(200, 1e-4, None, m_total)
+            iters = e.fit(200, 1e-4)         # (the metric over the shard's own SNPs: the iteration count of the whole matrix, 14)
             ctx.sync()
             dt = time.perf_counter() - t0
             b.codes_wait()
@@ -676,7 +687,7 @@ def shard_projection(ctx, device, wcomm, args, full_step_s, extra):
             b = device.DeviceBeagle(hi - lo, n4, g4, K4, site0=lo, ctx=ctx)
             b.synth(SEED, 2.0)
             e = device.EMBatch(b, np.arange(K4, dtype=np.int32))
-            e.fit(200, 1e-4, None, m4)
+            e.fit(200, 1e-4)
             af = np.empty((hi - lo, K4), dtype=np.float32)
             cnt = np.bincount(g4, minlength=K4)
             for k in range(K4):
@@ -793,6 +804,29 @@ def whole_paths(ctx, device, mode_name):
         res["identical_frequencies"] = bool(list(it3) == list(iters) and em3.get_f(0).tobytes() == em.get_f(0).tobytes())
         res["snp_updates_per_s_cold"] = float(b.m) * float(np.sum(iters)) / dt
         em3.close()
+        forced = None
+        if b.codes_state() != 1:
+            # the model kept the float32 slabs: what the codes WOULD have given, so that a "no" is accountable too (the model switched
+            # to "always" for two fits on the same matrix generated again, which is then generated once more: nothing built)
+            b.synth(SEED, 2.0)
+            ctx.sync()
+            old_sw = os.environ.get("WGSASSIGN_EM_CODES_SWEEPS")
+            os.environ["WGSASSIGN_EM_CODES_SWEEPS"] = "0"
+            try:
+                emf, dtf, itf, stf = one_fit(b, K)
+                emf.close()
+                if b.codes_state() == 1 and b.codes_info()["em_table_rows"] > 0:
+                    emw, dtw, itw, stw = one_fit(b, K)
+                    forced = {"seconds_cold": round(dtf, 4), "seconds_warm": round(dtw, 4), "build_ms": round(b.codes_info()["build_ms"], 2),
+                              "identical_frequencies": bool(list(itw) == list(iters) and emw.get_f(0).tobytes() == em.get_f(0).tobytes())}
+                    emw.close()
+            finally:
+                if old_sw is None:
+                    os.environ.pop("WGSASSIGN_EM_CODES_SWEEPS")
+                else:
+                    os.environ["WGSASSIGN_EM_CODES_SWEEPS"] = old_sw
+            b.synth(SEED, 2.0)
+            ctx.sync()
         # the cost model's own numbers (csrc/em_api.hip: em_codes_model -- what em_codes_pay decided with) beside what was measured:
         # the fit over the float32 slabs, and what the class codes saved of it cold (their build inside the fit) and warm
         md = b.codes_model(0)
@@ -808,6 +842,14 @@ def whole_paths(ctx, device, mode_name):
                              "saving_cold_ms": {"predicted": round(pred_cold, 3), "measured": round(meas_cold, 3)},
                              "saving_warm_ms": {"predicted": round(pred_warm, 3), "measured": round(meas_warm, 3)},
                              "abs_error_share_of_float32_fit": {"cold": round(abs(pred_cold - meas_cold) / f32_ms, 4), "warm": round(abs(pred_warm - meas_warm) / f32_ms, 4)}}
+        if forced is not None:
+            # the decision "no" beside what "yes" would have been: predicted (the same model, its share and encode estimate) and measured
+            p_warm = its * md["em_share_saved_by_a_coded_sweep"] * md["em_float32_sweep_ms"]
+            m_cold, m_warm = (dt3 - forced["seconds_cold"]) * 1e3, (dt3 - forced["seconds_warm"]) * 1e3
+            res["cost_model"]["had_it_built"] = {"measured": forced, "saving_cold_ms": {"predicted": round(p_warm - md["encode_ms"], 3), "measured": round(m_cold, 3)},
+                                                 "saving_warm_ms": {"predicted": round(p_warm, 3), "measured": round(m_warm, 3)},
+                                                 "the_no_was_right": bool(m_cold <= 0.02 * f32_ms),
+                                                 "abs_error_share_of_float32_fit": {"cold": round(abs(p_warm - md["encode_ms"] - m_cold) / f32_ms, 4), "warm": round(abs(p_warm - m_warm) / f32_ms, 4)}}
         return em, res
 
     def pop_like(b, em, K, counts):

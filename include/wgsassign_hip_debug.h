@@ -64,6 +64,10 @@ int wgs_debug_rcp_error(wgs_ctx *ctx, int exponent, double *max_rel);
 int wgs_debug_log_mismatch(wgs_ctx *ctx, uint32_t b0, uint32_t b1, uint64_t *count, uint32_t *first);
 int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, int use_libm);
 
+/* The sums of the last wgs_score_sums per chunk of 8192 sites (the addends of np.sum's running float64 total): out (NULL: only
+ * *nchunks is set) receives ceil(blocks / 2) x n*K float64, out[c * n*K + i * K + k]. */
+int wgs_debug_score_chunks(wgs_score *sc, double *out, int64_t *nchunks);
+
 /* Cross-check only: FLOAT64 partition sums parts[(i*P + p)*K + k] (labels = global site index % P) and totals from the
  * round-1 kernel (lanes <-> pairs of individuals, tile ranges combined with float64 atomics): ~1e-5 from the
  * reference's serial float32 partition sums, not reproducible run to run.  Not on the product path. */

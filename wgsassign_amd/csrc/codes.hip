@@ -232,13 +232,13 @@ double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots, bool with_sla
     return (double)b->bytes / 2.3e9 * (slots <= 64 ? 1.0 : (slots == 128 ? 1.4 : 2.4)) * (with_slab_numbering ? 1.0 : 0.78) + 0.5;
 }
 
-// Whether a scoring sweep with shared columns over K populations should build the codes: the direct sweep costs ~1.2e-11 s per
+// Whether a scoring sweep with shared columns over K populations should build the codes: the direct sweep costs ~1.2e-12 s per
 // (SNP, individual, population) (119 ms at 10M x 1000 x 10, on the FP64 issue roof), the coded one the share of it that is
 // table work (classes / individuals) + ~9 % for the look-ups (16.6 ms there; 6.5 of 25.7 ms with 73 classes among 1000).
 bool wgs_codes_scoring_model(wgs_beagle *b, int K, double *direct_ms, double *coded_share, double *build_ms)
 {
     const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
-    *direct_ms = 1.2e-8 * (double)b->m * (double)b->n * (double)K;
+    *direct_ms = 1.2e-9 * (double)b->m * (double)b->n * (double)K;      // (1.2e-8 until round 5: ten times the sweep's time -- found when bench.py began to print this beside the measurement)
     *coded_share = 1.0;
     *build_ms = 0.0;
     if (!P || P->state <= 0) return false;

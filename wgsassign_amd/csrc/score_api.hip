@@ -232,6 +232,22 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     return 0;
 }
 
+/* Test hook (include/wgsassign_hip_debug.h): the sums of the last wgs_score_sums per CHUNK of 8192 sites (two blocks; the addends of
+ * np.sum's running total, what wgs_score_total_from folds): out[c * cells + i * K + k], ceil(nblocks / 2) x cells float64.  Lets a
+ * test hold a full-size sweep to the oracle at any subset of the chunks: every float64 partial sum inside a chunk is exact. */
+int wgs_debug_score_chunks(wgs_score *sc, double *out, int64_t *nchunks)
+{
+    WGS_REQUIRE(sc && nchunks, "null argument");
+    WGS_REQUIRE(sc->d_chunks, "wgs_debug_score_chunks needs wgs_score_sums first");
+    *nchunks = (sc->nblocks + 1) / 2;
+    if (!out) return 0;
+    wgs_ctx *ctx = sc->b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(out, sc->d_chunks, sizeof(double) * (size_t)*nchunks * sc->cells, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 /* The same sums continued from the SNP shards before this one: out[i*K + k] = (((carry_in + C0) + C1) + ...) over this
  * shard's 8192-site chunk sums C (kept by wgs_score_sums), i.e. np.sum(vec, dtype=float) of glassy.py:38 carried on in
  * NumPy's own order when every shard starts at a multiple of 8192 sites (comm.shard_range sees to that).  carry_in (host,

@@ -637,6 +637,14 @@ class Score:
             carry = np.ascontiguousarray(mine.astype(np.float32))
         return carry
 
+    def chunk_sums(self):
+        """Test hook: the last sums() per chunk of 8192 sites, (chunks, n, K) float64 (wgs_debug_score_chunks)."""
+        nc = ctypes.c_int64()
+        check(_lib.load().wgs_debug_score_chunks(self._h, None, ctypes.byref(nc)))
+        out = np.empty((nc.value, self.n, self.K), dtype=np.float64)
+        check(_lib.load().wgs_debug_score_chunks(self._h, f64p(out), ctypes.byref(nc)))
+        return out
+
     def serial_blocks(self):
         """(blocks redone with the literal serial loop, (chain, block) pairs walked) of the last walk."""
         tot = ctypes.c_int64()
