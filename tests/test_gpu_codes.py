@@ -459,14 +459,22 @@ def test_codes_are_built_only_when_they_can_pay(dev, monkeypatch):
         em.close()
         b.close()
         # quality-dependent likelihoods, 26 classes per slab among 100 individuals: a coded EM sweep saves a fifth of the direct
-        # one and the encoder needs its largest tables -- the fit keeps the float32 slabs (the sample pass said so), the scoring
-        # sweep, which saves four fifths, builds the codes
+        # one and the encoder needs its largest tables -- the fit keeps the float32 slabs (the sample pass said so); ONE scoring
+        # sweep over 4 populations saves less than that encode pass costs (the model's direct-sweep time was ten times too long
+        # until round 5 put its predictions beside bench.py's measurements: it built here), one over 16 populations repays it
         b = dev.DeviceBeagle(m, n, group_of, K)
         b.synth_quality(77, 2.0)
         em = dev.EMBatch(b, np.arange(K, dtype=np.int32))
         em.fit(50, 0.0)
         assert b.codes_state() == 0
         afs = dev.AFSet.from_host(np.full((m, K), 0.3, dtype=np.float32))
+        dev.assign(b, afs)
+        assert b.codes_state() == 0
+        md = b.codes_model(K)
+        assert not md["builds_for_scoring"] and md["score_float32_sweep_ms"] * (1 - md["score_share_of_the_coded_sweep"]) < md["encode_for_scoring_ms"]
+        afs.close()
+        afs = dev.AFSet.from_host(np.full((m, 16), 0.3, dtype=np.float32))
+        assert b.codes_model(16)["builds_for_scoring"]
         dev.assign(b, afs)
         assert b.codes_state() == 1
         afs.close()

@@ -422,6 +422,7 @@ struct CodedScoreArgs {
     const float *const *acol;
     int64_t m, cells;
     int32_t K, nblocks;
+    int32_t table_rows;            // rows of the table in LDS (wgs_codes::rows_batch: the richest aligned batch of SNPs of the matrix)
     int32_t parts;                 // a block's 64 tiles are shared by `parts` workgroups (short matrices: enough workgroups
                                    // to fill the chip); their partial sums go to Sp[part][block][cell] and are added in a
                                    // fixed order by combine_parts_kernel
@@ -430,7 +431,7 @@ struct CodedScoreArgs {
 };
 constexpr int CODED_BATCH_MAX = 16; // SNPs per table: the code words of 16 SNPs of one quad are one 64-byte line; matrices with many
                                     // classes per SNP take 8 or 4 at a time (wgs_codes::score_batch) so that a batch's rows fit the table
-constexpr int CODED_LOG_REP = 4;   // LDS copies of the log table here (phase 1 is a third of the kernel; 8 KiB instead of 32)
+constexpr int CODED_LOG_REP = 2;   // LDS copies of the log table here (its reads are a twentieth of the kernel's LDS traffic: 4 KiB instead of 32)
 
 // Details of the table:
 //   * it holds only the classes a SNP HAS: row of (SNP j of the batch, class c) = rowoff[j] + c, rowoff = running sum of
@@ -447,16 +448,58 @@ struct CodedPrep {
     float aval[CODED_BATCH_MAX][10];   // allele frequencies [SNP of the batch][population of this pass]
 };
 
+// KB consecutive float64 of an LDS row as KB ds_read_b64 (byte address `addr`), and the point behind a wait at which they have arrived
+template <int KB, int X = 0>
+struct CodedRow {
+    static __device__ __forceinline__ void issue(double (&v)[KB], unsigned addr)
+    {
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[X]) : "v"(addr), "n"(8 * X));
+        CodedRow<KB, X + 1>::issue(v, addr);
+    }
+    static __device__ __forceinline__ void arrived(double (&v)[KB])
+    {
+        asm volatile("" : "+v"(v[X]));
+        CodedRow<KB, X + 1>::arrived(v);
+    }
+};
+template <int KB>
+struct CodedRow<KB, KB> {
+    static __device__ __forceinline__ void issue(double (&)[KB], unsigned) {}
+    static __device__ __forceinline__ void arrived(double (&)[KB]) {}
+};
+template <int N>
+__device__ __forceinline__ void lds_wait()
+{
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int CODED_ROWS_MAX = (WGS_BATCH_ROWS_CAP + 255) / 256;     // table rows whose dictionary entries a thread requests per batch
+
+// the SNP of the batch that table row r belongs to: the largest j with rowoff[j] <= r (rowoff is the running sum of the SNPs' classes)
+__device__ __forceinline__ int item_snp(const CodedPrep &P, int r, int batch)
+{
+    int j = 0;
+    for (int step = batch / 2; step >= 1; step >>= 1) j += P.rowoff[j + step] <= r ? step : 0;
+    return j;
+}
+
 template <int KB, int MODE, typename TV, int CODED_BATCH>
 __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
 {
     static_assert(CODED_BATCH == 16 || CODED_BATCH == 8 || CODED_BATCH == 4, "SNPs per table");
-    constexpr int KBP = sizeof(TV) == 8 ? ((KB + 1) & ~1) : ((KB + 3) & ~3);      // table rows padded to 16 bytes
+    // Row stride of the table.  Phase 2 reads rows by class id -- data-dependent addresses -- and the LDS serves a wide read in lane
+    // groups whose lanes must fall on different banks: with 16-byte reads of 80-byte rows (round 4) 16 lanes share 16 bank windows
+    // that the class id selects modulo 16, so a rare class (id >= 16) collides with a frequent one in most groups (SQ_LDS_BANK_CONFLICT
+    // was 36 % of the LDS-array cycles, 23 % once the encoder numbered the classes by first appearance).  Float64 rows are therefore
+    // an ODD number of 8-byte words and read 8 bytes at a time: 32 lanes per group on 32 two-bank windows that the id selects modulo
+    // 32 -- conflict-free up to 32 classes per SNP, the same LDS-array cycles per row.  (Float rows keep 16-byte reads.)
+    constexpr int KBP = sizeof(TV) == 8 ? (KB | 1) : ((KB + 3) & ~3);
     constexpr int KG = (KB + 1) / 2;                                                // populations per phase-1 item
     extern __shared__ __align__(16) unsigned char lds_raw[];
     double2 *tab_lds = reinterpret_cast<double2 *>(lds_raw);
     CodedPrep *prep = reinterpret_cast<CodedPrep *>(lds_raw + sizeof(double2) * WGS_LOG_N * CODED_LOG_REP);
-    TV *vtab = reinterpret_cast<TV *>(reinterpret_cast<unsigned char *>(prep) + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15));
+    float2 *stage = reinterpret_cast<float2 *>(reinterpret_cast<unsigned char *>(prep) + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15));   // [A.table_rows]
+    TV *vtab = reinterpret_cast<TV *>(stage + ((A.table_rows + 1) & ~1));
     if (MODE == WGS_MODE_EXACT) {
         for (int e = threadIdx.x; e < WGS_LOG_N * CODED_LOG_REP; e += blockDim.x) tab_lds[e] = A.logtab[e / CODED_LOG_REP];
     }
@@ -522,6 +565,35 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
         __syncthreads();                                       // the log table (first pass); the previous pass's last phase 2
         if (nbatch > 0) prepare(0);
         __syncthreads();
+        // The dictionary entries of a batch -- one per table row: [(tile * drows + class) * 64 + SNP of the tile] -- are fetched one
+        // batch AHEAD: every batch touches a fresh cache line per class row, so a load issued where phase 1 needs it costs a trip to
+        // HBM (three to four in a row per batch: 53 % of the wave-cycles of round 4's kernel were spent waiting).  They go straight
+        // into LDS (global_load_lds: no registers held across phase 2, whose 80 accumulator registers leave none): wave w moves rows
+        // 64 w + lane, 64 w + lane + 256, ... as two 4-byte transfers into the planes stage_x / stage_y, issued right behind the
+        // barrier that ends phase 1 (the next batch's row offsets are complete then) and drained by the barrier that ends phase 2.
+        typedef __attribute__((address_space(1))) const void *gl_src_t;
+        typedef __attribute__((address_space(3))) void *lds_dst_t;
+        float *const stage_x = reinterpret_cast<float *>(stage), *const stage_y = stage_x + ((A.table_rows + 1) & ~1);
+        auto dma_rows = [&](int b) {
+            const CodedPrep &Pn = prep[b & 1];
+            const int64_t s0n = s_begin + (int64_t)b * CODED_BATCH;
+            const int64_t tn = s0n >> 6;
+            const int l0n = (int)(s0n & 63);
+            const int rows_n = Pn.rowoff[CODED_BATCH];
+            const int wave0 = (int)__builtin_amdgcn_readfirstlane(tid & ~63);
+#pragma unroll
+            for (int x = 0; x < CODED_ROWS_MAX; ++x) {
+                const int r = tid + 256 * x;
+                if (r < rows_n) {
+                    const int j = item_snp(Pn, r, CODED_BATCH);
+                    const float *src = reinterpret_cast<const float *>(A.dict + ((tn * A.drows + (r - Pn.rowoff[j])) * 64 + l0n + j));
+                    __builtin_amdgcn_global_load_lds((gl_src_t)src, (lds_dst_t)(stage_x + wave0 + 256 * x), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gl_src_t)(src + 1), (lds_dst_t)(stage_y + wave0 + 256 * x), 4, 0, 0);
+                }
+            }
+        };
+        if (nbatch > 0) dma_rows(0);
+        __syncthreads();
         for (int b = 0; b < nbatch; ++b) {
             const CodedPrep &P = prep[b & 1];
             const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
@@ -538,15 +610,12 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                 for (int x = 0; x < CODED_BATCH / 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
             }
             if (b + 1 < nbatch) prepare(b + 1);
-            // phase 1: vtab[rowoff[j] + c][k]
+            // phase 1: vtab[rowoff[j] + c][k] from the staged dictionary entries
             const int items = 2 * P.rowoff[CODED_BATCH];
             for (int it = tid; it < items; it += 256) {
                 const int r = it >> 1, half = it & 1;
-                int j = 0;
-#pragma unroll
-                for (int step = CODED_BATCH / 2; step >= 1; step >>= 1) j += P.rowoff[j + step] <= r ? step : 0;
-                const int c = r - P.rowoff[j];
-                const float2 gl = A.dict[(t * A.drows + c) * 64 + l0 + j];
+                const int j = item_snp(P, r, CODED_BATCH);
+                const float2 gl = make_float2(stage_x[r], stage_y[r]);
                 const double g0d = (double)gl.x, g1d = (double)gl.y;
                 const double g1x2 = g1d * 2.0, g2d = (1.0 - g0d) - g1d;
                 const float g2f = (1.0f - gl.x) - gl.y;
@@ -559,8 +628,10 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                         if (MODE == WGS_MODE_EXACT) {
                             const double ad = (double)a;
                             const float ssum = like_sum_exact(g0d, g1x2, g2d, ad, 1.0 - ad);
-                            const float plain = (float)log_f32arg<CODED_LOG_REP>((double)ssum, tab);
-                            v = __builtin_isfpclass(ssum, FP_POS_FINITE) ? plain : __builtin_amdgcn_logf(ssum);
+                            v = (float)log_f32arg<CODED_LOG_REP>((double)ssum, tab);
+                            // a likelihood of exactly 0, NaN data: libm's special value (v_log_f32 returns exactly -inf / NaN there); a
+                            // branch no lane of the wavefront takes on ordinary data, instead of a quarter-rate log and a select per element
+                            if (__builtin_expect(!__builtin_isfpclass(ssum, FP_POS_FINITE), 0)) v = __builtin_amdgcn_logf(ssum);
                         } else {
                             v = site_ll_fast(gl.x, gl.y, g2f, a);
                         }
@@ -569,35 +640,67 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                 }
             }
             __syncthreads();
+            // (the staged entries of this batch have been consumed; the code words, requested before phase 1, are here -- said explicitly,
+            // because with a transfer to LDS in flight the compiler waits for ALL outstanding loads at the next use of a loaded value)
+#pragma unroll
+            for (int x = 0; x < CODED_BATCH / 4; ++x) asm volatile("" : "+v"(cw[x].x), "+v"(cw[x].y), "+v"(cw[x].z), "+v"(cw[x].w));
+            if (b + 1 < nbatch) dma_rows(b + 1);
             // phase 2: look up and add
             const unsigned *cwv = reinterpret_cast<const unsigned *>(cw);
             const unsigned uncoded_snps = (unsigned)__builtin_amdgcn_readfirstlane(P.rowoff[17]);
+            if (sizeof(TV) == 8) {
+                // float64 rows: KB reads of 8 bytes per (SNP, individual), written as ds_read_b64 by hand -- the compiler pairs adjacent
+                // 8-byte LDS loads into ds_read2_b64, which the LDS serves at half the rate and with the 32-bank mapping -- and pipelined by
+                // hand: the reads of the next individual are in flight while the current one's values are added (counted lgkmcnt waits;
+                // LDS operations complete in order, and anything else that counts on lgkmcnt only makes a counted wait wait longer)
+                const unsigned vtab_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)reinterpret_cast<unsigned char *>(vtab);
 #pragma unroll
-            for (int j = 0; j < CODED_BATCH; ++j) {
-                if (j < nj && !((uncoded_snps >> j) & 1u)) {
-                    const unsigned w = cwv[j];
-                    const TV *rows_j = vtab + P.rowoff[j] * KBP;
+                for (int j = 0; j < CODED_BATCH; ++j) {
+                    if (j < nj && !((uncoded_snps >> j) & 1u)) {
+                        const unsigned w = cwv[j];
+                        const unsigned base_j = vtab_addr + (unsigned)P.rowoff[j] * (unsigned)(KBP * 8);
+                        double va[KB], vb[KB];
+                        CodedRow<KB>::issue(va, base_j + ((w >> 0) & 255u) * (unsigned)(KBP * 8));
+                        CodedRow<KB>::issue(vb, base_j + ((w >> 8) & 255u) * (unsigned)(KBP * 8));
+                        lds_wait<KB>();
+                        CodedRow<KB>::arrived(va);
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const int code = (w >> (8 * h)) & 255;
-                        TV vals[KBP];
-                        if (sizeof(TV) == 8) {
-                            const double2 *row = reinterpret_cast<const double2 *>(rows_j + code * KBP);
+                        for (int k = 0; k < KB; ++k) acc[0][k] += va[k];
+                        CodedRow<KB>::issue(va, base_j + ((w >> 16) & 255u) * (unsigned)(KBP * 8));
+                        lds_wait<KB>();
+                        CodedRow<KB>::arrived(vb);
 #pragma unroll
-                            for (int x = 0; x < KBP / 2; ++x) {
-                                const double2 f = row[x];
-                                vals[2 * x] = (TV)f.x, vals[2 * x + 1] = (TV)f.y;
-                            }
-                        } else {
+                        for (int k = 0; k < KB; ++k) acc[1][k] += vb[k];
+                        CodedRow<KB>::issue(vb, base_j + ((w >> 24) & 255u) * (unsigned)(KBP * 8));
+                        lds_wait<KB>();
+                        CodedRow<KB>::arrived(va);
+#pragma unroll
+                        for (int k = 0; k < KB; ++k) acc[2][k] += va[k];
+                        lds_wait<0>();
+                        CodedRow<KB>::arrived(vb);
+#pragma unroll
+                        for (int k = 0; k < KB; ++k) acc[3][k] += vb[k];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CODED_BATCH; ++j) {
+                    if (j < nj && !((uncoded_snps >> j) & 1u)) {
+                        const unsigned w = cwv[j];
+                        const TV *rows_j = vtab + P.rowoff[j] * KBP;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const int code = (w >> (8 * h)) & 255;
+                            TV vals[KBP];
                             const float4 *row = reinterpret_cast<const float4 *>(rows_j + code * KBP);
 #pragma unroll
                             for (int x = 0; x < KBP / 4; ++x) {
                                 const float4 f = row[x];
                                 vals[4 * x] = (TV)f.x, vals[4 * x + 1] = (TV)f.y, vals[4 * x + 2] = (TV)f.z, vals[4 * x + 3] = (TV)f.w;
                             }
-                        }
 #pragma unroll
-                        for (int k = 0; k < KB; ++k) acc[h][k] += (double)vals[k];
+                            for (int k = 0; k < KB; ++k) acc[h][k] += (double)vals[k];
+                        }
                     }
                 }
             }
@@ -636,7 +739,7 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                     }
                 }
             }
-            __syncthreads();
+            __syncthreads();                                   // (also drains the transfers into the stage: vmcnt(0))
         }
 #pragma unroll
         for (int h = 0; h < 4; ++h)
@@ -1213,8 +1316,9 @@ static bool score_coded_wide(int kb)
 }
 size_t score_coded_lds_bytes(int rows, int kb, int batch)
 {
-    const size_t row = (batch < 16 || score_coded_wide(kb)) ? sizeof(double) * ((kb + 1) & ~1) : sizeof(float) * ((kb + 3) & ~3);
-    return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15) + row * (size_t)rows;
+    const size_t row = (batch < 16 || score_coded_wide(kb)) ? sizeof(double) * (kb | 1) : sizeof(float) * ((kb + 3) & ~3);
+    return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15) + sizeof(float2) * (size_t)((rows + 1) & ~1) +
+           row * (size_t)rows;
 }
 
 // The scoring sweep through the class codes (shared columns only).  d_slabs: n_slabs CodedSlab records in device memory.
@@ -1236,6 +1340,7 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     A.K = K;
     A.nblocks = nblocks;
     A.S = S;
+    A.table_rows = c->rows_batch;
     void *sym = nullptr;
     HIP_TRY(hipGetSymbolAddress(&sym, HIP_SYMBOL(wgs_log_table_dev)));
     A.logtab = reinterpret_cast<const double2 *>(sym);
@@ -1245,8 +1350,29 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     const size_t lds = score_coded_lds_bytes(c->rows_batch, kb, batch);
     WGS_REQUIRE(lds <= 64 * 1024, "class table too large for LDS");
     const unsigned ygroups = (unsigned)((total_quads + 255) / 256);
+    // A block's 64 tiles go to `parts` workgroups: enough of them to fill the chip (short matrices), and -- the workgroups all take
+    // the same time -- a count that does not leave the last round of workgroups mostly empty: 2442 blocks on 768 places (3 per CU by
+    // registers, fewer when the table is large) are 3.18 rounds, i.e. a fifth of the chip-time idle; in halves 6.36 of 7, in quarters
+    // 12.7 of 13.  The smallest split within 4 % of full rounds (or the best there is) is taken.
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / std::max<size_t>(lds, 1)));
+    const double places = (double)std::max(1, ctx->cus) * per_cu;
     int parts = 1;
     while (parts < 16 && (int64_t)nblocks * ygroups * parts < 1536) parts *= 2;   // >= 6 workgroups per CU, or 4 tiles per part
+    {
+        int best = parts;
+        double best_eff = 0.0;
+        for (int p = parts; p <= 16; p *= 2) {
+            const double rounds = (double)nblocks * ygroups * p / places;
+            const double eff = rounds / ceil(rounds);
+            if (eff > best_eff + 1e-9) best = p, best_eff = eff;
+            if (eff >= 0.96) break;
+        }
+        parts = best;
+    }
+    if (const char *pe = getenv("WGS_SCORE_CODED_PARTS")) {        // experiments: 1, 2, 4, 8, 16
+        const int v = atoi(pe);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) parts = v;
+    }
     A.parts = parts;
     const int64_t total = (int64_t)nblocks * cells;
     if (parts > 1) {

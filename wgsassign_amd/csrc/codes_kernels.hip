@@ -15,14 +15,16 @@
 //                (low-depth data with fixed error has ~27 classes per SNP among 1000 individuals, likelihoods from binned base
 //                qualities 70-100).  The 64 / SNPS lanes of a SNP share its table (real atomics) and take alternate quads.
 //   walk         per slab: the lane's quads, two 16-byte loads each (the slab's native layout, lane <-> SNP), 4 lookups per
-//                quad, the four SLOT numbers written as the quad's code word, a byte per (slot, SNP) in LDS marked "seen in
-//                this slab".
-//   slab end     the seen slots of each SNP are ranked in slot order (16 slots per lane, prefix over the lanes of the SNP):
-//                that rank is the slab's OWN class number; the slab's dictionary rows are written coalesced (ldict), its
-//                code words re-read (they were written moments ago) and written as local ranks (lcodes), the most local
-//                classes of the tile's SNPs goes to tile_rows (what the coded EM sweep sizes its table by).
-//   end          the occupied slots are ranked the same way: dictionary rows (dict), ncls, and every slab's code words
-//                rewritten in place from slot numbers to class ids.
+//                quad.  A lookup that finds its slot EMPTY has met a NEW class: classes are numbered in the order they appear
+//                (round 5; a byte per slot holds the number, a byte per number the slot), so the quad's code word -- four class
+//                ids -- is final when it is written, frequent classes have low numbers, and a bit per class in registers
+//                remembers what the lane met in this slab.
+//   slab end     the slab's OWN class number = the rank of a class among the classes met in the slab (a popcount of the bits
+//                below it); the slab's dictionary rows are written coalesced (ldict), its code words re-read (they were
+//                written moments ago) and written as local ranks (lcodes), the most local classes of the tile's SNPs goes to
+//                tile_rows (what the coded EM sweep sizes its table by).
+//   end          dictionary rows (dict) in class order, ncls.  (Round 4 numbered the classes by hash slot after the walk and
+//                rewrote every slab's code words: a sixth of the pass's traffic and instructions.)
 // A SNP whose table overflows (more than RMAX probes, i.e. too many classes for T), with more classes than the dictionary
 // has rows, or holding the one bit pattern used as EMPTY is RICH: ncls = 0 and tile_rows = 255 tell the sweeps to take that
 // SNP (scoring) / that tile of that slab (EM) from the float32 slab.  Nothing about a rich SNP affects the others.
@@ -84,12 +86,12 @@ enum EncStat {
 template <int SNPS, bool SAMPLE>
 __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_kernel(EncodeArgs A)
 {
-    constexpr int COLS = 64 / SNPS, T = ENC_SLOTS / SNPS, SCAN = ENC_SLOTS / 64;    // SCAN slots per lane when a table is ranked
+    constexpr int COLS = 64 / SNPS, T = ENC_SLOTS / SNPS, NW = T / 64;              // NW 64-bit words hold a bit per class of a SNP
     constexpr unsigned TMASK = T - 1, HSHIFT = T == 64 ? 26 : (T == 128 ? 25 : 24);
     constexpr int NL = 4 * ENC_UQ;                         // lookups per lane and buffer
     __shared__ unsigned long long keys[ENC_SLOTS];         // [slot * SNPS + s]
-    __shared__ __align__(16) uint8_t flag[ENC_SLOTS];      // [slot * SNPS + s]: seen in the current slab; then the slot's rank
-    __shared__ __align__(16) uint8_t order[ENC_SLOTS];     // [rank * SNPS + s]: the slot of the rank-th class
+    __shared__ __align__(16) uint8_t gid_of[ENC_SLOTS];    // [slot * SNPS + s]: the class id of the key in that slot
+    __shared__ __align__(16) uint8_t slot_of[ENC_SLOTS];   // [class id * SNPS + s]: the slot of that class
     const int lane = threadIdx.x;
     const int s = lane & (SNPS - 1), col = lane / SNPS;
     const int64_t unit = (int64_t)blockIdx.x * A.unit_stride;
@@ -99,18 +101,13 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
     const int ls = sub * SNPS + s;                         // this lane's SNP within the tile
     const int64_t snp = tile * 64 + ls;
 
-    auto clear_flags = [&]() {
-#pragma unroll
-        for (int i = 0; i < ENC_SLOTS / 1024; ++i) reinterpret_cast<uint4 *>(flag)[i * 64 + lane] = make_uint4(0, 0, 0, 0);
-        static_assert(ENC_SLOTS % 1024 == 0, "the marks are cleared sixteen bytes per lane at a time");
-    };
 #pragma unroll
     for (int i = 0; i < ENC_SLOTS / 64; ++i) keys[i * 64 + lane] = KEY_EMPTY;
-    clear_flags();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
     bool rich = false;                                     // this lane gave up on its SNP (combined over the SNP's lanes at slab ends)
     unsigned n_rounds = 0, n_buffers = 0;
+    int nid = 0;                                           // classes of this lane's SNP so far: the same number in all lanes of the SNP
 
     // lanes of one SNP: col = 0 .. COLS-1 at lane distance SNPS
     auto snp_or = [&](bool v) {
@@ -118,6 +115,15 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
 #pragma unroll
         for (int d = SNPS; d < 64; d <<= 1) x |= __shfl_xor(x, d, 64);
         return x != 0;
+    };
+    auto snp_or64 = [&](unsigned long long v) {
+        unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+#pragma unroll
+        for (int d = SNPS; d < 64; d <<= 1) {
+            lo |= (unsigned)__shfl_xor((int)lo, d, 64);
+            hi |= (unsigned)__shfl_xor((int)hi, d, 64);
+        }
+        return ((unsigned long long)hi << 32) | lo;
     };
     // (exclusive prefix over the SNP's lanes in col order, total)
     auto snp_scan = [&](int cnt, int &pre, int &tot) {
@@ -135,10 +141,42 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
         for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
         return v;
     };
-    // one probe of lookup `key` at `slot`: true when it ended there (inserted or found)
-    auto probe = [&](unsigned slot, unsigned long long key) {
-        const unsigned long long old = atomicCAS(&keys[slot * SNPS + s], KEY_EMPTY, key);
-        return old;
+    // one probe of lookup `key` at `slot`: what the slot held (EMPTY: the key went in; the key: found; another key: go on)
+    auto probe = [&](unsigned slot, unsigned long long key) { return atomicCAS(&keys[slot * SNPS + s], KEY_EMPTY, key); };
+    // a bit per class id in NW words
+    auto set_bit = [&](unsigned long long (&m)[NW], unsigned id) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            if (NW == 1 || (id >> 6) == (unsigned)w) m[w] |= 1ull << (id & 63u);
+    };
+    auto bits_below = [&](const unsigned long long (&m)[NW], unsigned id) {      // set bits at positions < id: the class's rank among the set
+        int r = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const unsigned long long below = (id >> 6) > (unsigned)w ? ~0ull : ((id >> 6) == (unsigned)w ? (1ull << (id & 63u)) - 1ull : 0ull);
+            r += __popcll(m[w] & below);
+        }
+        return r;
+    };
+    auto count_bits = [&](const unsigned long long (&m)[NW]) {
+        int r = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) r += __popcll(m[w]);
+        return r;
+    };
+    // walks the set bits of m in ascending order: lowest set bit (position), then cleared
+    auto pop_lowest = [&](unsigned long long (&m)[NW]) {
+        int pos = 0;
+        bool done = false;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            if (!done && m[w]) {
+                pos = 64 * w + __builtin_ctzll(m[w]);
+                m[w] &= m[w] - 1ull;
+                done = true;
+            }
+        }
+        return pos;
     };
 
     for (int g = 0; g < A.n_slabs; ++g) {
@@ -148,6 +186,9 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
         if (nquads == 0) continue;
         gf4_ptr src = (gf4_ptr)A.base[g] + tile * np * 64 + ls;
         gu32_ptr cw = (gu32_ptr)sc.codes + tile * nquads * 64 + ls;
+        unsigned long long seen[NW];                       // classes this lane met in this slab
+#pragma unroll
+        for (int w = 0; w < NW; ++w) seen[w] = 0ull;
         // ---- the walk: this lane's quads col, col + COLS, ...; the loads of the next buffer are in flight while this one is hashed
         // (two buffers ahead: the walk is bound by memory latency -- a wavefront has few loads in flight -- and that latency varies
         // with how the driver could place the matrix; 16 KiB in flight per wavefront while 8 KiB are being hashed)
@@ -185,7 +226,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
                     slot[4 * u + h] = hash32(g0, g1) >> HSHIFT;
                 }
             }
-            bool pend[NL];                                 // lane masks in scalar registers
+            bool pend[NL], live[NL];                       // lane masks in scalar registers
             // a buffer whose 4 x ENC_UQ x COLS individuals all exist, in a wavefront without a rich SNP: no per-lookup predicates
             const bool plain = 4 * (qb + COLS * ENC_UQ) <= nc && !__any(rich);
             if (plain) {
@@ -193,6 +234,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
                 for (int i = 0; i < NL; ++i) old[i] = probe(slot[i], key[i]);
 #pragma unroll
                 for (int i = 0; i < NL; ++i) {
+                    live[i] = true;
                     pend[i] = old[i] != KEY_EMPTY && old[i] != key[i];
                 }
             } else {
@@ -202,14 +244,13 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
 #pragma unroll
                     for (int h = 0; h < 4; ++h) {
                         const int i = 4 * u + h;
-                        const bool live = 4 * q + h < nc && !rich;
+                        live[i] = 4 * q + h < nc && !rich;
                         old[i] = key[i];
-                        if (live) old[i] = probe(slot[i], key[i]);
-                        pend[i] = live;
+                        if (live[i]) old[i] = probe(slot[i], key[i]);
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < NL; ++i) pend[i] = pend[i] && !rich && old[i] != KEY_EMPTY && old[i] != key[i];
+                for (int i = 0; i < NL; ++i) pend[i] = live[i] && old[i] != KEY_EMPTY && old[i] != key[i];
             }
             bool any_pend = false;
 #pragma unroll
@@ -238,38 +279,55 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
             }
             n_rounds += (unsigned)rounds;
             ++n_buffers;
-            // seen marks and code words (slot numbers for now); a rich SNP's are never read
-            if (plain) {
+            // A lookup that found its slot EMPTY put a NEW class there: classes are numbered in the order they appear -- per SNP the
+            // lanes of the SNP number this buffer's newcomers after the nid classes known so far (column order, then lookup order;
+            // nid stays the same number in all lanes of a SNP).  New classes are rare once the first few buffers of the first slab
+            // are through: the whole step is skipped as a wave.  Frequent classes come early, i.e. get low numbers -- the numbers
+            // are what the sweeps index their tables by, and nothing has to be renumbered at the end (round 4 numbered the classes
+            // by hash slot after the walk and rewrote every code word: 20 GB of the pass's 150).
+            int ins = 0;
 #pragma unroll
-                for (int i = 0; i < NL; ++i) flag[slot[i] * SNPS + s] = 1;
-            } else {
+            for (int i = 0; i < NL; ++i) ins += (live[i] && !pend[i] && old[i] == KEY_EMPTY) ? 1 : 0;
+            if (__any(ins != 0)) {
+                int pre, tot;
+                snp_scan(ins, pre, tot);
+                int id = nid + pre;
 #pragma unroll
-                for (int u = 0; u < ENC_UQ; ++u)
-#pragma unroll
-                    for (int h = 0; h < 4; ++h)
-                        if (4 * (qb + u * COLS + col) + h < nc) flag[slot[4 * u + h] * SNPS + s] = 1;
+                for (int i = 0; i < NL; ++i) {
+                    if (live[i] && !pend[i] && old[i] == KEY_EMPTY) {
+                        gid_of[slot[i] * SNPS + s] = (uint8_t)min(id, 255);
+                        if (id < T) slot_of[id * SNPS + s] = (uint8_t)slot[i];
+                        ++id;
+                    }
+                }
+                nid += tot;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
+            // the lookups' class ids: the code words, and the classes met in this slab (a rich SNP's are never read)
+            unsigned cid[NL];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) cid[i] = gid_of[slot[i] * SNPS + s];
+            if (!plain) {                                  // (individuals beyond the slab's last, lookups given up: class 0 in the code word)
+#pragma unroll
+                for (int i = 0; i < NL; ++i) cid[i] = (live[i] && !pend[i]) ? cid[i] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < NL; ++i)
+                if (plain || (live[i] && !pend[i])) set_bit(seen, cid[i] < (unsigned)T ? cid[i] : 0u);
             if (!SAMPLE) {
 #pragma unroll
                 for (int u = 0; u < ENC_UQ; ++u) {
                     const int q = qb + u * COLS + col;
-                    if (plain || q < nquads) cw[(int64_t)q * 64] = slot[4 * u] | (slot[4 * u + 1] << 8) | (slot[4 * u + 2] << 16) | (slot[4 * u + 3] << 24);
+                    if (plain || q < nquads) cw[(int64_t)q * 64] = cid[4 * u] | (cid[4 * u + 1] << 8) | (cid[4 * u + 2] << 16) | (cid[4 * u + 3] << 24);
                 }
             }
         }
-        // ---- slab end: the slab's own numbering
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int cnt = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN; ++k) {
-            const int f = flag[(col * SCAN + k) * SNPS + s];
-            cnt += f;
-            // a slot marked seen that holds no key: the one bit pattern used as EMPTY was looked up -- that SNP cannot be coded
-            if (f && keys[(col * SCAN + k) * SNPS + s] == KEY_EMPTY) rich = true;
-        }
+        // ---- slab end: the slab's own numbering = the rank of a class among the classes met in this slab
+        if (nid > T || nid > 254) rich = true;
         rich = snp_or(rich);
-        int pre, nloc;
-        snp_scan(cnt, pre, nloc);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) seen[w] = snp_or64(seen[w]);
+        const int nloc = count_bits(seen);
         if (SAMPLE) {
             if (col == 0) A.sample[((int64_t)blockIdx.x * (A.n_slabs + 1) + g) * SNPS + s] = (uint8_t)(snp < A.m ? (rich ? 255 : min(nloc, 254)) : 0);
         } else {
@@ -277,24 +335,22 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
             // one byte per group of WGS_ENC_MIN_SNPS SNPs of the tile (this wave's share of them): plain stores, the EM sweep takes the largest
             if (lane < SNPS / WGS_ENC_MIN_SNPS) ((gu8_ptr)sc.tile_rows)[tile * WGS_TILE_ROWS_BYTES + sub * (SNPS / WGS_ENC_MIN_SNPS) + lane] = (uint8_t)wmax;
             if (A.lrows > 0 && wmax <= A.lrows) {          // wave-uniform: this wave's SNPs fit the EM sweep's table
-                int r = pre;
-#pragma unroll 8
-                for (int k = 0; k < SCAN; ++k) {
-                    const int sl = col * SCAN + k;
-                    if (flag[sl * SNPS + s]) {
-                        flag[sl * SNPS + s] = (uint8_t)r;
-                        order[r * SNPS + s] = (uint8_t)sl;
-                        ++r;
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 // dictionary rows: as many as the richest of this wave's SNPs has (the EM sweep requests rows eight at a time and never
-                // looks at a row beyond a SNP's own classes: what it finds in the unwritten ones does not matter)
+                // looks at a row beyond a SNP's own classes: what it finds in the unwritten ones does not matter); this lane writes
+                // ranks col, col + COLS, ... of its SNP
                 const int rows_w = wmax;
                 gu64_ptr ld = (gu64_ptr)sc.ldict + (tile * A.lrows) * 64 + ls;
+                unsigned long long walk[NW];
+#pragma unroll
+                for (int w = 0; w < NW; ++w) walk[w] = seen[w];
+                for (int c = 0; c < col; ++c) (void)pop_lowest(walk);
                 for (int r0 = col; r0 < rows_w; r0 += COLS) {
                     unsigned long long e = 0;
-                    if (r0 < nloc) e = keys[(unsigned)order[r0 * SNPS + s] * SNPS + s];
+                    if (r0 < nloc) {
+                        const int id = pop_lowest(walk);
+                        e = keys[(unsigned)slot_of[id * SNPS + s] * SNPS + s];
+                        for (int c = 1; c < COLS; ++c) (void)pop_lowest(walk);
+                    }
                     ld[(int64_t)r0 * 64] = e;
                 }
                 // the code words again, as local ranks
@@ -309,27 +365,22 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
                         if (q0 + u * COLS < nquads) {
                             uint32_t o = 0;
 #pragma unroll
-                            for (int h = 0; h < 4; ++h) o |= (uint32_t)flag[((w[u] >> (8 * h)) & 255u) * SNPS + s] << (8 * h);
+                            for (int h = 0; h < 4; ++h) o |= (uint32_t)(bits_below(seen, (w[u] >> (8 * h)) & 255u) & 255) << (8 * h);
                             lw[(int64_t)(q0 + u * COLS) * 64] = o;
                         }
                     }
                 }
             }
         }
-        // the marks of this slab are done with
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        clear_flags();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     }
 
-    // ---- end: the SNP's classes = the occupied slots, ranked in slot order
+    // ---- end: the SNP's classes are numbered already; its dictionary rows, in that order
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    int cnt = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN; ++k) cnt += keys[(col * SCAN + k) * SNPS + s] != KEY_EMPTY ? 1 : 0;
-    int pre, ncls;
-    snp_scan(cnt, pre, ncls);
-    if (ncls > A.drows || ncls > 254) rich = true;
+    const int ncls = nid;
+    if (ncls > A.drows || ncls > 254 || ncls > T) rich = true;
+    // the one bit pattern used as EMPTY, looked up: it "went in" without changing its slot -- that SNP cannot be coded
+    for (int r0 = col; r0 < min(ncls, T); r0 += COLS)
+        if (keys[(unsigned)slot_of[r0 * SNPS + s] * SNPS + s] == KEY_EMPTY) rich = true;
     rich = snp_or(rich);
     if (SAMPLE) {
         if (col == 0) A.sample[((int64_t)blockIdx.x * (A.n_slabs + 1) + A.n_slabs) * SNPS + s] = (uint8_t)(snp < A.m ? (rich ? 255 : min(ncls, 254)) : 0);
@@ -376,42 +427,10 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
             rec[1] = u4{n_rounds, n_buffers, 0u, 0u};
         }
     }
-    int r = pre;
-#pragma unroll 8
-    for (int k = 0; k < SCAN; ++k) {
-        const int sl = col * SCAN + k;
-        if (keys[sl * SNPS + s] != KEY_EMPTY) {
-            flag[sl * SNPS + s] = (uint8_t)min(r, 255);
-            order[min(r, 255) * SNPS + s] = (uint8_t)sl;
-            ++r;
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int wmax = min(wave_max(eff), A.drows);
     gu64_ptr dd = (gu64_ptr)A.dict + (tile * A.drows) * 64 + ls;
     for (int r0 = col; r0 < wmax; r0 += COLS)
-        if (r0 < eff) dd[(int64_t)r0 * 64] = keys[(unsigned)order[r0 * SNPS + s] * SNPS + s];
-    // every slab's code words: slot numbers -> class ids, in place
-    for (int g = 0; g < A.n_slabs; ++g) {
-        const SlabCodes sc = A.slabs[g];
-        const int nquads = sc.nquads;
-        gu32_ptr cw = (gu32_ptr)sc.codes + tile * nquads * 64 + ls;
-        constexpr int PF = 8;
-        for (int q0 = col; q0 < nquads; q0 += COLS * PF) {
-            uint32_t w[PF];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) w[u] = cw[(int64_t)min(q0 + u * COLS, nquads - 1) * 64];
-#pragma unroll
-            for (int u = 0; u < PF; ++u) {
-                if (q0 + u * COLS < nquads) {
-                    uint32_t o = 0;
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) o |= (uint32_t)flag[((w[u] >> (8 * h)) & 255u) * SNPS + s] << (8 * h);
-                    cw[(int64_t)(q0 + u * COLS) * 64] = o;
-                }
-            }
-        }
-    }
+        if (r0 < eff) dd[(int64_t)r0 * 64] = keys[(unsigned)slot_of[r0 * SNPS + s] * SNPS + s];
 }
 
 // After the sample pass: hist[c] = sampled SNPs with c classes, hist[256 + c] = sampled (slab, SNP) pairs with c classes in the slab

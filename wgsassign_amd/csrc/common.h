@@ -144,7 +144,7 @@ static inline int64_t wgs_ntiles(int64_t m) { return (m + 63) / 64; }
 #endif
 constexpr int WGS_ENC_MIN_SNPS = WGS_ENC_SLOTS / 256;      // SNPs per wavefront with the largest tables (256 slots per SNP)
 constexpr int WGS_TILE_ROWS_BYTES = 64 / WGS_ENC_MIN_SNPS;  // tile_rows entries per tile: one per WGS_ENC_MIN_SNPS SNPs
-constexpr int WGS_BATCH_ROWS_CAP = 672;  // classes the SNPs of one batch of the coded scoring sweep may sum to: 672 rows of 80 bytes + the log table fit 64 KiB of LDS
+constexpr int WGS_BATCH_ROWS_CAP = 616;  // classes the SNPs of one batch of the coded scoring sweep may sum to: 616 rows of 80 bytes + their 8-byte dictionary entries + the log table fit 64 KiB of LDS
 struct SlabCodes {
     uint32_t *codes = nullptr;
     uint32_t *lcodes = nullptr;
