@@ -992,6 +992,38 @@ def realistic_gl(ctx, device, fit, pop_like, m=2_000_000, n=1000, K=10):
            "hash_slots_per_snp": info.get("hash_slots"), "snps_per_scoring_table": info.get("score_batch_snps"),
            "uncoded_snp_share": info.get("rich_snp_share"), "em_table_rows": info.get("em_table_rows"), "em_direct_tile_share": info.get("em_direct_tile_share")}
     b.close()
+    # A class-RICH matrix (every read's quality drawn uniformly from eight values between Q20 and Q40: hundreds of classes per SNP among 1000 individuals): the
+    # sample pass turns the class codes away and --get_pop_like runs over the float32 slabs.  Both arithmetic modes, and the rule that
+    # chooses between them: EXACT unless the user sets WGSASSIGN_MODE=fast.  The float32 mode is inside north_star's 1e-6 on every matrix
+    # measured (deviation below), but "inside 1e-6" is a measurement, not a bound the library can prove for the matrix at hand -- a sum of
+    # m float32-rounded terms has no a-priori bound tighter than m x 2^-24 -- and bit-identity with the reference is what every parity
+    # test of this build pins.  So the default pays the 3x and says so (README); the switch is one environment variable.
+    from wgsassign_amd._lib import MODE_EXACT, MODE_FAST
+    b = device.DeviceBeagle(m, n, group_of, K, ctx=ctx)
+    b.synth_quality(SEED, 2.0, quals=(20, 23, 26, 29, 32, 35, 38, 40), probs=tuple([0.125] * 8))
+    ctx.sync()
+    A = np.random.default_rng(5).uniform(0.02, 0.98, size=(m, K)).astype(np.float32)
+    afs = device.AFSet.from_host(A, ctx=ctx)
+    device.assign(b, afs)                        # (sample pass, code objects)
+    t0 = time.perf_counter()
+    oe, _ = device.assign(b, afs, mode=MODE_EXACT)
+    te, ke, state = time.perf_counter() - t0, device.assign.last_ms, b.codes_state()
+    device.assign(b, afs, mode=MODE_FAST)
+    t0 = time.perf_counter()
+    of, _ = device.assign(b, afs, mode=MODE_FAST)
+    tf, kf = time.perf_counter() - t0, device.assign.last_ms
+    md = b.codes_model(K)
+    res["class_rich_uniform_Q20_40"] = {"classes_per_snp_in_the_sample": round(md["sample_classes_per_snp"], 1), "codes_state": state,
+                                        "get_pop_like_exact": {"seconds": round(te, 4), "kernel_ms": round(ke, 3),
+                                                               "kernel": "score_coded_kernel<exact>" if state == 1 else "score_sweep_kernel<exact>"},
+                                        "get_pop_like_float32_mode": {"seconds": round(tf, 4), "kernel_ms": round(kf, 3), "kernel": "score_sweep_kernel<fast>",
+                                                                      "max_rel_dev_of_sums_vs_exact": float(np.max(np.abs(of - oe) / np.abs(oe)))},
+                                        "price_of_exact": round(ke / kf, 2) if kf > 0 else None,
+                                        "rule": "exact (bit-identical per-site values) unless WGSASSIGN_MODE=fast; the library does not switch by itself: "
+                                                "the float32 mode's deviation is measured per matrix, not bounded a priori",
+                                        "chosen": "exact"}
+    afs.close()
+    b.close()
     return res
 
 
