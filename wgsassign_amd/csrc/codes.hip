@@ -213,7 +213,7 @@ const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b)
         int groups = 0;
         for (int g = 0; g < b->n_groups; ++g) groups += b->slabs[g].ncols > 0;
         const double cols = (double)b->n / std::max(1, groups);
-        const double saves = std::max(0.0, std::min(0.6, 0.92 - 2.72 * P.mean_l / std::max(1.0, cols)));
+        const double saves = std::max(0.0, std::min(0.6, 1.0 - 2.2 * P.mean_l / std::max(1.0, cols)));      // (= em_api.hip: em_codes_model)
         if (!getenv("WGSASSIGN_EM_TABLE_ROWS") && !getenv("WGSASSIGN_EM_CODES_SWEEPS") &&
             14.0 * saves * ((double)b->bytes / 6.0e9) <= wgs_codes_build_ms_estimate(b, P.slots))
             P.lrows = 0;
@@ -233,8 +233,7 @@ double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots, bool with_sla
 }
 
 // Whether a scoring sweep with shared columns over K populations should build the codes: the direct sweep costs ~1.2e-12 s per
-// (SNP, individual, population) (119 ms at 10M x 1000 x 10, on the FP64 issue roof), the coded one the share of it that is
-// table work (classes / individuals) + ~9 % for the look-ups (16.6 ms there; 6.5 of 25.7 ms with 73 classes among 1000).
+// (SNP, individual, population) (119 ms at 10M x 1000 x 10, on the FP64 issue roof); the coded one: wgs_codes_scoring_model.
 bool wgs_codes_scoring_model(wgs_beagle *b, int K, double *direct_ms, double *coded_share, double *build_ms)
 {
     const wgs_codes_plan *P = wgs_beagle_codes_plan(b);
@@ -242,7 +241,14 @@ bool wgs_codes_scoring_model(wgs_beagle *b, int K, double *direct_ms, double *co
     *coded_share = 1.0;
     *build_ms = 0.0;
     if (!P || P->state <= 0) return false;
-    *coded_share = std::min(1.0, 1.25 * P->mean_g / (double)std::max<int64_t>(1, b->n) + 0.09);
+    // the coded sweep: per SNP and population the table work (one evaluation per class, 3.35e-9 ms) and the look-ups of one workgroup's
+    // 1024 individuals, whether they exist or not (4.2e-8 ms) -- a workgroup per 1024 individuals, each filling its own table.  Fitted
+    // to 10M x 1000 x 10 (26 classes: 13.0 ms), 2M x 1000 x 10 with 73 classes (5.7 ms); 2M x 500 x 8 (2.4 ms), 6.25M x 2000 x 20
+    // (39.7 ms) and 5M x 180 x 5 (where building for ONE sweep loses a millisecond: round 4's share, 1.25 x classes / individuals +
+    // 0.09, built there) check it to 10-20 %.
+    const double groups = (double)((b->n + 1023) / 1024);
+    const double coded_ms = (double)b->m * (double)K * groups * (3.35e-9 * P->mean_g + 4.2e-8);
+    *coded_share = std::min(1.0, coded_ms / std::max(1e-9, *direct_ms));
     *build_ms = wgs_codes_build_ms_estimate(b, P->slots, false);
     return true;
 }

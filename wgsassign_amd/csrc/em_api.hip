@@ -125,8 +125,8 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
 /* Whether building the class codes pays for the EM sweeps still to come (codes.hip builds them in one pass over the matrix):
  *   the encode pass costs wgs_codes_build_ms_estimate (the matrix's bytes at ~1.8 TB/s, more with larger hash tables);
  *   a coded sweep saves a share of the direct sweep (the slabs' bytes at ~6 TB/s) that depends on how many of a population's
- *   individuals share a class: measured 52 % at 14.7 classes per (slab, SNP) among 100 individuals, 39 % at 12.7 among 62, 21 %
- *   at 10.5 among 40 and at 26 among 100 (quality-dependent likelihoods) -- 0.92 - 2.72 x classes / individuals fits all four;
+ *   individuals share a class: min(0.6, 1.0 - 2.2 x classes / individuals) (em_codes_model has the measurements; round 4's
+ *   0.92 - 2.72 x was fitted before a coded sweep ran two iterations);
  *   sweeps to come: what the caller knows -- wgs_em_fit its iteration limit, of which a fit rarely uses more than ~14 (the
  *   reference's default tolerance: 11-17 iterations on every data set here); a step-by-step caller nothing, so there a matrix
  *   that has been swept directly three times is taken to be in a long run.
@@ -155,7 +155,10 @@ struct EmCodesModel {
 static EmCodesModel em_codes_model(wgs_beagle *b, double swept, double cols, bool shared, bool sample)
 {
     EmCodesModel M;
-    auto saves = [&](double classes_per_slab) { return std::max(0.0, std::min(0.6, 0.92 - 2.72 * classes_per_slab / std::max(1.0, cols))); };
+    // share of a float32 fit's time the coded sweeps save once the codes are there, two iterations per sweep (measured round 5, warm
+    // fits: 0.59 at 14.7 classes per (slab, SNP) among 100 individuals, 0.55 at 12.7 among 62, 0.31 at ~11 among 36; round 4's fit
+    // 0.92 - 2.72 x predated the fused sweeps and turned the 36-individual shape away, which gains a third)
+    auto saves = [&](double classes_per_slab) { return std::max(0.0, std::min(0.6, 1.0 - 2.2 * classes_per_slab / std::max(1.0, cols))); };
     if (shared) {
         constexpr double LOO_MS_PER_TERM = 7.6e-10;          // em_sweep_group_kernel, per (fit, SNP, individual)
         M.direct_ms = swept / 8.0 * LOO_MS_PER_TERM;

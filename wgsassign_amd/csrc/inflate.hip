@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
     }
     uint8_t *const out0 = A.out + (have ? A.out_off[blk] : 0);
     const uint32_t want = have ? A.isize[blk] : 0;
-    uint32_t pos = 0, last = 0, left = 0, dist = 0;
+    uint32_t pos = 0, last = 0, left = 0, dist = 0, done = 0;
     int state = have ? ST_HEADER : ST_DONE;
     bool bad = false;
     while (__any(state != ST_DONE)) {
@@ -322,11 +322,15 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
                     dist = (ds < 4 ? 1u + ds : ((2u + (ds & 1u)) << db) + 1u) + br.peek(db);
                     br.drop(db);
                     left = len;
+                    done = 0;
                     if (dist > pos || pos + len > want) bad = true, state = ST_DONE;
                     else state = ST_COPY;
                 }
             }
-        } else if (state == ST_COPY) {
+        }
+        // (no `else`: a lane that has just decoded a match moves its first bytes in the same trip -- a match is one trip shorter, and
+        // the wavefront runs this code in every trip anyway, for the lanes that are in the middle of a copy)
+        if (state == ST_COPY) {
             // matches in this kind of text are long (51 bytes on average) and come from far back (half of them from more
             // than 2 KiB), or repeat a short period ("0.333333\t" three times per unobserved genotype: distance 9)
             struct __attribute__((packed)) B16 { uint64_t a, b; };
@@ -339,19 +343,31 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
                 const uint32_t step = left < 64 ? left : 64;
                 pos += step;
                 left -= step;
+                done += step;
             } else if (pos + 16 <= want) {
-                // sixteen bytes are moved whatever the distance; the first min(dist, 16) of them are right (a source that
-                // overlaps the destination repeats with period dist), the rest -- and what lies past the match -- is
-                // overwritten by what follows
-                *reinterpret_cast<B16 *>(out0 + pos) = *reinterpret_cast<const B16 *>(out0 + pos - dist);
-                uint32_t step = dist < 16 ? dist : 16;
+                // sixteen bytes are moved whatever the distance.  A source that overlaps the destination repeats with period dist:
+                // of the bytes behind `pos`, dist + done follow that period (done = what this match has written so far), so the source
+                // may lie any multiple of dist back within them -- the largest one below sixteen plus one more if it fits: once
+                // sixteen periodic bytes exist every trip moves sixteen ("0.333333\t" three times per unobserved genotype is a
+                // distance of 9: 9, then 16 per trip instead of 9 every time).  What lies past the valid bytes is overwritten by
+                // what follows.
+                uint32_t back = dist;
+                if (dist < 16) {
+                    const uint32_t have_bytes = dist + done;
+                    const uint32_t k = (15u + dist) / dist;                 // periods that cover sixteen bytes
+                    back = k * dist <= have_bytes ? k * dist : (have_bytes / dist) * dist;
+                }
+                *reinterpret_cast<B16 *>(out0 + pos) = *reinterpret_cast<const B16 *>(out0 + pos - back);
+                uint32_t step = back < 16 ? back : 16;
                 step = left < step ? left : step;
                 pos += step;
                 left -= step;
+                done += step;
             } else {
                 out0[pos] = out0[pos - dist];
                 ++pos;
                 --left;
+                ++done;
             }
             if (left == 0) state = ST_SYMBOL;
         } else if (state == ST_STORED) {
