@@ -39,6 +39,48 @@ int64_t wgs_hook(const char *name)
         if (h.first == name) return h.second;
     return 0;
 }
+struct LiveEntry {
+    void *obj, *parent, *parent2;
+    int kind;
+};
+static std::mutex g_live_mutex;
+static std::vector<LiveEntry> g_live;
+void wgs_live_add(void *obj, int kind, void *parent, void *parent2)
+{
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    g_live.push_back(LiveEntry{obj, parent, parent2, kind});
+}
+bool wgs_live_remove(void *obj)
+{
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    for (size_t i = 0; i < g_live.size(); ++i)
+        if (g_live[i].obj == obj) {
+            g_live[i] = g_live.back();
+            g_live.pop_back();
+            return true;
+        }
+    return false;
+}
+extern "C" void wgs_em_destroy(wgs_em *em);
+extern "C" void wgs_score_destroy(wgs_score *sc);
+void wgs_live_destroy_children(void *parent)
+{
+    for (;;) {
+        LiveEntry e{nullptr, nullptr, nullptr, 0};
+        {
+            std::lock_guard<std::mutex> lock(g_live_mutex);
+            for (const LiveEntry &x : g_live)
+                if (x.parent == parent || x.parent2 == parent) {
+                    e = x;
+                    break;
+                }
+        }
+        if (!e.obj) return;
+        if (e.kind == WGS_LIVE_EM) wgs_em_destroy(reinterpret_cast<wgs_em *>(e.obj));
+        else wgs_score_destroy(reinterpret_cast<wgs_score *>(e.obj));
+    }
+}
+
 extern "C" int wgs_debug_hook(const char *name, int64_t value)
 {
     WGS_REQUIRE(name, "null argument");
@@ -104,6 +146,7 @@ void wgs_ctx_destroy(wgs_ctx *ctx)
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->ws_b) (void)hipFree(ctx->ws_b);
+    for (wgs_ctx::PoolBlock &b : ctx->pool) (void)hipFree(b.p);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->enc_ev0) (void)hipEventDestroy(ctx->enc_ev0);
@@ -112,6 +155,65 @@ void wgs_ctx_destroy(wgs_ctx *ctx)
 }
 
 }   // extern "C"
+
+hipError_t wgs_pool_malloc(wgs_ctx *ctx, void **p, size_t bytes)
+{
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {           // the smallest idle block that holds it without wasting more than half
+        const wgs_ctx::PoolBlock &b = ctx->pool[i];
+        if (!b.used && b.bytes >= bytes && b.bytes <= 2 * bytes + 4096 && (best < 0 || b.bytes < ctx->pool[best].bytes)) best = (int)i;
+    }
+    if (best >= 0) {
+        ctx->pool[best].used = true;
+        *p = ctx->pool[best].p;
+        return hipSuccess;
+    }
+    void *q = nullptr;
+    hipError_t e = wgs_malloc(&q, bytes);
+    if (e != hipSuccess) {                                     // no memory: give the idle blocks back and try once more
+        (void)hipGetLastError();
+        for (size_t i = 0; i < ctx->pool.size();) {
+            if (!ctx->pool[i].used) {
+                (void)hipFree(ctx->pool[i].p);
+                ctx->pool[i] = ctx->pool.back();
+                ctx->pool.pop_back();
+            } else {
+                ++i;
+            }
+        }
+        e = wgs_malloc(&q, bytes);
+        if (e != hipSuccess) return e;
+    }
+    ctx->pool.push_back(wgs_ctx::PoolBlock{q, bytes, true});
+    *p = q;
+    return hipSuccess;
+}
+
+void wgs_pool_free(wgs_ctx *ctx, void *p)
+{
+    if (!p) return;
+    size_t idle = 0;
+    bool found = false;
+    for (wgs_ctx::PoolBlock &b : ctx->pool) {
+        if (b.p == p) b.used = false, found = true;
+        if (!b.used) idle += b.bytes;
+    }
+    if (!found) {
+        (void)hipFree(p);
+        return;
+    }
+    while (idle > ((size_t)1 << 30) || ctx->pool.size() > 64) {      // keep the cache small: the largest idle block goes first
+        int big = -1;
+        for (size_t i = 0; i < ctx->pool.size(); ++i)
+            if (!ctx->pool[i].used && (big < 0 || ctx->pool[i].bytes > ctx->pool[big].bytes)) big = (int)i;
+        if (big < 0) break;
+        idle -= ctx->pool[big].bytes;
+        (void)hipFree(ctx->pool[big].p);
+        ctx->pool[big] = ctx->pool.back();
+        ctx->pool.pop_back();
+    }
+}
 
 int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out)
 {
@@ -192,6 +294,7 @@ extern "C" {
 void wgs_beagle_destroy(wgs_beagle *b)
 {
     if (!b) return;
+    wgs_live_destroy_children(b);             // EM batches and scores over this matrix go first
     wgs_beagle_drop_codes(b);
     (void)hipSetDevice(b->ctx->device);
     wgs_beagle_release_pool(b);
@@ -374,6 +477,7 @@ int wgs_afset_create(wgs_ctx *ctx, int64_t m, int32_t K, wgs_afset **out)
 void wgs_afset_destroy(wgs_afset *a)
 {
     if (!a) return;
+    wgs_live_destroy_children(a);             // scores over these columns go first
     (void)hipSetDevice(a->ctx->device);
     if (a->buf) (void)hipFree(a->buf);
     delete a;

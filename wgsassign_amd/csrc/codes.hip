@@ -141,6 +141,21 @@ static bool codes_switched_off()
     return env && env[0] == '0';
 }
 
+// Share of a float32 fit's time that coded sweeps save once the codes are there (two iterations per sweep): what em_codes_pay and the
+// plan below decide with.  Measured round 5, warm fits: 0.59 at 14.7 classes per (slab, SNP) among 100 individuals, 0.55 at 12.7 among
+// 62, 0.31 at ~11 among 36 -- min(0.6, 1.0 - 2.2 x classes / individuals) (round 4's 0.92 - 2.72 x predated the fused sweeps and turned
+// the 36-individual shape away, which gains a third).  The sweep is bound by how many wavefronts a CU holds (24.3 / 13.2 /
+// 9.4 / 7.5 ms at 2 / 4 / 6 / 8 per CU), i.e. by its table of lrows x 512 bytes: beyond the 24 rows of fixed-error data (13 wavefronts
+// per CU) what is NOT saved grows by (13 / wavefronts)^0.8 -- quality-dependent likelihoods (26 classes per slab, ~56 rows: 5 wavefronts)
+// save nothing, as measured in round 4.
+double wgs_em_codes_saving(double classes_per_slab, double cols, int lrows)
+{
+    const double saves = std::max(0.0, std::min(0.6, 1.0 - 2.2 * classes_per_slab / std::max(1.0, cols)));
+    if (lrows <= 24) return saves;
+    const double waves = std::max(1.0, std::min(13.0, floor(160.0 * 1024.0 / ((double)lrows * 512.0))));
+    return std::max(0.0, 1.0 - (1.0 - saves) * pow(13.0 / waves, 0.8));
+}
+
 // Smallest c with at least `share` of the histogram's mass at or below it (the overflow bin 255 counts as 255).
 static int hist_quantile(const unsigned long long *h, double share)
 {
@@ -213,7 +228,7 @@ const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b)
         int groups = 0;
         for (int g = 0; g < b->n_groups; ++g) groups += b->slabs[g].ncols > 0;
         const double cols = (double)b->n / std::max(1, groups);
-        const double saves = std::max(0.0, std::min(0.6, 1.0 - 2.2 * P.mean_l / std::max(1.0, cols)));      // (= em_api.hip: em_codes_model)
+        const double saves = wgs_em_codes_saving(P.mean_l, cols, P.lrows);
         if (!getenv("WGSASSIGN_EM_TABLE_ROWS") && !getenv("WGSASSIGN_EM_CODES_SWEEPS") &&
             14.0 * saves * ((double)b->bytes / 6.0e9) <= wgs_codes_build_ms_estimate(b, P.slots))
             P.lrows = 0;

@@ -98,11 +98,27 @@ struct wgs_ctx {
                                                 // (tools/ubench_alloc3.hip; kernel launches, copies and synchronisation do not), so elapsed times
                                                 // are read when somebody asks and no allocation of this library is in flight (wgs_assign_last_ms)
     std::atomic<int> allocs_in_flight{0};       // helper-thread hipMallocs under way (codes.hip)
+    struct PoolBlock {
+        void *p;
+        size_t bytes;
+        bool used;
+    };
+    std::vector<PoolBlock> pool;                // wgs_pool_malloc's blocks, in use and idle
     int64_t dyn_lds_base = -1;                  // LDS address at which a kernel's dynamic allocation starts (em_coded_usable probes it once; -1: not yet)
     hipEvent_t enc_ev0 = nullptr, enc_ev1 = nullptr;   // bracket the class encoder (its own pair: ev0 / ev1 may still hold an unread scoring time)
 };
 // Device workspace of at least `bytes` (256-byte aligned); contents are not preserved across calls.
 int wgs_ctx_workspace(wgs_ctx *ctx, size_t bytes, void **out);
+// Buffers of short-lived objects (a wgs_score lives for one call of --get_pop_like or one leave-one-out batch) come from a small cache
+// kept with the context: hipMalloc / hipFree cost ~50-100 us each and hipFree synchronises the device -- a dozen of them were 0.9 ms of
+// a 2.7 ms scoring call on one rank's shard of 8 (bench.py: shard_projection).  At most 1 GiB of idle blocks is kept.
+hipError_t wgs_pool_malloc(wgs_ctx *ctx, void **p, size_t bytes);
+void wgs_pool_free(wgs_ctx *ctx, void *p);
+template <typename T>
+static inline hipError_t wgs_pool_malloc(wgs_ctx *ctx, T **p, size_t bytes)
+{
+    return wgs_pool_malloc(ctx, reinterpret_cast<void **>(p), bytes);
+}
 
 // One population slab: the (g0,g1) pairs of the individuals of one group (file order), stored
 // TILE-INTERLEAVED for lane<->SNP kernels:
@@ -220,6 +236,7 @@ struct wgs_beagle {
 wgs_codes *wgs_beagle_codes(wgs_beagle *b, bool build = true, bool wait = true, bool for_scoring_only = false);
 const wgs_codes_plan *wgs_beagle_codes_plan(wgs_beagle *b);
 double wgs_codes_build_ms_estimate(const wgs_beagle *b, int slots, bool with_slab_numbering = true);
+double wgs_em_codes_saving(double classes_per_slab, double cols, int lrows);     // share of a float32 fit's time the coded sweeps save (codes.hip)
 bool wgs_codes_pay_for_scoring(wgs_beagle *b, int K);
 // the numbers that decision is made from: the direct sweep's time, the share of it the coded sweep costs, the encode pass (false: not worth coding)
 bool wgs_codes_scoring_model(wgs_beagle *b, int K, double *direct_ms, double *coded_share, double *build_ms);
@@ -244,6 +261,15 @@ constexpr size_t wgs_comm_tail_doubles() { return (size_t)WGS_COMM_MAX_WORLD * W
 constexpr size_t wgs_comm_tail_bytes() { return wgs_comm_tail_doubles() * sizeof(double); }
 extern "C" int wgs_comm_allreduce_tagged(wgs_comm *c, double *dev_buf, int64_t n, const wgs_coll_tag *tag);
 extern "C" int wgs_comm_bcast_tagged(wgs_comm *c, void *dev_buf, int64_t bytes, int root, const wgs_coll_tag *tag);
+
+// ---- objects of the C ABI that point at a parent (an EM batch at its matrix, a score at its matrix and frequency set).  Destroying a
+// parent destroys them first, and destroying something that is no longer alive returns at once: a caller's garbage collector may
+// release its handles in any order (Python finalises the objects of a reference cycle in arbitrary order; before round 5 an EM batch
+// finalised after its matrix was a use after free).
+enum { WGS_LIVE_EM = 1, WGS_LIVE_SCORE = 2 };
+void wgs_live_add(void *obj, int kind, void *parent, void *parent2 = nullptr);
+bool wgs_live_remove(void *obj);               // false: not alive (never created through the ABI, or destroyed already)
+void wgs_live_destroy_children(void *parent);
 
 // ---- test hooks (include/wgsassign_hip_debug.h: wgs_debug_hook): process-wide switches only the test suite sets, by name
 int64_t wgs_hook(const char *name);        // 0 unless a test set it

@@ -21,7 +21,7 @@ extern "C" {
 
 void wgs_em_destroy(wgs_em *em)
 {
-    if (!em) return;
+    if (!em || !wgs_live_remove(em)) return;          // (destroyed already, e.g. together with its matrix)
     (void)hipSetDevice(em->b->ctx->device);
     for (int i = 0; i < 3; ++i)
         if (em->fbuf[i]) (void)hipFree(em->fbuf[i]);
@@ -64,6 +64,7 @@ int wgs_em_create(wgs_beagle *b, int32_t n_fits, const int32_t *fit_group, const
     WGS_REQUIRE(mode == WGS_MODE_EXACT || mode == WGS_MODE_FAST, "unknown mode %d", mode);
     HIP_TRY(hipSetDevice(b->ctx->device));
     wgs_em *em = new wgs_em();
+    wgs_live_add(em, WGS_LIVE_EM, b);
     auto guard = on_failure([&] { wgs_em_destroy(em); });
     em->b = b;
     em->n_fits = n_fits;
@@ -155,10 +156,7 @@ struct EmCodesModel {
 static EmCodesModel em_codes_model(wgs_beagle *b, double swept, double cols, bool shared, bool sample)
 {
     EmCodesModel M;
-    // share of a float32 fit's time the coded sweeps save once the codes are there, two iterations per sweep (measured round 5, warm
-    // fits: 0.59 at 14.7 classes per (slab, SNP) among 100 individuals, 0.55 at 12.7 among 62, 0.31 at ~11 among 36; round 4's fit
-    // 0.92 - 2.72 x predated the fused sweeps and turned the 36-individual shape away, which gains a third)
-    auto saves = [&](double classes_per_slab) { return std::max(0.0, std::min(0.6, 1.0 - 2.2 * classes_per_slab / std::max(1.0, cols))); };
+    auto saves = [&](double classes_per_slab, int lrows) { return wgs_em_codes_saving(classes_per_slab, cols, lrows); };
     if (shared) {
         constexpr double LOO_MS_PER_TERM = 7.6e-10;          // em_sweep_group_kernel, per (fit, SNP, individual)
         M.direct_ms = swept / 8.0 * LOO_MS_PER_TERM;
@@ -172,7 +170,7 @@ static EmCodesModel em_codes_model(wgs_beagle *b, double swept, double cols, boo
     }
     M.direct_ms = swept / 6.0e9;
     // fixed-error 2x data shows ~4.6 * cols^0.25 classes per (slab, SNP): 14.7 at 100, 12.7 at 62, 10.5 at 40
-    M.saves = saves(4.6 * pow(std::max(1.0, cols), 0.25));
+    M.saves = saves(4.6 * pow(std::max(1.0, cols), 0.25), 24);
     M.build_ms = wgs_codes_build_ms_estimate(b, 64);
     M.codable = true;
     if (!sample) return M;
@@ -183,7 +181,7 @@ static EmCodesModel em_codes_model(wgs_beagle *b, double swept, double cols, boo
         M.saves = 0.0;
         return M;
     }
-    M.saves = saves(P->mean_l);
+    M.saves = saves(P->mean_l, P->lrows);
     M.build_ms = wgs_codes_build_ms_estimate(b, P->slots);
     return M;
 }

@@ -52,13 +52,13 @@ struct wgs_score {
 
 void wgs_score_destroy(wgs_score *sc)
 {
-    if (!sc) return;
+    if (!sc || !wgs_live_remove(sc)) return;          // (destroyed already, e.g. together with its matrix or frequency set)
     (void)hipSetDevice(sc->b->ctx->device);
     (void)hipStreamSynchronize(sc->b->ctx->stream);
     void *bufs[] = {sc->d_acol, sc->d_colptr, sc->d_slabs[0], sc->d_slabs[1] == sc->d_slabs[0] ? nullptr : sc->d_slabs[1], sc->d_S,
                     sc->d_out, sc->d_start, sc->d_run, sc->d_coded, sc->d_cand, sc->d_carry, sc->d_parts, sc->d_nserial, sc->d_chunks};
     for (void *p : bufs)
-        if (p) (void)hipFree(p);
+        if (p) wgs_pool_free(sc->b->ctx, p);
     delete sc;
 }
 
@@ -90,7 +90,7 @@ static int build_slab_table(wgs_score *sc, int np, int which)
     sc->n_slabs[which] = (int)tab.size();
     sc->total_pg[which] = pg;
     if (tab.empty()) return 0;
-    HIP_TRY(wgs_malloc(&sc->d_slabs[which], sizeof(ScoreSlab) * tab.size()));
+    HIP_TRY(wgs_pool_malloc(sc->b->ctx, &sc->d_slabs[which], sizeof(ScoreSlab) * tab.size()));
     HIP_TRY(hipMemcpy(sc->d_slabs[which], tab.data(), sizeof(ScoreSlab) * tab.size(), hipMemcpyHostToDevice));
     return 0;
 }
@@ -104,6 +104,7 @@ int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, in
     wgs_ctx *ctx = b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     wgs_score *sc = new wgs_score();
+    wgs_live_add(sc, WGS_LIVE_SCORE, b, a);
     auto guard = on_failure([&] { wgs_score_destroy(sc); });
     sc->b = b;
     sc->a = a;
@@ -116,10 +117,10 @@ int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, in
     sc->nblocks = (int32_t)((wgs_ntiles(b->m) + WGS_BLOCK_TILES - 1) / WGS_BLOCK_TILES);
     std::vector<const float *> acol(a->K);
     for (int k = 0; k < a->K; ++k) acol[k] = a->buf + (size_t)k * a->m;
-    HIP_TRY(wgs_malloc(&sc->d_acol, sizeof(float *) * a->K));
+    HIP_TRY(wgs_pool_malloc(ctx, &sc->d_acol, sizeof(float *) * a->K));
     HIP_TRY(hipMemcpy(sc->d_acol, acol.data(), sizeof(float *) * a->K, hipMemcpyHostToDevice));
     if (colptr) {
-        HIP_TRY(wgs_malloc(&sc->d_colptr, sizeof(float *) * sc->cells));
+        HIP_TRY(wgs_pool_malloc(ctx, &sc->d_colptr, sizeof(float *) * sc->cells));
         HIP_TRY(hipMemcpy(sc->d_colptr, colptr, sizeof(float *) * sc->cells, hipMemcpyHostToDevice));
     }
     const int np_sweep = score_pairs_per_wave(a->K, sc->per_ind), np_chain = chain_pairs_per_wave(a->K, sc->per_ind);
@@ -131,11 +132,11 @@ int wgs_score_create(wgs_beagle *b, wgs_afset *a, const float *const *colptr, in
     } else if (build_slab_table(sc, np_chain, 1)) {
         return 1;
     }
-    if (wgs_malloc(&sc->d_S, sizeof(double) * (size_t)sc->nblocks * sc->cells) != hipSuccess) {
+    if (wgs_pool_malloc(ctx, &sc->d_S, sizeof(double) * (size_t)sc->nblocks * sc->cells) != hipSuccess) {
         wgs_set_error("hipMalloc of %zu bytes for the block sums failed", sizeof(double) * (size_t)sc->nblocks * sc->cells);
         return 1;
     }
-    HIP_TRY(wgs_malloc(&sc->d_out, sizeof(double) * sc->cells));
+    HIP_TRY(wgs_pool_malloc(ctx, &sc->d_out, sizeof(double) * sc->cells));
     guard.dismiss();
     *out = sc;
     return 0;
@@ -199,12 +200,12 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
             quad0 += e.nquads;
             tab.push_back(e);
         }
-        if (sc->d_coded) HIP_TRY(hipFree(sc->d_coded));
+        if (sc->d_coded) wgs_pool_free(ctx, sc->d_coded);
         sc->d_coded = nullptr;
         sc->n_coded = (int)tab.size();
         sc->coded_quads = quad0;
         if (!tab.empty()) {
-            HIP_TRY(wgs_malloc(&sc->d_coded, sizeof(CodedSlabHost) * tab.size()));
+            HIP_TRY(wgs_pool_malloc(ctx, &sc->d_coded, sizeof(CodedSlabHost) * tab.size()));
             HIP_TRY(hipMemcpy(sc->d_coded, tab.data(), sizeof(CodedSlabHost) * tab.size(), hipMemcpyHostToDevice));
         }
         sc->coded_generation = codes->generation;
@@ -219,7 +220,7 @@ int wgs_score_sums(wgs_score *sc, int mode, double *out)
     } else if (launch_score_sweep(ctx, score_args(sc, 0), mode)) {
         return 1;
     }
-    if (!sc->d_chunks && wgs_malloc(&sc->d_chunks, sizeof(double) * (size_t)((sc->nblocks + 1) / 2) * sc->cells) != hipSuccess) {
+    if (!sc->d_chunks && wgs_pool_malloc(ctx, &sc->d_chunks, sizeof(double) * (size_t)((sc->nblocks + 1) / 2) * sc->cells) != hipSuccess) {
         wgs_set_error("hipMalloc of the chunk sums failed");
         return 1;
     }
@@ -258,7 +259,7 @@ int wgs_score_total_from(wgs_score *sc, const double *carry_in, double *out)
     WGS_REQUIRE(sc->d_chunks, "wgs_score_total_from needs wgs_score_sums first");
     wgs_ctx *ctx = sc->b->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
-    if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, sizeof(double) * sc->cells));
+    if (!sc->d_start) HIP_TRY(wgs_pool_malloc(ctx, &sc->d_start, sizeof(double) * sc->cells));
     if (carry_in) HIP_TRY(hipMemcpyAsync(sc->d_start, carry_in, sizeof(double) * sc->cells, hipMemcpyHostToDevice, ctx->stream));
     if (launch_chunk_total(ctx, sc->d_chunks, (sc->nblocks + 1) / 2, sc->cells, carry_in ? sc->d_start : nullptr, sc->d_out)) return 1;
     HIP_TRY(hipMemcpyAsync(out, sc->d_out, sizeof(double) * sc->cells, hipMemcpyDeviceToHost, ctx->stream));
@@ -281,8 +282,8 @@ int wgs_score_totals_all(wgs_score *sc, wgs_comm *comm, double *totals_out, doub
     int world = 1, rank = 0;
     if (comm) wgs_comm_rank(comm, &rank, &world);
     const size_t bytes = sizeof(double) * sc->cells;
-    if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, bytes));
-    if (!sc->d_run) HIP_TRY(wgs_malloc(&sc->d_run, bytes + wgs_comm_tail_bytes()));      // (+ the sender's tag row behind the totals)
+    if (!sc->d_start) HIP_TRY(wgs_pool_malloc(ctx, &sc->d_start, bytes));
+    if (!sc->d_run) HIP_TRY(wgs_pool_malloc(ctx, &sc->d_run, bytes + wgs_comm_tail_bytes()));      // (+ the sender's tag row behind the totals)
     HIP_TRY(hipMemsetAsync(sc->d_start, 0, bytes, ctx->stream));
     const int32_t generation = comm ? wgs_comm_next_generation(comm) : 0;
     for (int r = 0; r < world; ++r) {
@@ -316,18 +317,18 @@ int wgs_score_chains_prepare(wgs_score *sc, int32_t P, const double *start)
     if (sc->P != P) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (void *p : {(void *)sc->d_cand, (void *)sc->d_carry, (void *)sc->d_parts})
-            if (p) (void)hipFree(p);
+            if (p) wgs_pool_free(ctx, p);
         sc->d_cand = nullptr;
         sc->d_carry = sc->d_parts = nullptr;
         sc->P = 0;
-        if (wgs_malloc(&sc->d_cand, sizeof(uint32_t) * chains * sc->nblocks) != hipSuccess) {
+        if (wgs_pool_malloc(ctx, &sc->d_cand, sizeof(uint32_t) * chains * sc->nblocks) != hipSuccess) {
             wgs_set_error("hipMalloc of %zu bytes for the partition-chain block functions failed", sizeof(uint32_t) * chains * sc->nblocks);
             return 1;
         }
-        HIP_TRY(wgs_malloc(&sc->d_carry, sizeof(float) * chains));
-        HIP_TRY(wgs_malloc(&sc->d_parts, sizeof(float) * chains + wgs_comm_tail_bytes()));   // (+ the sender's tag row behind the carries)
-        if (!sc->d_nserial) HIP_TRY(wgs_malloc(&sc->d_nserial, sizeof(int32_t)));
-        if (!sc->d_start) HIP_TRY(wgs_malloc(&sc->d_start, sizeof(double) * sc->cells));
+        HIP_TRY(wgs_pool_malloc(ctx, &sc->d_carry, sizeof(float) * chains));
+        HIP_TRY(wgs_pool_malloc(ctx, &sc->d_parts, sizeof(float) * chains + wgs_comm_tail_bytes()));   // (+ the sender's tag row behind the carries)
+        if (!sc->d_nserial) HIP_TRY(wgs_pool_malloc(ctx, &sc->d_nserial, sizeof(int32_t)));
+        if (!sc->d_start) HIP_TRY(wgs_pool_malloc(ctx, &sc->d_start, sizeof(double) * sc->cells));
         sc->P = P;
     }
     HIP_TRY(hipMemsetAsync(sc->d_cand, 0, sizeof(uint32_t) * chains * sc->nblocks, ctx->stream));

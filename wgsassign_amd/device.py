@@ -151,6 +151,7 @@ class DeviceBeagle:
         h = ctypes.c_void_p()
         check(_lib.load().wgs_beagle_create(self.ctx.handle, self.m, self.n, gp, n_groups, self.site0, ctypes.byref(h)))
         self._h = h
+        self._children = weakref.WeakSet()      # EM batches and scores over this matrix: closed before it, whatever order a collector picks
         _live.add(self)
 
     @classmethod
@@ -231,6 +232,8 @@ class DeviceBeagle:
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                child.close()
             _lib.load().wgs_beagle_destroy(self._h)
             self._h = None
 
@@ -250,6 +253,7 @@ class AFSet:
         h = ctypes.c_void_p()
         check(_lib.load().wgs_afset_create(self.ctx.handle, self.m, self.K, ctypes.byref(h)))
         self._h = h
+        self._children = weakref.WeakSet()      # scores over these columns
         _live.add(self)
 
     @classmethod
@@ -276,6 +280,8 @@ class AFSet:
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                child.close()
             _lib.load().wgs_afset_destroy(self._h)
             self._h = None
 
@@ -304,6 +310,7 @@ class EMBatch:
         h = ctypes.c_void_p()
         check(_lib.load().wgs_em_create(beagle.handle, self.n_fits, i32p(g), i32p(s), self.mode, ctypes.byref(h)))
         self._h = h
+        beagle._children.add(self)
         _live.add(self)
         self.active = np.ones(self.n_fits, dtype=bool)
 
@@ -571,6 +578,8 @@ class Score:
         h = ctypes.c_void_p()
         check(_lib.load().wgs_score_create(beagle.handle, afset.handle, cp, lo, hi, ctypes.byref(h)))
         self._h = h
+        beagle._children.add(self)
+        afset._children.add(self)
         _live.add(self)
         self.local = None
         self.ms = {}
