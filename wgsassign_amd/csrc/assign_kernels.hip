@@ -533,12 +533,24 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
 
     for (int kb = 0; kb < A.K; kb += KB) {
         // what phase 1 needs of batch b, written by threads 0..15 (row offsets) and 16.. (frequencies)
-        auto prepare = [&](int b) {
+        // (in two steps: the loads are issued at the start of a batch, their values go to LDS behind its phase 1 -- written where they
+        // are loaded they cost every wavefront a trip to memory per batch)
+        auto prepare_load = [&](int b) -> int {
+            const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
+            if (tid < CODED_BATCH) return s0 + tid < s_end ? (int)A.ncls[s0 + tid] : 0;
+            if (tid >= 64 && tid - 64 < CODED_BATCH * KB) {
+                const int e = tid - 64, j = e / KB, k = e - j * KB;
+                const int kk = kb + k < A.K ? kb + k : A.K - 1;
+                return __float_as_int(s0 + j < s_end ? A.acol[kk][s0 + j] : 0.5f);
+            }
+            return 0;
+        };
+        auto prepare_store = [&](int b, int val) {
             CodedPrep &P = prep[b & 1];
             const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
             if (tid < 64) {                                    // the first wavefront: a running sum of ncls over the batch's SNPs
                 const int j = tid & 15;
-                const int n = tid < CODED_BATCH && s0 + j < s_end ? (int)A.ncls[s0 + j] : 0;
+                const int n = tid < CODED_BATCH ? val : 0;
                 int incl = n;
 #pragma unroll
                 for (int off = 1; off < CODED_BATCH; off <<= 1) {
@@ -553,10 +565,10 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                 if (tid == 0) P.rowoff[17] = (int)(uncoded & 0xFFFFu);     // bit j: SNP j of the batch was left uncoded by the encoder
             } else if (tid - 64 < CODED_BATCH * KB) {
                 const int e = tid - 64, j = e / KB, k = e - j * KB;
-                const int kk = kb + k < A.K ? kb + k : A.K - 1;
-                P.aval[j][k] = s0 + j < s_end ? A.acol[kk][s0 + j] : 0.5f;
+                P.aval[j][k] = __int_as_float(val);
             }
         };
+        auto prepare = [&](int b) { prepare_store(b, prepare_load(b)); };
         double acc[4][KB];
 #pragma unroll
         for (int h = 0; h < 4; ++h)
@@ -609,7 +621,7 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
 #pragma unroll
                 for (int x = 0; x < CODED_BATCH / 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
             }
-            if (b + 1 < nbatch) prepare(b + 1);
+            const int next_val = b + 1 < nbatch ? prepare_load(b + 1) : 0;
             // phase 1: vtab[rowoff[j] + c][k] from the staged dictionary entries
             const int items = 2 * P.rowoff[CODED_BATCH];
             for (int it = tid; it < items; it += 256) {
@@ -639,6 +651,7 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                     }
                 }
             }
+            if (b + 1 < nbatch) prepare_store(b + 1, next_val);
             __syncthreads();
             // (the staged entries of this batch have been consumed; the code words, requested before phase 1, are here -- said explicitly,
             // because with a transfer to LDS in flight the compiler waits for ALL outstanding loads at the next use of a loaded value)
