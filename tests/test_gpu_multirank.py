@@ -506,3 +506,40 @@ def test_ranks_out_of_step_in_the_fit_fail_loudly(tmp_path):
         assert "OK" not in o.replace("MISMATCH", "")
         assert "collective mismatch" in o and "EM convergence sums" in o
         assert "shape 3 / 6" in o and "shape 3 / 3" in o, o[-3000:]
+
+
+def test_command_line_leaves_with_76_when_ranks_fall_out_of_step(tmp_path):
+    """The same divergence through the COMMAND LINE (two ranks over the TCP star on the one GPU, the bundled AMRE file, populations
+    of 13-23 individuals sent through the class codes): rank 1's codes arrive after its fourth sweep and the agreement is switched
+    off, so the first all-reduce of the fit pairs a sweep of two iterations with a sweep of one.  Every rank must print the
+    mismatch and leave with status 76 (wgsassign_amd.comm.COMM_DIVERGED) -- no output file of the fit, nothing retried."""
+    from conftest import GOLDEN
+    data = os.path.join(GOLDEN, "data")
+    port = free_port()
+    script = tmp_path / "rank.py"
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, %r)
+rank = int(os.environ["RANK"])
+if rank == 1:
+    os.environ["WGSASSIGN_CODES_ALLOC_WAIT_MS"] = "0"
+from wgsassign_amd import device
+if rank == 1:
+    device.debug_hook("codes_alloc_release_after_sweeps", 4)
+device.debug_hook("em_fuse_without_agreement", 1)
+from wgsassign_amd.WGSassign import main
+main(sys.argv[1:])
+''' % ROOT)
+    args = ["--beagle", os.path.join(data, "amre.breeding.ind85.ds_2x.sites-filter.top_50_each.beagle.gz"),
+            "--pop_af_IDs", os.path.join(data, "amre.breeding.ind85.reference_k5.IDs.txt"), "--get_reference_af", "--out", "diverged"]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   WGSASSIGN_COMM="socket", WGSASSIGN_DEVICE="0", WGSASSIGN_EM_CODES_MIN="8", WGSASSIGN_INDEX_DIR=str(tmp_path), PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)] + args, cwd=tmp_path, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 76, "rank %d: status %s\n%s" % (r, p.returncode, o[-3000:])
+        assert "collective mismatch" in o and "EM convergence sums" in o, o[-3000:]
+    assert not (tmp_path / "diverged.pop_af.npy").exists()

@@ -62,3 +62,55 @@ rg = (ex.get("paths") or {}).get("realistic_gl_2Mx1000_K10")
 if rg:
     print("\nQuality-dependent likelihoods (%s): classes per SNP mean / max %s, %s hash slots per SNP, %s SNPs per scoring table, uncoded SNPs %.4f %%, EM table rows %s." %
           (rg["generator"], rg["classes_per_snp_mean_max"], rg["hash_slots_per_snp"], rg["snps_per_scoring_table"], 100 * (rg["uncoded_snp_share"] or 0), rg["em_table_rows"]))
+    cr = rg.get("class_rich_uniform_Q20_40")
+    if cr:
+        print("\nClass-rich matrix (qualities uniform over eight values Q20..Q40: %s classes per SNP in the sample, not coded): `--get_pop_like` exact %.1f ms, float32 mode %.1f ms "
+              "(max relative deviation of the sums %.1e): the default stays exact and pays %.2fx (%s)." %
+              (cr["classes_per_snp_in_the_sample"], cr["get_pop_like_exact"]["kernel_ms"], cr["get_pop_like_float32_mode"]["kernel_ms"],
+               cr["get_pop_like_float32_mode"]["max_rel_dev_of_sums_vs_exact"], cr["price_of_exact"], cr["rule"]))
+
+
+def cm_rows():
+    out = []
+
+    def add(name, cm, key):
+        if not cm:
+            return
+        e = cm.get(key, {})
+        out.append((name, "yes" if cm["builds_the_codes"] else "no", "%s / %s" % (cm["saving_cold_ms"]["predicted"], cm["saving_cold_ms"]["measured"]),
+                    "%s / %s" % (cm["saving_warm_ms"]["predicted"], cm["saving_warm_ms"]["measured"]), "%s / %s" % (e.get("cold"), e.get("warm")),
+                    ("had it built: cold %s / %s, warm %s / %s; the no was right: %s" % (cm["had_it_built"]["saving_cold_ms"]["predicted"], cm["had_it_built"]["saving_cold_ms"]["measured"],
+                                                                                         cm["had_it_built"]["saving_warm_ms"]["predicted"], cm["had_it_built"]["saving_warm_ms"]["measured"],
+                                                                                         cm["had_it_built"]["the_no_was_right"])) if "had_it_built" in cm else ""))
+    if c:
+        add("10M x 1000 x K=10 fit", c.get("cost_model"), "abs_error_share_of_float32_fit")
+    for name, v in (ex.get("paths") or {}).items():
+        if not isinstance(v, dict):
+            continue
+        fit = v if "seconds_cold" in v else v.get("get_reference_af")
+        if fit:
+            add(name + " fit", fit.get("cost_model"), "abs_error_share_of_float32_fit")
+        if v.get("get_pop_like"):
+            add("... `--get_pop_like`", v["get_pop_like"].get("cost_model"), "abs_error_share_of_float32_sweep")
+    return out
+
+
+rows = cm_rows()
+if rows:
+    print("\n## The cost models' predictions beside the measurements (ms saved against the float32 path: predicted / measured)\n")
+    print("| path | model builds the codes | saving cold | saving warm | abs. error as share of the float32 time (cold / warm) | |\n|---|---|---|---|---|---|")
+    for r in rows:
+        print("| " + " | ".join(str(x) for x in r) + " |")
+sp = ex.get("shard_projection")
+if sp:
+    print("\n## Projection of the SNP-sharded path from one GPU (%s)\n" % sp["note"])
+    print("one tagged all-reduce on a one-rank RCCL communicator: %s us\n" % sp["collectives"].get("allreduce_us"))
+    print("| leg | whole matrix | shard of 2 | shard of 4 | shard of 8 | collectives at 8 | speedup 2 / 4 / 8 | >= 6x at 8 | headroom per collective (us) |\n|---|---|---|---|---|---|---|---|---|")
+    legs = [k for k in sp["N=8"] if isinstance(sp["N=8"][k], dict)]
+    for k in legs:
+        r = [sp["N=%d" % N].get(k) for N in (2, 4, 8)]
+        if not all(r):
+            continue
+        print("| %s | %s | %s | %s | %s | %d all-reduces, %d broadcasts | %s / %s / %s | %s | %s |" % (
+            k, ms(sp["seconds_on_the_whole_matrix"][k]), ms(r[0]["shard_seconds"]), ms(r[1]["shard_seconds"]), ms(r[2]["shard_seconds"]),
+            r[2]["allreduces"], r[2]["broadcasts"], r[0]["speedup"], r[1]["speedup"], r[2]["speedup"], r[2]["holds_6x"], r[2]["headroom_us_per_collective"]))
