@@ -27,10 +27,16 @@ def main():
     ap.add_argument("--reblock", type=int, default=0, help="re-cut the text into BGZF blocks of this many bytes (0: the pool file's own blocks)")
     ap.add_argument("--lowdepth", action="store_true", help="text of a simulated 2x matrix (tests/synth.make_beagle: few distinct likelihoods, "
                                                             "long far matches, 10x compression) instead of the pool file's random digits (3x)")
+    ap.add_argument("--benchfile", action="store_true", help="the file of bench.py's ingest leg (tools/beagle_files.write_lowdepth_bgzf: one line "
+                                                             "per member, its name in a stored block in front of it)")
     a = ap.parse_args()
     d = tempfile.mkdtemp()
     path = os.path.join(d, "x.beagle.gz")
-    if a.lowdepth:
+    if a.benchfile:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import beagle_files
+        beagle_files.write_lowdepth_bgzf(path, a.inds, a.sites)
+    elif a.lowdepth:
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_cli
         L, IDs = synth.make_beagle(a.sites, a.inds, 5, seed=4242)

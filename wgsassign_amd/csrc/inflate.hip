@@ -13,6 +13,8 @@
 // Every block is checked: the stream must end with its final block exactly at ISIZE bytes of output and inside its input;
 // anything else only marks the block, which the host then inflates itself (none for files bgzip or ANGSD wrote).
 // CRC32 is not checked (neither does the host path, reader.cpp: BlockInflater).
+#include <stdio.h>
+
 #include "common.h"
 
 namespace {
@@ -55,13 +57,16 @@ struct BitReader {
     // three aligned 64-bit words of input held in registers: the one `p` points into and the two behind it.  A refill takes
     // its eight bytes from them and, when `p` moves on to the next word, requests the word after the window -- a load whose
     // result is not needed for at least eight more bytes of input, so the trips in between do not wait for memory.
-    const uint64_t *a = nullptr;
+    // (a pointer into GLOBAL memory by type: a generic one makes these flat loads, which count as LDS traffic too, and the table
+    // lookup that follows a refill then waits for the word requested ahead)
+    typedef const __attribute__((address_space(1))) uint64_t *GlobalWords;
+    GlobalWords a = nullptr;
     uint64_t w0 = 0, w1 = 0, w2 = 0;
     __device__ __forceinline__ void start(const uint8_t *first, const uint8_t *last)
     {
         p = first;
         end = last;
-        a = reinterpret_cast<const uint64_t *>((uintptr_t)first & ~(uintptr_t)7);
+        a = (GlobalWords)((uintptr_t)first & ~(uintptr_t)7);
         w0 = a[0], w1 = a[1], w2 = a[2];
     }
     // At least 56 valid bits afterwards.  (The chunk is padded, so reading a little past a stream is harmless: a valid stream
@@ -75,12 +80,39 @@ struct BitReader {
         const int nbytes = (63 - cnt) >> 3;
         p += nbytes;
         cnt += nbytes * 8;
-        if (reinterpret_cast<const uint64_t *>((uintptr_t)p & ~(uintptr_t)7) != a) {     // at most one word further
+        if (((uintptr_t)p & ~(uintptr_t)7) != (uintptr_t)a) {     // at most one word further
             ++a;
             w0 = w1;
             w1 = w2;
             w2 = a[2];
         }
+    }
+    // The same for the decode loop, without a branch and in two halves.  `refill_take` (top of a trip; `on` says whether this lane
+    // refills at all) moves bits from the window into `buf` and requests the word behind the window -- whether or not the window
+    // moves (the same word again if not: a hit in L1), because a request that ends a conditional block is waited for at once,
+    // where the compiler merges the two paths' registers.  `refill_commit` shifts the window and is the first use of the
+    // requested word: the loop calls it between a copy's loads and its stores, where the wavefront waits for memory anyway and
+    // the request (older than the copy's loads) has long been answered.  Used at the top of the next trip instead, it cost that
+    // trip a wait for the previous trip's STORES (vmcnt counts loads and stores in one sequence on this architecture).
+    uint64_t requested = 0;
+    bool moves = false;
+    __device__ __forceinline__ void refill_take(bool on)
+    {
+        const int sh = (int)((uintptr_t)p & 7) * 8;
+        const uint64_t v = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+        const int nbytes = on ? (63 - cnt) >> 3 : 0;
+        buf |= on ? v << cnt : 0;
+        p += nbytes;
+        cnt += nbytes * 8;
+        moves = ((uintptr_t)p & ~(uintptr_t)7) != (uintptr_t)a;
+        a += moves ? 1 : 0;
+        requested = a[2];
+    }
+    __device__ __forceinline__ void refill_commit()
+    {
+        w0 = moves ? w1 : w0;
+        w1 = moves ? w2 : w1;
+        w2 = requested;
     }
     __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(buf & ((1ull << n) - 1)); }
     __device__ __forceinline__ void drop(int n)
@@ -151,7 +183,9 @@ __device__ __noinline__ bool build_table(const uint8_t *lens, int n, uint16_t *t
 }
 
 // The canonical walk (RFC 1951 3.2.2) for a code the table does not hold: (length << 9) | symbol, or 0 for an invalid code.
-__device__ __noinline__ uint32_t walk_symbol(uint64_t b, const uint16_t *sorted, const uint16_t *count)
+// (Inlined into the decode loop: a call makes the compiler wait for every load in flight, the input word requested ahead of
+// its use among them.)
+__device__ __forceinline__ uint32_t walk_symbol_inline(uint64_t b, const uint16_t *sorted, const uint16_t *count)
 {
     int code = 0, first = 0, index = 0;
 #pragma nounroll
@@ -167,7 +201,20 @@ __device__ __noinline__ uint32_t walk_symbol(uint64_t b, const uint16_t *sorted,
     }
     return 0;
 }
+__device__ __noinline__ uint32_t walk_symbol(uint64_t b, const uint16_t *sorted, const uint16_t *count)
+{
+    return walk_symbol_inline(b, sorted, count);
+}
 
+// Sixteen bytes at any alignment.
+typedef uint32_t Bytes16 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Bytes16 load16(const uint8_t *p)
+{
+    Bytes16 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void store16(uint8_t *p, Bytes16 v) { __builtin_memcpy(p, &v, 16); }
 // One symbol where lockstep does not matter (the trees of a dynamic block).  -1 = invalid code.
 __device__ __forceinline__ int decode_symbol(BitReader &br, const uint16_t *table, int bits, const uint16_t *sorted, const uint16_t *count)
 {
@@ -249,7 +296,21 @@ __device__ __noinline__ int read_block_header(BitReader &br, LaneTables &T, uint
 // instructions together, and so do the lanes that are copying.  (The first version let every lane run its own
 // symbol-by-symbol loop: 64 different instruction streams per wavefront, 5 GB/s.)  Only block headers -- a few per 64 KiB --
 // leave the common path, and the lanes that reach one at the same trip build their tables together.
-enum : int { ST_HEADER = 0, ST_SYMBOL = 1, ST_COPY = 2, ST_STORED = 3, ST_DONE = 4 };
+enum : int { ST_HEADER = 0, ST_SYMBOL = 1, ST_COPY = 2, ST_STORED = 3, ST_DONE = 4, ST_WALK_LIT = 5, ST_WALK_DIST = 6 };
+
+#ifdef WGS_INFLATE_STATS
+// (experiments: -DWGS_INFLATE_STATS adds up, per launch and over all wavefronts: [0] lockstep trips, trips in which some lane [1] read
+// a block header, [2] [3] walked a long literal/length / distance code, [4] copied ([5] a far piece), [6] decoded a symbol; [7] the
+// most trips of any wavefront; [8] lanes at work summed over trips; clock cycles [9] in all, [10] in block headers, [11] from
+// the refill to the memory phase, [12] waiting for memory, [13] in the memory phase behind the wait.  Counted in registers, one
+// atomic per wavefront and counter at the end.)
+__device__ unsigned long long g_inflate_stats[16];
+#define INFLATE_STAT(i, cond) do { if (__any(cond)) ++stat[i]; } while (0)
+#define INFLATE_CLOCK(i) do { const unsigned long long now_ = clock64(); stat[i] += now_ - mark; mark = now_; } while (0)
+#else
+#define INFLATE_STAT(i, cond) do { } while (0)
+#define INFLATE_CLOCK(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
 {
@@ -265,13 +326,37 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
     }
     uint8_t *const out0 = A.out + (have ? A.out_off[blk] : 0);
     const uint32_t want = have ? A.isize[blk] : 0;
-    uint32_t pos = 0, last = 0, left = 0, dist = 0, done = 0;
+    uint32_t pos = 0, last = 0, left = 0, dist = 0, done = 0, trip = 0;
     int state = have ? ST_HEADER : ST_DONE;
     bool bad = false;
-    while (__any(state != ST_DONE)) {
+    // the piece of a match whose bytes were REQUESTED in the previous trip and are written in this one (see "memory phase")
+    Bytes16 v0 = {0, 0, 0, 0}, v1 = v0, v2 = v0, v3 = v0, v4 = v0;
+    uint32_t one = 0, due_at = 0, due_bytes = 0;
+    bool due_far = false, due_near = false, due_byte = false;
+#ifdef WGS_INFLATE_STATS
+    unsigned long long stat[16] = {0}, mark = clock64();
+    const unsigned long long started = mark;
+#endif
+    while (__any(state != ST_DONE || due_far || due_near || due_byte)) {
+        INFLATE_STAT(0, true);
+        INFLATE_STAT(1, state == ST_HEADER);
+#ifdef WGS_INFLATE_STATS
+        stat[8] += (unsigned long long)__popcll(__ballot(state != ST_DONE));
+        mark = clock64();
+#endif
         if (state == ST_HEADER) {
-            uint32_t stored = 0;
-            const int type = read_block_header(br, T, L, &last, &stored);
+            // (the header code is a call and takes the reader by reference: on a copy, so that the loop's own reader, `last` and
+            // `stored` stay in registers -- handed over directly they lived in scratch, and every trip of the loop went through
+            // a dozen dependent scratch loads and waited for the "prefetched" input word in order to store it there)
+            uint32_t stored = 0, final_block = 0;
+            BitReader hr = br;
+            const int type = read_block_header(hr, T, L, &final_block, &stored);
+            br = hr;
+            last = final_block;
+            // (everything read back from the copy has arrived before the paths join again: otherwise the compiler, which counts
+            // outstanding memory operations per path and assumes the worst at a join, makes EVERY trip wait for most of the
+            // previous trip's stores at its first use of one of these registers)
+            __builtin_amdgcn_s_waitcnt(0);
             if (type < 0 || (type == 0 && pos + stored > want)) {
                 bad = true;
                 state = ST_DONE;
@@ -282,23 +367,47 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
                 state = ST_SYMBOL;
             }
         }
-        if (state != ST_DONE && br.cnt < 48) br.refill();
+        INFLATE_CLOCK(10);
+        br.refill_take(state != ST_DONE && br.cnt < 48);
         if (state != ST_DONE && br.ran_past_end()) {
             // input that belongs to the next member (or to nobody): a damaged stream -- e.g. empty stored blocks or end-of-block
             // codes that never set the final bit -- would otherwise decode on through the following members and past the chunk
             bad = true;
             state = ST_DONE;
         }
+        // Codes longer than the tables' 8 / 7 bits go through the canonical walk: fifteen dependent LDS reads and a load from the
+        // lane's scratch in device memory.  One lane in 140 needs it per trip -- but with 64 lanes in lockstep that was a walk in 37 %
+        // (literal/length) and 34 % (distance) of all trips, for which the other lanes stood still: half of the kernel's time
+        // (-DWGS_INFLATE_STATS counts them).  A lane that meets a long code now WAITS (ST_WALK_*), and the wavefront walks for all
+        // waiting lanes at once: when a dozen have gathered, when they are a quarter of the lanes still decoding, or every sixteenth trip.
+        const unsigned long long waiting = __ballot(state == ST_WALK_LIT || state == ST_WALK_DIST);
+        const int n_wait = __popcll(waiting), n_active = __popcll(__ballot(state != ST_DONE));
+        const bool do_walk = n_wait > 0 && (n_wait >= 12 || 4 * n_wait >= n_active || (trip & 15u) == 15u);
+        ++trip;
+        INFLATE_STAT(6, state == ST_SYMBOL);
+        uint32_t e = 0, literal_at = 0, literal_byte = 0;
+        bool have_e = false, literal = false;
         if (state == ST_SYMBOL) {
-            uint32_t e = L[LDS_LIT + br.peek(LIT_BITS) * 64];
-            if (!e) e = walk_symbol(br.buf, T.lit_sorted, L + LDS_LIT_COUNT);
+            e = L[LDS_LIT + br.peek(LIT_BITS) * 64];
+            if (e) have_e = true;
+            else state = ST_WALK_LIT;
+        }
+        INFLATE_STAT(2, do_walk && state == ST_WALK_LIT);
+        if (do_walk && state == ST_WALK_LIT) {
+            e = walk_symbol_inline(br.buf, T.lit_sorted, L + LDS_LIT_COUNT);
+            have_e = true;
+            state = ST_SYMBOL;
+        }
+        uint32_t d = 0;
+        bool have_d = false;
+        if (have_e) {
             const uint32_t sym = e & 511;
             br.drop((int)(e >> 9));
             if (!e || sym > 285) {
                 bad = true;
                 state = ST_DONE;
             } else if (sym < 256) {
-                if (pos < want) out0[pos++] = (uint8_t)sym;
+                if (pos < want) literal = true, literal_at = pos++, literal_byte = sym;       // (written in the memory phase)
                 else bad = true, state = ST_DONE;
             } else if (sym == 256) {
                 state = last ? ST_DONE : ST_HEADER;
@@ -308,73 +417,126 @@ __global__ __launch_bounds__(64) void inflate_kernel(InflateArgs A)
                 const int li = (int)sym - 257;
                 const int xb = li < 8 || li == 28 ? 0 : (li >> 2) - 1;
                 const uint32_t lbase = li < 8 ? 3u + (uint32_t)li : li == 28 ? 258u : ((4u + ((uint32_t)li & 3u)) << xb) + 3u;
-                const uint32_t len = lbase + br.peek(xb);
+                left = lbase + br.peek(xb);
                 br.drop(xb);
-                uint32_t d = L[LDS_DIST + br.peek(DIST_BITS) * 64];
-                if (!d) d = walk_symbol(br.buf, T.dist_sorted, L + LDS_DIST_COUNT);
-                const uint32_t ds = d & 511;
-                br.drop((int)(d >> 9));
-                if (!d || ds > 29) {
-                    bad = true;
-                    state = ST_DONE;
-                } else {
-                    const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;           // two distance codes per number of extra bits
-                    dist = (ds < 4 ? 1u + ds : ((2u + (ds & 1u)) << db) + 1u) + br.peek(db);
-                    br.drop(db);
-                    left = len;
-                    done = 0;
-                    if (dist > pos || pos + len > want) bad = true, state = ST_DONE;
-                    else state = ST_COPY;
-                }
+                d = L[LDS_DIST + br.peek(DIST_BITS) * 64];
+                if (d) have_d = true;
+                else state = ST_WALK_DIST;                 // (the match's length waits in `left`)
             }
         }
-        // (no `else`: a lane that has just decoded a match moves its first bytes in the same trip -- a match is one trip shorter, and
-        // the wavefront runs this code in every trip anyway, for the lanes that are in the middle of a copy)
-        if (state == ST_COPY) {
-            // matches in this kind of text are long (51 bytes on average) and come from far back (half of them from more
-            // than 2 KiB), or repeat a short period ("0.333333\t" three times per unobserved genotype: distance 9)
-            struct __attribute__((packed)) B16 { uint64_t a, b; };
-            if (dist >= 64 && left > 16 && pos + 64 <= want) {
-                // a long match from far back: sixty-four bytes in one trip (four loads in flight, then four stores)
-                const B16 *src = reinterpret_cast<const B16 *>(out0 + pos - dist);
-                const B16 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                B16 *dst = reinterpret_cast<B16 *>(out0 + pos);
-                dst[0] = v0, dst[1] = v1, dst[2] = v2, dst[3] = v3;
-                const uint32_t step = left < 64 ? left : 64;
-                pos += step;
-                left -= step;
-                done += step;
-            } else if (pos + 16 <= want) {
-                // sixteen bytes are moved whatever the distance.  A source that overlaps the destination repeats with period dist:
-                // of the bytes behind `pos`, dist + done follow that period (done = what this match has written so far), so the source
-                // may lie any multiple of dist back within them -- the largest one below sixteen plus one more if it fits: once
-                // sixteen periodic bytes exist every trip moves sixteen ("0.333333\t" three times per unobserved genotype is a
-                // distance of 9: 9, then 16 per trip instead of 9 every time).  What lies past the valid bytes is overwritten by
-                // what follows.
-                uint32_t back = dist;
-                if (dist < 16) {
-                    const uint32_t have_bytes = dist + done;
-                    const uint32_t k = (15u + dist) / dist;                 // periods that cover sixteen bytes
-                    back = k * dist <= have_bytes ? k * dist : (have_bytes / dist) * dist;
-                }
-                *reinterpret_cast<B16 *>(out0 + pos) = *reinterpret_cast<const B16 *>(out0 + pos - back);
-                uint32_t step = back < 16 ? back : 16;
-                step = left < step ? left : step;
-                pos += step;
-                left -= step;
-                done += step;
+        INFLATE_STAT(3, do_walk && state == ST_WALK_DIST);
+        if (do_walk && state == ST_WALK_DIST) {
+            d = walk_symbol_inline(br.buf, T.dist_sorted, L + LDS_DIST_COUNT);
+            have_d = true;
+            state = ST_SYMBOL;
+        }
+        if (have_d) {
+            const uint32_t ds = d & 511;
+            br.drop((int)(d >> 9));
+            if (!d || ds > 29) {
+                bad = true;
+                state = ST_DONE;
             } else {
-                out0[pos] = out0[pos - dist];
-                ++pos;
-                --left;
-                ++done;
+                const int db = ds < 4 ? 0 : (int)(ds >> 1) - 1;           // two distance codes per number of extra bits
+                dist = (ds < 4 ? 1u + ds : ((2u + (ds & 1u)) << db) + 1u) + br.peek(db);
+                br.drop(db);
+                done = 0;
+                if (dist > pos || pos + left > want) bad = true, state = ST_DONE;
+                else state = ST_COPY;
             }
+        }
+        // (a lane that has just decoded a match moves its first bytes in the same trip -- a match is one trip shorter, and the wavefront
+        // runs this code in every trip anyway, for the lanes that are in the middle of a copy)
+        INFLATE_STAT(4, state == ST_COPY);
+        INFLATE_STAT(5, state == ST_COPY && dist >= 64 && left > 16);
+        // matches in this kind of text are long (51 bytes on average) and come from far back (half of them from more than 2 KiB),
+        // or repeat a short period ("0.333333\t" three times per unobserved genotype: distance 9).  Three ways to move a piece:
+        //   far    a long match from far back: sixty-four bytes in one trip (four loads in flight, then four stores);
+        //   near   sixteen bytes whatever the distance.  A source that overlaps the destination repeats with period dist: of the
+        //          bytes behind `pos`, dist + done follow that period (done = what this match has written so far), so the source
+        //          may lie any multiple of dist back within them -- the largest one below sixteen plus one more if it fits: once
+        //          sixteen periodic bytes exist every trip moves sixteen (a distance of 9: 9, then 16 per trip instead of 9 every
+        //          time).  What lies past the valid bytes is overwritten by what follows;
+        //   byte   one byte, within sixteen bytes of the member's end.
+        //
+        // The memory phase.  A lane's decoding depends on its input alone, never on what it has written; and the bytes of a match
+        // come from DRAM as often as not (64 lanes x 32 KiB of history per wavefront, 600 MB for a chunk: no cache holds that).
+        // So a piece's bytes are requested at the end of one trip and written at the end of the NEXT, with that trip's decoding
+        // in between instead of a wait: per trip one wait for memory, which by then has had a whole trip's time.  In program
+        // order -- which is all a lane's own loads and stores need (a load sees the lane's earlier stores without waiting for
+        // them) -- every piece is still written before anything that follows it is written or read:
+        //   1. wait for what the previous trip requested (the piece and the reader's next word),
+        //   2. write that piece, then this trip's literal (which may lie in the bytes a piece writes past its end),
+        //   3. request the next piece.
+        // The requests are inline assembly for one reason: the registers stay the variables' own.  A load in a conditional block
+        // that the compiler knows about is followed, at the block's end, by a copy into the merged variable's register -- and by
+        // a wait for the load at that point.  (The compiler's own waits elsewhere stay safe: they may count too few operations
+        // in flight, never too many.)
+        INFLATE_CLOCK(11);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0), nothing else
+        INFLATE_CLOCK(12);
+        br.refill_commit();
+        if (due_far) {
+            uint8_t *dst = out0 + due_at;
+            store16(dst, v0), store16(dst + 16, v1);
+            if (due_bytes > 32) store16(dst + 32, v2);
+            if (due_bytes > 48) store16(dst + 48, v3);
+        }
+        if (due_near) store16(out0 + due_at, v4);
+        if (due_byte) out0[due_at] = (uint8_t)one;
+        if (literal) out0[literal_at] = (uint8_t)literal_byte;
+        const bool copying = state == ST_COPY;
+        const bool far = copying && dist >= 64 && left > 16 && pos + 64 <= want;
+        const bool near = copying && !far && pos + 16 <= want;
+        const bool bytewise = copying && !far && !near;
+        uint32_t back = dist;
+        if (near && dist < 16) {
+            const uint32_t have_bytes = dist + done;
+            const uint32_t k = (15u + dist) / dist;                 // periods that cover sixteen bytes
+            back = k * dist <= have_bytes ? k * dist : (have_bytes / dist) * dist;
+        }
+        if (far) {
+            // (the third and fourth sixteen bytes only in the lanes whose piece has them: what a divergent access costs the
+            // compute unit's address unit -- the kernel's bottleneck once three wavefronts share one -- goes by the lanes in it)
+            const uint8_t *src = out0 + pos - dist;
+            asm volatile("global_load_dwordx4 %0, %2, off\n\t"
+                         "global_load_dwordx4 %1, %2, off offset:16"
+                         : "+v"(v0), "+v"(v1)
+                         : "v"(src)
+                         : "memory");
+            if (left > 32) asm volatile("global_load_dwordx4 %0, %1, off offset:32" : "+v"(v2) : "v"(src) : "memory");
+            if (left > 48) asm volatile("global_load_dwordx4 %0, %1, off offset:48" : "+v"(v3) : "v"(src) : "memory");
+        }
+        if (near) {
+            const uint8_t *src = out0 + pos - back;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v4) : "v"(src) : "memory");
+        }
+        if (bytewise) {
+            const uint8_t *src = out0 + pos - dist;
+            asm volatile("global_load_ubyte %0, %1, off" : "+v"(one) : "v"(src) : "memory");
+        }
+        due_far = far, due_near = near, due_byte = bytewise, due_at = pos, due_bytes = left;
+        if (copying) {
+            uint32_t step = far ? 64u : near ? (back < 16 ? back : 16u) : 1u;
+            step = left < step ? left : step;
+            pos += step;
+            left -= step;
+            done += step;
             if (left == 0) state = ST_SYMBOL;
         } else if (state == ST_STORED) {
             out0[pos++] = (uint8_t)br.take(8);
             if (--left == 0) state = last ? ST_DONE : ST_HEADER;
         }
+        INFLATE_CLOCK(13);
     }
+#ifdef WGS_INFLATE_STATS
+    stat[9] = clock64() - started;
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 16; ++i)
+            if (i != 7 && stat[i]) atomicAdd(&g_inflate_stats[i], stat[i]);
+        atomicMax(&g_inflate_stats[7], stat[0]);
+    }
+#endif
     if (have) A.status[blk] = (bad || pos != want || br.consumed_past_end()) ? 1 : 0;
 }
 
@@ -446,6 +608,21 @@ int wgs_debug_inflate(wgs_ctx *ctx, const uint8_t *comp, int64_t comp_bytes, con
     HIP_TRY(hipMemcpyAsync(status, d_status, (size_t)nblocks, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (kernel_ms) (void)hipEventElapsedTime(kernel_ms, ctx->ev0, ctx->ev1);
+#ifdef WGS_INFLATE_STATS
+    {
+        unsigned long long st[16] = {0};
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_inflate_stats), sizeof st);
+        const int waves = (nblocks + 63) / 64;
+        fprintf(stderr, "[inflate stats] %d wavefronts, %llu trips (most in one: %llu), lanes at work per trip %.1f; trips with a header %llu, a long "
+                "literal/length walk %llu, a long distance walk %llu, a copy %llu (far %llu), a symbol %llu\n", waves, st[0], st[7],
+                st[0] ? (double)st[8] / (double)st[0] : 0.0, st[1], st[2], st[3], st[4], st[5], st[6]);
+        fprintf(stderr, "[inflate stats] cycles per wavefront %.0f: headers %.0f, decode %.0f, waiting for memory %.0f, memory phase %.0f; per trip: decode "
+                "%.0f, wait %.0f, memory phase %.0f\n", (double)st[9] / waves, (double)st[10] / waves, (double)st[11] / waves, (double)st[12] / waves,
+                (double)st[13] / waves, (double)st[11] / st[0], (double)st[12] / st[0], (double)st[13] / st[0]);
+        unsigned long long zero[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_inflate_stats), zero, sizeof zero);
+    }
+#endif
     guard.dismiss();
     for (void *p : {(void *)d_comp, (void *)d_out, (void *)d_status, (void *)d_io, (void *)d_oo, (void *)d_il, (void *)d_is, d_tab}) (void)hipFree(p);
     return 0;
