@@ -1050,11 +1050,13 @@ def ingest_path(ctx, device, n, m, K):
             os.environ["WGSASSIGN_INFLATE"] = inflate
             best = None
             for _ in range(2):                       # the second run has the page-locked staging and the code objects warm
+                mal0 = device.malloc_seconds()
                 t0 = time.perf_counter()
                 b, _, _, _ = reader_cy.stream_to_device(path, group_of, K, ctx=ctx, names="ends")
                 ctx.sync()
                 dt = time.perf_counter() - t0
-                st = b.ingest_stats
+                st = dict(b.ingest_stats)
+                st["malloc_s"] = device.malloc_seconds() - mal0
                 probe = [0, m // 3, m - 1]
                 same = all(b.download_rows(r, 1).tobytes() == vals[pick[r]].tobytes() for r in probe)
                 b.close()
@@ -1063,6 +1065,9 @@ def ingest_path(ctx, device, n, m, K):
             dt, st, same = best
             res[label] = {"seconds": round(dt, 4), "sites_per_s": round(m / dt), "text_GB_per_s": round(text_bytes / 1e9 / dt, 2),
                           "device_ms": round(st["device_ms"], 1), "inflate_kernel_ms": round(st["device_inflate_kernel_ms"], 1),
+                          # (hipMalloc of VRAM an earlier process used is cleared by the driver: 0.3 ms or 0.1 s for the same 1.6 GB matrix,
+                          # by the box -- profiles/r04_alloc_ubench.txt)
+                          "of_which_hipMalloc_ms": round(st["malloc_s"] * 1e3, 1),
                           "waited_for_producer_s": round(st["wait_s"], 3), "lines_parsed_on_host": int(st["host_lines"]),
                           "members_left_to_host_inflater": int(st["blocks_left_to_host_inflater"]), "probed_rows_equal_source": bool(same)}
         return res

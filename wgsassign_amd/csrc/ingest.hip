@@ -21,9 +21,14 @@
 //     (reader_text_parse_line) and uploads those rows -- none for ANGSD output.
 // Bound: the host's inflate rate; the kernel reads 27 bytes of text and writes 8 bytes per (SNP, individual).
 #include <string.h>
+#include <sys/mman.h>
 
+#include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "common.h"
@@ -361,13 +366,69 @@ __global__ __launch_bounds__(256) void dst_names_kernel(DstArgs a)
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// Page-locked staging.  hipHostMalloc takes 0.18 s per GB on this platform and hipHostFree 0.1 s (tools/ubench_pin.hip: 48 and
+// 28 ms for the 272 MB of bench.py's ingest leg -- half of that leg's time); anonymous memory in transparent huge pages, faulted
+// in by a few threads and then registered, takes 4 ms for the same 272 MB and copies to the device at the same 57 GB/s.  Without
+// huge pages (the kernel's setting) it is 4 KiB pages as before, still three times cheaper; what mmap or the registration
+// refuses falls back to hipHostMalloc.  The pages go back to the system on a thread of their own (munmap: 12-20 ms).
+struct PinnedBlock {
+    void *raw = nullptr;          // nullptr: from hipHostMalloc
+    size_t raw_bytes = 0;
+};
+std::mutex g_pinned_mu;
+std::unordered_map<void *, PinnedBlock> g_pinned;
+
 void *pinned_alloc(size_t bytes, void *user)                  // called from the producer thread too
 {
-    void *p = nullptr;
     if (hipSetDevice((int)(intptr_t)user) != hipSuccess) return nullptr;
-    return hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+    const size_t huge = (size_t)2 << 20;
+    if (bytes >= 4 * huge) {
+        const size_t len = (bytes + huge - 1) & ~(huge - 1);
+        void *raw = mmap(nullptr, len + huge, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (raw != MAP_FAILED) {
+            char *p = reinterpret_cast<char *>(((uintptr_t)raw + huge - 1) & ~(uintptr_t)(huge - 1));
+            (void)madvise(p, len, MADV_HUGEPAGE);
+            const int T = (int)std::max<size_t>(1, std::min<size_t>(8, std::min<size_t>(std::thread::hardware_concurrency(), len / (16 * huge))));
+            std::vector<std::thread> th;
+            for (int t = 1; t < T; ++t)
+                th.emplace_back([=] {
+                    for (size_t i = len * (size_t)t / (size_t)T; i < len * (size_t)(t + 1) / (size_t)T; i += 4096) p[i] = 0;
+                });
+            for (size_t i = 0; i < len / (size_t)T; i += 4096) p[i] = 0;
+            for (auto &x : th) x.join();
+            if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+                std::lock_guard<std::mutex> lk(g_pinned_mu);
+                g_pinned[p] = PinnedBlock{raw, len + huge};
+                return p;
+            }
+            (void)hipGetLastError();
+            munmap(raw, len + huge);
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    g_pinned[p] = PinnedBlock{};
+    return p;
 }
-void pinned_release(void *p, void *) { (void)hipHostFree(p); }
+void pinned_release(void *p, void *)
+{
+    if (!p) return;
+    PinnedBlock blk;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        auto it = g_pinned.find(p);
+        if (it == g_pinned.end()) return;
+        blk = it->second;
+        g_pinned.erase(it);
+    }
+    if (!blk.raw) {
+        (void)hipHostFree(p);
+        return;
+    }
+    (void)hipHostUnregister(p);
+    std::thread([blk] { munmap(blk.raw, blk.raw_bytes); }).detach();
+}
 
 }  // namespace
 
@@ -828,8 +889,7 @@ int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t 
         g->resident = true;
         if (limit_rows == 0) g->done = true;
         // page-locked staging for the compressed members: an eighth of the text (low-depth ANGSD output deflates 10 : 1 and
-        // more; where a file compresses less a chunk simply ends early), one buffer when the rest of the file fits into it --
-        // page-locking costs ~0.1 s per GB
+        // more; where a file compresses less a chunk simply ends early), one buffer when the rest of the file fits into it
         else {
             size_t staging = std::max<size_t>(g->chunk_text / 8, 1u << 20);
             const int64_t left = reader_comp_bytes_left(r);
@@ -840,9 +900,7 @@ int wgs_ingest_create(wgs_beagle *b, wgs_reader *r, int64_t limit_rows, int64_t 
             }
             // one lane per member and three wavefronts per CU (52 KiB of tables each): members beyond that many wait for a
             // second round of the launch
-            hipDeviceProp_t prop;
-            HIP_TRY(hipGetDeviceProperties(&prop, b->ctx->device));
-            const size_t lanes = (size_t)std::max(1, prop.multiProcessorCount) * 3 * 64;
+            const size_t lanes = (size_t)std::max(1, b->ctx->cus) * 3 * 64;
             if (int rc = reader_comp_start(r, staging, g->chunk_text, nbuf, a, lanes)) return rc;
         }
     } else if (int rc = reader_text_start(r, (size_t)chunk_bytes, 3, a, limit_rows)) {

@@ -103,10 +103,11 @@ class BeagleStream:
             names = ctypes.string_at(ptr, nbytes.value).decode().split("\n")[:-1]
             yield rows[:got.value], names
 
-    def ingest(self, beagle, row0=0, limit=None, keep=None, chunk_bytes=None):
+    def ingest(self, beagle, row0=0, limit=None, keep=None, chunk_bytes=None, names="all"):
         """Device-side ingest (csrc/ingest.hip): the rest of the file -- at most `limit` sites -- goes as TEXT to the
         GPU, which tokenises it straight into the slabs of `beagle` from row `row0` on.  keep: bool array over those
-        sites (False = the site takes no row).  Yields (rows_written, site_names of the chunk's kept sites)."""
+        sites (False = the site takes no row).  Yields (rows_written, site_names of the chunk's kept sites); names="ends" (and
+        no keep mask): only the first and the last four names of a chunk of more than eight sites."""
         lib = _lib.load()
         if chunk_bytes is None:
             chunk_bytes = int(os.environ.get("WGSASSIGN_TEXT_CHUNK_BYTES", 0))
@@ -127,12 +128,20 @@ class BeagleStream:
                     break
                 nbytes = ctypes.c_int64()
                 ptr = lib.wgs_ingest_chunk_sites(g, ctypes.byref(nbytes))
-                names = ctypes.string_at(ptr, nbytes.value).decode().split("\n")[:-1]
-                if keep is not None:
-                    names = [x for x, k in zip(names, keep[consumed:consumed + nfile.value]) if k]
+                raw = ctypes.string_at(ptr, nbytes.value)
+                if names == "ends" and keep is None and nfile.value > 8:
+                    # only the first and the last four names of the chunk are wanted (stream_to_device, names="ends"): a Python string
+                    # per site is 10 ms per 100 000 sites, as much as the device needs for them
+                    head = raw.split(b"\n", 4)[:4]
+                    tail = raw[-4096:].split(b"\n")[-5:-1] if raw.count(b"\n", -4096) >= 5 else raw.split(b"\n")[-5:-1]
+                    names_out = [x.decode() for x in head + tail]
+                else:
+                    names_out = raw.decode().split("\n")[:-1]
+                    if keep is not None:
+                        names_out = [x for x, k in zip(names_out, keep[consumed:consumed + nfile.value]) if k]
                 consumed += nfile.value
                 row0 += nrows.value
-                yield nrows.value, names
+                yield nrows.value, names_out
             st = (ctypes.c_double * 14)()
             _lib.check(lib.wgs_ingest_stats(g, st))
             self.ingest_stats = dict(zip(("wait_s", "inflate_s", "scan_s", "device_ms", "host_lines", "text_bytes", "lines",
@@ -382,7 +391,7 @@ def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, ra
                     yield rows.shape[0], names
         else:
             def chunks():
-                return st.ingest(beagle, 0, r1 - r0, None if keep is None else keep[r0:r1])
+                return st.ingest(beagle, 0, r1 - r0, None if keep is None else keep[r0:r1], names=names_mode)
         for nrows, names in chunks():
             row0 += nrows
             if names_mode == "all":
