@@ -1,4 +1,4 @@
-# After, on the GPU box:  tools/gpu_prof.sh r05 bench.py --no-coded --no-paths --no-projection --no-cpu --steps 10 --warmup 3
+# After, on the GPU box:  tools/gpu_prof.sh r05 /root/repo/bench.py --no-coded --no-paths --no-projection --no-cpu --steps 10 --warmup 3
 #                         tools/prof_codes.sh r05c ; tools/prof_em_coded.sh ; tools/prof_ingest.sh ; tools/prof_loo.sh
 # gather gpurun_out/ into profiles/r05_* (run here, in the repository root).
 set -e
