@@ -107,6 +107,11 @@ int wgs_beagle_synth(wgs_beagle *b, uint64_t seed, double depth);
  * error of wgs_beagle_synth (bench.py: extra.realistic_gl; the NumPy twin of the model is tests/synth.py: make_beagle_quality). */
 int wgs_beagle_synth_quality(wgs_beagle *b, uint64_t seed, double depth, int32_t n_bins, const double *quals, const double *probs);
 int64_t wgs_beagle_bytes(const wgs_beagle *b);
+/* A matrix created with room for more sites than the file turned out to hold (wgs_reader_estimate_sites): rows becomes its
+ * number of sites (0 < rows <= the rows it was created with; the rows behind were never written).  Slabs more than a tenth
+ * too large are moved into allocations of the right size.  Only before anything was made FROM the matrix (EM batches,
+ * scores: rc 2 otherwise); its class codes are dropped. */
+int wgs_beagle_set_rows(wgs_beagle *b, int64_t rows);
 /* Class codes of the matrix: low-depth genotype likelihoods take few distinct (g0, g1) values per SNP (29 on average in
  * the bundled 85-individual data, 27 among 1000 individuals of the 2x synthetic matrices, ~80 with binned base qualities), so
  * the kernels evaluate the EM term's quotient / the per-site log-likelihood once per CLASS and SNP and look it up per
@@ -375,6 +380,10 @@ int wgs_reader_skip_names(wgs_reader *r, int64_t max_rows, int64_t *nrows);
 const char *wgs_reader_chunk_sites(wgs_reader *r, int64_t *bytes);
 /* Number of data lines (sites) of a gzipped Beagle file: one inflate pass, no parsing. */
 int wgs_reader_count_sites(const char *path, int64_t *sites);
+/* About how many sites a BGZF file holds, from five samples of a quarter megabyte (newlines per compressed byte x file size):
+ * milliseconds.  For sizing a device matrix before the exact count is known (wgs_beagle_set_rows trims it afterwards).
+ * rc 3: not BGZF. */
+int wgs_reader_estimate_sites(const char *path, int64_t *estimate);
 /* The same pass can leave an INDEX behind (index_path): header fields, the site count and at most max_points
  * access points about span_bytes of text apart (deflate-block boundaries with their 32 KiB dictionaries; member
  * boundaries of BGZF / concatenated gzip need none), and the site names, '\n'-terminated (names_path) -- so that

@@ -232,3 +232,81 @@ def test_members_the_device_rejects_and_damaged_files(tmp_path, monkeypatch):
         fh.write(bytes(open(p, "rb").read()[:-3000]))
     with pytest.raises(RuntimeError, match="read error|corrupt|truncated"):
         device_rows(cut)
+
+
+def test_cold_file_goes_through_in_one_pass(tmp_path, monkeypatch):
+    """A BGZF file without an index, one rank (reader_cy._stream_cold_file): the index pass and the device ingest run at the same
+    time, the matrix is created for an ESTIMATE of the site count and cut to the file's sites afterwards.  Same slabs, names,
+    site count and cached index as the usual way (index pass first); an estimate that is too small by more than the margin
+    falls back to the usual way; fits over the trimmed matrix have the bits of fits over a matrix created at its size."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import beagle_files
+    from wgsassign_amd import device as dev
+    from wgsassign_amd import reader_cy
+    n, m, K = 120, 9000, 3
+    p = str(tmp_path / "cold.beagle.gz")
+    _, vals, pick = beagle_files.write_lowdepth_bgzf(p, n, m, pool=256)
+    want = vals[pick]
+    group_of = (np.arange(n) % K).astype(np.int32)
+    est = reader_cy.estimate_sites(p)
+    assert est is not None and abs(est - m) <= m // 50
+
+    def run(index_dir, one_pass, estimate=None):
+        monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(index_dir))
+        monkeypatch.setenv("WGSASSIGN_COLD_ONE_PASS", "1" if one_pass else "0")
+        os.makedirs(index_dir, mode=0o700, exist_ok=True)
+        calls = []
+        real, real_estimate = reader_cy._stream_cold_file, reader_cy.estimate_sites
+
+        def spy(*a, **k):
+            out = real(*a, **k)
+            calls.append(out is not None)
+            return out
+        monkeypatch.setattr(reader_cy, "_stream_cold_file", spy)
+        if estimate is not None:
+            monkeypatch.setattr(reader_cy, "estimate_sites", lambda path: estimate)
+        try:
+            b, samples, sites, m_total = reader_cy.stream_to_device(p, group_of, K, names="all")
+        finally:
+            monkeypatch.setattr(reader_cy, "_stream_cold_file", real)
+            if estimate is not None:
+                monkeypatch.setattr(reader_cy, "estimate_sites", real_estimate)
+        idx = reader_cy.index_paths(p)[0]
+        return b, samples, sites, m_total, calls, os.path.exists(idx)
+
+    b0, samples0, sites0, m0, calls0, idx0 = run(tmp_path / "usual", False)
+    assert calls0 == [] and idx0 and m0 == m and b0.m == m
+    b1, samples1, sites1, m1, calls1, idx1 = run(tmp_path / "cold", True)
+    assert calls1 == [True] and idx1 and m1 == m and b1.m == m            # the one-pass way was taken, and left the index behind
+    assert samples1 == samples0 and sites1 == sites0
+    r0, r1 = b0.download_rows(0, m), b1.download_rows(0, m)
+    assert same_bits(r0, want) and same_bits(r1, want)
+    assert open(reader_cy.index_paths(p)[0], "rb").read() == open(str(tmp_path / "usual" / os.path.basename(reader_cy.index_paths(p)[0])), "rb").read()
+    # a second call finds the index and goes the usual way
+    b2, _, _, _, calls2, _ = run(tmp_path / "cold", True)
+    assert calls2 == [False] and same_bits(b2.download_rows(0, m), want)
+    b2.close()
+    # an estimate of a third of the sites: the ingest runs out of rows, the usual way takes over
+    b3, _, sites3, m3, calls3, _ = run(tmp_path / "small", True, estimate=m // 3)
+    assert calls3 == [False] and m3 == m and sites3 == sites0 and same_bits(b3.download_rows(0, m), want)
+    b3.close()
+    # the trimmed matrix (created for ~11 k rows, cut to 9000; nbytes of the rows in use) fits like one created at its size
+    assert b1.nbytes() == b0.nbytes()
+    pops = np.arange(K, dtype=np.int32)
+    f0 = dev.EMBatch(b0, pops)
+    f1 = dev.EMBatch(b1, pops)
+    f0.fit(40, 1e-4)
+    f1.fit(40, 1e-4)
+    for k in range(K):
+        assert same_bits(f0.get_f(k), f1.get_f(k)), k
+    with pytest.raises(ValueError, match="in use"):
+        b1.set_rows(m - 1)
+    f0.close()
+    f1.close()
+    with pytest.raises(ValueError, match="cannot be set"):
+        b1.set_rows(m + 1)
+    b1.set_rows(m - 64 * 20)                                               # fewer tiles: still the first rows
+    assert b1.m == m - 1280 and same_bits(b1.download_rows(0, b1.m), want[:b1.m])
+    b0.close()
+    b1.close()

@@ -44,6 +44,19 @@ def main():
             same = all(b.download_rows(r, 1).tobytes() == vals[pick[r]].tobytes() for r in (0, a.sites // 3, a.sites - 1))
             b.close()
             res["runs"].append({"seconds": round(dt, 4), "rows_equal_source": bool(same), **st})
+        res["cold_one_pass"] = []
+        for _ in range(a.runs):
+            for f in reader_cy.index_paths(path):
+                if os.path.exists(f):
+                    os.unlink(f)
+            t0 = time.perf_counter()
+            b, _, _, m_seen = reader_cy.stream_to_device(path, group_of, a.pops, ctx=ctx, names="ends")
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            same = m_seen == a.sites and all(b.download_rows(r, 1).tobytes() == vals[pick[r]].tobytes() for r in (0, a.sites // 3, a.sites - 1))
+            b.close()
+            res["cold_one_pass"].append({"seconds": round(dt, 4), "rows_equal_source": bool(same), "index_left": os.path.exists(reader_cy.index_paths(path)[0])})
+        reader_cy.ensure_index(path)
         # the same steps one by one (reader_cy.stream_to_device), each with its own clock
         from wgsassign_amd.device import DeviceBeagle
         for _ in range(2):

@@ -47,6 +47,7 @@ SIGNATURES = {
     "wgs_beagle_download_rows": (c_int, [c_vp, c_f32p, c_i64, c_i64]),
     "wgs_beagle_synth": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_double]),
     "wgs_beagle_bytes": (c_i64, [c_vp]),
+    "wgs_beagle_set_rows": (c_int, [c_vp, c_i64]),
     "wgs_beagle_synth_quality": (c_int, [c_vp, ctypes.c_uint64, ctypes.c_double, c_i32, c_f64p, c_f64p]),
     "wgs_beagle_codes_info": (c_int, [c_vp, c_f64p]),
     "wgs_beagle_codes_prepare": (c_int, [c_vp, c_int]),
@@ -105,6 +106,7 @@ SIGNATURES = {
     "wgs_reader_skip_names": (c_int, [c_vp, c_i64, ctypes.POINTER(c_i64)]),
     "wgs_reader_chunk_sites": (c_vp, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_reader_count_sites": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
+    "wgs_reader_estimate_sites": (c_int, [ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "wgs_reader_build_index": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, c_i64, c_i32, ctypes.POINTER(c_i64)]),
     "wgs_reader_index_sites": (c_int, [ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "wgs_reader_index_part": (c_int, [ctypes.c_char_p, ctypes.c_char_p, c_int, c_int, c_int]),

@@ -376,6 +376,53 @@ int wgs_beagle_create(wgs_ctx *ctx, int64_t m, int64_t n, const int32_t *group_o
 
 int64_t wgs_beagle_bytes(const wgs_beagle *b) { return b ? b->bytes : 0; }
 
+static bool wgs_live_has_children(void *parent)
+{
+    std::lock_guard<std::mutex> lock(g_live_mutex);
+    for (const LiveEntry &x : g_live)
+        if (x.parent == parent || x.parent2 == parent) return true;
+    return false;
+}
+
+/* A matrix created with room for more sites than its file held (include/wgsassign_hip.h).  The slabs are tile-major (64 SNPs per
+ * tile): the rows of a smaller matrix are the first tiles of the larger one, unchanged, and the rows of its last tile beyond
+ * `rows` are the zeros they were created with. */
+int wgs_beagle_set_rows(wgs_beagle *b, int64_t rows)
+{
+    WGS_REQUIRE(b, "null argument");
+    WGS_REQUIRE(rows > 0 && rows <= b->m, "a matrix of %lld rows cannot be set to %lld", (long long)b->m, (long long)rows);
+    WGS_REQUIRE(!wgs_live_has_children(b), "the matrix is in use (EM batches or scores were made from it)");
+    if (rows == b->m) return 0;
+    HIP_TRY(hipSetDevice(b->ctx->device));
+    wgs_beagle_drop_codes(b);
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    const int64_t tiles_old = wgs_ntiles(b->m), tiles_new = wgs_ntiles(rows);
+    if (tiles_old > tiles_new + tiles_new / 10) {
+        std::vector<float4 *> bases(b->n_groups, nullptr);
+        for (int g = 0; g < b->n_groups; ++g) {
+            Slab &s = b->slabs[g];
+            bases[g] = s.base;
+            if (s.ncols == 0) continue;
+            const size_t bytes = (size_t)tiles_new * s.npairs * 64 * sizeof(float4);
+            float4 *fresh = nullptr;
+            if (wgs_malloc(reinterpret_cast<void **>(&fresh), bytes) != hipSuccess) {
+                (void)hipGetLastError();                    // no room for the copy: the larger allocation stays
+                continue;
+            }
+            HIP_TRY(hipMemcpyAsync(fresh, s.base, bytes, hipMemcpyDeviceToDevice, b->ctx->stream));
+            HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+            HIP_TRY(hipFree(s.base));
+            s.base = fresh;
+            bases[g] = fresh;
+        }
+        HIP_TRY(hipMemcpy(b->d_base, bases.data(), sizeof(float4 *) * b->n_groups, hipMemcpyHostToDevice));
+    }
+    b->m = rows;
+    b->bytes = 0;                                           // (of the rows in use: what the sweeps read and the cost models go by)
+    for (const Slab &s : b->slabs) b->bytes += (int64_t)((size_t)tiles_new * s.npairs * 64 * sizeof(float4));
+    return 0;
+}
+
 static int64_t staging_rows(const wgs_beagle *b, int64_t nrows)
 {
     const int64_t row_bytes = b->n * 2 * (int64_t)sizeof(float);

@@ -1806,6 +1806,50 @@ static int skip_impl(wgs_reader *r, int64_t max_rows, int64_t *nrows, bool names
 
 int wgs_reader_count_sites(const char *path, int64_t *sites) { return wgs_reader_build_index(path, nullptr, nullptr, 0, 0, sites); }
 
+/* About how many sites a BGZF file holds, from five samples of a quarter megabyte each (start, quartiles, end): the newlines of the
+ * blocks that start there, per compressed byte, times the file's size.  Milliseconds instead of the index pass's inflate of
+ * everything -- for the caller that wants to size a device matrix BEFORE it knows (stream_to_device's one-pass cold path: the exact
+ * count arrives with the index, which is built meanwhile).  rc 3: not BGZF, or a sample fell off the block chain. */
+int wgs_reader_estimate_sites(const char *path, int64_t *estimate)
+{
+    if (!path || !estimate) {
+        wgs_set_error("null argument");
+        return 2;
+    }
+    *estimate = 0;
+    uint64_t file_size = 0, mtime = 0;
+    if (!file_identity(path, file_size, mtime)) {
+        wgs_set_error("cannot open Beagle file %s", path);
+        return 2;
+    }
+    {
+        FILE *fp = fopen(path, "rb");
+        if (!fp) {
+            wgs_set_error("cannot open Beagle file %s", path);
+            return 2;
+        }
+        BgzfBlock b;
+        const int k = bgzf_block_at(fileno(fp), file_size, 0, b);
+        fclose(fp);
+        if (k <= 0) return 3;
+    }
+    const uint64_t window = 256u << 10;
+    double newlines = 0.0, comp = 0.0;
+    for (int q = 0; q < 5; ++q) {
+        uint64_t lo = q == 4 ? (file_size > window ? file_size - window : 0) : file_size / 4 * (uint64_t)q;
+        if (q > 0 && lo < window) continue;                           // a file smaller than the samples: the first one is all of it
+        PartData pd;
+        if (!bgzf_part_thread(path, file_size, lo, std::min(file_size, lo + window), false, pd)) return 3;
+        for (size_t i = 0; i < pd.blocks.size(); ++i) {
+            newlines += (double)pd.sum[i].lines_after_first + (pd.sum[i].has_nl ? 1.0 : 0.0);
+            comp += (double)pd.blocks[i].csize;
+        }
+    }
+    if (comp <= 0.0) return 3;
+    *estimate = (int64_t)(newlines / comp * (double)file_size);
+    return 0;
+}
+
 const char *wgs_reader_chunk_sites(wgs_reader *r, int64_t *bytes)
 {
     if (!r) return nullptr;

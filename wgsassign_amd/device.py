@@ -192,6 +192,12 @@ class DeviceBeagle:
     def nbytes(self):
         return int(_lib.load().wgs_beagle_bytes(self._h))
 
+    def set_rows(self, m):
+        """A matrix created with room for more sites than its file held (reader_cy.estimate_sites) becomes one of m sites
+        (include/wgsassign_hip.h: wgs_beagle_set_rows) -- before any EM batch or score is made from it."""
+        check(_lib.load().wgs_beagle_set_rows(self._h, int(m)))
+        self.m = int(m)
+
     def prepare_codes(self, em=True):
         """Build the class codes now (em: and the slabs' own numbering for the coded EM sweep) instead of at first use."""
         check(_lib.load().wgs_beagle_codes_prepare(self._h, 1 if em else 0))

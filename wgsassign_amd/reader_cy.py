@@ -173,6 +173,14 @@ def count_sites(path):
     return n.value
 
 
+def estimate_sites(path):
+    """About how many sites a BGZF Beagle file holds (five samples of a quarter megabyte: milliseconds), or None where that
+    cannot be said (not BGZF)."""
+    n = ctypes.c_int64()
+    rc = _lib.load().wgs_reader_estimate_sites(os.fsencode(path), ctypes.byref(n))
+    return n.value if rc == 0 and n.value > 0 else None
+
+
 def cache_dir():
     """Where indices and site-name lists are cached: WGSASSIGN_INDEX_DIR, else a per-user directory
     ($XDG_CACHE_HOME/wgsassign or ~/.cache/wgsassign; the per-user temporary directory when there is no home), created
@@ -341,6 +349,81 @@ def readBeagle_py(beagle):
     return L, sample_names, site_names
 
 
+def _index_is_cached(path):
+    idx, _ = index_paths(path)
+    n = ctypes.c_int64()
+    return _private_file(idx) and _lib.load().wgs_reader_index_sites(os.fsencode(path), os.fsencode(idx), ctypes.byref(n)) == 0
+
+
+def _stream_cold_file(path, group_of, n_groups, ctx, threads, names):
+    """A BGZF file that has no index yet, one rank: the index pass (all host threads inflate and count: its result is the site
+    count and the cached index, as ever) and the device ingest run AT THE SAME TIME instead of one after the other -- the host
+    has little to do during the ingest (the device inflates) and the device nothing during the index pass.  The matrix is
+    created for the estimate of wgs_reader_estimate_sites plus a quarter and cut to the file's sites afterwards
+    (DeviceBeagle.set_rows); the two passes must agree about their number.  Returns None where this does not apply (an index
+    exists, not BGZF, the host inflates, the estimate was too small): the caller then goes the usual way."""
+    import threading
+    from .device import DeviceBeagle
+    if os.environ.get("WGSASSIGN_INFLATE", "device") in ("host", "zlib") or os.environ.get("WGSASSIGN_INGEST", "device") == "host":
+        return None
+    if _index_is_cached(path):
+        return None
+    est = estimate_sites(path)
+    if est is None:
+        return None
+    box = {}
+
+    def index_pass():
+        try:
+            box["index"] = ensure_index(path)
+        except BaseException as e:          # handed to the caller's thread below
+            box["error"] = e
+
+    th = threading.Thread(target=index_pass, name="wgs-index-pass")
+    th.start()
+    beagle = None
+    try:
+        with BeagleStream(path, threads, index=None, first_row=0) as st:
+            if callable(group_of):
+                group_of, n_groups = group_of(list(st.sample_names))
+            cap = est + est // 4 + 1024
+            beagle = DeviceBeagle(cap, st.n, group_of, n_groups, site0=0, ctx=ctx)
+            rows, site_names, tail = 0, [], []
+            try:
+                for nrows, chunk_names in st.ingest(beagle, 0, None, None, names=names):
+                    rows += nrows
+                    if names == "all":
+                        site_names.extend(chunk_names)
+                    else:
+                        if len(site_names) < 4:
+                            site_names = (site_names + chunk_names)[:4]
+                        tail = (tail + chunk_names)[-4:]
+            except (RuntimeError, ValueError) as e:
+                if "outside the device matrix" not in str(e):
+                    raise
+                beagle.close()                  # more sites than estimated plus a quarter: the usual way, with the exact count
+                beagle = None
+                return None
+            stats = getattr(st, "ingest_stats", None)
+            samples = list(st.sample_names)
+        th.join()
+        if "error" in box:
+            raise box["error"]
+        m_file = box["index"][2]
+        if rows != m_file:
+            raise RuntimeError("Beagle file changed while reading: the index pass counted %d sites, the ingest parsed %d" % (m_file, rows))
+        beagle.set_rows(rows)
+        beagle.ingest_stats = stats
+        if names != "all" and rows > 4:
+            site_names = site_names + tail
+        out, beagle = beagle, None
+        return out, samples, site_names, m_file
+    finally:
+        th.join()
+        if beagle is not None:
+            beagle.close()
+
+
 def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, rank=0, world=1, m_total=None,
                      keep=None, comm=None, names="all"):
     """The file goes chunk by chunk straight into the device slabs -- host memory stays bounded by two chunks
@@ -354,6 +437,10 @@ def stream_to_device(path, group_of=None, n_groups=1, ctx=None, threads=None, ra
     Returns (DeviceBeagle, sample_names, site_names of the range, m_total)."""
     from .comm import shard_range
     from .device import DeviceBeagle
+    if world == 1 and keep is None and m_total is None and os.environ.get("WGSASSIGN_COLD_ONE_PASS", "1") != "0":
+        cold = _stream_cold_file(path, group_of, n_groups, ctx, threads, names)
+        if cold is not None:
+            return cold
     index, _, m_file = ensure_index(path, comm)
     if keep is not None:
         keep = np.asarray(keep, dtype=bool)
