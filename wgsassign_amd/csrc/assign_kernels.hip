@@ -448,24 +448,25 @@ struct CodedPrep {
     float aval[CODED_BATCH_MAX][10];   // allele frequencies [SNP of the batch][population of this pass]
 };
 
-// KB consecutive float64 of an LDS row as KB ds_read_b64 (byte address `addr`), and the point behind a wait at which they have arrived
-template <int KB, int X = 0>
+// Float64 number X .. HI-1 of an LDS row as ds_read_b64 (byte address `addr` of the row), and the point behind a wait at which they have
+// arrived; v[0] is number LO
+template <int HI, int LO, int X = LO>
 struct CodedRow {
-    static __device__ __forceinline__ void issue(double (&v)[KB], unsigned addr)
+    static __device__ __forceinline__ void issue(double (&v)[HI - LO], unsigned addr)
     {
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[X]) : "v"(addr), "n"(8 * X));
-        CodedRow<KB, X + 1>::issue(v, addr);
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[X - LO]) : "v"(addr), "n"(8 * X));
+        CodedRow<HI, LO, X + 1>::issue(v, addr);
     }
-    static __device__ __forceinline__ void arrived(double (&v)[KB])
+    static __device__ __forceinline__ void arrived(double (&v)[HI - LO])
     {
-        asm volatile("" : "+v"(v[X]));
-        CodedRow<KB, X + 1>::arrived(v);
+        asm volatile("" : "+v"(v[X - LO]));
+        CodedRow<HI, LO, X + 1>::arrived(v);
     }
 };
-template <int KB>
-struct CodedRow<KB, KB> {
-    static __device__ __forceinline__ void issue(double (&)[KB], unsigned) {}
-    static __device__ __forceinline__ void arrived(double (&)[KB]) {}
+template <int HI, int LO>
+struct CodedRow<HI, LO, HI> {
+    static __device__ __forceinline__ void issue(double (&)[HI - LO], unsigned) {}
+    static __device__ __forceinline__ void arrived(double (&)[HI - LO]) {}
 };
 template <int N>
 __device__ __forceinline__ void lds_wait()
@@ -474,6 +475,16 @@ __device__ __forceinline__ void lds_wait()
 }
 
 constexpr int CODED_ROWS_MAX = (WGS_BATCH_ROWS_CAP + 255) / 256;     // table rows whose dictionary entries a thread requests per batch
+
+#ifdef WGS_SCORE_STATS
+// (experiments: -DWGS_SCORE_STATS adds up, per launch of score_coded_kernel and over all wavefronts, the clock cycles [0] from a batch's
+// start to its phase 1, [1] in phase 1, [2] at the barrier behind it, [3] in phase 2, [4] at the barrier behind it; [5] batches,
+// [6] wavefronts; printed by launch_score_coded.)
+__device__ unsigned long long g_score_stats[8];
+#define SCORE_CLOCK(i) do { const unsigned long long now_ = clock64(); stat_[i] += now_ - mark_; mark_ = now_; } while (0)
+#else
+#define SCORE_CLOCK(i) do { } while (0)
+#endif
 
 // the SNP of the batch that table row r belongs to: the largest j with rowoff[j] <= r (rowoff is the running sum of the SNPs' classes)
 __device__ __forceinline__ int item_snp(const CodedPrep &P, int r, int batch)
@@ -484,7 +495,10 @@ __device__ __forceinline__ int item_snp(const CodedPrep &P, int r, int batch)
 }
 
 template <int KB, int MODE, typename TV, int CODED_BATCH>
-__global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
+#ifndef WGS_SCORE_CODED_WAVES
+#define WGS_SCORE_CODED_WAVES 3
+#endif
+__global__ __launch_bounds__(256, WGS_SCORE_CODED_WAVES) void score_coded_kernel(CodedScoreArgs A)
 {
     static_assert(CODED_BATCH == 16 || CODED_BATCH == 8 || CODED_BATCH == 4, "SNPs per table");
     // Row stride of the table.  Phase 2 reads rows by class id -- data-dependent addresses -- and the LDS serves a wide read in lane
@@ -504,6 +518,7 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
         for (int e = threadIdx.x; e < WGS_LOG_N * CODED_LOG_REP; e += blockDim.x) tab_lds[e] = A.logtab[e / CODED_LOG_REP];
     }
     const double2 *tab = tab_lds + (threadIdx.x & (CODED_LOG_REP - 1));
+    if (sizeof(TV) == 8 && threadIdx.x < KBP) vtab[(size_t)A.table_rows * KBP + threadIdx.x] = (TV)0;     // the row of zeros behind the table (phase 2)
     const int tid = threadIdx.x;
     const int64_t blk = blockIdx.x;
     const int64_t ntiles = (A.m + 63) >> 6;
@@ -513,20 +528,19 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
     double *const Sout = A.S + ((int64_t)blockIdx.z * A.nblocks + blk) * A.cells;
     const int Q = (int)blockIdx.y * 256 + tid;
     const bool have = Q < A.total_quads;
-    int g = 0;
-    if (have)
-        while (g + 1 < A.n_slabs && Q >= A.slabs[g + 1].quad0) ++g;
-    const CodedSlab sl = A.slabs[g];
-    const int q = have ? Q - sl.quad0 : 0;
-    int ind[4];
-    bool ok[4];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        const int col = 4 * q + h;
-        ok[h] = have && col >= sl.col_lo && col < sl.col_hi;
-        ind[h] = sl.members[ok[h] ? col : sl.col_lo];
-    }
-    const uint4 *cptr = reinterpret_cast<const uint4 *>(sl.codes + (int64_t)q * 64);
+    auto slab_of = [&]() -> int {                          // (found again where it is needed rather than kept: see below)
+        int g = 0;
+        if (have)
+            while (g + 1 < A.n_slabs && Q >= A.slabs[g + 1].quad0) ++g;
+        return g;
+    };
+    const int g = slab_of();
+    // (Of the lane's slab only the address of its code words and their stride per tile stay in registers through the batches; the
+    // record itself is read again where it is needed -- for a SNP the encoder left uncoded, and for the sums' destinations at the end.
+    // Held throughout, its twelve registers and the four member indices were spilled, and a reload from scratch behind the batch's
+    // loads waits for those loads: vector memory returns in order.)
+    const uint4 *cptr = reinterpret_cast<const uint4 *>(A.slabs[g].codes + (int64_t)(have ? Q - A.slabs[g].quad0 : 0) * 64);
+    const int tile_words = A.slabs[g].nquads * 16;                                    // uint4 per tile of this slab's code words
     const int64_t s_begin = t0 << 6;
     const int64_t s_end = (t1 << 6) < A.m ? (t1 << 6) : A.m;
     const int nbatch = s_end > s_begin ? (int)((s_end - s_begin + CODED_BATCH - 1) / CODED_BATCH) : 0;
@@ -535,14 +549,30 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
         // what phase 1 needs of batch b, written by threads 0..15 (row offsets) and 16.. (frequencies)
         // (in two steps: the loads are issued at the start of a batch, their values go to LDS behind its phase 1 -- written where they
         // are loaded they cost every wavefront a trip to memory per batch)
-        auto prepare_load = [&](int b) -> int {
+        // (Round 5, late: every thread requests ONE byte and ONE float per batch from addresses of its own -- the class count of "its"
+        // SNP, the frequency of "its" (SNP, population) -- whether or not it has a use for them, through pointers typed as GLOBAL: a
+        // load inside a conditional block is waited for where the block ends (the compiler merges the two paths' registers there), a
+        // flat load counts as an LDS operation too (phase 1's LDS reads then wait for it), and the column pointer A.acol[k], fetched
+        // from device memory per batch, made it two dependent trips to memory -- together a sixth of the kernel's time, spent between
+        // a batch's start and its phase 1 (-DWGS_SCORE_STATS).  Not inline assembly: the compiler must know which registers have
+        // loads in flight, or it moves them -- a version that requested the code words by asm gave wrong sums at some launch shapes.)
+        typedef const __attribute__((address_space(1))) uint8_t *gl_u8_t;
+        typedef const __attribute__((address_space(1))) float *gl_f32_t;
+        const int pe = tid >= 64 && tid - 64 < CODED_BATCH * KB ? tid - 64 : 0, pj = pe / KB, pk = pe - pj * KB;
+        const gl_f32_t my_col = (gl_f32_t)A.acol[kb + pk < A.K ? kb + pk : A.K - 1];
+        const gl_u8_t all_ncls = (gl_u8_t)A.ncls;
+        auto prepare_load = [&](int b, int &got_ncls, float &got_a) {
             const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
-            if (tid < CODED_BATCH) return s0 + tid < s_end ? (int)A.ncls[s0 + tid] : 0;
-            if (tid >= 64 && tid - 64 < CODED_BATCH * KB) {
-                const int e = tid - 64, j = e / KB, k = e - j * KB;
-                const int kk = kb + k < A.K ? kb + k : A.K - 1;
-                return __float_as_int(s0 + j < s_end ? A.acol[kk][s0 + j] : 0.5f);
-            }
+            const int64_t sn = s0 + (tid & (CODED_BATCH - 1)) < s_end ? s0 + (tid & (CODED_BATCH - 1)) : s_end - 1;
+            const int64_t sa = s0 + pj < s_end ? s0 + pj : s_end - 1;
+            got_ncls = all_ncls[sn];
+            got_a = my_col[sa];
+        };
+        // what the two values mean for this thread (after a wait for them: vmcnt)
+        auto prepare_value = [&](int b, int got_ncls, float got_a) -> int {
+            const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
+            if (tid < CODED_BATCH) return s0 + tid < s_end ? got_ncls : 0;
+            if (tid >= 64 && tid - 64 < CODED_BATCH * KB) return __float_as_int(s0 + pj < s_end ? got_a : 0.5f);
             return 0;
         };
         auto prepare_store = [&](int b, int val) {
@@ -568,7 +598,12 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                 P.aval[j][k] = __int_as_float(val);
             }
         };
-        auto prepare = [&](int b) { prepare_store(b, prepare_load(b)); };
+        auto prepare = [&](int b) {
+            int got_ncls;
+            float got_a;
+            prepare_load(b, got_ncls, got_a);
+            prepare_store(b, prepare_value(b, got_ncls, got_a));
+        };
         double acc[4][KB];
 #pragma unroll
         for (int h = 0; h < 4; ++h)
@@ -606,23 +641,32 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
         };
         if (nbatch > 0) dma_rows(0);
         __syncthreads();
+#ifdef WGS_SCORE_STATS
+        unsigned long long stat_[8] = {0}, mark_ = clock64();
+#endif
         for (int b = 0; b < nbatch; ++b) {
             const CodedPrep &P = prep[b & 1];
             const int64_t s0 = s_begin + (int64_t)b * CODED_BATCH;
             const int64_t t = s0 >> 6;
             const int l0 = (int)(s0 & 63);
             const int nj = s_end - s0 < CODED_BATCH ? (int)(s_end - s0) : CODED_BATCH;
+            // the batch's code words (a lane without a quad reads quad 0's: valid classes, sums that nobody stores) and the next batch's
+            // class counts and frequencies: requested here, used behind phase 1
             uint4 cw[CODED_BATCH / 4];
-            if (have) {
-                const uint4 *line = cptr + (t * sl.nquads * 64 + l0) / 4;
+            {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                const __attribute__((address_space(1))) u32x4 *line = (const __attribute__((address_space(1))) u32x4 *)(cptr + (t * (int64_t)tile_words + l0 / 4));
 #pragma unroll
-                for (int x = 0; x < CODED_BATCH / 4; ++x) cw[x] = line[x];
-            } else {
-#pragma unroll
-                for (int x = 0; x < CODED_BATCH / 4; ++x) cw[x] = make_uint4(0, 0, 0, 0);
+                for (int x = 0; x < CODED_BATCH / 4; ++x) {
+                    const u32x4 v = line[x];
+                    cw[x] = make_uint4(v.x, v.y, v.z, v.w);
+                }
             }
-            const int next_val = b + 1 < nbatch ? prepare_load(b + 1) : 0;
+            int next_ncls;
+            float next_a;
+            prepare_load(b + 1 < nbatch ? b + 1 : b, next_ncls, next_a);      // (unconditionally: a register with a load in flight must not be merged with another value)
             // phase 1: vtab[rowoff[j] + c][k] from the staged dictionary entries
+            SCORE_CLOCK(0);
             const int items = 2 * P.rowoff[CODED_BATCH];
             for (int it = tid; it < items; it += 256) {
                 const int r = it >> 1, half = it & 1;
@@ -651,8 +695,11 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                     }
                 }
             }
-            if (b + 1 < nbatch) prepare_store(b + 1, next_val);
+            // (what was requested at the batch's start has had phase 1 to arrive)
+            if (b + 1 < nbatch) prepare_store(b + 1, prepare_value(b + 1, next_ncls, next_a));
+            SCORE_CLOCK(1);
             __syncthreads();
+            SCORE_CLOCK(2);
             // (the staged entries of this batch have been consumed; the code words, requested before phase 1, are here -- said explicitly,
             // because with a transfer to LDS in flight the compiler waits for ALL outstanding loads at the next use of a loaded value)
 #pragma unroll
@@ -666,34 +713,43 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                 // 8-byte LDS loads into ds_read2_b64, which the LDS serves at half the rate and with the 32-bank mapping -- and pipelined by
                 // hand: the reads of the next individual are in flight while the current one's values are added (counted lgkmcnt waits;
                 // LDS operations complete in order, and anything else that counts on lgkmcnt only makes a counted wait wait longer)
+                //
+                // Round 5 (late): ONE pipeline over the batch's 4 x CODED_BATCH (SNP, individual) items instead of one per SNP.  The
+                // per-SNP version read the SNP's row offset from LDS and waited for it with every earlier read drained, skipped absent /
+                // uncoded SNPs by a (uniform) branch, and drained again behind the SNP's fourth individual: two exposed LDS round trips
+                // per SNP and wavefront.  Now the row offsets are fetched once per batch into scalar registers, an absent or uncoded
+                // SNP reads class 0 of a ROW OF ZEROS behind the table (x + 0.0 = x bit for bit; a sum that starts at +0.0 is never
+                // -0.0) so that the sixteen SNPs are the same straight-line code, and the next item's reads are in flight while the
+                // current one's values are added all the way through the batch.
                 const unsigned vtab_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)reinterpret_cast<unsigned char *>(vtab);
+                const unsigned zero_addr = vtab_addr + (unsigned)A.table_rows * (unsigned)(KBP * 8);
+                unsigned base[CODED_BATCH], word[CODED_BATCH];
 #pragma unroll
                 for (int j = 0; j < CODED_BATCH; ++j) {
-                    if (j < nj && !((uncoded_snps >> j) & 1u)) {
-                        const unsigned w = cwv[j];
-                        const unsigned base_j = vtab_addr + (unsigned)P.rowoff[j] * (unsigned)(KBP * 8);
-                        double va[KB], vb[KB];
-                        CodedRow<KB>::issue(va, base_j + ((w >> 0) & 255u) * (unsigned)(KBP * 8));
-                        CodedRow<KB>::issue(vb, base_j + ((w >> 8) & 255u) * (unsigned)(KBP * 8));
-                        lds_wait<KB>();
-                        CodedRow<KB>::arrived(va);
+                    const bool skip = j >= nj || ((uncoded_snps >> j) & 1u);
+                    const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane(P.rowoff[j]);
+                    base[j] = skip ? zero_addr : vtab_addr + off * (unsigned)(KBP * 8);
+                    word[j] = skip ? 0u : cwv[j];
+                }
+                auto row_addr = [&](int i) -> unsigned { return base[i >> 2] + ((word[i >> 2] >> (8 * (i & 3))) & 255u) * (unsigned)(KBP * 8); };
+                double va[KB], vb[KB];
+                CodedRow<KB, 0>::issue(va, row_addr(0));
 #pragma unroll
-                        for (int k = 0; k < KB; ++k) acc[0][k] += va[k];
-                        CodedRow<KB>::issue(va, base_j + ((w >> 16) & 255u) * (unsigned)(KBP * 8));
-                        lds_wait<KB>();
-                        CodedRow<KB>::arrived(vb);
+                for (int i = 0; i < 4 * CODED_BATCH; i += 2) {
+                    CodedRow<KB, 0>::issue(vb, row_addr(i + 1));
+                    lds_wait<KB>();
+                    CodedRow<KB, 0>::arrived(va);
 #pragma unroll
-                        for (int k = 0; k < KB; ++k) acc[1][k] += vb[k];
-                        CodedRow<KB>::issue(vb, base_j + ((w >> 24) & 255u) * (unsigned)(KBP * 8));
+                    for (int k = 0; k < KB; ++k) acc[i & 3][k] += va[k];
+                    if (i + 2 < 4 * CODED_BATCH) {
+                        CodedRow<KB, 0>::issue(va, row_addr(i + 2));
                         lds_wait<KB>();
-                        CodedRow<KB>::arrived(va);
-#pragma unroll
-                        for (int k = 0; k < KB; ++k) acc[2][k] += va[k];
+                    } else {
                         lds_wait<0>();
-                        CodedRow<KB>::arrived(vb);
-#pragma unroll
-                        for (int k = 0; k < KB; ++k) acc[3][k] += vb[k];
                     }
+                    CodedRow<KB, 0>::arrived(vb);
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) acc[(i + 1) & 3][k] += vb[k];
                 }
             } else {
 #pragma unroll
@@ -723,6 +779,9 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
             for (int j = 0; j < (uncoded_snps ? nj : 0); ++j) {
                 if ((uncoded_snps >> j) & 1u) {
                     if (have) {
+                        const int gu = slab_of();
+                        const CodedSlab sl = A.slabs[gu];
+                        const int q = Q - sl.quad0;
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) {
                             const int pair = 2 * q + pr < sl.npairs ? 2 * q + pr : sl.npairs - 1;
@@ -746,19 +805,39 @@ __global__ __launch_bounds__(256, 3) void score_coded_kernel(CodedScoreArgs A)
                                         v = site_ll_fast(g0, g1, g2f, a);
                                     }
                                     acc[2 * pr + hh][k] += (double)v;
+                                    // (one evaluation after the other: interleaved, this rare path's forty evaluations set the
+                                    // kernel's register need and made the common path spill)
+                                    __builtin_amdgcn_sched_barrier(0);
                                 }
                             }
                         }
                     }
                 }
             }
+            SCORE_CLOCK(3);
             __syncthreads();                                   // (also drains the transfers into the stage: vmcnt(0))
+            SCORE_CLOCK(4);
         }
+#ifdef WGS_SCORE_STATS
+        if ((tid & 63) == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_score_stats[i], stat_[i]);
+            atomicAdd(&g_score_stats[5], (unsigned long long)nbatch);
+            atomicAdd(&g_score_stats[6], 1ull);
+        }
+#endif
+        {
+            const CodedSlab sl = A.slabs[slab_of()];
+            const int qs = have ? Q - sl.quad0 : 0;
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
+            for (int h = 0; h < 4; ++h) {
+                const int col = 4 * qs + h;
+                const bool ok = have && col >= sl.col_lo && col < sl.col_hi;
+                const int ind = sl.members[ok ? col : sl.col_lo];
 #pragma unroll
-            for (int k = 0; k < KB; ++k)
-                if (ok[h] && kb + k < A.K) Sout[(int64_t)ind[h] * A.K + kb + k] = acc[h][k];
+                for (int k = 0; k < KB; ++k)
+                    if (ok && kb + k < A.K) Sout[(int64_t)ind * A.K + kb + k] = acc[h][k];
+            }
+        }
     }
 }
 
@@ -1331,7 +1410,7 @@ size_t score_coded_lds_bytes(int rows, int kb, int batch)
 {
     const size_t row = (batch < 16 || score_coded_wide(kb)) ? sizeof(double) * (kb | 1) : sizeof(float) * ((kb + 3) & ~3);
     return sizeof(double2) * WGS_LOG_N * CODED_LOG_REP + ((2 * sizeof(CodedPrep) + 15) & ~(size_t)15) + sizeof(float2) * (size_t)((rows + 1) & ~1) +
-           row * (size_t)rows;
+           row * (size_t)(rows + 1);                      // (+ the row of zeros that absent and uncoded SNPs read)
 }
 
 // The scoring sweep through the class codes (shared columns only).  d_slabs: n_slabs CodedSlab records in device memory.
@@ -1414,6 +1493,17 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     WGS_FOR_KB(WGS_CODED, K)
 #undef WGS_CODED
     HIP_TRY(hipGetLastError());
+#ifdef WGS_SCORE_STATS
+    {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned long long st[8] = {0}, zero[8] = {0};
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_score_stats), sizeof st);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_score_stats), zero, sizeof zero);
+        const double w = st[6] ? (double)st[6] : 1.0, nb = st[5] ? (double)st[5] : 1.0;
+        fprintf(stderr, "[score stats] %llu wavefronts, %.0f batches each; cycles per wavefront and batch: before phase 1 %.0f, phase 1 %.0f, barrier %.0f, phase 2 %.0f, "
+                "barrier %.0f\n", st[6], nb / w, st[0] / nb, st[1] / nb, st[2] / nb, st[3] / nb, st[4] / nb);
+    }
+#endif
     if (parts > 1) {
         hipLaunchKernelGGL(combine_parts_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, A.S, S, total, parts);
         HIP_TRY(hipGetLastError());
