@@ -256,13 +256,13 @@ bool wgs_codes_scoring_model(wgs_beagle *b, int K, double *direct_ms, double *co
     *coded_share = 1.0;
     *build_ms = 0.0;
     if (!P || P->state <= 0) return false;
-    // the coded sweep: per SNP and population the table work (one evaluation per class, 3.35e-9 ms) and the look-ups of one workgroup's
-    // 1024 individuals, whether they exist or not (4.2e-8 ms) -- a workgroup per 1024 individuals, each filling its own table.  Fitted
-    // to 10M x 1000 x 10 (26 classes: 13.0 ms), 2M x 1000 x 10 with 73 classes (5.7 ms); 2M x 500 x 8 (2.4 ms), 6.25M x 2000 x 20
-    // (39.7 ms) and 5M x 180 x 5 (where building for ONE sweep loses a millisecond: round 4's share, 1.25 x classes / individuals +
-    // 0.09, built there) check it to 10-20 %.
+    // the coded sweep: per SNP and population the table work (one evaluation per class, 2.9e-9 ms) and the look-ups of one workgroup's
+    // 1024 individuals, whether they exist or not (3.65e-8 ms) -- a workgroup per 1024 individuals, each filling its own table.  Fitted
+    // to 10M x 1000 x 10 (26 classes: 11.3 ms since the kernel stopped waiting for its own loads, 13.0 before: both constants x 0.87),
+    // 2M x 1000 x 10 with 73 classes (4.8 ms); 2M x 500 x 8 (2.35 ms), 6.25M x 2000 x 20 (32 ms) and 5M x 180 x 5 (where building
+    // for ONE sweep loses a millisecond: round 4's share, 1.25 x classes / individuals + 0.09, built there) check it to 10-20 %.
     const double groups = (double)((b->n + 1023) / 1024);
-    const double coded_ms = (double)b->m * (double)K * groups * (3.35e-9 * P->mean_g + 4.2e-8);
+    const double coded_ms = (double)b->m * (double)K * groups * (2.9e-9 * P->mean_g + 3.65e-8);
     *coded_share = std::min(1.0, coded_ms / std::max(1e-9, *direct_ms));
     *build_ms = wgs_codes_build_ms_estimate(b, P->slots, false);
     return true;
