@@ -489,14 +489,35 @@ __device__ __forceinline__ float coded_phase2(const QTable &q, gu32_ptr src, int
     return tmp;
 }
 
+#ifdef WGS_EM_STATS
+// (experiments: -DWGS_EM_STATS adds up over the wavefronts of em_coded_kernel the clock cycles [0] from the wavefront's start until the
+// tile's row count is known, [1] until its dictionary rows have arrived, [2] in phase 1, [3] in phase 2, [4] finishing (divide, store,
+// the tile's share of the sum of squares); [5] iterations, [6] wavefronts; printed and reset by wgs_debug_em_stats.)
+__device__ unsigned long long g_em_stats[8];
+#define EM_CLOCK(i) do { const unsigned long long now_ = clock64(); stat_[i] += now_ - mark_; mark_ = now_; } while (0)
+#else
+#define EM_CLOCK(i) do { } while (0)
+#endif
+
 template <int U, int ILP, int ROWS>
-__device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], const QTable &q, int nrows, gu32_ptr src, int nquads, int ncols, int skip, float f_old)
+__device__ __forceinline__ float coded_iteration(const double (&r)[ROWS], const QTable &q, int nrows, gu32_ptr src, int nquads, int ncols, int skip, float f_old
+#ifdef WGS_EM_STATS
+                                                 , unsigned long long (&stat_)[8], unsigned long long &mark_
+#endif
+)
 {
     const int last = nquads - 1;
     uint32_t cur[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = src[(u < last ? u : last) * 64];      // in flight during phase 1
     coded_phase1_lane<ILP, ROWS>(r, q, nrows, f_old);
+#ifdef WGS_EM_STATS
+    {
+        const unsigned long long now_ = clock64();
+        stat_[2] += now_ - mark_;
+        mark_ = now_;
+    }
+#endif
     return coded_phase2<U, ROWS>(q, src, nquads, ncols, skip, cur);
 }
 
@@ -512,6 +533,9 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
     const int lane = threadIdx.x;
     const int64_t row0 = tile * 64;
     if (row0 >= m) return;                       // wave-uniform; no barriers below
+#ifdef WGS_EM_STATS
+    unsigned long long stat_[8] = {0}, mark_ = clock64();
+#endif
     const QTable q = qtable_of(qtab_all, lane);
 
     const int64_t my_row = row0 + lane;
@@ -549,6 +573,7 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
         }
         nrows = (int)__builtin_amdgcn_readfirstlane((int)mx);
     }
+    EM_CLOCK(0);
     if (nrows > ROWS || nrows > fd.lrows) {
         // a SNP of this tile shows more classes in this slab than the table has rows (~1 % of the tiles, codes.hip):
         // the tile is swept from the float32 slab, term by term as em_sweep_kernel does
@@ -582,11 +607,36 @@ __global__ __launch_bounds__(64) void em_coded_kernel(const FitDesc *__restrict_
             }
         }
     }
+#ifdef WGS_EM_STATS
+    {
+        double any = 0.0;                                    // (the rows' arrival, made visible to the clock)
+#pragma unroll
+        for (int x = 0; x < ROWS; x += 4)
+            if (x < nrows) any += r[x];
+        asm volatile("" : "+v"(any));
+        EM_CLOCK(1);
+    }
+#endif
     for (int it = 0; it < n_iter; ++it) {
+#ifdef WGS_EM_STATS
+        const float tmp = coded_iteration<U, ILP, ROWS>(r, q, nrows, src, nquads, fd.ncols, fd.skip, f_old, stat_, mark_);
+        EM_CLOCK(3);
+        f_old = finish(tmp, it);
+        EM_CLOCK(4);
+#else
         const float tmp = coded_iteration<U, ILP, ROWS>(r, q, nrows, src, nquads, fd.ncols, fd.skip, f_old);     // (the second iteration finds the code words in cache)
         f_old = finish(tmp, it);
+#endif
         // (the table of the next iteration is written by the same lanes that read this one's: program order suffices)
     }
+#ifdef WGS_EM_STATS
+    if (lane == 0 && (blockIdx.x & 127u) < 8u) {                // (a sample: atomics from 1.5 M wavefronts to seven addresses would BE the kernel's time)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) atomicAdd(&g_em_stats[i], stat_[i]);
+        atomicAdd(&g_em_stats[5], (unsigned long long)n_iter);
+        atomicAdd(&g_em_stats[6], 1ull);
+    }
+#endif
 }
 
 // Leave-one-out batches through the codes: groups[g] = (first descriptor, count) into `fits`, all of one slab (as for
@@ -684,7 +734,12 @@ __global__ __launch_bounds__(64) void em_coded_group_kernel(const FitDesc *__res
         const float f_old = f_next;
         if (f + 1 < gd.y) f_next = ((gf32_ptr)fd[1].f_old)[my_row_c];       // in flight during this fit's arithmetic
         if (fd->state && *fd->state != EM_ACTIVE) continue;                  // decided on the device: skip (wave-uniform)
+#ifdef WGS_EM_STATS
+        unsigned long long stat_[8] = {0}, mark_ = 0;              // (this kernel is not the one being timed)
+        const float tmp = coded_iteration<U, ILP, ROWS>(r, q, nrows, src, nquads, ncols, fd->skip, f_old, stat_, mark_);
+#else
         const float tmp = coded_iteration<U, ILP, ROWS>(r, q, nrows, src, nquads, ncols, fd->skip, f_old);
+#endif
         finish(fd, tmp, f_old);
     }
 }
@@ -1254,6 +1309,17 @@ int launch_em_coded(wgs_ctx *ctx, const FitDesc *d_descs, int32_t n_fits, int64_
     }
 #undef WGS_EMC
     HIP_TRY(hipGetLastError());
+#ifdef WGS_EM_STATS
+    {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned long long st[8] = {0}, zero[8] = {0};
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_em_stats), sizeof st);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_em_stats), zero, sizeof zero);
+        const double w = st[6] ? (double)st[6] : 1.0;
+        fprintf(stderr, "[em stats] %llu wavefronts, %.2f iterations each; cycles per wavefront: until the row count %.0f, until the dictionary rows %.0f, phase 1 %.0f, "
+                "phase 2 %.0f, finishing %.0f\n", st[6], st[5] / w, st[0] / w, st[1] / w, st[2] / w, st[3] / w, st[4] / w);
+    }
+#endif
     return 0;
 }
 
