@@ -83,9 +83,22 @@ enum EncStat {
     ST_COUNT = 8
 };
 
+#ifdef WGS_ENC_STATS
+// (experiments: -DWGS_ENC_STATS adds up over a sample of class_encode_kernel's wavefronts the clock cycles [0] before the first slab,
+// [1] in the slabs' walks (hash, insert, code words), [2] at the slabs' ends (the slab's own numbering), [3] at the end (dictionary
+// rows, records); [4] wavefronts sampled; printed and reset by launch_class_encode.)
+__device__ unsigned long long g_enc_stats[8];
+#define ENC_CLOCK(i) do { const unsigned long long now_ = clock64(); stat_[i] += now_ - mark_; mark_ = now_; } while (0)
+#else
+#define ENC_CLOCK(i) do { } while (0)
+#endif
+
 template <int SNPS, bool SAMPLE>
 __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_kernel(EncodeArgs A)
 {
+#ifdef WGS_ENC_STATS
+    unsigned long long stat_[4] = {0, 0, 0, 0}, mark_ = clock64();
+#endif
     constexpr int COLS = 64 / SNPS, T = ENC_SLOTS / SNPS, NW = T / 64;              // NW 64-bit words hold a bit per class of a SNP
     constexpr unsigned TMASK = T - 1, HSHIFT = T == 64 ? 26 : (T == 128 ? 25 : 24);
     constexpr int NL = 4 * ENC_UQ;                         // lookups per lane and buffer
@@ -179,6 +192,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
         return pos;
     };
 
+    ENC_CLOCK(0);
     for (int g = 0; g < A.n_slabs; ++g) {
         const int np = A.npairs[g], nc = A.ncols[g];
         const SlabCodes sc = A.slabs[g];
@@ -323,6 +337,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
             }
         }
         // ---- slab end: the slab's own numbering = the rank of a class among the classes met in this slab
+        ENC_CLOCK(1);
         if (nid > T || nid > 254) rich = true;
         rich = snp_or(rich);
 #pragma unroll
@@ -376,6 +391,7 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
 
     // ---- end: the SNP's classes are numbered already; its dictionary rows, in that order
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    ENC_CLOCK(2);
     const int ncls = nid;
     if (ncls > A.drows || ncls > 254 || ncls > T) rich = true;
     // the one bit pattern used as EMPTY, looked up: it "went in" without changing its slot -- that SNP cannot be coded
@@ -431,6 +447,14 @@ __global__ __launch_bounds__(64, ENC_SLOTS >= 2048 ? 2 : 4) void class_encode_ke
     gu64_ptr dd = (gu64_ptr)A.dict + (tile * A.drows) * 64 + ls;
     for (int r0 = col; r0 < wmax; r0 += COLS)
         if (r0 < eff) dd[(int64_t)r0 * 64] = keys[(unsigned)slot_of[r0 * SNPS + s] * SNPS + s];
+#ifdef WGS_ENC_STATS
+    ENC_CLOCK(3);
+    if (lane == 0 && (blockIdx.x & 63u) == 0u) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(&g_enc_stats[i], stat_[i]);
+        atomicAdd(&g_enc_stats[4], 1ull);
+    }
+#endif
 }
 
 // After the sample pass: hist[c] = sampled SNPs with c classes, hist[256 + c] = sampled (slab, SNP) pairs with c classes in the slab
@@ -597,6 +621,16 @@ int launch_class_encode(wgs_beagle *b, wgs_codes *c)
     unsigned long long *h = reinterpret_cast<unsigned long long *>(b->ctx->pinned);
     HIP_TRY(hipMemcpyAsync(h, d_stats, sizeof(unsigned long long) * 8, hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+#ifdef WGS_ENC_STATS
+    {
+        unsigned long long st[8] = {0}, zero[8] = {0};
+        (void)hipMemcpyFromSymbol(st, HIP_SYMBOL(g_enc_stats), sizeof st);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_enc_stats), zero, sizeof zero);
+        const double w = st[4] ? (double)st[4] : 1.0;
+        fprintf(stderr, "[encode stats] %llu wavefronts sampled; cycles per wavefront: before the slabs %.0f, the slabs' walks %.0f, the slabs' ends %.0f, the end %.0f\n",
+                st[4], st[0] / w, st[1] / w, st[2] / w, st[3] / w);
+    }
+#endif
     float ev_ms = 0.0f;
     if (hipEventElapsedTime(&ev_ms, b->ctx->enc_ev0, b->ctx->enc_ev1) == hipSuccess) c->kernel_ms = ev_ms;     // the encode kernel alone (HIP events)
     c->sum_ncls = (double)h[ST_SUM_NCLS];
