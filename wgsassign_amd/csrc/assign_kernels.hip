@@ -522,9 +522,11 @@ __global__ __launch_bounds__(256, WGS_SCORE_CODED_WAVES) void score_coded_kernel
     const int tid = threadIdx.x;
     const int64_t blk = blockIdx.x;
     const int64_t ntiles = (A.m + 63) >> 6;
-    const int tiles_per_part = WGS_BLOCK_TILES / A.parts;
+    // (a block's tiles in `parts` runs of ceil(64 / parts) tiles, the last one shorter: any count up to 16, not only the powers of two)
+    const int tiles_per_part = (WGS_BLOCK_TILES + A.parts - 1) / A.parts;
     const int64_t t0 = blk * WGS_BLOCK_TILES + (int64_t)blockIdx.z * tiles_per_part;
-    const int64_t t1 = t0 + tiles_per_part < ntiles ? t0 + tiles_per_part : ntiles;
+    const int64_t block_end = (blk + 1) * WGS_BLOCK_TILES < ntiles ? (blk + 1) * WGS_BLOCK_TILES : ntiles;
+    const int64_t t1 = t0 + tiles_per_part < block_end ? t0 + tiles_per_part : block_end;
     double *const Sout = A.S + ((int64_t)blockIdx.z * A.nblocks + blk) * A.cells;
     const int Q = (int)blockIdx.y * 256 + tid;
     const bool have = Q < A.total_quads;
@@ -1445,25 +1447,28 @@ int launch_score_coded(wgs_ctx *ctx, const wgs_codes *c, const void *d_slabs, in
     // A block's 64 tiles go to `parts` workgroups: enough of them to fill the chip (short matrices), and -- the workgroups all take
     // the same time -- a count that does not leave the last round of workgroups mostly empty: 2442 blocks on 768 places (3 per CU by
     // registers, fewer when the table is large) are 3.18 rounds, i.e. a fifth of the chip-time idle; in halves 6.36 of 7, in quarters
-    // 12.7 of 13.  The smallest split within 4 % of full rounds (or the best there is) is taken.
+    // 12.7 of 13.
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (160 * 1024) / std::max<size_t>(lds, 1)));
     const double places = (double)std::max(1, ctx->cus) * per_cu;
+    // Any count from 1 to 16 whose runs of ceil(64 / parts) tiles are all non-empty (round 5, late: the powers of two alone left a
+    // shard of 1.25M SNPs -- 306 blocks -- at 6.4 rounds of 7 with 16 parts; 5 parts are 1.99 rounds of 2).  The workgroups all take
+    // about the same time, a run's tiles plus what a workgroup costs before its first one (the log table, the first batch's trips to
+    // memory: about a tile's worth), so the split with the fewest rounds x (tiles per run + 1) wins -- tools/probe_score_parts.py
+    // times every split: 5 at 1.25M SNPs (1.44 ms; 16: 1.59), 10 at 300 k (0.45 ms; 16: 0.46, 4: 0.73), 3-5 or 12 at 10M (within 2 %).
+    auto usable = [](int p) { return (p - 1) * ((WGS_BLOCK_TILES + p - 1) / p) < WGS_BLOCK_TILES; };
     int parts = 1;
-    while (parts < 16 && (int64_t)nblocks * ygroups * parts < 1536) parts *= 2;   // >= 6 workgroups per CU, or 4 tiles per part
     {
-        int best = parts;
-        double best_eff = 0.0;
-        for (int p = parts; p <= 16; p *= 2) {
-            const double rounds = (double)nblocks * ygroups * p / places;
-            const double eff = rounds / ceil(rounds);
-            if (eff > best_eff + 1e-9) best = p, best_eff = eff;
-            if (eff >= 0.96) break;
+        double best_cost = 0.0;
+        for (int p = 1; p <= 16; ++p) {
+            if (!usable(p)) continue;
+            const double rounds = ceil((double)nblocks * ygroups * p / places);
+            const double cost = rounds * (double)((WGS_BLOCK_TILES + p - 1) / p + 1);
+            if (p == 1 || cost < best_cost - 1e-9) parts = p, best_cost = cost;
         }
-        parts = best;
     }
-    if (const char *pe = getenv("WGS_SCORE_CODED_PARTS")) {        // experiments: 1, 2, 4, 8, 16
+    if (const char *pe = getenv("WGS_SCORE_CODED_PARTS")) {        // experiments: 1 .. 16
         const int v = atoi(pe);
-        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) parts = v;
+        if (v >= 1 && v <= 16 && usable(v)) parts = v;
     }
     A.parts = parts;
     const int64_t total = (int64_t)nblocks * cells;
