@@ -738,3 +738,28 @@ def test_compressed_hand_over_reports_damaged_files(tmp_path, monkeypatch):
         fh.write(bytes(bad))
     with pytest.raises(RuntimeError, match="corrupt or truncated"):
         _comp_text(dmg, 2 << 20, 8 << 20, threads=2, cap=200 << 20)
+
+
+@pytest.mark.parametrize("block", [700, 60000])
+def test_site_estimate_of_a_bgzf_file(tmp_path, block):
+    """wgs_reader_estimate_sites (what sizes the device matrix of a file met for the first time, before its index pass has counted
+    the sites): five samples of a quarter megabyte, newlines per compressed byte times the file size -- within a few per cent of
+    the count on homogeneous text, whatever the block size; nothing to say about a plain gzip file (rc 3 -> None)."""
+    import gzip
+    from wgsassign_amd import reader_cy
+    m, n = 9000, 23
+    L, _ = synth.make_beagle(m, n, 2, seed=29)
+    text = _text_of(L)
+    p = str(tmp_path / "e.beagle.gz")
+    _bgzf_write(p, text, block=block)
+    est = reader_cy.estimate_sites(p)
+    assert est is not None and abs(est - m) <= m // 20, est
+    assert reader_cy.count_sites(p) == m
+    q = str(tmp_path / "plain.beagle.gz")
+    with gzip.open(q, "wb") as fh:
+        fh.write(text.encode())
+    assert reader_cy.estimate_sites(q) is None
+    tiny = str(tmp_path / "tiny.beagle.gz")                       # smaller than one sample: the first sample is all of it
+    _bgzf_write(tiny, _text_of(L[:40]), block=block)
+    t = reader_cy.estimate_sites(tiny)
+    assert t is not None and 35 <= t <= 48, t
