@@ -68,6 +68,13 @@ int wgs_debug_log_values(wgs_ctx *ctx, const float *x, float *out, int64_t n, in
  * *nchunks is set) receives ceil(blocks / 2) x n*K float64, out[c * n*K + i * K + k]. */
 int wgs_debug_score_chunks(wgs_score *sc, double *out, int64_t *nchunks);
 
+/* The two device kernels around a tagged RCCL collective (csrc/rccl_comm.hip: the row every rank writes behind the payload, the
+ * comparison of all ranks' rows with one's own behind the all-reduce) on rows made up by the caller: what the ranks of a world-rank
+ * job would run -- RCCL refuses two ranks on one GPU, so no test reaches them otherwise.  rows: world x 8 float64 {sequence number,
+ * step, generation, iteration, shape, shape, payload elements, free word}; as_rank: whose check runs.  fault_out (18 float64):
+ * [0] = 1 when the check reported a difference, [1] the other rank, [2..9] this rank's row, [10..17] the other's. */
+int wgs_debug_comm_tag_kernels(wgs_ctx *ctx, int32_t world, const double *rows, int32_t as_rank, double *fault_out);
+
 /* Cross-check only: FLOAT64 partition sums parts[(i*P + p)*K + k] (labels = global site index % P) and totals from the
  * round-1 kernel (lanes <-> pairs of individuals, tile ranges combined with float64 atomics): ~1e-5 from the
  * reference's serial float32 partition sums, not reproducible run to run.  Not on the product path. */

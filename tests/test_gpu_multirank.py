@@ -322,6 +322,44 @@ def test_three_ranks_sums_are_the_single_gpu_sums_bit_for_bit(tmp_path):
         assert "RANK %d OK" % r in o
 
 
+def test_the_tag_kernels_of_an_rccl_collective_on_made_up_ranks():
+    """The device code an N > 1 RCCL job runs around every collective -- the row each rank writes behind the payload, and, behind the
+    all-reduce, the comparison of ALL ranks' rows with one's own (csrc/rccl_comm.hip) -- on rows made up here for 2, 8 and 64 ranks
+    (RCCL refuses two ranks on one GPU, and no multi-GPU box has been available): rows that agree pass for every rank; a difference in
+    any compared word of any rank is reported by every other rank, with both rows; the free word is not compared."""
+    import ctypes
+    import numpy as np
+    from wgsassign_amd import _lib, device
+    lib = _lib.load()
+    ctx = device.get_context()
+
+    def check(rows, as_rank):
+        rows = np.ascontiguousarray(rows, dtype=np.float64)
+        out = np.zeros(18, dtype=np.float64)
+        _lib.check(lib.wgs_debug_comm_tag_kernels(ctx.handle, rows.shape[0], rows.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), as_rank,
+                                                  out.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
+        return out
+
+    base = np.array([41.0, 1.0, 7.0, 3.0, 10.0, 2.0, 20.0, 0.0])        # sequence number, step, generation, iteration, shapes, size, free word
+    for world in (1, 2, 8, 64):
+        rows = np.tile(base, (world, 1))
+        rows[:, 7] = np.arange(world)                                    # the free word differs on purpose (the fuse agreement travels in it)
+        for r in {0, world // 2, world - 1}:
+            assert check(rows, r)[0] == 0.0, (world, r)
+        if world == 1:
+            continue
+        for word in range(7):                                            # every compared word
+            bad = world - 1 if word % 2 else world // 3
+            other = rows.copy()
+            other[bad, word] += 1.0
+            for r in {0, world // 2, world - 1} - {bad}:
+                out = check(other, r)
+                assert out[0] == 1.0 and int(out[1]) == bad, (world, word, r, out)
+                assert np.array_equal(out[2:10], other[r]) and np.array_equal(out[10:18], other[bad])
+            out = check(other, bad)                                      # the odd one out sees somebody else's row differ
+            assert out[0] == 1.0 and int(out[1]) != bad and np.array_equal(out[2:10], other[bad])
+
+
 def test_native_rccl_single_rank():
     """The library's own RCCL communicator (dlopen'ed librccl, no torch): with one rank the all-reduce
     is the identity -- exercises loading, unique id, init, the stream-ordered collective, destroy."""

@@ -141,6 +141,7 @@ SIGNATURES = {
     "wgs_score_last_serial_blocks": (c_int, [c_vp, ctypes.POINTER(c_i64)]),
     "wgs_debug_hook": (c_int, [ctypes.c_char_p, c_i64]),
     "wgs_debug_score_chunks": (c_int, [c_vp, c_f64p, ctypes.POINTER(c_i64)]),
+    "wgs_debug_comm_tag_kernels": (c_int, [c_vp, c_i32, c_f64p, c_i32, c_f64p]),
     "wgs_debug_parts_exact_literal": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_f32p, c_f32p]),
     "wgs_assign": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_int, c_f64p]),
     "wgs_debug_assign_parts_f64": (c_int, [c_vp, c_vp, ctypes.POINTER(c_vp), c_i32, c_int, c_f64p, c_f64p]),

@@ -588,4 +588,48 @@ int wgs_comm_allreduce_f64(wgs_comm *c, double *host_buf, int64_t n)
     return wgs_comm_allreduce_host_tagged(c, host_buf, n, nullptr, nullptr);
 }
 
+/* Test hook (include/wgsassign_hip_debug.h): the two kernels around a tagged RCCL collective, on rows made up by the caller -- what
+ * every rank of a `world`-rank job would run, with the sum all-reduce in between done here by adding the ranks' tables.  rows:
+ * world x 8 float64 (what each rank would issue); as_rank: whose check runs.  fault_out[0] = 1 if the check kernel reported a
+ * difference, then fault_out[1] = the other rank, fault_out[2..9] = this rank's row, fault_out[10..17] = the other's. */
+int wgs_debug_comm_tag_kernels(wgs_ctx *ctx, int32_t world, const double *rows, int32_t as_rank, double *fault_out)
+{
+    WGS_REQUIRE(ctx && rows && fault_out && world >= 1 && world <= WGS_COMM_MAX_WORLD && as_rank >= 0 && as_rank < world, "bad argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t words = (size_t)world * WGS_TAG_WORDS;
+    double *d_tab = nullptr, *d_sum = nullptr;
+    CommFault *fault = nullptr;
+    HIP_TRY(wgs_malloc(reinterpret_cast<void **>(&d_tab), sizeof(double) * words));
+    HIP_TRY(wgs_malloc(reinterpret_cast<void **>(&d_sum), sizeof(double) * words));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&fault), sizeof(CommFault), hipHostMallocDefault));
+    memset(fault, 0, sizeof(CommFault));
+    std::vector<double> sum(words, 0.0), one(words);
+    for (int r = 0; r < world; ++r) {                                  // every rank's table, as comm_tag_write_kernel lays it out
+        CommRow row;
+        for (int w = 0; w < WGS_TAG_WORDS; ++w) row.w[w] = rows[(size_t)r * WGS_TAG_WORDS + w];
+        hipLaunchKernelGGL(comm_tag_write_kernel, dim3(1), dim3(64), 0, ctx->stream, d_tab, world, r, row);
+        HIP_TRY(hipMemcpyAsync(one.data(), d_tab, sizeof(double) * words, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < words; ++i) sum[i] += one[i];           // (the sum all-reduce)
+    }
+    HIP_TRY(hipMemcpyAsync(d_sum, sum.data(), sizeof(double) * words, hipMemcpyHostToDevice, ctx->stream));
+    CommRow mine;
+    for (int w = 0; w < WGS_TAG_WORDS; ++w) mine.w[w] = rows[(size_t)as_rank * WGS_TAG_WORDS + w];
+    CommFault *fault_dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&fault_dev), fault, 0));
+    hipLaunchKernelGGL(comm_tag_check_kernel, dim3(1), dim3(64), 0, ctx->stream, d_sum, world, 0, as_rank, mine, fault_dev);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    fault_out[0] = (double)fault->flag;
+    fault_out[1] = (double)fault->other;
+    for (int w = 0; w < WGS_TAG_WORDS; ++w) {
+        fault_out[2 + w] = fault->mine[w];
+        fault_out[2 + WGS_TAG_WORDS + w] = fault->theirs[w];
+    }
+    (void)hipFree(d_tab);
+    (void)hipFree(d_sum);
+    (void)hipHostFree(fault);
+    return 0;
+}
+
 }  // extern "C"
