@@ -310,3 +310,34 @@ def test_cold_file_goes_through_in_one_pass(tmp_path, monkeypatch):
     assert b1.m == m - 1280 and same_bits(b1.download_rows(0, b1.m), want[:b1.m])
     b0.close()
     b1.close()
+
+
+def test_cold_file_one_pass_at_the_streamed_configurations_width(tmp_path, monkeypatch):
+    """The one-pass way on a shard as wide as BASELINE configs[4] (n = 2000, K = 20; 60 k sites = 3.2 GB of text, several chunks,
+    an estimate from five samples of a 160 MB file): EVERY row of the trimmed matrix equals the matrix of the usual way (index
+    first), which equals the source values; the estimate is within 2 %."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import beagle_files
+    from wgsassign_amd import reader_cy
+    n, m, K = 2000, 60_000, 20
+    p = str(tmp_path / "wide.beagle.gz")
+    _, vals, pick = beagle_files.write_lowdepth_bgzf(p, n, m)
+    group_of = (np.arange(n) % K).astype(np.int32)
+    est = reader_cy.estimate_sites(p)
+    assert est is not None and abs(est - m) <= m // 50
+    out = {}
+    for label, one_pass in (("usual", "0"), ("cold", "1")):
+        monkeypatch.setenv("WGSASSIGN_INDEX_DIR", str(tmp_path / label))
+        os.makedirs(str(tmp_path / label), mode=0o700, exist_ok=True)
+        monkeypatch.setenv("WGSASSIGN_COLD_ONE_PASS", one_pass)
+        b, samples, sites, m_total = reader_cy.stream_to_device(p, group_of, K, names="ends")
+        assert m_total == m and b.m == m and os.path.exists(reader_cy.index_paths(p)[0])
+        digests = []
+        for r0 in range(0, m, 10_000):                              # 160 MB of rows at a time
+            rows = b.download_rows(r0, min(10_000, m - r0))
+            assert same_bits(rows, vals[pick[r0:r0 + rows.shape[0]]]), (label, r0)
+            digests.append(synth.digest(rows))
+        out[label] = (digests, samples, sites, b.nbytes(), b.ingest_stats["chunks"])
+        b.close()
+    assert out["usual"][:4] == out["cold"][:4] and out["cold"][4] >= 2
