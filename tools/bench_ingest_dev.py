@@ -59,8 +59,22 @@ def main():
         reader_cy.ensure_index(path)
         # the same steps one by one (reader_cy.stream_to_device), each with its own clock
         from wgsassign_amd.device import DeviceBeagle
+        from wgsassign_amd import _lib
+        lib = _lib.load()
+        spent = {}
+        for fn in ("wgs_ingest_destroy", "wgs_ingest_create", "wgs_ingest_next", "wgs_reader_close"):
+            def wrap(name, real):
+                def timed(*a):
+                    t = time.perf_counter()
+                    try:
+                        return real(*a)
+                    finally:
+                        spent[name] = spent.get(name, 0.0) + time.perf_counter() - t
+                return timed
+            setattr(lib, fn, wrap(fn, getattr(lib, fn)))
         for _ in range(2):
             steps = {}
+            spent.clear()
             t0 = time.perf_counter()
 
             def lap(name):
@@ -83,6 +97,7 @@ def main():
             lap("close_stream")
             b.close()
             lap("close_matrix")
+            steps.update({"in_" + k: round(v, 4) for k, v in spent.items()})
             steps["ingest_create_s"] = round(st.ingest_stats["create_s"], 4)
             steps["ingest_next_s"] = round(st.ingest_stats["next_s"], 4)
             res.setdefault("steps", []).append(steps)
