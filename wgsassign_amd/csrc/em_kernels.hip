@@ -1018,45 +1018,123 @@ __global__ __launch_bounds__(256) void rmse_candidates_kernel(const ChainJob *__
 __global__ __launch_bounds__(64) void rmse_walk_kernel(const ChainJob *__restrict__ jobs, int64_t m, const int *__restrict__ expo_all,
                                                        const long long *__restrict__ cand_all, int nblocks, float *out_all, int *n_serial_all)
 {
-    __shared__ float sq[RB];
+    __shared__ __attribute__((aligned(16))) float sq[RB];
     const int lane = threadIdx.x;
     const float *__restrict__ a = jobs[blockIdx.x].a, *__restrict__ b = jobs[blockIdx.x].b;
     const int *__restrict__ expo = expo_all + (size_t)blockIdx.x * nblocks;
     const long long *__restrict__ cand = cand_all + (size_t)blockIdx.x * nblocks * 6;
     float *out = out_all + blockIdx.x;
     int *n_serial = n_serial_all ? n_serial_all + blockIdx.x : nullptr;
-    float res = jobs[blockIdx.x].carry_in;
+    // (the running value as BITS in a scalar register -- every lane holds the same one, and a step is integer arithmetic on it: said
+    // this way the compiler keeps the steps on the scalar unit instead of hopping between the units for every comparison)
+    unsigned rbits = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(jobs[blockIdx.x].carry_in));
     int serial = 0;
-    for (int blk = 0; blk < nblocks; ++blk) {
-        const int e = expo[blk];
+#ifdef WGS_WALK_STATS
+    unsigned long long t_serial = 0, t_all0 = clock64();
+#endif
+    // Lane l fetches block l's exponent and six candidates for sixty-four blocks at once -- nothing of that depends on the running
+    // value -- and a step takes its block's from that lane's registers (v_readlane).  Read where they are needed, they were two
+    // dependent loads per step: 1070 cycles per step, two thirds of the walk (-DWGS_WALK_STATS).  (The values are made opaque to
+    // the compiler, which otherwise re-issues the loads of this read-only memory inside the steps instead of keeping registers.)
+    for (int blk0 = 0; blk0 < nblocks; blk0 += 64) {
+      const int nb = nblocks - blk0 < 64 ? nblocks - blk0 : 64;
+      const int mine = blk0 + lane < nblocks ? blk0 + lane : nblocks - 1;
+      int my_e = expo[mine];
+      unsigned my_lo[6], my_hi[6];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+          const unsigned long long v = (unsigned long long)cand[(int64_t)mine * 6 + c];
+          my_lo[c] = (unsigned)v, my_hi[c] = (unsigned)(v >> 32);
+      }
+      asm volatile("" : "+v"(my_e));
+#pragma unroll
+      for (int c = 0; c < 6; ++c) asm volatile("" : "+v"(my_lo[c]), "+v"(my_hi[c]));
+      for (int i = 0; i < nb; ++i) {
+        const int blk = blk0 + i;
+        const int e = __builtin_amdgcn_readlane(my_e, i);
         if (e == -1) continue;                                   // res + 0.0f == res
-        const unsigned int bits = __float_as_uint(res);
+        const unsigned int bits = rbits;
         const int be = (int)((bits >> 23) & 0xFF);
         bool done = false;
         if (e > 0 && be >= 1 && be <= 254 && !(bits >> 31) && be >= e - 1 && be <= e + 1) {
             const unsigned int M = (bits & 0x7FFFFF) | 0x800000u;
-            const long long D = cand[(int64_t)blk * 6 + 2 * (be - e + 1) + (M & 1)];
+            const int which = 2 * (be - e + 1) + (int)(M & 1);
+            unsigned lo = 0, hi = 0;
+            switch (which) {
+                case 0: lo = (unsigned)__builtin_amdgcn_readlane((int)my_lo[0], i), hi = (unsigned)__builtin_amdgcn_readlane((int)my_hi[0], i); break;
+                case 1: lo = (unsigned)__builtin_amdgcn_readlane((int)my_lo[1], i), hi = (unsigned)__builtin_amdgcn_readlane((int)my_hi[1], i); break;
+                case 2: lo = (unsigned)__builtin_amdgcn_readlane((int)my_lo[2], i), hi = (unsigned)__builtin_amdgcn_readlane((int)my_hi[2], i); break;
+                case 3: lo = (unsigned)__builtin_amdgcn_readlane((int)my_lo[3], i), hi = (unsigned)__builtin_amdgcn_readlane((int)my_hi[3], i); break;
+                case 4: lo = (unsigned)__builtin_amdgcn_readlane((int)my_lo[4], i), hi = (unsigned)__builtin_amdgcn_readlane((int)my_hi[4], i); break;
+                default: lo = (unsigned)__builtin_amdgcn_readlane((int)my_lo[5], i), hi = (unsigned)__builtin_amdgcn_readlane((int)my_hi[5], i); break;
+            }
+            const long long D = (long long)(((unsigned long long)hi << 32) | lo);
             if ((long long)M + D < (1ll << 24)) {
                 const unsigned int M2 = (unsigned int)((long long)M + D);
-                res = __uint_as_float(((unsigned int)be << 23) | (M2 & 0x7FFFFF));
+                rbits = ((unsigned int)be << 23) | (M2 & 0x7FFFFF);
                 done = true;
             }
         }
         if (!done) {                                             // literal serial loop for this block
+            float res = __uint_as_float(rbits);
             ++serial;
+#ifdef WGS_WALK_STATS
+            const unsigned long long ts0 = clock64();
+#endif
             const int64_t base = (int64_t)blk * RB;
-            for (int k = 0; k < RB / 64; ++k) {
-                const int64_t i = base + k * 64 + lane;
-                sq[k * 64 + lane] = i < m ? sqdiff(a, b, i) : 0.0f;
+            // the block's 4096 squares into LDS, sixteen pairs of loads in flight per lane (one pair at a time -- each waited for
+            // before the next was issued -- this staging was 64 trips to memory per block, a third of the walk: -DWGS_WALK_STATS)
+            for (int k0 = 0; k0 < RB / 64; k0 += 16) {
+                float av[16], bv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int64_t idx = base + (int64_t)(k0 + u) * 64 + lane;
+                    const int64_t at = idx < m ? idx : m - 1;
+                    av[u] = a[at], bv[u] = b[at];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int64_t idx = base + (int64_t)(k0 + u) * 64 + lane;
+                    const float d = av[u] - bv[u];              // emMAF_cy.pyx:31, float32 sub and mul (sqdiff)
+                    sq[(k0 + u) * 64 + lane] = idx < m ? d * d : 0.0f;
+                }
             }
             __syncthreads();
             const int cnt = (m - base) < RB ? (int)(m - base) : RB;
-            for (int t = 0; t < cnt; ++t) res = res + sq[t];
+            // float32 += float32 in element order.  The adds are one dependent chain; the LDS reads are not: sixteen values per
+            // batch of four 16-byte reads, requested while the sixteen before them are added (as chain_walk_kernel does it).
+            int t = 0;
+            if (cnt >= 16) {                                      // (the next sixteen are requested before the current sixteen are added)
+                const float4 *q = reinterpret_cast<const float4 *>(sq);
+                float4 v0 = q[0], v1 = q[1], v2 = q[2], v3 = q[3];
+                for (; t + 32 <= cnt; t += 16) {
+                    const float4 w0 = q[t / 4 + 4], w1 = q[t / 4 + 5], w2 = q[t / 4 + 6], w3 = q[t / 4 + 7];
+                    res = res + v0.x; res = res + v0.y; res = res + v0.z; res = res + v0.w;
+                    res = res + v1.x; res = res + v1.y; res = res + v1.z; res = res + v1.w;
+                    res = res + v2.x; res = res + v2.y; res = res + v2.z; res = res + v2.w;
+                    res = res + v3.x; res = res + v3.y; res = res + v3.z; res = res + v3.w;
+                    v0 = w0, v1 = w1, v2 = w2, v3 = w3;
+                }
+                res = res + v0.x; res = res + v0.y; res = res + v0.z; res = res + v0.w;
+                res = res + v1.x; res = res + v1.y; res = res + v1.z; res = res + v1.w;
+                res = res + v2.x; res = res + v2.y; res = res + v2.z; res = res + v2.w;
+                res = res + v3.x; res = res + v3.y; res = res + v3.z; res = res + v3.w;
+                t += 16;
+            }
+            for (; t < cnt; ++t) res = res + sq[t];
+            rbits = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(res));
             __syncthreads();
+#ifdef WGS_WALK_STATS
+            t_serial += clock64() - ts0;
+#endif
         }
+      }
     }
+#ifdef WGS_WALK_STATS
+    if (lane == 0 && blockIdx.x == 0) printf("[walk stats] %d blocks, %d serial; cycles: all %llu, serial blocks %llu\n", nblocks, serial, clock64() - t_all0, t_serial);
+#endif
     if (lane == 0) {
-        *out = res;
+        *out = __uint_as_float(rbits);
         if (n_serial) *n_serial = serial;
     }
 }
